@@ -1,0 +1,135 @@
+/*
+ * pastix_amd.h -- C ABI of the MI355X-native sopalin (numerical factorization) path.
+ *
+ * Drop-in boundary.  The reference's numerical factorization is entered through
+ *     void {po,ge,sy,he}_sopalin_thread(SolverMatrix *m, SopalinParam *sopar)
+ * (src/sopalin/src/sopalin3d.h:381-467, body sopalin3d.c:1388-1422, sole caller
+ * pastix_task_sopalin, src/sopalin/src/pastix.c:3561-3575).  A PaStiX maintainer binds the
+ * functions below at exactly that call site: the layout structs are the
+ * read-only subset of SolverMatrix / SolverCblk / SolverBlok the path reads
+ * (src/blend/src/solver.h:94-168), with 64-bit indices (200^3 needs coefnbr > 2^31).
+ *
+ * All functions return 0 on success or a negative PASTIX_AMD_ERR_* code; nothing aborts.
+ * Plain pointers and sizes only: no C++/torch types cross this boundary.
+ */
+#ifndef PASTIX_AMD_H
+#define PASTIX_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t pastix_amd_int_t;
+
+/* IPARM_FACTORIZATION values (src/common/src/api.h:381-384) */
+enum { PASTIX_AMD_FACT_LLT = 0, PASTIX_AMD_FACT_LDLT = 1, PASTIX_AMD_FACT_LU = 2, PASTIX_AMD_FACT_LDLH = 3 };
+/* IPARM_FLOAT values (api.h:522-525): only double real is built in round 1 */
+enum { PASTIX_AMD_REALSINGLE = 0, PASTIX_AMD_REALDOUBLE = 1, PASTIX_AMD_COMPLEXSINGLE = 2, PASTIX_AMD_COMPLEXDOUBLE = 3 };
+
+enum {
+  PASTIX_AMD_OK = 0,
+  PASTIX_AMD_ERR_BADPARAMETER = -1,   /* api.h BADPARAMETER_ERR */
+  PASTIX_AMD_ERR_ALLOC = -2,          /* out of host/device memory */
+  PASTIX_AMD_ERR_DEVICE = -3,         /* HIP runtime error / no gfx950 device */
+  PASTIX_AMD_ERR_NUMERIC = -4,        /* non-finite pivot met (reference would produce NaNs, compute_diag.c:143) */
+  PASTIX_AMD_ERR_UNSUPPORTED = -5,    /* precision/factorization variant not built yet */
+  PASTIX_AMD_ERR_LAYOUT = -6          /* layout violates the SolverMatrix invariants (solver_check.c) */
+};
+
+/* SolverCblk subset (solver.h:94-107). cblktab has cblknbr+1 entries (last: bloknum = bloknbr). */
+typedef struct pastix_amd_cblk_s {
+  pastix_amd_int_t fcolnum;   /* first column (0-based, inclusive) */
+  pastix_amd_int_t lcolnum;   /* last column (inclusive) */
+  pastix_amd_int_t bloknum;   /* first blok = the diagonal blok */
+  pastix_amd_int_t stride;    /* panel leading dimension = sum of blok heights */
+} pastix_amd_cblk_t;
+
+/* SolverBlok subset (solver.h:111-117) */
+typedef struct pastix_amd_blok_s {
+  pastix_amd_int_t frownum;   /* first row (inclusive) */
+  pastix_amd_int_t lrownum;   /* last row (inclusive) */
+  pastix_amd_int_t cblknum;   /* facing cblk */
+  pastix_amd_int_t coefind;   /* row offset of the blok inside the panel */
+} pastix_amd_blok_t;
+
+typedef struct pastix_amd_layout_s {
+  pastix_amd_int_t cblknbr;
+  pastix_amd_int_t bloknbr;
+  const pastix_amd_cblk_t *cblktab;   /* [cblknbr+1] */
+  const pastix_amd_blok_t *bloktab;   /* [bloknbr]   */
+} pastix_amd_layout_t;
+
+/* Tunables of the device engine (all have defaults when the struct is zeroed). */
+typedef struct pastix_amd_options_s {
+  int device;            /* HIP device ordinal */
+  int lookahead;         /* update window D: a contribution k->t is applied at launch slot
+                            max(level(k)+1, level(t)-D); 0 = left-looking, large = right-looking.
+                            default 4 */
+  int verbose;
+  int reserved[13];
+} pastix_amd_options_t;
+
+/* Statistics of a plan / a factorization. */
+typedef struct pastix_amd_stats_s {
+  double fact_flops;       /* DPARM_FACT_FLOPS definition (blend_symbol_cost.c:52-88) on this layout */
+  double fact_time;        /* seconds, first kernel launch -> last kernel done (DPARM_FACT_TIME semantics) */
+  double update_time;      /* seconds inside the update (GEMM+scatter) kernel, from HIP events */
+  double h2d_time, d2h_time;
+  pastix_amd_int_t nbpivot;  /* static pivots (IPARM_STATIC_PIVOTING) */
+  pastix_amd_int_t coefnbr;  /* panel elements (one of L/U) */
+  pastix_amd_int_t nlevels, ntasks, npieces, nupdate_launches;
+  double update_flops;     /* 2*m*n*k summed over update pieces actually issued (incl. MFMA tile padding excluded) */
+  double reserved[6];
+} pastix_amd_stats_t;
+
+typedef struct pastix_amd_plan_s pastix_amd_plan_t;
+
+/* ---- one-shot drop-ins for {po,ge,sy}_sopalin_thread (double real) -------------------------
+ * coeftab[k] / ucoeftab[k]: host panel of cblk k, column-major stride(k) x width(k), already filled
+ * (CoefMatrix_Init, coefinit.c:283-296); factorized in place, as the reference leaves them for
+ * updo.c.  critere: pivot threshold (sopalin3d.c:586-606).  nbpivot -> sopar->diagchange. */
+int pastix_amd_d_po_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab, double *const *ucoeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+
+/* ---- staged API (analysis once, many factorizations; panels may stay on the device) -------- */
+int pastix_amd_plan_create(const pastix_amd_layout_t *layout, int factotype, int floattype,
+                           const pastix_amd_options_t *opts, pastix_amd_plan_t **plan);
+void pastix_amd_plan_destroy(pastix_amd_plan_t *plan);
+int pastix_amd_plan_stats(const pastix_amd_plan_t *plan, pastix_amd_stats_t *stats);
+
+/* panels <-> device arena.  "packed": all panels concatenated in cblk order (offset of cblk k =
+ * sum_{c<k} stride(c)*width(c)); "tabs": the reference's one-buffer-per-cblk arrays. */
+int pastix_amd_upload_packed(pastix_amd_plan_t *plan, const void *L, const void *U);
+int pastix_amd_download_packed(pastix_amd_plan_t *plan, void *L, void *U);
+int pastix_amd_upload_tabs(pastix_amd_plan_t *plan, void *const *coeftab, void *const *ucoeftab);
+int pastix_amd_download_tabs(pastix_amd_plan_t *plan, void *const *coeftab, void *const *ucoeftab);
+
+/* coefficient fill on the device: CoefMatrix_Init + Csc2solv_cblk (coefinit.c:283-296,
+ * csc_intern_solve.c:65-132).  CSC 1-based; sym!=0: lower triangle only; perm 0-based old->new. */
+int pastix_amd_fill_csc(pastix_amd_plan_t *plan, int sym, pastix_amd_int_t n, const pastix_amd_int_t *colptr,
+                        const pastix_amd_int_t *rows, const void *vals, const pastix_amd_int_t *perm);
+
+/* numerical factorization of the device-resident panels (the hot path). */
+int pastix_amd_factorize(pastix_amd_plan_t *plan, double critere, pastix_amd_stats_t *stats);
+
+/* triangular solves on the device-resident factors, x (permuted numbering, n x nrhs, ld n) in place */
+int pastix_amd_solve(pastix_amd_plan_t *plan, void *x, pastix_amd_int_t nrhs);
+
+/* raw device pointers of the arenas (for callers that own device-side pipelines, e.g. RCCL fan-in) */
+int pastix_amd_device_arenas(pastix_amd_plan_t *plan, void **dL, void **dU);
+
+/* DPARM_FACT_FLOPS on a layout (host only) */
+double pastix_amd_fact_flops(const pastix_amd_layout_t *layout, int factotype, int floattype);
+
+const char *pastix_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASTIX_AMD_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of pastix_amd/lib/libpastix_amd.so (the C ABI of include/pastix_amd.h).
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 device is visible the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure and is never
+imported from this package.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpastix_amd.so")
+
+i64 = ctypes.c_int64
+
+
+class CBlk(ctypes.Structure):
+    _fields_ = [("fcolnum", i64), ("lcolnum", i64), ("bloknum", i64), ("stride", i64)]
+
+
+class Blok(ctypes.Structure):
+    _fields_ = [("frownum", i64), ("lrownum", i64), ("cblknum", i64), ("coefind", i64)]
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [("cblknbr", i64), ("bloknbr", i64),
+                ("cblktab", ctypes.c_void_p), ("bloktab", ctypes.c_void_p)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
+                ("reserved", ctypes.c_int * 13)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("fact_flops", ctypes.c_double), ("fact_time", ctypes.c_double),
+                ("update_time", ctypes.c_double), ("h2d_time", ctypes.c_double),
+                ("d2h_time", ctypes.c_double), ("nbpivot", i64), ("coefnbr", i64),
+                ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64),
+                ("update_flops", ctypes.c_double), ("reserved", ctypes.c_double * 6)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+ERRORS = {0: "OK", -1: "BADPARAMETER", -2: "ALLOC", -3: "DEVICE", -4: "NUMERIC", -5: "UNSUPPORTED",
+          -6: "LAYOUT"}
+
+
+class PastixAmdError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__("%s failed: %s (%d)" % (where, ERRORS.get(code, "?"), code))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/pastix_amd.h declares
+EXPORTS = [
+    "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin",
+    "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats",
+    "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
+    "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_factorize", "pastix_amd_solve",
+    "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("pastix_amd: %s is missing; run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.pastix_amd_fact_flops.restype = ctypes.c_double
+        L.pastix_amd_version.restype = ctypes.c_char_p
+        L.pastix_amd_plan_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code != 0:
+        raise PastixAmdError(code, where)
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class LayoutArrays:
+    """Keeps the numpy arrays alive that a Layout struct points into."""
+
+    def __init__(self, cblk4, blok4):
+        self.cblk4 = as_i64(cblk4).reshape(-1, 4)
+        self.blok4 = as_i64(blok4).reshape(-1, 4)
+        self.c = Layout(len(self.cblk4) - 1, len(self.blok4), ptr(self.cblk4), ptr(self.blok4))
+
+    @property
+    def cblknbr(self):
+        return len(self.cblk4) - 1
+
+    def widths(self):
+        return self.cblk4[:-1, 1] - self.cblk4[:-1, 0] + 1
+
+    def panel_offsets(self):
+        sz = self.widths() * self.cblk4[:-1, 3]
+        return np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
+
+    def coefnbr(self):
+        return int(self.panel_offsets()[-1])

@@ -1,0 +1,372 @@
+// api.cpp -- the C ABI declared in include/pastix_amd.h: plan life cycle, panel transfers, the device
+// factorization driver (the GPU replacement of sopalin_thread / sopalin_smp, sopalin3d.c:666-1422).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "plan.h"
+
+namespace pastix_amd {
+void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks);
+void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int* errflag);
+void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
+void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
+}  // namespace pastix_amd
+
+using namespace pastix_amd;
+
+struct pastix_amd_plan_s {
+  Plan host;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* dL = nullptr;
+  double* dU = nullptr;
+  double* dDinv = nullptr;
+  Task* dTasks = nullptr;
+  Piece* dPieces = nullptr;
+  PanelTask* dPanel = nullptr;
+  TrsmTask* dTrsm = nullptr;
+  long long* dNbpivot = nullptr;
+  int* dErr = nullptr;
+  int maxw = 0;
+  std::vector<hipEvent_t> ev;      // event pairs around update launches
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  pastix_amd_stats_t stats{};
+};
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "pastix_amd: HIP error '%s' at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? PASTIX_AMD_ERR_ALLOC : PASTIX_AMD_ERR_DEVICE;   \
+    }                                                                                    \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+static int to_device(T** d, const std::vector<T>& h) {
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" {
+
+const char* pastix_amd_version(void) { return "pastix_amd 0.1 (gfx950)"; }
+
+double pastix_amd_fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype) {
+  if (!layout) return 0.0;
+  return fact_flops(layout, factotype, floattype);
+}
+
+int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int floattype,
+                           const pastix_amd_options_t* opts, pastix_amd_plan_t** out) {
+  if (!out) return PASTIX_AMD_ERR_BADPARAMETER;
+  *out = nullptr;
+  pastix_amd_plan_s* p = new (std::nothrow) pastix_amd_plan_s();
+  if (!p) return PASTIX_AMD_ERR_ALLOC;
+  int rc;
+  try {
+    rc = build_plan(layout, factotype, floattype, opts, p->host);
+  } catch (const std::bad_alloc&) {
+    rc = PASTIX_AMD_ERR_ALLOC;
+  }
+  if (rc) { delete p; return rc; }
+  if (factotype != PASTIX_AMD_FACT_LLT) { delete p; return PASTIX_AMD_ERR_UNSUPPORTED; }
+  Plan& H = p->host;
+  p->device = H.opts.device;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= p->device) {
+    fprintf(stderr, "pastix_amd: no HIP device %d (the product path has no CPU fallback)\n", p->device);
+    delete p;
+    return PASTIX_AMD_ERR_DEVICE;
+  }
+#define CHK(x) do { int r_ = (x); if (r_) { pastix_amd_plan_destroy(p); return r_; } } while (0)
+  auto body = [&]() -> int {
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void**)&p->dL, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+    if (H.factotype != PASTIX_AMD_FACT_LLT)
+      HIPCHK(hipMalloc((void**)&p->dU, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&p->dDinv, std::max<int64_t>(H.dinv_ws, 256) * sizeof(double)));
+    int r;
+    if ((r = to_device(&p->dTasks, H.tasks))) return r;
+    if ((r = to_device(&p->dPieces, H.pieces))) return r;
+    if ((r = to_device(&p->dPanel, H.panel_tasks))) return r;
+    if ((r = to_device(&p->dTrsm, H.trsm_tasks))) return r;
+    HIPCHK(hipMalloc((void**)&p->dNbpivot, sizeof(long long)));
+    HIPCHK(hipMalloc((void**)&p->dErr, sizeof(int)));
+    HIPCHK(hipEventCreate(&p->ev0));
+    HIPCHK(hipEventCreate(&p->ev1));
+    p->ev.resize(2 * (size_t)H.nlevels);
+    for (auto& e : p->ev) HIPCHK(hipEventCreate(&e));
+    return 0;
+  };
+  CHK(body());
+#undef CHK
+  for (int64_t k = 0; k < H.cblknbr; k++)
+    p->maxw = std::max<int>(p->maxw, (int)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1));
+  pastix_amd_stats_t& S = p->stats;
+  S.fact_flops = H.fact_flops;
+  S.coefnbr = H.coefnbr;
+  S.nlevels = H.nlevels;
+  S.ntasks = (int64_t)H.tasks.size();
+  S.npieces = (int64_t)H.pieces.size();
+  S.update_flops = H.update_flops;
+  // the piece/task tables now live on the device; keep only what the host driver reads
+  std::vector<Piece>().swap(H.pieces);
+  std::vector<Task>().swap(H.tasks);
+  *out = p;
+  return PASTIX_AMD_OK;
+}
+
+void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  (void)hipFree(p->dL); (void)hipFree(p->dU); (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
+  (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
+  (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
+  for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  if (p->ev0) (void)hipEventDestroy(p->ev0);
+  if (p->ev1) (void)hipEventDestroy(p->ev1);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int pastix_amd_plan_stats(const pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
+  if (!p || !stats) return PASTIX_AMD_ERR_BADPARAMETER;
+  *stats = p->stats;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_device_arenas(pastix_amd_plan_t* p, void** dL, void** dU) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (dL) *dL = p->dL;
+  if (dU) *dU = p->dU;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U) {
+  if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  double t0 = now_s();
+  HIPCHK(hipMemcpy(p->dL, L, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+  if (p->dU && U) HIPCHK(hipMemcpy(p->dU, U, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+  p->stats.h2d_time = now_s() - t0;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
+  if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  double t0 = now_s();
+  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipMemcpy(L, p->dL, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+  if (p->dU && U) HIPCHK(hipMemcpy(U, p->dU, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+  p->stats.d2h_time = now_s() - t0;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
+  if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  const Plan& H = p->host;
+  double t0 = now_s();
+  for (int64_t k = 0; k < H.cblknbr; k++) {
+    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
+    HIPCHK(hipMemcpyAsync(p->dL + H.poff[k], coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
+    if (p->dU && ucoeftab && ucoeftab[k])
+      HIPCHK(hipMemcpyAsync(p->dU + H.poff[k], ucoeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  p->stats.h2d_time = now_s() - t0;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
+  if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  const Plan& H = p->host;
+  double t0 = now_s();
+  for (int64_t k = 0; k < H.cblknbr; k++) {
+    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
+    HIPCHK(hipMemcpyAsync(coeftab[k], p->dL + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
+    if (p->dU && ucoeftab && ucoeftab[k])
+      HIPCHK(hipMemcpyAsync(ucoeftab[k], p->dU + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
+  }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  p->stats.d2h_time = now_s() - t0;
+  return PASTIX_AMD_OK;
+}
+
+// CoefMatrix_Init + Csc2solv_cblk (coefinit.c:283-296, csc_intern_solve.c:65-132): zero the panels,
+// then place every entry of the permuted (and, for symmetric input, mirrored) matrix whose row is
+// >= fcolnum of its column's cblk into its blok.  Destinations are computed on the host (binary
+// search over the cblk's bloks instead of the reference's linear walk :94-99), the scatter runs on
+// the device.
+int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const pastix_amd_int_t* colptr,
+                        const pastix_amd_int_t* rows, const void* vals_, const pastix_amd_int_t* perm) {
+  if (!p || !colptr || !rows || !vals_ || !perm) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
+  const double* vals = (const double*)vals_;
+  HIPCHK(hipSetDevice(p->device));
+  std::vector<int32_t> col2cblk((size_t)n);
+  for (int64_t k = 0; k < H.cblknbr; k++)
+    for (int64_t j = H.cblk[k].fcolnum; j <= H.cblk[k].lcolnum; j++) col2cblk[j] = (int32_t)k;
+  const int64_t nnz = colptr[n] - 1;
+  std::vector<int64_t> idxL, idxU;
+  std::vector<double> valL, valU;
+  idxL.reserve((size_t)nnz * (sym ? 2 : 1));
+  valL.reserve((size_t)nnz * (sym ? 2 : 1));
+  auto locate = [&](int64_t pr, int64_t pc, bool offdiag_only) -> int64_t {
+    const int64_t kc = col2cblk[pc];
+    if (pr < H.cblk[kc].fcolnum) return -1;
+    int64_t lo = H.cblk[kc].bloknum, hi = H.cblk[kc + 1].bloknum - 1, fb = lo;
+    while (lo < hi) {
+      int64_t mid = (lo + hi + 1) >> 1;
+      if (H.blok[mid].frownum <= pr) lo = mid; else hi = mid - 1;
+    }
+    if (H.blok[lo].frownum > pr || H.blok[lo].lrownum < pr) return -1;
+    if (offdiag_only && lo == fb) return -1;
+    return H.poff[kc] + H.blok[lo].coefind + (pr - H.blok[lo].frownum) + (pc - H.cblk[kc].fcolnum) * H.cblk[kc].stride;
+  };
+  const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
+  for (int64_t j = 0; j < n; j++)
+    for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+      const int64_t i = rows[q] - 1;
+      if (i < 0 || i >= n) return PASTIX_AMD_ERR_BADPARAMETER;
+      const int npass = (sym && i != j) ? 2 : 1;
+      for (int pass = 0; pass < npass; pass++) {
+        const int64_t pr = perm[pass ? j : i], pc = perm[pass ? i : j];
+        int64_t d = locate(pr, pc, false);
+        if (d >= 0) { idxL.push_back(d); valL.push_back(vals[q]); }
+        if (lu) {
+          d = locate(pc, pr, true);
+          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[q]); }
+        }
+      }
+    }
+  HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
+  auto scatter = [&](double* dst, std::vector<int64_t>& idx, std::vector<double>& val) -> int {
+    if (idx.empty()) return 0;
+    int64_t* di = nullptr;
+    double* dv = nullptr;
+    HIPCHK(hipMalloc((void**)&di, idx.size() * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void**)&dv, val.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(di, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(dv, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    launch_scatter(p->stream, dst, di, dv, (int64_t)idx.size());
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipFree(di));
+    HIPCHK(hipFree(dv));
+    return 0;
+  };
+  int r;
+  if ((r = scatter(p->dL, idxL, valL))) return r;
+  if (lu && (r = scatter(p->dU, idxU, valU))) return r;
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return PASTIX_AMD_OK;
+}
+
+// The device replacement of sopalin_smp's task loop (sopalin3d.c:790-1025): for every dependency
+// level s: apply the contributions scheduled into slot s (k_update), then factorize the cblks of
+// level s (k_diag + k_trsm).  Time is measured like DPARM_FACT_TIME: panels resident, first launch
+// to last completion (sopalin3d.c:775,1031,1125-1132).
+int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  HIPCHK(hipMemsetAsync(p->dNbpivot, 0, sizeof(long long), s));
+  HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipEventRecord(p->ev0, s));
+  int nupd = 0;
+  for (int l = 0; l < H.nlevels; l++) {
+    const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
+    if (t1 > t0) {
+      HIPCHK(hipEventRecord(p->ev[2 * nupd], s));
+      launch_update(s, p->dL, p->dU, p->dTasks + t0, p->dPieces, t1 - t0);
+      HIPCHK(hipEventRecord(p->ev[2 * nupd + 1], s));
+      nupd++;
+    }
+    launch_diag_llt(s, p->dL, p->dPanel + H.lvl_panel_ptr[l], H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l],
+                    p->dDinv, critere, p->dNbpivot, p->dErr);
+    launch_trsm_llt(s, p->dL, p->dTrsm + H.lvl_trsm_ptr[l], H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l],
+                    p->dDinv, p->maxw);
+  }
+  HIPCHK(hipEventRecord(p->ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+  p->stats.fact_time = ms * 1e-3;
+  double upd = 0;
+  for (int i = 0; i < nupd; i++) {
+    float m2 = 0;
+    HIPCHK(hipEventElapsedTime(&m2, p->ev[2 * i], p->ev[2 * i + 1]));
+    upd += m2 * 1e-3;
+  }
+  p->stats.update_time = upd;
+  p->stats.nupdate_launches = nupd;
+  long long nb = 0;
+  int err = 0;
+  HIPCHK(hipMemcpy(&nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&err, p->dErr, sizeof(err), hipMemcpyDeviceToHost));
+  p->stats.nbpivot = nb;
+  if (stats) *stats = p->stats;
+  return err ? PASTIX_AMD_ERR_NUMERIC : PASTIX_AMD_OK;
+}
+
+int pastix_amd_solve(pastix_amd_plan_t* p, void* x, pastix_amd_int_t nrhs) {
+  (void)p; (void)x; (void)nrhs;
+  return PASTIX_AMD_ERR_UNSUPPORTED;
+}
+
+static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
+                    double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
+                    pastix_amd_stats_t* stats) {
+  pastix_amd_plan_t* plan = nullptr;
+  int rc = pastix_amd_plan_create(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, &plan);
+  if (rc) return rc;
+  rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+  int rcf = 0;
+  if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
+  if (!rc && (rcf == 0 || rcf == PASTIX_AMD_ERR_NUMERIC))
+    rc = pastix_amd_download_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+  if (stats) pastix_amd_plan_stats(plan, stats);
+  pastix_amd_plan_destroy(plan);
+  return rc ? rc : rcf;
+}
+
+int pastix_amd_d_po_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LLT, layout, coeftab, nullptr, critere, opts, stats);
+}
+int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LDLT, layout, coeftab, nullptr, critere, opts, stats);
+}
+int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double* const* ucoeftab,
+                            double critere, const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LU, layout, coeftab, ucoeftab, critere, opts, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) device kernels of the sopalin numerical factorization.
+//
+// Three kernels replace the reference's per-cblk CPU step compute_1d (sopalin_compute.c:747-863):
+//   k_diag   : factor_diag  (compute_diag.c:538-605)  blocked LLt of the w x w diagonal blok with the
+//              static-pivot clamp (compute_diag.c:133-137), plus the 16x16 diagonal-block inverses
+//              the panel solve uses;
+//   k_trsm   : factor_trsm1d (compute_trsm.c:128-171) panel solve X = A L^-T held entirely in MFMA
+//              accumulator registers (v_mfma_f64_16x16x4_f64), one wave per 16 panel rows;
+//   k_update : compute_1dgemm = compute_contrib_compact + add_contrib_local
+//              (sopalin_compute.c:865-1032, :270-374, :391-598) fused: every workgroup owns one
+//              128x128 tile of a target panel and accumulates all contributions ("pieces") that the
+//              plan scheduled into this launch in MFMA accumulators, then subtracts them from the
+//              tile once.  Tile ownership replaces mutex_blok[] and makes the result deterministic.
+//
+// MFMA f64 16x16x4 lane maps (measured on gfx950, tools/probe_mfma_f64.hip):
+//   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: lane l holds B[k = l>>4][j = l&15];
+//   C/D: lane l, register q holds D[i = (l>>4) + 4q][j = l&15].
+// The update kernel feeds the target COLUMN index as MFMA "i" and the target ROW index as MFMA "j" so
+// that each accumulator register maps to 16 consecutive rows of the column-major panel (128-byte
+// segments for the read-modify-write of the tile).
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace pastix_amd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// k_update
+// ------------------------------------------------------------------------------------------------
+constexpr int KC = 16;        // k-chunk staged per barrier
+constexpr int SLD = 144;      // LDS line length in doubles: 128 rows + 16 pad -> lanes 16-31 of a
+                              // ds_read_b64 land on banks 32-63 (conflict-free, MI355X_MICROARCH LDS)
+
+struct Stage {
+  double a[KC / 2];
+  double b[KC / 2];
+};
+
+__device__ __forceinline__ void stage_load(Stage& st, const double* __restrict__ Ab, const double* __restrict__ Bb,
+                                           const Piece& pc, int kc, int tid) {
+  const int row = tid & 127, k0 = tid >> 7;
+  const int ra = row - (int)pc.dr, rb = row - (int)pc.dc;
+  const bool va = ra >= 0 && ra < (int)pc.m, vb = rb >= 0 && rb < (int)pc.n;
+  const double* pa = Ab + ra + (int64_t)(kc + k0) * pc.lda;
+  const double* pb = Bb + rb + (int64_t)(kc + k0) * pc.lda;
+  const int64_t step = 2 * (int64_t)pc.lda;
+#pragma unroll
+  for (int q = 0; q < KC / 2; q++) {
+    const bool kv = kc + k0 + 2 * q < (int)pc.k;
+    st.a[q] = (va && kv) ? pa[q * step] : 0.0;
+    st.b[q] = (vb && kv) ? pb[q * step] : 0.0;
+  }
+}
+
+__device__ __forceinline__ void stage_store(const Stage& st, double* sA, double* sB, int tid) {
+  const int row = tid & 127, k0 = tid >> 7;
+#pragma unroll
+  for (int q = 0; q < KC / 2; q++) {
+    sA[(k0 + 2 * q) * SLD + row] = st.a[q];
+    sB[(k0 + 2 * q) * SLD + row] = st.b[q];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_update(double* __restrict__ L, double* __restrict__ U,
+                                                  const Task* __restrict__ tasks,
+                                                  const Piece* __restrict__ pieces) {
+  __shared__ double sh[2][2][KC * SLD];   // [buffer][A|B]  73,728 bytes
+  const Task tk = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*64.., cols wc*64.. of the tile
+  const int l15 = lane & 15, g = lane >> 4;
+
+  d4 acc[4][4];                                 // [mi][ni]
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
+
+  int pi = tk.p0;
+  const int pend = tk.p0 + tk.pn;
+  Piece cur = pieces[pi];
+  int kc = 0, buf = 0;
+  unsigned touched = 0;                         // union of active (mi | ni<<4) masks
+  Stage st;
+  {
+    const double* Ab = ((cur.flags & 1) ? U : L) + cur.a_off;
+    const double* Bb = ((cur.flags & 2) ? U : L) + cur.b_off;
+    stage_load(st, Ab, Bb, cur, 0, tid);
+    stage_store(st, sh[0][0], sh[0][1], tid);
+  }
+  __syncthreads();
+  while (true) {
+    Piece nxt = cur;
+    int npi = pi, nkc = kc + KC;
+    if (nkc >= (int)cur.k) {
+      npi = pi + 1;
+      nkc = 0;
+      if (npi < pend) nxt = pieces[npi];
+    }
+    const bool has_next = npi < pend;
+    if (has_next) {
+      const double* Ab = ((nxt.flags & 1) ? U : L) + nxt.a_off;
+      const double* Bb = ((nxt.flags & 2) ? U : L) + nxt.b_off;
+      stage_load(st, Ab, Bb, nxt, nkc, tid);
+    }
+    // ---- MFMA on the staged chunk ----
+    {
+      unsigned am = 0, an = 0;                  // wave-uniform sub-tile activity
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const int r0 = wr * 64 + s * 16, c0 = wc * 64 + s * 16;
+        if (r0 < (int)cur.dr + (int)cur.m && r0 + 16 > (int)cur.dr) am |= 1u << s;
+        if (c0 < (int)cur.dc + (int)cur.n && c0 + 16 > (int)cur.dc) an |= 1u << s;
+      }
+      if (am && an) {
+        touched |= am | (an << 4);
+        const double* sA = sh[buf][0] + wr * 64 + l15;
+        const double* sB = sh[buf][1] + wc * 64 + l15;
+        const int ksteps = (min(KC, (int)cur.k - kc) + 3) >> 2;
+        for (int ks = 0; ks < ksteps; ks++) {
+          const int kk = (ks * 4 + g) * SLD;
+          double bm[4], an_[4];
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            bm[s] = sA[kk + s * 16];            // rows  -> MFMA B operand
+            an_[s] = sB[kk + s * 16];           // cols  -> MFMA A operand
+          }
+#pragma unroll
+          for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+              if ((am >> mi) & (an >> ni) & 1u)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    if (has_next) stage_store(st, sh[buf ^ 1][0], sh[buf ^ 1][1], tid);
+    __syncthreads();
+    if (!has_next) break;
+    cur = nxt;
+    pi = npi;
+    kc = nkc;
+    buf ^= 1;
+  }
+
+  // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column) ----
+  double* C = ((tk.flags & 1) ? U : L) + tk.c_off;
+#pragma unroll
+  for (int mi = 0; mi < 4; mi++) {
+    if (!((touched >> mi) & 1u)) continue;
+    const int r = wr * 64 + mi * 16 + l15;
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+      if (!((touched >> (4 + ni)) & 1u)) continue;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = wc * 64 + ni * 16 + g + 4 * q;
+        if (r < (int)tk.tm && c < (int)tk.tn) {
+          double* p = C + r + (int64_t)c * tk.ldc;
+          *p -= acc[mi][ni][q];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_diag : LLt of the diagonal blok, one workgroup (256 threads) per cblk, 16-column block steps
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag_llt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                  double* __restrict__ dinv_ws, double critere,
+                                                  long long* __restrict__ nbpivot, int* __restrict__ errflag) {
+  __shared__ double Ts[16][17];
+  __shared__ double Lo[16][17];
+  __shared__ double Ti[16][17];
+  __shared__ double Xs[16][244];
+  const PanelTask tk = tasks[blockIdx.x];
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x;
+  const int ti = tid & 15, tc = tid >> 4;
+  int npiv = 0;
+
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb);
+    const int rem = w - kb - nb;
+    // (1) diagonal tile -> LDS
+    if (ti < nb && tc < nb && ti >= tc) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
+    // (2) unblocked LLt of the tile: PASTIX_potrf (compute_diag.c:124-153), one barrier per column
+    for (int j = 0; j < nb; j++) {
+      __syncthreads();
+      double d = Ts[j][j];
+      if (fabs(d) < critere) {                     // compute_diag.c:133-137
+        d = critere;
+        if (tid == 0) npiv++;
+      }
+      if (!(d > 0.0) && tid == 0) atomicOr(errflag, 1);   // sqrt of a non-positive pivot
+      d = sqrt(d);
+      const double inv = 1.0 / d;                  // SCAL by 1/d (compute_diag.c:150)
+      if (ti < nb && tc < nb) {
+        if (tc == j) {
+          if (ti == j) Lo[j][j] = d;
+          else if (ti > j) Lo[ti][j] = Ts[ti][j] * inv;
+        } else if (tc > j && ti >= tc) {
+          Ts[ti][tc] -= (Ts[ti][j] * inv) * (Ts[tc][j] * inv);   // SYR "L" (compute_diag.c:151)
+        }
+      }
+    }
+    __syncthreads();
+    // (3) tile back to global; 16x16 inverse by 16 threads; rows below by the other threads
+    if (ti < nb && tc < nb && ti >= tc) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
+    if (tid < 16) {
+      // column c of inv(T): forward substitution; identity padding beyond nb
+      const int c = tid;
+      for (int i = 0; i < 16; i++) {
+        double x;
+        if (i >= nb || c >= nb) x = (i == c) ? 1.0 : 0.0;
+        else if (i < c) x = 0.0;
+        else {
+          double s = (i == c) ? 1.0 : 0.0;
+          for (int p = c; p < i; p++) s -= Lo[i][p] * Ti[p][c];
+          x = s / Lo[i][i];
+        }
+        Ti[i][c] = x;
+      }
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+      for (int i = 0; i < 16; i++) dst[i + 16 * c] = Ti[i][c];
+    } else if (tid - 16 < rem) {
+      // TRSM "R","L","T","N" on the rows of the diagonal blok below the tile (compute_diag.c:191-195)
+      const int rr = tid - 16;
+      double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) x[c] = (c < nb) ? ap[(int64_t)c * ld] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          double s = x[c];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < c) s -= x[p] * Lo[c][p];
+          x[c] = s / Lo[c][c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) ap[(int64_t)c * ld] = x[c];
+        Xs[c][rr] = x[c];
+      }
+    }
+    __syncthreads();
+    // (4) SYRK "L","N" on the trailing part of the diagonal blok (compute_diag.c:197-200)
+    if (rem > 0) {
+      const int nt = (rem + 3) >> 2;
+      double* Cb = A + (kb + nb) + (int64_t)(kb + nb) * ld;
+      for (int id = tid; id < nt * nt; id += 256) {
+        const int tr = id % nt, tcc = id / nt;
+        if (tr < tcc) continue;
+        double c[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
+        for (int p = 0; p < nb; p++) {
+          double xa[4], xb[4];
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            xa[a] = Xs[p][min(4 * tr + a, 243)];
+            xb[a] = Xs[p][min(4 * tcc + a, 243)];
+          }
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            const int r = 4 * tr + a, cc = 4 * tcc + b;
+            if (r < rem && cc < rem && r >= cc) Cb[r + (int64_t)cc * ld] -= c[a][b];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trsm : X = A * L_d^-T for 64 panel rows per workgroup (one wave per 16 rows), X^T tiles live in
+// MFMA accumulators: X^T[ct] = Tinv[ct] * (A^T[ct] - sum_{p<ct} L[ct,p] X^T[p]).  The accumulator of
+// tile p (register q = rows g+4q of X^T[p]) is used directly as the B operand of k-step q; the A
+// operand supplies the matching column g+4q of L[ct,p], so no lane shuffles or LDS are needed.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
+                                                  const double* __restrict__ dinv_ws) {
+  const TrsmTask tk = tasks[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int nbk = (w + 15) >> 4;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  double* Ap = L + tk.off + tk.row0 + rloc;          // panel row of this lane
+  const double* Ld = L + tk.off;                     // diagonal blok (factored)
+  const double* Ti = dinv_ws + tk.dinv_off;
+
+  d4 acc[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      acc[ct][q] = (rvalid && col < w) ? Ap[(int64_t)col * ld] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+    if (ct < nbk) {
+      const int li = ct * 16 + l15;                  // row of L supplied by this lane
+#pragma unroll
+      for (int p = 0; p < ct; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int lc = p * 16 + g + 4 * q;
+          const double a = (li < w) ? -Ld[li + (int64_t)lc * ld] : 0.0;
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[p][q], acc[ct], 0, 0, 0);
+        }
+      }
+      d4 t = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double a = Ti[ct * 256 + l15 + 16 * (g + 4 * q)];
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[ct][q], t, 0, 0, 0);
+      }
+      acc[ct] = t;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      if (rvalid && col < w) Ap[(int64_t)col * ld] = acc[ct][q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// coefficient fill: scatter (destination, value) pairs  (Csc2solv_cblk, csc_intern_solve.c:65-132)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_scatter(double* __restrict__ dst, const int64_t* __restrict__ idx,
+                          const double* __restrict__ val, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[idx[i]] = val[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------------
+void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_update, dim3((unsigned)ntasks), dim3(256), 0, s, L, U, tasks, pieces);
+}
+
+void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int* errflag) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_diag_llt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
+}
+
+void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw) {
+  if (n <= 0) return;
+  if (maxw <= 128)
+    hipLaunchKernelGGL(k_trsm_llt<8>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
+  else
+    hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
+}
+
+void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n) {
+  if (n <= 0) return;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(256), 0, s, dst, idx, val, n);
+}
+
+}  // namespace pastix_amd

@@ -1,0 +1,319 @@
+// plan.cpp -- host-side analysis of a SolverMatrix layout for the device engine.
+//
+// What the reference does at run time with counters, mutexes and linear searches
+// (sopalin3d.c:790-1025, sopalin_compute.c:865-1032) is resolved here once:
+//   * dependency levels: cblk t can be factorized once every source cblk k with a blok facing t
+//     has been factorized and its contributions applied (TASK_CTRBCNT semantics, solver.h:71-75);
+//   * for every (source cblk k, blok i, blok j >= i) the destination of the contribution inside
+//     the facing cblk (add_contrib_local, sopalin_compute.c:427-429) is precomputed and cut into
+//     TM x TN tiles of the target panel ("pieces");
+//   * pieces are grouped by (launch slot, target tile): within one launch a target tile is
+//     owned by exactly one workgroup, which replaces mutex_blok[b3] (sopalin_compute.c:563-580)
+//     and makes the accumulation order deterministic.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace pastix_amd {
+
+// DPARM_FACT_FLOPS: symbCost (blend_symbol_cost.c:52-88), flops_dpotrf (:382-430),
+// flops_dgetrf (:282-330), macros flops.h:74-75,91-100,103-108,116-117,211-214.
+double fact_flops(const pastix_amd_layout_t* L, int factotype, int floattype) {
+  auto fmuls_potrf = [](double n) { return n * (((1. / 6.) * n + 0.5) * n + (1. / 3.)); };
+  auto fadds_potrf = [](double n) { return n * (((1. / 6.) * n) * n - (1. / 6.)); };
+  auto fmuls_getrf = [](double n) { return 0.5 * n * (n * (n - (1. / 3.) * n - 1.) + n) + (2. / 3.) * n; };
+  auto fadds_getrf = [](double n) { return 0.5 * n * (n * (n - (1. / 3.) * n) - n) + (1. / 6.) * n; };
+  const bool lu = factotype == PASTIX_AMD_FACT_LU;
+  const bool cplx = floattype == PASTIX_AMD_COMPLEXSINGLE || floattype == PASTIX_AMD_COMPLEXDOUBLE;
+  double muls = 0, adds = 0;
+  for (int64_t k = 0; k < L->cblknbr; k++) {
+    const auto& c = L->cblktab[k];
+    double N = double(c.lcolnum - c.fcolnum + 1), M = double(c.stride) - N, rem = M, fac = lu ? 2. : 1.;
+    if (lu) { muls += fmuls_getrf(N); adds += fadds_getrf(N); }
+    else    { muls += fmuls_potrf(N); adds += fadds_potrf(N); }
+    muls += fac * 0.5 * M * N * (N + 1.);
+    adds += fac * 0.5 * M * N * (N + 1.);   // FADDS_TRSM is defined as FMULS_TRMM (flops.h:99-100)
+    for (int64_t b = c.bloknum + 1; b < L->cblktab[k + 1].bloknum; b++) {
+      double h = double(L->bloktab[b].lrownum - L->bloktab[b].frownum + 1);
+      muls += fac * rem * h * N;
+      adds += fac * rem * h * N;
+      rem -= h;
+    }
+  }
+  return cplx ? 6. * muls + 2. * adds : muls + adds;
+}
+
+namespace {
+struct RawPiece {
+  uint64_t key;   // (slot << 40) | tile id
+  Piece p;
+  uint8_t carena; // 0: L arena, 1: U arena
+};
+}  // namespace
+
+static int check_layout(const pastix_amd_layout_t* L) {
+  if (!L || L->cblknbr <= 0 || !L->cblktab || !L->bloktab) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (L->cblktab[L->cblknbr].bloknum != L->bloknbr) return PASTIX_AMD_ERR_LAYOUT;
+  int64_t prevl = -1;
+  for (int64_t k = 0; k < L->cblknbr; k++) {
+    const auto& c = L->cblktab[k];
+    int64_t fb = c.bloknum, lb = L->cblktab[k + 1].bloknum;
+    if (c.fcolnum != prevl + 1 || c.lcolnum < c.fcolnum || lb <= fb) return PASTIX_AMD_ERR_LAYOUT;
+    prevl = c.lcolnum;
+    // first blok is the diagonal blok (compute_diag.c:550)
+    if (L->bloktab[fb].frownum != c.fcolnum || L->bloktab[fb].lrownum != c.lcolnum) return PASTIX_AMD_ERR_LAYOUT;
+    int64_t off = 0, lastrow = -1;
+    for (int64_t b = fb; b < lb; b++) {
+      const auto& bl = L->bloktab[b];
+      if (bl.coefind != off || bl.lrownum < bl.frownum || bl.frownum <= lastrow) return PASTIX_AMD_ERR_LAYOUT;
+      if (bl.cblknum < k || bl.cblknum >= L->cblknbr) return PASTIX_AMD_ERR_LAYOUT;
+      if (b > fb && bl.cblknum <= k) return PASTIX_AMD_ERR_LAYOUT;
+      const auto& f = L->cblktab[bl.cblknum];
+      if (bl.frownum < f.fcolnum || bl.lrownum > f.lcolnum) return PASTIX_AMD_ERR_LAYOUT;
+      off += bl.lrownum - bl.frownum + 1;
+      lastrow = bl.lrownum;
+    }
+    if (off != c.stride) return PASTIX_AMD_ERR_LAYOUT;
+  }
+  return PASTIX_AMD_OK;
+}
+
+int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
+               const pastix_amd_options_t* opts, Plan& P) {
+  int rc = check_layout(L);
+  if (rc) return rc;
+  if (floattype != PASTIX_AMD_REALDOUBLE) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT && factotype != PASTIX_AMD_FACT_LU)
+    return PASTIX_AMD_ERR_UNSUPPORTED;
+  P.factotype = factotype;
+  P.floattype = floattype;
+  if (opts) P.opts = *opts;
+  if (P.opts.lookahead <= 0) P.opts.lookahead = (opts && opts->lookahead < 0) ? 0 : 4;
+  const int D = P.opts.lookahead;
+  const int64_t nc = L->cblknbr;
+  P.cblknbr = nc;
+  P.bloknbr = L->bloknbr;
+  P.cblk.assign(L->cblktab, L->cblktab + nc + 1);
+  P.blok.assign(L->bloktab, L->bloktab + L->bloknbr);
+  P.poff.resize(nc + 1);
+  P.poff[0] = 0;
+  for (int64_t k = 0; k < nc; k++) {
+    int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+    if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
+    if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
+    P.poff[k + 1] = P.poff[k] + P.cblk[k].stride * w;
+  }
+  P.coefnbr = P.poff[nc];
+  P.ncol = P.cblk[nc - 1].lcolnum + 1;
+  P.fact_flops = fact_flops(L, factotype, floattype);
+
+  // ---- dependency levels -----------------------------------------------------------------
+  P.level.assign(nc, 0);
+  for (int64_t k = 0; k < nc; k++)
+    for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++) {
+      int64_t t = P.blok[b].cblknum;
+      P.level[t] = std::max(P.level[t], P.level[k] + 1);
+    }
+  P.nlevels = 1 + *std::max_element(P.level.begin(), P.level.end());
+  const int NL = P.nlevels;
+
+  // cblks by level
+  P.lvl_cblk_ptr.assign(NL + 1, 0);
+  for (int64_t k = 0; k < nc; k++) P.lvl_cblk_ptr[P.level[k] + 1]++;
+  for (int l = 0; l < NL; l++) P.lvl_cblk_ptr[l + 1] += P.lvl_cblk_ptr[l];
+  P.lvl_cblk.resize(nc);
+  {
+    std::vector<int64_t> pos(P.lvl_cblk_ptr.begin(), P.lvl_cblk_ptr.end() - 1);
+    for (int64_t k = 0; k < nc; k++) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
+  }
+
+  // ---- panel / trsm tasks per level ------------------------------------------------------------
+  P.lvl_panel_ptr.assign(NL + 1, 0);
+  P.lvl_trsm_ptr.assign(NL + 1, 0);
+  P.panel_tasks.resize(nc);
+  P.dinv_ws = 0;
+  for (int l = 0; l < NL; l++) {
+    int64_t ws = 0;
+    P.lvl_panel_ptr[l] = P.lvl_cblk_ptr[l];
+    P.lvl_trsm_ptr[l] = (int64_t)P.trsm_tasks.size();
+    // widest / tallest first: better tail behaviour inside a launch
+    std::sort(P.lvl_cblk.begin() + P.lvl_cblk_ptr[l], P.lvl_cblk.begin() + P.lvl_cblk_ptr[l + 1],
+              [&](int32_t a, int32_t b) {
+                int64_t wa = P.cblk[a].lcolnum - P.cblk[a].fcolnum, wb = P.cblk[b].lcolnum - P.cblk[b].fcolnum;
+                if (wa != wb) return wa > wb;
+                return a < b;
+              });
+    for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
+      int32_t k = P.lvl_cblk[q];
+      int32_t w = (int32_t)(P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1), s = (int32_t)P.cblk[k].stride;
+      PanelTask pt{P.poff[k], s, w, ws};
+      P.panel_tasks[q] = pt;
+      for (int32_t r = w; r < s; r += 64) {
+        TrsmTask tt{P.poff[k], s, w, r, std::min(64, s - r), ws};
+        P.trsm_tasks.push_back(tt);
+      }
+      ws += (int64_t)((w + 15) / 16) * 256;
+    }
+    P.dinv_ws = std::max(P.dinv_ws, ws);
+  }
+  P.lvl_panel_ptr[NL] = nc;
+  P.lvl_trsm_ptr[NL] = (int64_t)P.trsm_tasks.size();
+
+  // ---- update pieces -----------------------------------------------------------------------------
+  // tile numbering: tile_base[t] + rt * nct(t) + ct, times 2 arenas for LU
+  std::vector<int64_t> tile_base(nc + 1, 0);
+  for (int64_t t = 0; t < nc; t++) {
+    int64_t w = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
+    tile_base[t + 1] = tile_base[t] + ((P.cblk[t].stride + TM - 1) / TM) * ((w + TN - 1) / TN);
+  }
+  const int64_t ntile = tile_base[nc];
+  const bool lu = factotype == PASTIX_AMD_FACT_LU;
+  const bool ldlt = factotype == PASTIX_AMD_FACT_LDLT;
+  std::vector<RawPiece> raw;
+  raw.reserve((size_t)P.bloknbr * 8);
+  double uflops = 0;
+
+  auto emit = [&](int64_t k, int64_t t, int slot, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
+                  int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
+    // split the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t into tiles
+    const int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
+    const int64_t nct = (w_t + TN - 1) / TN;
+    const int64_t sk = P.cblk[k].stride;
+    const int64_t wk = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+    for (int64_t rt = trow / TM; rt * TM < trow + nrows; rt++) {
+      int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
+      for (int64_t ct = tcol / TN; ct * TN < tcol + ncols; ct++) {
+        int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
+        RawPiece rp;
+        int64_t tile = tile_base[t] + rt * nct + ct + (carena ? ntile : 0);
+        rp.key = ((uint64_t)slot << 40) | (uint64_t)tile;
+        rp.carena = carena;
+        rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
+        rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
+        rp.p.lda = (int32_t)sk;
+        rp.p.k = (uint16_t)wk;
+        rp.p.dr = (uint16_t)(r0 - rt * TM);
+        rp.p.m = (uint16_t)(r1 - r0);
+        rp.p.dc = (uint16_t)(c0 - ct * TN);
+        rp.p.n = (uint16_t)(c1 - c0);
+        rp.p.flags = flags;
+        raw.push_back(rp);
+        uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
+      }
+    }
+  };
+
+  for (int64_t k = 0; k < nc; k++) {
+    const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
+    for (int64_t i = fb + 1; i < lb; i++) {
+      const int64_t t = P.blok[i].cblknum;
+      const int64_t tf = P.cblk[t].fcolnum;
+      const int64_t tfb = P.cblk[t].bloknum, tlb = P.cblk[t + 1].bloknum;
+      const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
+      const int64_t tcol = P.blok[i].frownum - tf;
+      const int slot = std::max(P.level[k] + 1, P.level[t] - D);
+      int64_t b3 = tfb;
+      // runs of source bloks that land contiguously in the target panel
+      int64_t run_src = -1, run_dst = -1, run_len = 0;
+      bool run_diag = false;
+      auto flush = [&]() {
+        if (run_len <= 0) return;
+        if (!lu) {
+          // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
+          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? 2 : 0, 0);
+        } else if (!run_diag) {
+          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // L U^T -> L arena
+          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 1, 1);   // U L^T -> U arena
+        } else {
+          // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
+          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // lower/diag part
+        }
+        run_len = 0;
+      };
+      for (int64_t j = i; j < lb; j++) {
+        const int64_t fj = P.blok[j].frownum, lj = P.blok[j].lrownum, hj = lj - fj + 1;
+        while (b3 < tlb && !(fj >= P.blok[b3].frownum && lj <= P.blok[b3].lrownum)) b3++;
+        if (b3 >= tlb) return PASTIX_AMD_ERR_LAYOUT;   // containment (sopalin_compute.c:558-559)
+        const int64_t dst = P.blok[b3].coefind + (fj - P.blok[b3].frownum);
+        const bool diag = (b3 == tfb);
+        if (run_len > 0 && dst == run_dst + run_len && diag == run_diag && !(lu && diag)) {
+          run_len += hj;
+        } else {
+          flush();
+          run_src = P.blok[j].coefind; run_dst = dst; run_len = hj; run_diag = diag;
+        }
+        if (lu && diag) {
+          // flush per blok: the transposed U contribution needs (i,j) roles individually
+          flush();
+          if (j != i) {
+            // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
+            // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
+            emit(k, t, slot, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, 2, 0);
+          }
+        }
+      }
+      flush();
+    }
+  }
+  P.update_flops = uflops;
+
+  // ---- group into tasks --------------------------------------------------------------------------
+  std::sort(raw.begin(), raw.end(), [](const RawPiece& a, const RawPiece& b) {
+    if (a.key != b.key) return a.key < b.key;
+    if (a.p.a_off != b.p.a_off) return a.p.a_off < b.p.a_off;   // deterministic accumulation order
+    return a.p.b_off < b.p.b_off;
+  });
+  P.pieces.resize(raw.size());
+  P.tasks.clear();
+  P.slot_task_ptr.assign(NL + 1, 0);
+  std::vector<double> task_work;
+  // tile -> (t, rt, ct): binary search in tile_base
+  for (size_t q = 0; q < raw.size();) {
+    size_t e = q;
+    double work = 0;
+    while (e < raw.size() && raw[e].key == raw[q].key) {
+      P.pieces[e] = raw[e].p;
+      work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k + 4096.0;
+      e++;
+    }
+    int slot = (int)(raw[q].key >> 40);
+    int64_t tile = (int64_t)(raw[q].key & ((1ULL << 40) - 1));
+    uint8_t carena = raw[q].carena;
+    if (carena) tile -= ntile;
+    int64_t t = std::upper_bound(tile_base.begin(), tile_base.end(), tile) - tile_base.begin() - 1;
+    int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1, nct = (w_t + TN - 1) / TN;
+    int64_t rt = (tile - tile_base[t]) / nct, ct = (tile - tile_base[t]) % nct;
+    Task tk{};
+    tk.c_off = P.poff[t] + rt * TM + ct * TN * P.cblk[t].stride;
+    tk.ldc = (int32_t)P.cblk[t].stride;
+    tk.tm = (uint16_t)std::min<int64_t>(TM, P.cblk[t].stride - rt * TM);
+    tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
+    tk.p0 = (int32_t)q;
+    tk.pn = (int32_t)(e - q);
+    tk.flags = carena;
+    P.tasks.push_back(tk);
+    task_work.push_back(work);
+    P.slot_task_ptr[slot + 1]++;
+    q = e;
+  }
+  if (raw.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+  for (int s = 0; s < NL; s++) P.slot_task_ptr[s + 1] += P.slot_task_ptr[s];
+  // heaviest tasks first inside each slot
+  {
+    std::vector<int64_t> idx(P.tasks.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    for (int s = 0; s < NL; s++)
+      std::sort(idx.begin() + P.slot_task_ptr[s], idx.begin() + P.slot_task_ptr[s + 1],
+                [&](int64_t a, int64_t b) { return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b; });
+    std::vector<Task> sorted(P.tasks.size());
+    for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
+    P.tasks.swap(sorted);
+  }
+  return PASTIX_AMD_OK;
+}
+
+}  // namespace pastix_amd

@@ -1,0 +1,92 @@
+// plan.h -- internal data model of the MI355X sopalin engine (host plan + device tables).
+//
+// The plan is derived once from the SolverMatrix layout (cblk/blok tables, solver.h:94-168) and
+// replaces the reference's mutable scheduling state (TASK_CTRBCNT counters, per-blok mutexes,
+// sopalin3d.c:790-1025): dependencies become launch slots, the linear facing-blok search
+// (sopalin_compute.c:938-945) becomes precomputed piece descriptors.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/pastix_amd.h"
+
+namespace pastix_amd {
+
+constexpr int TM = 128;   // update tile rows   (target panel row space)
+constexpr int TN = 128;   // update tile cols   (target cblk column space)
+constexpr int MAXW = 256; // widest cblk the panel kernels accept
+
+// One GEMM contribution into one target tile:  C[dr:dr+m, dc:dc+n] -= A(m x k) * B(n x k)^T
+// A = rows of the source panel from some blok j (or a run of bloks that land contiguously),
+// B = rows of the source blok i facing the target cblk (compute_contrib_compact,
+// sopalin_compute.c:270-374, fused with add_contrib_local :391-598).
+struct Piece {
+  int64_t a_off;      // arena offset of A(0,0)  (column-major, ld = lda)
+  int64_t b_off;      // arena offset of B(0,0)  (ld = lda: same source panel)
+  int32_t lda;
+  uint16_t k;         // source cblk width
+  uint16_t dr, m;     // destination rows inside the tile
+  uint16_t dc, n;     // destination cols inside the tile
+  uint16_t flags;     // bit0: A in U arena, bit1: B in U arena
+};
+static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
+
+struct Task {
+  int64_t c_off;      // arena offset of the tile origin
+  int32_t ldc;
+  uint16_t tm, tn;    // valid extent of the tile (<= TM, TN)
+  int32_t p0, pn;     // piece range
+  uint32_t flags;     // bit0: C in U arena
+  uint32_t pad;
+};
+static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
+
+struct PanelTask {    // one cblk for the diagonal-block kernel
+  int64_t off;        // arena offset of the panel
+  int32_t stride, width;
+  int64_t dinv_off;   // offset (doubles) in the Tinv workspace: ceil(w/16) blocks of 16x16
+};
+
+struct TrsmTask {     // 64 panel rows of one cblk for the panel-solve kernel
+  int64_t off;
+  int32_t stride, width;
+  int32_t row0, nrows;   // panel rows [row0, row0+nrows), row0 >= width
+  int64_t dinv_off;
+};
+
+struct Plan {
+  int factotype = 0, floattype = 1;
+  pastix_amd_options_t opts{};
+  int64_t cblknbr = 0, bloknbr = 0, coefnbr = 0, ncol = 0;
+  std::vector<pastix_amd_cblk_t> cblk;   // [cblknbr+1]
+  std::vector<pastix_amd_blok_t> blok;
+  std::vector<int64_t> poff;             // panel offsets [cblknbr+1]
+  std::vector<int32_t> level;            // dependency level of each cblk
+  int32_t nlevels = 0;
+
+  // per level
+  std::vector<int64_t> lvl_panel_ptr;    // [nlevels+1] into panel_tasks
+  std::vector<PanelTask> panel_tasks;
+  std::vector<int64_t> lvl_trsm_ptr;     // [nlevels+1] into trsm_tasks
+  std::vector<TrsmTask> trsm_tasks;
+  int64_t dinv_ws = 0;                   // doubles needed for the Tinv workspace
+
+  // per slot (slot s runs right before level s is factorized)
+  std::vector<int64_t> slot_task_ptr;    // [nlevels+1]
+  std::vector<Task> tasks;
+  std::vector<Piece> pieces;
+  double update_flops = 0;
+  double fact_flops = 0;
+
+  // solve schedule: cblks grouped by level (same levels as the factorization)
+  std::vector<int64_t> lvl_cblk_ptr;     // [nlevels+1]
+  std::vector<int32_t> lvl_cblk;
+};
+
+// Build the host plan. Returns PASTIX_AMD_OK or an error code.
+int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
+               const pastix_amd_options_t* opts, Plan& plan);
+
+double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
+
+}  // namespace pastix_amd

@@ -1,0 +1,115 @@
+"""Host-side handle on the device engine: plan once, fill / upload, factorize, download.
+
+Mirrors the life cycle around the reference's sopalin step (pastix_task_sopalin,
+src/sopalin/src/pastix.c:3439-3956): coefficient fill -> {po,sy,ge}_sopalin_thread -> factors
+left in the panels for the solve.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import LayoutArrays, Options, Stats, check
+
+FACT_LLT, FACT_LDLT, FACT_LU, FACT_LDLH = 0, 1, 2, 3
+REALDOUBLE = 1
+
+
+def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
+    la = LayoutArrays(cblk4, blok4)
+    return _lib.lib().pastix_amd_fact_flops(ctypes.byref(la.c), factotype, floattype)
+
+
+class Plan:
+    def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0):
+        self.layout = LayoutArrays(cblk4, blok4)
+        self.factotype = factotype
+        self._h = ctypes.c_void_p()
+        opts = Options()
+        opts.device = device
+        opts.lookahead = lookahead
+        check(_lib.lib().pastix_amd_plan_create(ctypes.byref(self.layout.c), factotype, floattype,
+                                                ctypes.byref(opts), ctypes.byref(self._h)),
+              "pastix_amd_plan_create")
+
+    def close(self):
+        if self._h:
+            _lib.lib().pastix_amd_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def coefnbr(self):
+        return self.layout.coefnbr()
+
+    def stats(self):
+        s = Stats()
+        check(_lib.lib().pastix_amd_plan_stats(self._h, ctypes.byref(s)), "pastix_amd_plan_stats")
+        return s.as_dict()
+
+    def upload(self, L, U=None):
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        assert L.size == self.coefnbr
+        U = np.ascontiguousarray(U, dtype=np.float64) if U is not None else None
+        check(_lib.lib().pastix_amd_upload_packed(self._h, _lib.ptr(L), _lib.ptr(U)), "pastix_amd_upload_packed")
+
+    def download(self):
+        L = np.empty(self.coefnbr, dtype=np.float64)
+        U = np.empty(self.coefnbr, dtype=np.float64) if self.factotype == FACT_LU else None
+        check(_lib.lib().pastix_amd_download_packed(self._h, _lib.ptr(L), _lib.ptr(U)), "pastix_amd_download_packed")
+        return L, U
+
+    def fill_csc(self, sym, n, colptr, rows, vals, perm):
+        colptr, rows, perm = _lib.as_i64(colptr), _lib.as_i64(rows), _lib.as_i64(perm)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        check(_lib.lib().pastix_amd_fill_csc(self._h, int(sym), ctypes.c_int64(n), _lib.ptr(colptr),
+                                             _lib.ptr(rows), _lib.ptr(vals), _lib.ptr(perm)),
+              "pastix_amd_fill_csc")
+
+    def factorize(self, critere, allow_numeric_error=False):
+        s = Stats()
+        rc = _lib.lib().pastix_amd_factorize(self._h, ctypes.c_double(critere), ctypes.byref(s))
+        if rc != 0 and not (allow_numeric_error and rc == -4):
+            check(rc, "pastix_amd_factorize")
+        d = s.as_dict()
+        d["rc"] = rc
+        return d
+
+    def solve(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nrhs = 1 if x.ndim == 1 else x.shape[1]
+        xf = np.asfortranarray(x.reshape(len(x), nrhs))
+        check(_lib.lib().pastix_amd_solve(self._h, _lib.ptr(xf), ctypes.c_int64(nrhs)), "pastix_amd_solve")
+        return xf.reshape(x.shape) if x.ndim == 1 else np.ascontiguousarray(xf)
+
+
+def sopalin_tabs(factotype, cblk4, blok4, coeftab, ucoeftab=None, critere=0.0, lookahead=0):
+    """One-shot drop-in call {po,sy,ge}_sopalin with the reference's per-cblk host buffers
+    (lists of 1-D float64 arrays, factorized in place)."""
+    la = LayoutArrays(cblk4, blok4)
+    n = la.cblknbr
+    arr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in coeftab])
+    opts = Options()
+    opts.lookahead = lookahead
+    s = Stats()
+    L = _lib.lib()
+    if factotype == FACT_LLT:
+        rc = L.pastix_amd_d_po_sopalin(ctypes.byref(la.c), arr, ctypes.c_double(critere), ctypes.byref(opts), ctypes.byref(s))
+    elif factotype == FACT_LDLT:
+        rc = L.pastix_amd_d_sy_sopalin(ctypes.byref(la.c), arr, ctypes.c_double(critere), ctypes.byref(opts), ctypes.byref(s))
+    else:
+        uarr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in ucoeftab])
+        rc = L.pastix_amd_d_ge_sopalin(ctypes.byref(la.c), arr, uarr, ctypes.c_double(critere), ctypes.byref(opts), ctypes.byref(s))
+    check(rc, "pastix_amd_d_*_sopalin")
+    return s.as_dict()

@@ -1,0 +1,66 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden outputs of the real reference
+and against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import golden_names
+from pastix_amd import Plan, sopalin_tabs
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12   # per entry relative to max|L_ref|
+
+
+@pytest.mark.parametrize("lookahead", [-1, 2, 1000])
+@pytest.mark.parametrize("name", golden_names("llt"))
+def test_llt_matches_reference_golden(name, lookahead, golden):
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], lookahead=lookahead) as p:
+        p.upload(g["L0"])
+        st = p.factorize(g["critere"])
+        L1, _ = p.download()
+    scale = np.abs(g["L1"]).max()
+    assert np.abs(L1 - g["L1"]).max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", golden_names("llt"))
+def test_device_fill_matches_reference(name, golden):
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        L0, _ = p.download()
+    assert np.array_equal(L0, g["L0"])
+
+
+def test_one_shot_tabs_dropin(golden):
+    g = golden("rlap3d_10_llt")
+    c4 = g["cblk4"]
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    tabs = [g["L0"][off[k]:off[k + 1]].copy() for k in range(len(w))]
+    st = sopalin_tabs(0, c4, g["blok4"], tabs, critere=g["critere"])
+    L1 = np.concatenate(tabs)
+    assert np.abs(L1 - g["L1"]).max() <= TOL * np.abs(g["L1"]).max()
+    assert st["fact_time"] > 0
+
+
+def test_static_pivot_clamp_matches_oracle(golden):
+    """Force tiny pivots: zero a few diagonal entries; the clamp count must match the oracle."""
+    g = golden("lap3d_8_llt")
+    L0 = g["L0"].copy()
+    c4 = g["cblk4"]
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    for k in (0, 5, 17):
+        L0[off[k]] = 1e-30
+    crit = 1e-6
+    Lo, _, nbo = oracle_lib.sopalin(0, c4, g["blok4"], L0, None, crit)
+    with Plan(c4, g["blok4"], 0) as p:
+        p.upload(L0)
+        st = p.factorize(crit, allow_numeric_error=True)
+        L1, _ = p.download()
+    assert nbo >= 3 and st["nbpivot"] == nbo
+    fin = np.isfinite(Lo)
+    assert np.allclose(L1[fin], Lo[fin], rtol=1e-9, atol=1e-9 * np.abs(Lo[fin]).max())
