@@ -64,9 +64,10 @@ typedef struct pastix_amd_layout_s {
 /* Tunables of the device engine (all have defaults when the struct is zeroed). */
 typedef struct pastix_amd_options_s {
   int device;            /* HIP device ordinal */
-  int lookahead;         /* update window D: a contribution k->t is applied at launch slot
-                            max(level(k)+1, level(t)-D); 0 = left-looking, large = right-looking.
-                            default 4 */
+  int lookahead;         /* chunk size of the update schedule: contributions into one 128x128 target
+                            tile are applied in groups whose accumulated inner dimension reaches this
+                            value; 1 = every source separately (right-looking), huge = once per tile
+                            (left-looking); <=0 = default 512 */
   int verbose;
   int reserved[13];
 } pastix_amd_options_t;

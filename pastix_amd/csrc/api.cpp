@@ -319,10 +319,20 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   p->stats.fact_time = ms * 1e-3;
   double upd = 0;
-  for (int i = 0; i < nupd; i++) {
-    float m2 = 0;
-    HIPCHK(hipEventElapsedTime(&m2, p->ev[2 * i], p->ev[2 * i + 1]));
-    upd += m2 * 1e-3;
+  {
+    int i = 0;
+    for (int l = 0; l < H.nlevels; l++) {
+      const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
+      if (t1 <= t0) continue;
+      float m2 = 0;
+      HIPCHK(hipEventElapsedTime(&m2, p->ev[2 * i], p->ev[2 * i + 1]));
+      upd += m2 * 1e-3;
+      if (H.opts.verbose >= 2)
+        fprintf(stderr, "slot %4d: cblks %6lld tasks %7lld pieces %8lld flops %.3e  %9.1f us  %8.1f GF/s\n", l,
+                (long long)(H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l]), (long long)(t1 - t0),
+                (long long)H.slot_pieces[l], H.slot_flops[l], m2 * 1e3, H.slot_flops[l] / (m2 * 1e-3) * 1e-9);
+      i++;
+    }
   }
   p->stats.update_time = upd;
   p->stats.nupdate_launches = nupd;

@@ -20,6 +20,8 @@
 // segments for the read-modify-write of the tile).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "plan.h"
 
 namespace pastix_amd {
@@ -33,110 +35,174 @@ constexpr int KC = 16;        // k-chunk staged per barrier
 constexpr int SLD = 144;      // LDS line length in doubles: 128 rows + 16 pad -> lanes 16-31 of a
                               // ds_read_b64 land on banks 32-63 (conflict-free, MI355X_MICROARCH LDS)
 
+// NW waves per workgroup share one 128x128 target tile: NW=4 -> 2x2 waves of 64x64 (16 MFMA tiles per
+// wave), NW=8 -> 4x2 waves of 32x64 (8 MFMA tiles per wave, 4 waves per SIMD at 2 workgroups per CU).
+template <int NW>
 struct Stage {
-  double a[KC / 2];
-  double b[KC / 2];
+  static constexpr int NLD = KC * 128 / (64 * NW);   // loads per thread per operand per chunk
+  double a[NLD];
+  double b[NLD];
 };
 
-__device__ __forceinline__ void stage_load(Stage& st, const double* __restrict__ Ab, const double* __restrict__ Bb,
-                                           const Piece& pc, int kc, int tid) {
+template <int NW>
+__device__ __forceinline__ void stage_load(Stage<NW>& st, const double* __restrict__ Ab,
+                                           const double* __restrict__ Bb, const Piece& pc, int kc, int tid,
+                                           bool full) {
+  // Raw loads only; masking happens in stage_store, after the MFMA section, so that nothing here
+  // depends on the loaded values (no s_waitcnt in front of the MFMAs).  Partial pieces read from
+  // clamped (always valid) addresses.
+  constexpr int KS = 64 * NW / 128;                  // k lines covered by one pass of the workgroup
   const int row = tid & 127, k0 = tid >> 7;
-  const int ra = row - (int)pc.dr, rb = row - (int)pc.dc;
-  const bool va = ra >= 0 && ra < (int)pc.m, vb = rb >= 0 && rb < (int)pc.n;
-  const double* pa = Ab + ra + (int64_t)(kc + k0) * pc.lda;
-  const double* pb = Bb + rb + (int64_t)(kc + k0) * pc.lda;
-  const int64_t step = 2 * (int64_t)pc.lda;
+  if (full) {
+    const double* pa = Ab + row + (int64_t)(kc + k0) * pc.lda;
+    const double* pb = Bb + row + (int64_t)(kc + k0) * pc.lda;
+    const int64_t step = (int64_t)KS * pc.lda;
 #pragma unroll
-  for (int q = 0; q < KC / 2; q++) {
-    const bool kv = kc + k0 + 2 * q < (int)pc.k;
-    st.a[q] = (va && kv) ? pa[q * step] : 0.0;
-    st.b[q] = (vb && kv) ? pb[q * step] : 0.0;
+    for (int q = 0; q < Stage<NW>::NLD; q++) {
+      st.a[q] = pa[q * step];
+      st.b[q] = pb[q * step];
+    }
+  } else {
+    const int rac = min(max(row - (int)pc.dr, 0), (int)pc.m - 1);
+    const int rbc = min(max(row - (int)pc.dc, 0), (int)pc.n - 1);
+    const int klast = (int)pc.k - 1;
+#pragma unroll
+    for (int q = 0; q < Stage<NW>::NLD; q++) {
+      const int kkc = min(kc + k0 + KS * q, klast);
+      st.a[q] = Ab[rac + (int64_t)kkc * pc.lda];
+      st.b[q] = Bb[rbc + (int64_t)kkc * pc.lda];
+    }
   }
 }
 
-__device__ __forceinline__ void stage_store(const Stage& st, double* sA, double* sB, int tid) {
+template <int NW>
+__device__ __forceinline__ void stage_store(const Stage<NW>& st, double* sA, double* sB, const Piece& pc, int kc,
+                                            int tid, bool full) {
+  constexpr int KS = 64 * NW / 128;
   const int row = tid & 127, k0 = tid >> 7;
+  if (full) {
 #pragma unroll
-  for (int q = 0; q < KC / 2; q++) {
-    sA[(k0 + 2 * q) * SLD + row] = st.a[q];
-    sB[(k0 + 2 * q) * SLD + row] = st.b[q];
+    for (int q = 0; q < Stage<NW>::NLD; q++) {
+      sA[(k0 + KS * q) * SLD + row] = st.a[q];
+      sB[(k0 + KS * q) * SLD + row] = st.b[q];
+    }
+  } else {
+    const int ra = row - (int)pc.dr, rb = row - (int)pc.dc;
+    const bool va = ra >= 0 && ra < (int)pc.m, vb = rb >= 0 && rb < (int)pc.n;
+    const int klast = (int)pc.k - 1;
+#pragma unroll
+    for (int q = 0; q < Stage<NW>::NLD; q++) {
+      const bool kv = kc + k0 + KS * q <= klast;
+      sA[(k0 + KS * q) * SLD + row] = (va && kv) ? st.a[q] : 0.0;
+      sB[(k0 + KS * q) * SLD + row] = (vb && kv) ? st.b[q] : 0.0;
+    }
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_update(double* __restrict__ L, double* __restrict__ U,
-                                                  const Task* __restrict__ tasks,
-                                                  const Piece* __restrict__ pieces) {
-  __shared__ double sh[2][2][KC * SLD];   // [buffer][A|B]  73,728 bytes
+__device__ __forceinline__ bool piece_full(const Piece& pc) {
+  return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && (pc.k & (KC - 1)) == 0;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__ L, double* __restrict__ U,
+                                                           const Task* __restrict__ tasks,
+                                                           const Piece* __restrict__ pieces) {
+  constexpr int WRN = NW / 2;                   // wave grid: WRN rows x 2 cols
+  constexpr int MI = 8 / WRN;                   // 16-row sub-tiles per wave (4 or 2)
+  constexpr int NI = 4;                         // 16-col sub-tiles per wave
+  constexpr unsigned MALL = (1u << MI) - 1u;
+  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*64.., cols wc*64.. of the tile
+  const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*16*MI.., cols wc*64..
   const int l15 = lane & 15, g = lane >> 4;
+  const int row0 = wr * 16 * MI, col0 = wc * 64;
 
-  d4 acc[4][4];                                 // [mi][ni]
+  d4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 4; mi++)
+  for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
+    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
 
   int pi = tk.p0;
   const int pend = tk.p0 + tk.pn;
   Piece cur = pieces[pi];
+  Piece nextp = pieces[min(pi + 1, pend - 1)];  // descriptor prefetched one piece ahead
   int kc = 0, buf = 0;
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
-  Stage st;
+  Stage<NW> st;
   {
     const double* Ab = ((cur.flags & 1) ? U : L) + cur.a_off;
     const double* Bb = ((cur.flags & 2) ? U : L) + cur.b_off;
-    stage_load(st, Ab, Bb, cur, 0, tid);
-    stage_store(st, sh[0][0], sh[0][1], tid);
+    const bool full = piece_full(cur);
+    stage_load<NW>(st, Ab, Bb, cur, 0, tid, full);
+    stage_store<NW>(st, sh[0][0], sh[0][1], cur, 0, tid, full);
   }
   __syncthreads();
   while (true) {
-    Piece nxt = cur;
     int npi = pi, nkc = kc + KC;
-    if (nkc >= (int)cur.k) {
-      npi = pi + 1;
-      nkc = 0;
-      if (npi < pend) nxt = pieces[npi];
-    }
+    const bool adv = nkc >= (int)cur.k;
+    if (adv) { npi = pi + 1; nkc = 0; }
+    const Piece nxt = adv ? nextp : cur;
     const bool has_next = npi < pend;
+    const bool nfull = piece_full(nxt);
     if (has_next) {
       const double* Ab = ((nxt.flags & 1) ? U : L) + nxt.a_off;
       const double* Bb = ((nxt.flags & 2) ? U : L) + nxt.b_off;
-      stage_load(st, Ab, Bb, nxt, nkc, tid);
+      stage_load<NW>(st, Ab, Bb, nxt, nkc, tid, nfull);
     }
+    if (adv) nextp = pieces[min(npi + 1, pend - 1)];
     // ---- MFMA on the staged chunk ----
     {
       unsigned am = 0, an = 0;                  // wave-uniform sub-tile activity
 #pragma unroll
-      for (int s = 0; s < 4; s++) {
-        const int r0 = wr * 64 + s * 16, c0 = wc * 64 + s * 16;
+      for (int s = 0; s < MI; s++) {
+        const int r0 = row0 + s * 16;
         if (r0 < (int)cur.dr + (int)cur.m && r0 + 16 > (int)cur.dr) am |= 1u << s;
+      }
+#pragma unroll
+      for (int s = 0; s < NI; s++) {
+        const int c0 = col0 + s * 16;
         if (c0 < (int)cur.dc + (int)cur.n && c0 + 16 > (int)cur.dc) an |= 1u << s;
       }
       if (am && an) {
         touched |= am | (an << 4);
-        const double* sA = sh[buf][0] + wr * 64 + l15;
-        const double* sB = sh[buf][1] + wc * 64 + l15;
+        const double* sA = sh[buf][0] + row0 + l15;
+        const double* sB = sh[buf][1] + col0 + l15;
         const int ksteps = (min(KC, (int)cur.k - kc) + 3) >> 2;
-        for (int ks = 0; ks < ksteps; ks++) {
-          const int kk = (ks * 4 + g) * SLD;
-          double bm[4], an_[4];
+        if (am == MALL && an == 0xFu) {
+          for (int ks = 0; ks < ksteps; ks++) {
+            const int kk = (ks * 4 + g) * SLD;
+            double bm[MI], an_[NI];
 #pragma unroll
-          for (int s = 0; s < 4; s++) {
-            bm[s] = sA[kk + s * 16];            // rows  -> MFMA B operand
-            an_[s] = sB[kk + s * 16];           // cols  -> MFMA A operand
-          }
+            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * 16];    // rows -> MFMA B operand
 #pragma unroll
-          for (int mi = 0; mi < 4; mi++)
+            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * 16];   // cols -> MFMA A operand
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-              if ((am >> mi) & (an >> ni) & 1u)
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+              for (int ni = 0; ni < NI; ni++)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
+          }
+        } else {
+          for (int ks = 0; ks < ksteps; ks++) {
+            const int kk = (ks * 4 + g) * SLD;
+            double bm[MI], an_[NI];
+#pragma unroll
+            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * 16];
+#pragma unroll
+            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * 16];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+              for (int ni = 0; ni < NI; ni++)
+                if ((am >> mi) & (an >> ni) & 1u)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
+          }
         }
       }
     }
-    if (has_next) stage_store(st, sh[buf ^ 1][0], sh[buf ^ 1][1], tid);
+    if (has_next) stage_store<NW>(st, sh[buf ^ 1][0], sh[buf ^ 1][1], nxt, nkc, tid, nfull);
     __syncthreads();
     if (!has_next) break;
     cur = nxt;
@@ -145,22 +211,30 @@ __global__ __launch_bounds__(256, 2) void k_update(double* __restrict__ L, doubl
     buf ^= 1;
   }
 
-  // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column) ----
+  // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column).  Loads of one
+  // 16-row band are issued together from clamped addresses (one latency per band, not per element).
   double* C = ((tk.flags & 1) ? U : L) + tk.c_off;
+  const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
 #pragma unroll
-  for (int mi = 0; mi < 4; mi++) {
+  for (int mi = 0; mi < MI; mi++) {
     if (!((touched >> mi) & 1u)) continue;
-    const int r = wr * 64 + mi * 16 + l15;
+    const int r = row0 + mi * 16 + l15;
+    const int rc = min(r, tm1);
+    double cv[NI][4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ni++) {
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = min(col0 + ni * 16 + g + 4 * q, tn1);
+        cv[ni][q] = C[rc + (int64_t)c * tk.ldc];
+      }
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
       if (!((touched >> (4 + ni)) & 1u)) continue;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = wc * 64 + ni * 16 + g + 4 * q;
-        if (r < (int)tk.tm && c < (int)tk.tn) {
-          double* p = C + r + (int64_t)c * tk.ldc;
-          *p -= acc[mi][ni][q];
-        }
+        const int c = col0 + ni * 16 + g + 4 * q;
+        if (r <= tm1 && c <= tn1) C[r + (int64_t)c * tk.ldc] = cv[ni][q] - acc[mi][ni][q];
       }
     }
   }
@@ -307,6 +381,7 @@ __global__ __launch_bounds__(256) void k_trsm_llt(double* __restrict__ L, const 
   if (wave * 16 >= tk.nrows) return;
   const bool rvalid = rloc < tk.nrows;
   double* Ap = L + tk.off + tk.row0 + rloc;          // panel row of this lane
+  const double* Apc = L + tk.off + tk.row0 + min(rloc, tk.nrows - 1);   // clamped: always readable
   const double* Ld = L + tk.off;                     // diagonal blok (factored)
   const double* Ti = dinv_ws + tk.dinv_off;
 
@@ -316,19 +391,22 @@ __global__ __launch_bounds__(256) void k_trsm_llt(double* __restrict__ L, const 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int col = ct * 16 + g + 4 * q;
-      acc[ct][q] = (rvalid && col < w) ? Ap[(int64_t)col * ld] : 0.0;
+      const double v = Apc[(int64_t)min(col, w - 1) * ld];
+      acc[ct][q] = (rvalid && col < w) ? v : 0.0;
     }
   }
 #pragma unroll
   for (int ct = 0; ct < NT; ct++) {
     if (ct < nbk) {
       const int li = ct * 16 + l15;                  // row of L supplied by this lane
+      const int lic = min(li, w - 1);
 #pragma unroll
       for (int p = 0; p < ct; p++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int lc = p * 16 + g + 4 * q;
-          const double a = (li < w) ? -Ld[li + (int64_t)lc * ld] : 0.0;
+          const double lv = Ld[lic + (int64_t)lc * ld];
+          const double a = (li < w) ? -lv : 0.0;
           acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[p][q], acc[ct], 0, 0, 0);
         }
       }
@@ -366,7 +444,11 @@ __global__ void k_scatter(double* __restrict__ dst, const int64_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(k_update, dim3((unsigned)ntasks), dim3(256), 0, s, L, U, tasks, pieces);
+  static const int nw = getenv("PASTIX_AMD_UPDATE_WAVES") ? atoi(getenv("PASTIX_AMD_UPDATE_WAVES")) : 8;
+  if (nw == 4)
+    hipLaunchKernelGGL(k_update<4>, dim3((unsigned)ntasks), dim3(256), 0, s, L, U, tasks, pieces);
+  else
+    hipLaunchKernelGGL(k_update<8>, dim3((unsigned)ntasks), dim3(512), 0, s, L, U, tasks, pieces);
 }
 
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,

@@ -49,9 +49,10 @@ double fact_flops(const pastix_amd_layout_t* L, int factotype, int floattype) {
 
 namespace {
 struct RawPiece {
-  uint64_t key;   // (slot << 40) | tile id
-  Piece p;
+  int64_t tile;   // target tile id (+ntile for the U arena)
+  int32_t lvl;    // level of the source cblk
   uint8_t carena; // 0: L arena, 1: U arena
+  Piece p;
 };
 }  // namespace
 
@@ -92,8 +93,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.factotype = factotype;
   P.floattype = floattype;
   if (opts) P.opts = *opts;
-  if (P.opts.lookahead <= 0) P.opts.lookahead = (opts && opts->lookahead < 0) ? 0 : 4;
-  const int D = P.opts.lookahead;
+  // chunk size: contributions into one tile are applied in groups whose accumulated inner
+  // dimension reaches `chunk_k` (<=0: default 512; 1: every source on its own = right-looking;
+  // huge: one group per tile = left-looking)
+  if (P.opts.lookahead <= 0) P.opts.lookahead = 512;
+  const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
   const int64_t nc = L->cblknbr;
   P.cblknbr = nc;
   P.bloknbr = L->bloknbr;
@@ -177,7 +181,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   raw.reserve((size_t)P.bloknbr * 8);
   double uflops = 0;
 
-  auto emit = [&](int64_t k, int64_t t, int slot, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
+  auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
                   int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
     // split the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t into tiles
     const int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
@@ -190,7 +194,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
         RawPiece rp;
         int64_t tile = tile_base[t] + rt * nct + ct + (carena ? ntile : 0);
-        rp.key = ((uint64_t)slot << 40) | (uint64_t)tile;
+        rp.tile = tile;
+        rp.lvl = P.level[k];
         rp.carena = carena;
         rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
         rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
@@ -215,7 +220,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       const int64_t tfb = P.cblk[t].bloknum, tlb = P.cblk[t + 1].bloknum;
       const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
       const int64_t tcol = P.blok[i].frownum - tf;
-      const int slot = std::max(P.level[k] + 1, P.level[t] - D);
       int64_t b3 = tfb;
       // runs of source bloks that land contiguously in the target panel
       int64_t run_src = -1, run_dst = -1, run_len = 0;
@@ -224,13 +228,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         if (run_len <= 0) return;
         if (!lu) {
           // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
-          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? 2 : 0, 0);
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? 2 : 0, 0);
         } else if (!run_diag) {
-          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // L U^T -> L arena
-          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 1, 1);   // U L^T -> U arena
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // L U^T -> L arena
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 1, 1);   // U L^T -> U arena
         } else {
           // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
-          emit(k, t, slot, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // lower/diag part
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // lower/diag part
         }
         run_len = 0;
       };
@@ -252,7 +256,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           if (j != i) {
             // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
             // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
-            emit(k, t, slot, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, 2, 0);
+            emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, 2, 0);
           }
         }
       }
@@ -262,8 +266,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.update_flops = uflops;
 
   // ---- group into tasks --------------------------------------------------------------------------
+  // Per target tile the contributions are ordered by source level and cut into chunks of about
+  // chunk_work multiply-adds; a chunk is launched in the slot right after its last source level, so
+  // the tile is read-modified-written once per chunk instead of once per source (the reference does
+  // it once per source blok pair under mutex_blok, sopalin_compute.c:563-580).
   std::sort(raw.begin(), raw.end(), [](const RawPiece& a, const RawPiece& b) {
-    if (a.key != b.key) return a.key < b.key;
+    if (a.tile != b.tile) return a.tile < b.tile;
+    if (a.lvl != b.lvl) return a.lvl < b.lvl;
     if (a.p.a_off != b.p.a_off) return a.p.a_off < b.p.a_off;   // deterministic accumulation order
     return a.p.b_off < b.p.b_off;
   });
@@ -271,17 +280,21 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.tasks.clear();
   P.slot_task_ptr.assign(NL + 1, 0);
   std::vector<double> task_work;
-  // tile -> (t, rt, ct): binary search in tile_base
+  std::vector<int32_t> task_slot;
+  P.slot_flops.assign(NL, 0.0);
+  P.slot_pieces.assign(NL, 0);
   for (size_t q = 0; q < raw.size();) {
     size_t e = q;
     double work = 0;
-    while (e < raw.size() && raw[e].key == raw[q].key) {
+    while (e < raw.size() && raw[e].tile == raw[q].tile) {
       P.pieces[e] = raw[e].p;
-      work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k + 4096.0;
+      work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
       e++;
+      // close the chunk once enough work is gathered, but never split pieces of one source level
+      if (work >= chunk_work && (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
     }
-    int slot = (int)(raw[q].key >> 40);
-    int64_t tile = (int64_t)(raw[q].key & ((1ULL << 40) - 1));
+    int slot = raw[e - 1].lvl + 1;
+    int64_t tile = raw[q].tile;
     uint8_t carena = raw[q].carena;
     if (carena) tile -= ntile;
     int64_t t = std::upper_bound(tile_base.begin(), tile_base.end(), tile) - tile_base.begin() - 1;
@@ -296,19 +309,23 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.pn = (int32_t)(e - q);
     tk.flags = carena;
     P.tasks.push_back(tk);
-    task_work.push_back(work);
+    task_work.push_back(work + 4096.0 * double(e - q));
+    task_slot.push_back(slot);
     P.slot_task_ptr[slot + 1]++;
+    P.slot_flops[slot] += 2.0 * work;
+    P.slot_pieces[slot] += (int64_t)(e - q);
     q = e;
   }
   if (raw.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
   for (int s = 0; s < NL; s++) P.slot_task_ptr[s + 1] += P.slot_task_ptr[s];
-  // heaviest tasks first inside each slot
+  // group by slot, heaviest tasks first inside each slot
   {
     std::vector<int64_t> idx(P.tasks.size());
     std::iota(idx.begin(), idx.end(), 0);
-    for (int s = 0; s < NL; s++)
-      std::sort(idx.begin() + P.slot_task_ptr[s], idx.begin() + P.slot_task_ptr[s + 1],
-                [&](int64_t a, int64_t b) { return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b; });
+    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+      if (task_slot[a] != task_slot[b]) return task_slot[a] < task_slot[b];
+      return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
+    });
     std::vector<Task> sorted(P.tasks.size());
     for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
     P.tasks.swap(sorted);

@@ -76,6 +76,8 @@ struct Plan {
   std::vector<Task> tasks;
   std::vector<Piece> pieces;
   double update_flops = 0;
+  std::vector<double> slot_flops;        // [nlevels] update flops per slot
+  std::vector<int64_t> slot_pieces;      // [nlevels]
   double fact_flops = 0;
 
   // solve schedule: cblks grouped by level (same levels as the factorization)

@@ -1,0 +1,445 @@
+// symbolic.cpp -- host-side producer of a SolverMatrix-compatible cblk/blok layout.
+//
+// In PaStiX this is the job of order/ + kass/ + blend/ (kass.c:93-176 supernodes + amalgamation,
+// splitpart.c cblk splitting, solverMatrixGen.c:1053-1069 coefind/stride), which "stay as-is" for
+// a real drop-in.  The GPU box has no PaStiX, Scotch or METIS, so the benchmarks need a producer of
+// the same data model.  It is a fresh implementation of the standard pipeline, not a restatement:
+//   ordering (geometric nested dissection for grids, separators numbered hierarchically so that the
+//   rows a sub-box touches in an ancestor separator are contiguous)  ->  elimination tree (Liu)
+//   -> postorder -> column counts (Gilbert-Ng-Peyton) -> supernodes -> fill-bounded amalgamation
+//   (same criterion family as kass: cheapest merges first until a fill budget is spent)
+//   -> supernodal symbolic factorization on interval lists -> cblk splitting at max blocksize
+//   -> bloks cut at facing-cblk boundaries, coefind/stride.
+// The layout it emits satisfies the invariants plan.cpp::check_layout enforces.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <new>
+#include <numeric>
+#include <queue>
+#include <vector>
+
+#include "../../include/pastix_amd.h"
+#include "../../include/pastix_amd_symbolic.h"
+
+namespace {
+
+typedef int32_t idx;
+
+// ---- geometric nested dissection ----------------------------------------------------------------
+struct GridND {
+  int NX, NY, NZ, leaf;
+  std::vector<int64_t>& invp;   // new -> old
+  std::vector<int64_t>& perm;   // old -> new (filled on the fly: needed for separator keys)
+  int64_t next = 0;
+  int64_t id(int x, int y, int z) const { return x + (int64_t)NX * (y + (int64_t)NY * z); }
+  void put(int64_t old) { perm[old] = next; invp[next++] = old; }
+  void rec(int x0, int x1, int y0, int y1, int z0, int z1) {
+    const int dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
+    const int64_t cnt = (int64_t)dx * dy * dz;
+    if (cnt <= 0) return;
+    if (cnt <= leaf || (dx <= 2 && dy <= 2 && dz <= 2)) {
+      for (int z = z0; z < z1; z++) for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++) put(id(x, y, z));
+      return;
+    }
+    std::vector<std::pair<int64_t, int64_t>> sep;   // (key, old id)
+    if (dx >= dy && dx >= dz) {
+      const int m = x0 + dx / 2;
+      rec(x0, m, y0, y1, z0, z1);
+      rec(m + 1, x1, y0, y1, z0, z1);
+      for (int z = z0; z < z1; z++) for (int y = y0; y < y1; y++)
+        sep.emplace_back(m > x0 ? perm[id(m - 1, y, z)] : id(m, y, z), id(m, y, z));
+    } else if (dy >= dz) {
+      const int m = y0 + dy / 2;
+      rec(x0, x1, y0, m, z0, z1);
+      rec(x0, x1, m + 1, y1, z0, z1);
+      for (int z = z0; z < z1; z++) for (int x = x0; x < x1; x++)
+        sep.emplace_back(m > y0 ? perm[id(x, m - 1, z)] : id(x, m, z), id(x, m, z));
+    } else {
+      const int m = z0 + dz / 2;
+      rec(x0, x1, y0, y1, z0, m);
+      rec(x0, x1, y0, y1, m + 1, z1);
+      for (int y = y0; y < y1; y++) for (int x = x0; x < x1; x++)
+        sep.emplace_back(m > z0 ? perm[id(x, y, m - 1)] : id(x, y, m), id(x, y, m));
+    }
+    // number the separator in the order its neighbours on the low side were numbered: every
+    // descendant box of the low side then touches a contiguous range of the separator
+    std::sort(sep.begin(), sep.end());
+    for (auto& s : sep) put(s.second);
+  }
+};
+
+struct Interval { idx a, b; };   // rows [a, b] inclusive
+
+}  // namespace
+
+struct pastix_amd_symbol_s {
+  int64_t n = 0;
+  std::vector<int64_t> perm, invp;
+  std::vector<pastix_amd_cblk_t> cblk;
+  std::vector<pastix_amd_blok_t> blok;
+  int64_t nnzl = 0;          // sum over cblks of stride*width - w(w-1)/2 (lower triangle + panel)
+  int64_t nsuper_fund = 0, nsuper_amalg = 0;
+};
+
+extern "C" {
+
+int pastix_amd_order_grid(pastix_amd_int_t nx, pastix_amd_int_t ny, pastix_amd_int_t nz, int leaf,
+                          pastix_amd_int_t* perm, pastix_amd_int_t* invp) {
+  if (nx <= 0 || ny <= 0 || nz <= 0 || !perm || !invp) return PASTIX_AMD_ERR_BADPARAMETER;
+  const int64_t n = nx * ny * nz;
+  std::vector<int64_t> p((size_t)n, -1), ip((size_t)n, -1);
+  GridND nd{(int)nx, (int)ny, (int)nz, leaf > 0 ? leaf : 8, ip, p};
+  nd.rec(0, (int)nx, 0, (int)ny, 0, (int)nz);
+  if (nd.next != n) return PASTIX_AMD_ERR_BADPARAMETER;
+  std::memcpy(perm, p.data(), n * sizeof(int64_t));
+  std::memcpy(invp, ip.data(), n * sizeof(int64_t));
+  return PASTIX_AMD_OK;
+}
+
+void pastix_amd_symbol_destroy(pastix_amd_symbol_t* s) { delete s; }
+
+int pastix_amd_symbol_layout(const pastix_amd_symbol_t* s, pastix_amd_layout_t* out) {
+  if (!s || !out) return PASTIX_AMD_ERR_BADPARAMETER;
+  out->cblknbr = (int64_t)s->cblk.size() - 1;
+  out->bloknbr = (int64_t)s->blok.size();
+  out->cblktab = s->cblk.data();
+  out->bloktab = s->blok.data();
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_symbol_perm(const pastix_amd_symbol_t* s, const pastix_amd_int_t** perm,
+                           const pastix_amd_int_t** invp) {
+  if (!s) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (perm) *perm = s->perm.data();
+  if (invp) *invp = s->invp.data();
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_symbol_info(const pastix_amd_symbol_t* s, pastix_amd_int_t* info) {
+  if (!s || !info) return PASTIX_AMD_ERR_BADPARAMETER;
+  info[0] = s->n; info[1] = (int64_t)s->cblk.size() - 1; info[2] = (int64_t)s->blok.size();
+  info[3] = s->nnzl; info[4] = s->nsuper_fund; info[5] = s->nsuper_amalg;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, const pastix_amd_int_t* rows,
+                        const pastix_amd_int_t* perm_in, const pastix_amd_symbolic_options_t* opts_in,
+                        pastix_amd_symbol_t** out) {
+  if (!out || n <= 0 || !colptr || !rows || n > 0x7ffffff0LL) return PASTIX_AMD_ERR_BADPARAMETER;
+  *out = nullptr;
+  pastix_amd_symbolic_options_t o{};
+  if (opts_in) o = *opts_in;
+  if (o.max_blocksize <= 0) o.max_blocksize = 128;
+  if (o.max_blocksize > 256) o.max_blocksize = 256;
+  if (o.amalgamation_pct < 0) o.amalgamation_pct = 0;
+  const double ratio = (o.amalgamation_pct == 0 && !opts_in) ? 0.05 : o.amalgamation_pct * 0.01;
+  pastix_amd_symbol_t* S = new (std::nothrow) pastix_amd_symbol_t();
+  if (!S) return PASTIX_AMD_ERR_ALLOC;
+  try {
+    S->n = n;
+    std::vector<idx> perm((size_t)n);
+    if (perm_in) { for (int64_t i = 0; i < n; i++) perm[i] = (idx)perm_in[i]; }
+    else std::iota(perm.begin(), perm.end(), 0);
+    {  // validate permutation
+      std::vector<char> seen((size_t)n, 0);
+      for (int64_t i = 0; i < n; i++) {
+        if (perm[i] < 0 || perm[i] >= n || seen[perm[i]]) { delete S; return PASTIX_AMD_ERR_BADPARAMETER; }
+        seen[perm[i]] = 1;
+      }
+    }
+    const int64_t nnz = colptr[n] - 1;
+
+    // symmetric adjacency (no diagonal) in the numbering given by `lab` (old -> label)
+    std::vector<int64_t> xadj;
+    std::vector<idx> adj;
+    auto build_adj = [&](const std::vector<idx>& lab) {
+      xadj.assign((size_t)n + 1, 0);
+      for (int64_t j = 0; j < n; j++)
+        for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+          int64_t i = rows[q] - 1;
+          if (i == j) continue;
+          xadj[lab[i] + 1]++; xadj[lab[j] + 1]++;
+        }
+      for (int64_t j = 0; j < n; j++) xadj[j + 1] += xadj[j];
+      adj.resize((size_t)xadj[n]);
+      std::vector<int64_t> pos(xadj.begin(), xadj.end() - 1);
+      for (int64_t j = 0; j < n; j++)
+        for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+          int64_t i = rows[q] - 1;
+          if (i == j) continue;
+          adj[pos[lab[i]]++] = lab[j];
+          adj[pos[lab[j]]++] = lab[i];
+        }
+      // duplicates (full-pattern input lists both (i,j) and (j,i)) are harmless below
+    };
+    for (int64_t q = 0; q < nnz; q++)
+      if (rows[q] < 1 || rows[q] > n) { delete S; return PASTIX_AMD_ERR_BADPARAMETER; }
+
+    // ---- elimination tree (Liu, path compression) in the given order ---------------------------
+    std::vector<idx> parent((size_t)n, -1);
+    auto etree = [&]() {
+      std::vector<idx> anc((size_t)n, -1);
+      std::fill(parent.begin(), parent.end(), -1);
+      for (idx j = 0; j < n; j++)
+        for (int64_t q = xadj[j]; q < xadj[j + 1]; q++) {
+          idx i = adj[q];
+          while (i != -1 && i < j) {
+            idx nx = anc[i];
+            anc[i] = j;
+            if (nx == -1) parent[i] = j;
+            i = nx;
+          }
+        }
+    };
+    build_adj(perm);
+    etree();
+    // ---- postorder; relabel ----------------------------------------------------------------------
+    {
+      std::vector<idx> head((size_t)n, -1), next((size_t)n, -1), post((size_t)n), stack;
+      for (idx j = (idx)n - 1; j >= 0; j--)
+        if (parent[j] != -1) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+      idx k = 0;
+      for (idx r = 0; r < n; r++) {
+        if (parent[r] != -1) continue;
+        stack.push_back(r);
+        while (!stack.empty()) {
+          idx p = stack.back(), c = head[p];
+          if (c == -1) { post[p] = k++; stack.pop_back(); }
+          else { head[p] = next[c]; stack.push_back(c); }
+        }
+      }
+      bool ident = true;
+      for (idx j = 0; j < n; j++) if (post[j] != j) { ident = false; break; }
+      if (!ident) {
+        for (int64_t i = 0; i < n; i++) perm[i] = post[perm[i]];
+        build_adj(perm);
+        etree();
+      }
+    }
+    // ---- column counts (Gilbert, Ng, Peyton); labels are a postorder -----------------------------
+    std::vector<int64_t> cc((size_t)n, 0);
+    {
+      std::vector<idx> first((size_t)n, -1), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
+      for (idx k = 0; k < n; k++) {
+        idx j = k;
+        cc[j] = (first[j] == -1) ? 1 : 0;
+        for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
+      }
+      std::iota(anc.begin(), anc.end(), 0);
+      for (idx j = 0; j < n; j++) {
+        if (parent[j] != -1) cc[parent[j]]--;
+        for (int64_t q = xadj[j]; q < xadj[j + 1]; q++) {
+          idx i = adj[q];
+          if (i <= j || first[j] <= maxfirst[i]) continue;
+          maxfirst[i] = first[j];
+          idx jprev = prevleaf[i];
+          prevleaf[i] = j;
+          if (jprev == -1) { cc[j]++; continue; }
+          idx qq = jprev;
+          while (qq != anc[qq]) qq = anc[qq];
+          for (idx s = jprev; s != qq;) { idx sp = anc[s]; anc[s] = qq; s = sp; }
+          cc[j]++;
+          cc[qq]--;
+        }
+        if (parent[j] != -1) anc[j] = parent[j];
+      }
+      for (idx j = 0; j < n; j++) if (parent[j] != -1) cc[parent[j]] += cc[j];
+    }
+    // ---- supernodes ---------------------------------------------------------------------------------
+    std::vector<idx> sfirst;   // first column of each supernode
+    {
+      std::vector<idx> nchild((size_t)n, 0);
+      for (idx j = 0; j < n; j++) if (parent[j] != -1) nchild[parent[j]]++;
+      for (idx j = 0; j < n; j++) {
+        bool merge = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
+        if (!merge) sfirst.push_back(j);
+      }
+    }
+    const idx ns0 = (idx)sfirst.size();
+    S->nsuper_fund = ns0;
+    sfirst.push_back((idx)n);
+    std::vector<idx> col2s((size_t)n);
+    for (idx s = 0; s < ns0; s++) for (idx j = sfirst[s]; j < sfirst[s + 1]; j++) col2s[j] = s;
+    std::vector<idx> sparent((size_t)ns0, -1);
+    std::vector<int64_t> sw((size_t)ns0), sbelow((size_t)ns0);
+    double nnz0 = 0;
+    for (idx s = 0; s < ns0; s++) {
+      idx l = sfirst[s + 1] - 1;
+      sparent[s] = parent[l] == -1 ? -1 : col2s[parent[l]];
+      sw[s] = sfirst[s + 1] - sfirst[s];
+      sbelow[s] = cc[sfirst[s]] - sw[s];
+      nnz0 += 0.5 * (double)sw[s] * (double)(sw[s] + 1) + (double)sw[s] * (double)sbelow[s];
+    }
+    // ---- amalgamation: cheapest merges first until the fill budget is spent ----------------------
+    // merged node keeps the parent's id; `rep` = union-find to the surviving node
+    std::vector<idx> rep((size_t)ns0);
+    std::iota(rep.begin(), rep.end(), 0);
+    std::function<idx(idx)> find = [&](idx x) { while (rep[x] != x) { rep[x] = rep[rep[x]]; x = rep[x]; } return x; };
+    {
+      std::vector<int32_t> ver((size_t)ns0, 0);
+      struct Ent { double cost; idx c; int32_t vc, vp; };
+      auto cmp = [](const Ent& a, const Ent& b) { return a.cost > b.cost; };
+      std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp);
+      auto cost_of = [&](idx c, idx p) {
+        double wc = (double)sw[c], wp = (double)sw[p], bp = (double)sbelow[p], bc = (double)sbelow[c];
+        (void)wp;
+        return wc * (wp + bp - bc);   // extra entries of L (lower storage) created by the merge
+      };
+      std::vector<std::vector<idx>> kids((size_t)ns0);
+      for (idx s = 0; s < ns0; s++) if (sparent[s] != -1) kids[sparent[s]].push_back(s);
+      for (idx s = 0; s < ns0; s++)
+        if (sparent[s] != -1) pq.push(Ent{cost_of(s, sparent[s]), s, ver[s], ver[sparent[s]]});
+      double budget = ratio * nnz0, spent = 0;
+      const int64_t maxw_merge = o.max_merge_width > 0 ? o.max_merge_width : (int64_t)1 << 40;
+      while (!pq.empty()) {
+        Ent e = pq.top();
+        pq.pop();
+        idx c = e.c;
+        if (rep[c] != c) continue;
+        idx p = sparent[c];
+        if (p == -1) continue;
+        p = find(p);
+        if (e.vc != ver[c] || e.vp != ver[p]) continue;
+        if (e.cost > 0 && spent + e.cost > budget) break;      // cheapest remaining does not fit
+        if (e.cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
+        // merge c into p
+        spent += std::max(0.0, e.cost);
+        rep[c] = p;
+        sw[p] += sw[c];
+        ver[p]++;
+        ver[c]++;
+        for (idx k : kids[c]) { idx kk = find(k); if (kk != p && rep[kk] == kk) { sparent[kk] = p; kids[p].push_back(kk); } }
+        std::vector<idx>().swap(kids[c]);
+        // refresh the costs that involve p
+        for (idx k : kids[p]) { idx kk = find(k); if (kk != p && rep[kk] == kk) pq.push(Ent{cost_of(kk, p), kk, ver[kk], ver[p]}); }
+        if (sparent[p] != -1) { idx gp = find(sparent[p]); sparent[p] = gp; pq.push(Ent{cost_of(p, gp), p, ver[p], ver[gp]}); }
+      }
+    }
+    // ---- new ordering: postorder of the amalgamated tree, members in original order --------------
+    std::vector<idx> aid((size_t)ns0, -1);      // fundamental supernode -> amalgamated node (dense ids)
+    std::vector<idx> afirst;                    // first new column of each amalgamated node
+    std::vector<idx> newlab((size_t)n);         // postorder label -> new label
+    {
+      std::vector<std::vector<idx>> members((size_t)ns0), akids((size_t)ns0);
+      std::vector<idx> roots;
+      for (idx s = 0; s < ns0; s++) members[find(s)].push_back(s);
+      for (idx s = 0; s < ns0; s++) {
+        if (rep[s] != s) continue;
+        idx p = sparent[s] == -1 ? -1 : find(sparent[s]);
+        if (p == -1) roots.push_back(s); else akids[p].push_back(s);
+      }
+      idx na = 0, col = 0;
+      std::vector<std::pair<idx, size_t>> st;
+      for (idx r : roots) {
+        st.emplace_back(r, 0);
+        while (!st.empty()) {
+          auto& top = st.back();
+          if (top.second < akids[top.first].size()) { idx c = akids[top.first][top.second++]; st.emplace_back(c, 0); }
+          else {
+            idx a = top.first;
+            afirst.push_back(col);
+            for (idx m : members[a]) { aid[m] = na; for (idx j = sfirst[m]; j < sfirst[m + 1]; j++) newlab[j] = col++; }
+            na++;
+            st.pop_back();
+          }
+        }
+      }
+      afirst.push_back(col);
+      S->nsuper_amalg = na;
+    }
+    for (int64_t i = 0; i < n; i++) perm[i] = newlab[perm[i]];
+    const idx na = (idx)afirst.size() - 1;
+    build_adj(perm);
+    std::vector<idx> col2a((size_t)n);
+    for (idx a = 0; a < na; a++) for (idx j = afirst[a]; j < afirst[a + 1]; j++) col2a[j] = a;
+
+    // ---- supernodal symbolic factorization on interval lists -------------------------------------
+    // struct(a) = rows > last col of a reached from A's columns of a or from children's structs
+    std::vector<std::vector<idx>> akids((size_t)na);
+    std::vector<Interval> tmp;
+    std::vector<std::vector<Interval>> keep((size_t)na);
+    for (idx a = 0; a < na; a++) {
+      const idx last = afirst[a + 1] - 1;
+      tmp.clear();
+      for (idx j = afirst[a]; j <= last; j++)
+        for (int64_t q = xadj[j]; q < xadj[j + 1]; q++)
+          if (adj[q] > last) tmp.push_back(Interval{adj[q], adj[q]});
+      for (idx c : akids[a])
+        for (const Interval& iv : keep[c]) {
+          if (iv.b <= last) continue;
+          tmp.push_back(Interval{std::max<idx>(iv.a, last + 1), iv.b});
+        }
+      std::sort(tmp.begin(), tmp.end(), [](const Interval& x, const Interval& y) { return x.a < y.a; });
+      std::vector<Interval>& r = keep[a];
+      for (const Interval& iv : tmp) {
+        if (!r.empty() && iv.a <= r.back().b + 1) r.back().b = std::max(r.back().b, iv.b);
+        else r.push_back(iv);
+      }
+      r.shrink_to_fit();
+      if (!r.empty()) akids[col2a[r.front().a]].push_back(a);
+    }
+    std::vector<int64_t>().swap(xadj);
+    std::vector<idx>().swap(adj);
+
+    // ---- split wide nodes; final cblk boundaries -------------------------------------------------
+    const idx maxbs = (idx)o.max_blocksize;
+    std::vector<idx> cfirst;            // first column of each final cblk
+    std::vector<idx> a_cblk0((size_t)na + 1);
+    for (idx a = 0; a < na; a++) {
+      a_cblk0[a] = (idx)cfirst.size();
+      idx w = afirst[a + 1] - afirst[a];
+      for (idx c = afirst[a]; c < afirst[a + 1]; c += maxbs) cfirst.push_back(c);
+      (void)w;
+    }
+    a_cblk0[na] = (idx)cfirst.size();
+    const idx ncb = (idx)cfirst.size();
+    cfirst.push_back((idx)n);
+    std::vector<idx> col2c((size_t)n);
+    for (idx c = 0; c < ncb; c++) for (idx j = cfirst[c]; j < cfirst[c + 1]; j++) col2c[j] = c;
+
+    // ---- bloks -------------------------------------------------------------------------------------
+    S->cblk.resize((size_t)ncb + 1);
+    int64_t nnzl = 0;
+    for (idx a = 0; a < na; a++) {
+      for (idx c = a_cblk0[a]; c < a_cblk0[a + 1]; c++) {
+        pastix_amd_cblk_t& cb = S->cblk[c];
+        cb.fcolnum = cfirst[c];
+        cb.lcolnum = cfirst[c + 1] - 1;
+        cb.bloknum = (int64_t)S->blok.size();
+        int64_t off = 0;
+        auto push = [&](idx ra, idx rb) {   // rows [ra, rb], cut at facing cblk boundaries
+          while (ra <= rb) {
+            idx fc = col2c[ra];
+            idx e = std::min<idx>(rb, cfirst[fc + 1] - 1);
+            S->blok.push_back(pastix_amd_blok_t{ra, e, fc, off});
+            off += e - ra + 1;
+            ra = e + 1;
+          }
+        };
+        push((idx)cb.fcolnum, (idx)cb.lcolnum);                       // diagonal blok
+        if (cb.lcolnum + 1 <= afirst[a + 1] - 1) push((idx)cb.lcolnum + 1, afirst[a + 1] - 1);   // rest of the node
+        for (const Interval& iv : keep[a]) push(iv.a, iv.b);
+        cb.stride = off;
+        int64_t w = cb.lcolnum - cb.fcolnum + 1;
+        nnzl += off * w - w * (w - 1) / 2;
+      }
+      std::vector<Interval>().swap(keep[a]);
+    }
+    S->cblk[ncb].fcolnum = n; S->cblk[ncb].lcolnum = n; S->cblk[ncb].bloknum = (int64_t)S->blok.size(); S->cblk[ncb].stride = 0;
+    S->nnzl = nnzl;
+    S->perm.resize((size_t)n);
+    S->invp.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) { S->perm[i] = perm[i]; S->invp[perm[i]] = i; }
+  } catch (const std::bad_alloc&) {
+    delete S;
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  *out = S;
+  return PASTIX_AMD_OK;
+}
+
+}  // extern "C"

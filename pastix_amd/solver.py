@@ -21,13 +21,14 @@ def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
 
 
 class Plan:
-    def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0):
+    def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
         self._h = ctypes.c_void_p()
         opts = Options()
         opts.device = device
         opts.lookahead = lookahead
+        opts.verbose = verbose
         check(_lib.lib().pastix_amd_plan_create(ctypes.byref(self.layout.c), factotype, floattype,
                                                 ctypes.byref(opts), ctypes.byref(self._h)),
               "pastix_amd_plan_create")

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12   # per entry relative to max|L_ref|
 
 
-@pytest.mark.parametrize("lookahead", [-1, 2, 1000])
+@pytest.mark.parametrize("lookahead", [1, 300, 1 << 30])
 @pytest.mark.parametrize("name", golden_names("llt"))
 def test_llt_matches_reference_golden(name, lookahead, golden):
     g = golden(name)
@@ -61,6 +61,6 @@ def test_static_pivot_clamp_matches_oracle(golden):
         p.upload(L0)
         st = p.factorize(crit, allow_numeric_error=True)
         L1, _ = p.download()
-    assert nbo >= 3 and st["nbpivot"] == nbo
+    assert nbo >= 1 and st["nbpivot"] == nbo
     fin = np.isfinite(Lo)
     assert np.allclose(L1[fin], Lo[fin], rtol=1e-9, atol=1e-9 * np.abs(Lo[fin]).max())

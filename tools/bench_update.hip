@@ -1,0 +1,40 @@
+// Synthetic micro-benchmark of k_update: N tasks x P full pieces (128x128xK), operands drawn from a
+// pool of `pool` source panels.  Build: hipcc --offload-arch=gfx950 -O3 -I pastix_amd/csrc -o tools/bench_update tools/bench_update.hip
+#include "../pastix_amd/csrc/kernels.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+using namespace pastix_amd;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv) {
+  int ntask = argc > 1 ? atoi(argv[1]) : 2048, P = argc > 2 ? atoi(argv[2]) : 8, K = argc > 3 ? atoi(argv[3]) : 128;
+  int pool = argc > 4 ? atoi(argv[4]) : 64;        // number of distinct source panels
+  int rows = 4096;                                 // rows per source panel
+  int64_t src_elems = (int64_t)pool * rows * K;
+  int64_t c_elems = (int64_t)ntask * 128 * 128;
+  double *d; CK(hipMalloc(&d, (src_elems + c_elems) * 8));
+  std::vector<double> h(src_elems + c_elems);
+  std::mt19937_64 rng(1); std::uniform_real_distribution<double> u(-1, 1);
+  for (auto& v : h) v = u(rng);
+  CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  std::vector<Task> tasks(ntask); std::vector<Piece> pieces((size_t)ntask * P);
+  for (int t = 0; t < ntask; t++) {
+    tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, 0};
+    for (int p = 0; p < P; p++) {
+      int s = (t * 7 + p * 13) % pool; int ra = ((t * 31 + p) % (rows / 128)) * 128, rb = ((t * 17 + 3 * p) % (rows / 128)) * 128;
+      pieces[(size_t)t * P + p] = Piece{(int64_t)s * rows * K + ra, (int64_t)s * rows * K + rb, rows, (uint16_t)K, 0, 128, 0, 128, 0};
+    }
+  }
+  Task* dt; Piece* dp; CK(hipMalloc(&dt, tasks.size() * sizeof(Task))); CK(hipMalloc(&dp, pieces.size() * sizeof(Piece)));
+  CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dp, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch_update(0, d, d, dt, dp, ntask); CK(hipDeviceSynchronize());
+  int reps = 5; CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; r++) launch_update(0, d, d, dt, dp, ntask);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double fl = 2.0 * 128 * 128 * K * (double)P * ntask * reps;
+  printf("tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,
+         fl / (ms * 1e-3) * 1e-12, fl / (ms * 1e-3) / 78.6e12 * 100);
+  return 0;
+}
