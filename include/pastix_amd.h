@@ -116,6 +116,9 @@ int pastix_amd_download_tabs(pastix_amd_plan_t *plan, void *const *coeftab, void
 int pastix_amd_fill_csc(pastix_amd_plan_t *plan, int sym, pastix_amd_int_t n, const pastix_amd_int_t *colptr,
                         const pastix_amd_int_t *rows, const void *vals, const pastix_amd_int_t *perm);
 
+/* re-apply the fill cached by the last pastix_amd_fill_csc (device only: memset + scatter). */
+int pastix_amd_refill(pastix_amd_plan_t *plan);
+
 /* numerical factorization of the device-resident panels (the hot path). */
 int pastix_amd_factorize(pastix_amd_plan_t *plan, double critere, pastix_amd_stats_t *stats);
 

@@ -8,21 +8,35 @@
 # (src/CMakeLists.txt:37-116, sopalin_define.h:453-465).
 # Outputs only into oracle/_ref/ (git-ignored; travels to the GPU box via gpurun).
 #
-# usage: oracle/build_ref.sh [PREC]   PREC = d (default) | z
+# usage: oracle/build_ref.sh [PREC] [BLAS]   PREC = d (default) | z ;  BLAS = mkl (default) | openblas
+#   openblas = the OpenBLAS that ships inside the image's scipy wheel (LP64, symbols prefixed
+#   scipy_): same reference sources, BLAS symbols renamed on the compiler command line.  It is the
+#   build used for the CPU baseline on AMD hosts, where MKL's dispatcher picks a slow generic path.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 REF=${PASTIX_REFERENCE:-/root/reference}
 PREC=${1:-d}
+BLAS=${2:-mkl}
 OUT="$HERE/_ref"
-OBJ="$OUT/obj_$PREC"
+SUF=""
+[ "$BLAS" = openblas ] && SUF="_ob"
+OBJ="$OUT/obj_$PREC$SUF"
 [ -d "$REF/src" ] || { echo "reference not present at $REF: keeping prebuilt oracle/_ref"; exit 0; }
 MKL=${MKL_LIBDIR:-/opt/conda/lib}
 [ -e "$MKL/libmkl_rt.so" ] || { echo "no MKL at $MKL: reference unbuildable here"; exit 0; }
+OB=$(ls /usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so 2>/dev/null | head -1)
+if [ "$BLAS" = openblas ]; then
+  [ -n "$OB" ] || { echo "no scipy OpenBLAS in this image"; exit 0; }
+  for f in scal axpy copy gemm trsv trsm syrk syr ger gemv swap dot nrm2; do
+    RENAMES="$RENAMES -Dd${f}_=scipy_d${f}_ -Dz${f}_=scipy_z${f}_"
+  done
+fi
 mkdir -p "$OBJ"
 S="$REF/src"
 INC="-I$S/common/src -I$S/symbol/src -I$S/order/src -I$S/fax/src -I$S/kass/src -I$S/blend/src -I$S/sopalin/src -I$S/perf/src -I$S/perf/src/num_recipes -I$S/sparse-matrix/src -I$S/matrix_drivers/src"
 DEFS="-DFORCE_NOMPI -DPREC_DOUBLE -DINTSIZE32 -DVERSION=\"ref\" -DX_ARCHi686_pc_linux -DDOF_CONSTANT -DFORCE_NO_CUDA"
 [ "$PREC" = z ] && DEFS="$DEFS -DTYPE_COMPLEX"
+DEFS="$DEFS $RENAMES"
 CC="gcc -O2 -fPIC -w -std=gnu99 $INC $DEFS"
 
 COMMON="common_integer common_error common_memory trace common"
@@ -60,5 +74,9 @@ done
 wait
 # the harness driver (ours) includes the reference's internal headers to read SolverMatrix
 $CC -DCHOL_SOPALIN -c "$HERE/ref_harness.c" -o "$OBJ/ref_harness.o"
-gcc -o "$OUT/ref_harness_$PREC" "$OBJ"/*.o -L"$MKL" -Wl,-rpath,"$MKL" -lmkl_rt -lpthread -lm -lrt
-echo "built $OUT/ref_harness_$PREC"
+if [ "$BLAS" = openblas ]; then
+  gcc -o "$OUT/ref_harness_$PREC$SUF" "$OBJ"/*.o "$OB" -Wl,-rpath,"$(dirname "$OB")" -lpthread -lm -lrt
+else
+  gcc -o "$OUT/ref_harness_$PREC" "$OBJ"/*.o -L"$MKL" -Wl,-rpath,"$MKL" -lmkl_rt -lpthread -lm -lrt
+fi
+echo "built $OUT/ref_harness_$PREC$SUF"

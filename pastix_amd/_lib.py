@@ -61,8 +61,14 @@ EXPORTS = [
     "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin",
     "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats",
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
-    "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_factorize", "pastix_amd_solve",
+    "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve",
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
+]
+# include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
+EXPORTS_HOST = [
+    "pastix_amd_order_grid", "pastix_amd_symbolic", "pastix_amd_symbol_layout", "pastix_amd_symbol_perm",
+    "pastix_amd_symbol_info", "pastix_amd_symbol_destroy", "pastix_amd_pastix", "pastix_amd_set_grid",
+    "pastix_amd_data_plan",
 ]
 
 

@@ -18,6 +18,8 @@ void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n
                      long long* nbpivot, int* errflag);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
+void launch_solve(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t n, const DevBlok* bl,
+                  double* x);
 }  // namespace pastix_amd
 
 using namespace pastix_amd;
@@ -36,6 +38,10 @@ struct pastix_amd_plan_s {
   long long* dNbpivot = nullptr;
   int* dErr = nullptr;
   int maxw = 0;
+  // cached coefficient fill (destinations + values) so that a re-fill is device-only
+  int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
+  int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
+  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr;
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};
@@ -139,6 +145,8 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dL); (void)hipFree(p->dU); (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
+  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
+  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -262,25 +270,31 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
         }
       }
     }
-  HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
-  if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
-  auto scatter = [&](double* dst, std::vector<int64_t>& idx, std::vector<double>& val) -> int {
+  auto cache = [&](std::vector<int64_t>& idx, std::vector<double>& val, int64_t** di, double** dv, int64_t* cnt) -> int {
+    (void)hipFree(*di); (void)hipFree(*dv);
+    *di = nullptr; *dv = nullptr; *cnt = (int64_t)idx.size();
     if (idx.empty()) return 0;
-    int64_t* di = nullptr;
-    double* dv = nullptr;
-    HIPCHK(hipMalloc((void**)&di, idx.size() * sizeof(int64_t)));
-    HIPCHK(hipMalloc((void**)&dv, val.size() * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(di, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice, p->stream));
-    HIPCHK(hipMemcpyAsync(dv, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice, p->stream));
-    launch_scatter(p->stream, dst, di, dv, (int64_t)idx.size());
-    HIPCHK(hipStreamSynchronize(p->stream));
-    HIPCHK(hipFree(di));
-    HIPCHK(hipFree(dv));
+    HIPCHK(hipMalloc((void**)di, idx.size() * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void**)dv, val.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(*di, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*dv, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
     return 0;
   };
   int r;
-  if ((r = scatter(p->dL, idxL, valL))) return r;
-  if (lu && (r = scatter(p->dU, idxU, valU))) return r;
+  if ((r = cache(idxL, valL, &p->dFillIdxL, &p->dFillValL, &p->nFillL))) return r;
+  if ((r = cache(idxU, valU, &p->dFillIdxU, &p->dFillValU, &p->nFillU))) return r;
+  return pastix_amd_refill(p);
+}
+
+// Re-apply the cached coefficient fill (device only): zero the panels, scatter the values.
+int pastix_amd_refill(pastix_amd_plan_t* p) {
+  if (!p || !p->dFillIdxL) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  HIPCHK(hipSetDevice(p->device));
+  HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
+  launch_scatter(p->stream, p->dL, p->dFillIdxL, p->dFillValL, p->nFillL);
+  if (p->dU && p->nFillU) launch_scatter(p->stream, p->dU, p->dFillIdxU, p->dFillValU, p->nFillU);
   HIPCHK(hipStreamSynchronize(p->stream));
   return PASTIX_AMD_OK;
 }
@@ -328,9 +342,10 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       HIPCHK(hipEventElapsedTime(&m2, p->ev[2 * i], p->ev[2 * i + 1]));
       upd += m2 * 1e-3;
       if (H.opts.verbose >= 2)
-        fprintf(stderr, "slot %4d: cblks %6lld tasks %7lld pieces %8lld flops %.3e  %9.1f us  %8.1f GF/s\n", l,
+        fprintf(stderr, "slot %4d: cblks %6lld tasks %7lld pieces %8lld maxpn %5d maxwork %.2e flops %.3e  %9.1f us  %8.1f GF/s\n", l,
                 (long long)(H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l]), (long long)(t1 - t0),
-                (long long)H.slot_pieces[l], H.slot_flops[l], m2 * 1e3, H.slot_flops[l] / (m2 * 1e-3) * 1e-9);
+                (long long)H.slot_pieces[l], (int)H.slot_maxpn[l], H.slot_maxwork[l], H.slot_flops[l], m2 * 1e3,
+                H.slot_flops[l] / (m2 * 1e-3) * 1e-9);
       i++;
     }
   }
@@ -345,9 +360,43 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   return err ? PASTIX_AMD_ERR_NUMERIC : PASTIX_AMD_OK;
 }
 
-int pastix_amd_solve(pastix_amd_plan_t* p, void* x, pastix_amd_int_t nrhs) {
-  (void)p; (void)x; (void)nrhs;
-  return PASTIX_AMD_ERR_UNSUPPORTED;
+// Forward / backward substitution on the device-resident factors (LLt), x in permuted numbering.
+int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
+  if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  if (H.factotype != PASTIX_AMD_FACT_LLT) return PASTIX_AMD_ERR_UNSUPPORTED;
+  HIPCHK(hipSetDevice(p->device));
+  if (!p->dSolve) {
+    std::vector<SolveTask> st((size_t)H.cblknbr);
+    for (int64_t q = 0; q < H.cblknbr; q++) {
+      const int32_t k = H.lvl_cblk[q];
+      st[q] = SolveTask{H.poff[k], (int32_t)H.cblk[k].stride, (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1),
+                        (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum};
+    }
+    std::vector<DevBlok> bl((size_t)H.bloknbr);
+    for (int64_t b = 0; b < H.bloknbr; b++)
+      bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
+    int r;
+    if ((r = to_device(&p->dSolve, st))) return r;
+    if ((r = to_device(&p->dBlok, bl))) return r;
+  }
+  double* dx = nullptr;
+  HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * sizeof(double)));
+  double* x = (double*)x_;
+  for (int64_t j = 0; j < nrhs; j++) {
+    HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    for (int l = 0; l < H.nlevels; l++)
+      launch_solve(p->stream, true, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                   p->dBlok, dx);
+    for (int l = H.nlevels - 1; l >= 0; l--)
+      launch_solve(p->stream, false, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                   p->dBlok, dx);
+    HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+  }
+  HIPCHK(hipFree(dx));
+  HIPCHK(hipGetLastError());
+  return PASTIX_AMD_OK;
 }
 
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,

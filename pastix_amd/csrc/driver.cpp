@@ -1,0 +1,237 @@
+// driver.cpp -- pastix()-signature stand-in above the C ABI (host side).
+//
+// The reference's step sequencer is pastix() (src/sopalin/src/pastix.c:4734-5098) driven by
+// iparm[IPARM_START_TASK..IPARM_END_TASK] (src/common/src/api.h:253-260) with defaults from
+// pastix_initParam (pastix.c:334-456).  In a real drop-in that driver stays as-is and only
+// {po,ge,sy}_sopalin_thread is rebound.  This stand-in keeps the same calling
+// convention (1-based CSC, lower triangle for symmetric input, perm/invp in the CSC's base, iparm /
+// dparm slots and enum values of api.h:124-234) so that the reference's example call sequence
+// (src/example/src/simple.c:59-256) runs unchanged on a box without PaStiX: ordering and symbolic
+// steps use this repo's producer (symbolic.cpp), the numerical factorization and the solves run on
+// the device.  Refinement is plain iterative refinement (the reference's API_RAF_PIVOT family); its
+// Krylov refiners are out of scope.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/pastix_amd.h"
+#include "../../include/pastix_amd_symbolic.h"
+#include "../../include/pastix_amd_driver.h"
+
+struct pastix_amd_data_s {
+  int64_t n = 0;
+  pastix_amd_symbol_t* sym = nullptr;
+  pastix_amd_plan_t* plan = nullptr;
+  std::vector<int64_t> perm, invp;   // 0-based, final
+  int64_t grid[3] = {0, 0, 0};
+  double norm1 = 0;
+  std::vector<double> rhs;           // right-hand side saved by the SOLVE step (sopar->b role)
+  bool factorized = false;
+};
+
+static void init_param(pastix_amd_int_t* iparm, double* dparm) {   // pastix_initParam, pastix.c:334-456
+  for (int i = 0; i < PASTIX_AMD_IPARM_SIZE; i++) iparm[i] = 0;
+  for (int i = 0; i < PASTIX_AMD_DPARM_SIZE; i++) dparm[i] = 0;
+  iparm[IPARM_MODIFY_PARAMETER] = API_YES;
+  iparm[IPARM_START_TASK] = API_TASK_ORDERING;
+  iparm[IPARM_END_TASK] = API_TASK_CLEAN;
+  iparm[IPARM_VERBOSE] = 1;
+  iparm[IPARM_DOF_NBR] = 1;
+  iparm[IPARM_ITERMAX] = 250;
+  iparm[IPARM_MATRIX_VERIFICATION] = API_YES;
+  iparm[IPARM_AMALGAMATION_LEVEL] = 5;
+  iparm[IPARM_ORDERING] = API_ORDER_SCOTCH;
+  iparm[IPARM_BASEVAL] = 1;
+  iparm[IPARM_MIN_BLOCKSIZE] = 60;
+  iparm[IPARM_MAX_BLOCKSIZE] = 120;
+  iparm[IPARM_FACTORIZATION] = PASTIX_AMD_FACT_LDLT;
+  iparm[IPARM_THREAD_NBR] = 1;
+  iparm[IPARM_CUDA_NBR] = 0;
+  iparm[IPARM_LEVEL_OF_FILL] = 1;
+  iparm[IPARM_RHS_MAKING] = 0;
+  iparm[IPARM_REFINEMENT] = 0;
+  iparm[IPARM_SYM] = API_SYM_YES;
+  iparm[IPARM_INERTIA] = -1;
+  iparm[IPARM_ESP_NBTASKS] = -1;
+  iparm[IPARM_FLOAT] = PASTIX_AMD_REALDOUBLE;
+  dparm[DPARM_EPSILON_REFINEMENT] = 1e-12;
+  dparm[DPARM_RELATIVE_ERROR] = -1;
+  dparm[DPARM_SCALED_RESIDUAL] = -1;
+  dparm[DPARM_EPSILON_MAGN_CTRL] = 1e-31;
+}
+
+extern "C" {
+
+int pastix_amd_set_grid(pastix_amd_data_t** pd, pastix_amd_int_t nx, pastix_amd_int_t ny, pastix_amd_int_t nz) {
+  if (!pd) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (!*pd) { *pd = new (std::nothrow) pastix_amd_data_s(); if (!*pd) return PASTIX_AMD_ERR_ALLOC; }
+  (*pd)->grid[0] = nx; (*pd)->grid[1] = ny; (*pd)->grid[2] = nz;
+  return PASTIX_AMD_OK;
+}
+
+pastix_amd_plan_t* pastix_amd_data_plan(pastix_amd_data_t* pd) { return pd ? pd->plan : nullptr; }
+
+void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_amd_int_t n,
+                       pastix_amd_int_t* colptr, pastix_amd_int_t* row, double* avals, pastix_amd_int_t* perm,
+                       pastix_amd_int_t* invp, double* b, pastix_amd_int_t rhs, pastix_amd_int_t* iparm,
+                       double* dparm) {
+  (void)pastix_comm;
+  if (!iparm || !dparm) return;
+  if (iparm[IPARM_MODIFY_PARAMETER] == API_NO) {      // pastix.c:4755-4761: fill defaults and return
+    init_param(iparm, dparm);
+    return;
+  }
+  iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_OK;
+#define FAIL(code) do { iparm[IPARM_ERROR_NUMBER] = (code); return; } while (0)
+  if (!pastix_data || n <= 0) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+  if (!*pastix_data) { *pastix_data = new (std::nothrow) pastix_amd_data_s(); if (!*pastix_data) FAIL(PASTIX_AMD_ERR_ALLOC); }
+  pastix_amd_data_s* D = *pastix_data;
+  const int first = (int)iparm[IPARM_START_TASK], last = (int)iparm[IPARM_END_TASK];
+  const int facto = (int)iparm[IPARM_FACTORIZATION];
+  const int sym = iparm[IPARM_SYM] == API_SYM_YES;
+  if (iparm[IPARM_FLOAT] != PASTIX_AMD_REALDOUBLE || iparm[IPARM_DOF_NBR] != 1) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
+  int rc;
+
+  for (int task = first; task <= last; task++) {
+    switch (task) {
+      case API_TASK_INIT:
+        D->n = n;
+        break;
+      case API_TASK_ORDERING: {
+        if (!colptr || !row) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        D->n = n;
+        D->perm.assign((size_t)n, 0);
+        D->invp.assign((size_t)n, 0);
+        if (iparm[IPARM_ORDERING] == API_ORDER_PERSONAL) {
+          if (!perm) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+          const int64_t base = colptr[0];            // "same base as the CSC" (kass.c:143-156)
+          for (int64_t i = 0; i < n; i++) D->perm[i] = perm[i] - base;
+        } else if (D->grid[0] * D->grid[1] * D->grid[2] == n) {
+          rc = pastix_amd_order_grid(D->grid[0], D->grid[1], D->grid[2], 8, D->perm.data(), D->invp.data());
+          if (rc) FAIL(rc);
+        } else {
+          for (int64_t i = 0; i < n; i++) D->perm[i] = i;   // no Scotch/METIS here: natural order
+        }
+        break;
+      }
+      case API_TASK_SYMBFACT: {
+        if (!colptr || !row || D->perm.empty()) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        pastix_amd_symbolic_options_t so{};
+        so.max_blocksize = (int)iparm[IPARM_MAX_BLOCKSIZE];
+        so.amalgamation_pct = (int)iparm[IPARM_AMALGAMATION_LEVEL];
+        if (D->sym) { pastix_amd_symbol_destroy(D->sym); D->sym = nullptr; }
+        rc = pastix_amd_symbolic(n, colptr, row, D->perm.data(), &so, &D->sym);
+        if (rc) FAIL(rc);
+        const pastix_amd_int_t *p, *ip;
+        pastix_amd_symbol_perm(D->sym, &p, &ip);
+        D->perm.assign(p, p + n);
+        D->invp.assign(ip, ip + n);
+        const int64_t base = colptr[0];
+        if (perm) for (int64_t i = 0; i < n; i++) perm[i] = D->perm[i] + base;    // pastix.c:1734
+        if (invp) for (int64_t i = 0; i < n; i++) invp[i] = D->invp[i] + base;
+        pastix_amd_int_t info[8];
+        pastix_amd_symbol_info(D->sym, info);
+        iparm[IPARM_NNZEROS] = info[3];
+        break;
+      }
+      case API_TASK_ANALYSE: {
+        if (!D->sym) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        pastix_amd_layout_t lay;
+        pastix_amd_symbol_layout(D->sym, &lay);
+        pastix_amd_options_t o{};
+        if (D->plan) { pastix_amd_plan_destroy(D->plan); D->plan = nullptr; }
+        rc = pastix_amd_plan_create(&lay, facto, PASTIX_AMD_REALDOUBLE, &o, &D->plan);
+        if (rc) FAIL(rc);
+        dparm[DPARM_FACT_FLOPS] = pastix_amd_fact_flops(&lay, facto, PASTIX_AMD_REALDOUBLE);
+        break;
+      }
+      case API_TASK_NUMFACT: {
+        if (!D->plan || !avals) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        // critere = ||A||_1 * sqrt(eps)   (sopalin3d.c:586-606, CscNorm1 csc_intern_compute.c:120)
+        std::vector<double> colsum((size_t)n, 0.0);
+        for (int64_t j = 0; j < n; j++)
+          for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+            const int64_t i = row[q] - 1;
+            colsum[j] += std::fabs(avals[q]);
+            if (sym && i != j) colsum[i] += std::fabs(avals[q]);
+          }
+        double nrm = 0;
+        for (double v : colsum) nrm = std::max(nrm, v);
+        D->norm1 = nrm;
+        const double eps = dparm[DPARM_EPSILON_MAGN_CTRL];
+        const double critere = eps < 0 ? -eps : nrm * std::sqrt(eps);
+        rc = pastix_amd_fill_csc(D->plan, sym, n, colptr, row, avals, D->perm.data());
+        if (rc) FAIL(rc);
+        pastix_amd_stats_t st;
+        rc = pastix_amd_factorize(D->plan, critere, &st);
+        dparm[DPARM_FACT_TIME] = st.fact_time;           // sopalin3d.c:1125-1132
+        iparm[IPARM_STATIC_PIVOTING] = st.nbpivot;        // pastix.c:3853
+        if (rc) FAIL(rc);
+        D->factorized = true;
+        break;
+      }
+      case API_TASK_SOLVE: {
+        if (!D->factorized || !b) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        std::vector<double> x((size_t)n);
+        D->rhs.assign(b, b + n * rhs);
+        for (int64_t r = 0; r < rhs; r++) {
+          double* br = b + r * n;
+          for (int64_t i = 0; i < n; i++) x[D->perm[i]] = br[i];
+          rc = pastix_amd_solve(D->plan, x.data(), 1);
+          if (rc) FAIL(rc);
+          for (int64_t i = 0; i < n; i++) br[i] = x[D->perm[i]];
+        }
+        break;
+      }
+      case API_TASK_REFINE: {
+        // plain iterative refinement x += A^-1 (b - A x) until ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT
+        if (!D->factorized || !b || !avals || (int64_t)D->rhs.size() != n * rhs) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        std::vector<double> r((size_t)n), d((size_t)n);
+        int64_t iters = 0;
+        double relerr = 0;
+        for (int64_t c = 0; c < rhs; c++) {
+          double* x = b + c * n;
+          const double* f = D->rhs.data() + c * n;
+          double nb = 0;
+          for (int64_t i = 0; i < n; i++) nb += f[i] * f[i];
+          nb = std::sqrt(nb);
+          for (int64_t it = 0; it <= iparm[IPARM_ITERMAX]; it++) {
+            for (int64_t i = 0; i < n; i++) r[i] = f[i];
+            for (int64_t j = 0; j < n; j++)
+              for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+                const int64_t i = row[q] - 1;
+                r[i] -= avals[q] * x[j];
+                if (sym && i != j) r[j] -= avals[q] * x[i];
+              }
+            double nr = 0;
+            for (int64_t i = 0; i < n; i++) nr += r[i] * r[i];
+            relerr = nb > 0 ? std::sqrt(nr) / nb : std::sqrt(nr);
+            if (relerr < dparm[DPARM_EPSILON_REFINEMENT] || it == iparm[IPARM_ITERMAX]) break;
+            for (int64_t i = 0; i < n; i++) d[D->perm[i]] = r[i];
+            rc = pastix_amd_solve(D->plan, d.data(), 1);
+            if (rc) FAIL(rc);
+            for (int64_t i = 0; i < n; i++) x[i] += d[D->perm[i]];
+            iters++;
+          }
+        }
+        iparm[IPARM_NBITER] = iters;
+        dparm[DPARM_RELATIVE_ERROR] = relerr;
+        break;
+      }
+      case API_TASK_CLEAN:
+        if (D->plan) pastix_amd_plan_destroy(D->plan);
+        if (D->sym) pastix_amd_symbol_destroy(D->sym);
+        delete D;
+        *pastix_data = nullptr;
+        return;
+      default:
+        FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+    }
+  }
+#undef FAIL
+}
+
+}  // extern "C"

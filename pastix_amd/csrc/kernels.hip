@@ -440,6 +440,70 @@ __global__ void k_scatter(double* __restrict__ dst, const int64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// triangular solves on the factored panels (the data flow of up_down_smp, updo.c:114, for LLt):
+// forward L y = b level by level (cblks of one level are independent; their off-diagonal
+// contributions collide on x rows -> f64 atomics), backward L^T x = y in reverse level order
+// (gather, no atomics).  One workgroup per cblk.  Memory-bound: every panel is read once.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int panel_row_to_global(const DevBlok* __restrict__ bl, int fb, int lb, int p) {
+  int lo = fb, hi = lb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bl[mid].coefind <= p) lo = mid; else hi = mid - 1;
+  }
+  return bl[lo].frow + (p - bl[lo].coefind);
+}
+
+__global__ __launch_bounds__(256) void k_solve_fwd(const double* __restrict__ L, const SolveTask* __restrict__ tasks,
+                                                   const DevBlok* __restrict__ bl, double* __restrict__ x) {
+  __shared__ double xs[MAXW];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
+  for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
+  __syncthreads();
+  for (int c = 0; c < w; c++) {            // diagonal blok: column-oriented forward substitution
+    const double xc = xs[c] / A[c + (int64_t)c * ld];
+    __syncthreads();
+    if (tid == 0) xs[c] = xc;
+    for (int r = c + 1 + tid; r < w; r += 256) xs[r] -= A[r + (int64_t)c * ld] * xc;
+    __syncthreads();
+  }
+  for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
+  for (int p = w + tid; p < ld; p += 256) { // off-diagonal rows: x[row] -= L[row,:] . x_k
+    double s = 0;
+    for (int c = 0; c < w; c++) s += A[p + (int64_t)c * ld] * xs[c];
+    unsafeAtomicAdd(&x[panel_row_to_global(bl, tk.fblok, tk.lblok, p)], -s);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_solve_bwd(const double* __restrict__ L, const SolveTask* __restrict__ tasks,
+                                                   const DevBlok* __restrict__ bl, double* __restrict__ x) {
+  __shared__ double xs[MAXW];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
+  __syncthreads();
+  for (int c = wave; c < w; c += 4) {       // x_k[c] -= sum_rows L[row,c] * x[row]
+    double s = 0;
+    for (int p = w + lane; p < ld; p += 64)
+      s += A[p + (int64_t)c * ld] * x[panel_row_to_global(bl, tk.fblok, tk.lblok, p)];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) xs[c] -= s;
+  }
+  __syncthreads();
+  for (int c = w - 1; c >= 0; c--) {        // L_kk^T x_k = rhs : row-oriented backward substitution
+    const double xc = xs[c] / A[c + (int64_t)c * ld];
+    __syncthreads();
+    if (tid == 0) xs[c] = xc;
+    for (int r = tid; r < c; r += 256) xs[r] -= A[c + (int64_t)r * ld] * xc;
+    __syncthreads();
+  }
+  for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks) {
@@ -463,6 +527,13 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
     hipLaunchKernelGGL(k_trsm_llt<8>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
   else
     hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
+}
+
+void launch_solve(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t n, const DevBlok* bl,
+                  double* x) {
+  if (n <= 0) return;
+  if (fwd) hipLaunchKernelGGL(k_solve_fwd, dim3((unsigned)n), dim3(256), 0, s, L, tasks, bl, x);
+  else     hipLaunchKernelGGL(k_solve_bwd, dim3((unsigned)n), dim3(256), 0, s, L, tasks, bl, x);
 }
 
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n) {

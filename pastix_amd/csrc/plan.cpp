@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -98,6 +99,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // huge: one group per tile = left-looking)
   if (P.opts.lookahead <= 0) P.opts.lookahead = 512;
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
+  const int max_pieces = getenv("PASTIX_AMD_MAXPIECES") ? atoi(getenv("PASTIX_AMD_MAXPIECES")) : 8;
   const int64_t nc = L->cblknbr;
   P.cblknbr = nc;
   P.bloknbr = L->bloknbr;
@@ -283,6 +285,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<int32_t> task_slot;
   P.slot_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
+  P.slot_maxpn.assign(NL, 0);
+  P.slot_maxwork.assign(NL, 0.0);
   for (size_t q = 0; q < raw.size();) {
     size_t e = q;
     double work = 0;
@@ -291,7 +295,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
       e++;
       // close the chunk once enough work is gathered, but never split pieces of one source level
-      if (work >= chunk_work && (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
+      // (many small pieces are flushed early by count: each costs a latency-bound pass, and keeping
+      // them for the tile's last chunk would put them on the critical path of the dependency chain)
+      if ((work >= chunk_work || (int)(e - q) >= max_pieces) &&
+          (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
     }
     int slot = raw[e - 1].lvl + 1;
     int64_t tile = raw[q].tile;
@@ -314,6 +321,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.slot_task_ptr[slot + 1]++;
     P.slot_flops[slot] += 2.0 * work;
     P.slot_pieces[slot] += (int64_t)(e - q);
+    P.slot_maxpn[slot] = std::max<int32_t>(P.slot_maxpn[slot], (int32_t)(e - q));
+    P.slot_maxwork[slot] = std::max(P.slot_maxwork[slot], work);
     q = e;
   }
   if (raw.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;

@@ -54,6 +54,15 @@ struct TrsmTask {     // 64 panel rows of one cblk for the panel-solve kernel
   int64_t dinv_off;
 };
 
+struct SolveTask {
+  int64_t off;                 // panel offset in the arena
+  int32_t stride, width;
+  int32_t fcol;                // first column = first row of the diagonal blok
+  int32_t fblok, lblok;        // blok range [fblok, lblok) in the device blok table (fblok = diagonal)
+};
+struct DevBlok { int32_t frow, lrow, coefind; };
+
+
 struct Plan {
   int factotype = 0, floattype = 1;
   pastix_amd_options_t opts{};
@@ -78,6 +87,8 @@ struct Plan {
   double update_flops = 0;
   std::vector<double> slot_flops;        // [nlevels] update flops per slot
   std::vector<int64_t> slot_pieces;      // [nlevels]
+  std::vector<int32_t> slot_maxpn;       // [nlevels] longest piece list of a task in the slot
+  std::vector<double> slot_maxwork;      // [nlevels] largest task (multiply-adds)
   double fact_flops = 0;
 
   // solve schedule: cblks grouped by level (same levels as the factorization)

@@ -78,6 +78,9 @@ class Plan:
                                              _lib.ptr(rows), _lib.ptr(vals), _lib.ptr(perm)),
               "pastix_amd_fill_csc")
 
+    def refill(self):
+        check(_lib.lib().pastix_amd_refill(self._h), "pastix_amd_refill")
+
     def factorize(self, critere, allow_numeric_error=False):
         s = Stats()
         rc = _lib.lib().pastix_amd_factorize(self._h, ctypes.c_double(critere), ctypes.byref(s))

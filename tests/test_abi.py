@@ -15,6 +15,12 @@ def test_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "pastix_amd.h")).read()
     declared = set(re.findall(r"\b(pastix_amd_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTS)
+    host = ""
+    for h in ("pastix_amd_symbolic.h", "pastix_amd_driver.h"):
+        host += open(os.path.join(ROOT, "include", h)).read()
+    declared_host = set(re.findall(r"\b(pastix_amd_[a-z_0-9]+)\s*\(", host))
+    assert declared_host == set(_lib.EXPORTS_HOST)
+    declared |= declared_host
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name

@@ -1,0 +1,117 @@
+"""GPU: device fill/refill, device solves, the pastix()/iparm/dparm entry point, and
+size-independent properties at sizes the oracle cannot reach."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle_lib
+from pastix_amd import Plan
+from pastix_amd import pastix as px
+from pastix_amd import symbolic as sy
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym_matvec(n, cp, r, v):
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    return A + sp.tril(A, -1).T
+
+
+def test_solve_matches_oracle(golden):
+    g = golden("rlap3d_12_llt")
+    bp = np.empty_like(g["b"])
+    bp[g["perm"]] = g["b"]
+    with Plan(g["cblk4"], g["blok4"], 0) as p:
+        p.upload(g["L0"])
+        p.factorize(g["critere"])
+        x = p.solve(bp)[g["perm"]]
+    assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
+
+
+def test_refill_is_idempotent_and_refactor_is_deterministic(golden):
+    g = golden("rlap3d_10_llt")
+    with Plan(g["cblk4"], g["blok4"], 0) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        p.factorize(g["critere"])
+        La, _ = p.download()
+        p.refill()
+        L0, _ = p.download()
+        assert np.array_equal(L0, g["L0"])
+        p.factorize(g["critere"])
+        Lb, _ = p.download()
+    assert np.array_equal(La, Lb)          # tile ownership => bitwise reproducible
+
+
+@pytest.mark.parametrize("N,bs", [(24, 128), (32, 64), (40, 256)])
+def test_own_layout_vs_oracle_and_residual(N, bs):
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=bs)
+    c4, b4 = s["cblk4"], s["blok4"]
+    with Plan(c4, b4, 0) as p:
+        p.fill_csc(1, n, cp, r, v, s["perm"])
+        st = p.factorize(1e-14)
+        L1, _ = p.download()
+        b = np.random.default_rng(3).random(n)
+        bp = np.empty(n)
+        bp[s["perm"]] = b
+        x = p.solve(bp)[s["perm"]]
+    assert st["nbpivot"] == 0
+    A = _sym_matvec(n, cp, r, v)
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10      # SURVEY 8d end-to-end bar
+    if N <= 32:
+        L0, _ = oracle_lib.fill(0, 1, n, cp, r, v, s["perm"], c4, b4)
+        Lo, _, _ = oracle_lib.sopalin(0, c4, b4, L0, None, 1e-14)
+        assert np.abs(L1 - Lo).max() <= 1e-12 * np.abs(Lo).max()
+
+
+def test_pastix_entry_point_config1():
+    """BASELINE config 1: the reference's -lap 1000 generator (1-D, diag 2, sub-diagonal -1,
+    laplacian.c:151-181), rhs e_1 + e_n, double LLt through pastix()/iparm/dparm."""
+    n = 1000
+    colptr = np.arange(1, 2 * n + 1, 2, dtype=np.int64)
+    colptr = np.concatenate([colptr[:n], [2 * n]]).astype(np.int64)
+    rows = np.empty(2 * n - 1, dtype=np.int64)
+    vals = np.empty(2 * n - 1)
+    rows[0::2] = np.arange(1, n + 1)
+    vals[0::2] = 2.0
+    rows[1::2] = np.arange(2, n + 1)
+    vals[1::2] = -1.0
+    b = np.zeros(n)
+    b[0] = b[-1] = 1.0
+    rhs = b.copy()
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    iparm, dparm = px.init_param()
+    assert iparm[px.IPARM["MAX_BLOCKSIZE"]] == 120 and dparm[px.DPARM["EPSILON_MAGN_CTRL"]] == 1e-31
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LLT
+    iparm[px.IPARM["SYM"]] = px.API_SYM_YES
+    iparm[px.IPARM["START_TASK"]] = px.API_TASK["ORDERING"]
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK["REFINE"]
+    pd = px.pastix(None, n, colptr, rows, vals, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    A = _sym_matvec(n, colptr, rows, vals)
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) <= 1e-12
+    assert dparm[px.DPARM["RELATIVE_ERROR"]] <= 1e-12 and dparm[px.DPARM["FACT_TIME"]] > 0
+    assert iparm[px.IPARM["STATIC_PIVOTING"]] == 0 and iparm[px.IPARM["NNZEROS"]] > 0
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
+    px.pastix(pd, n, colptr, rows, vals, perm, invp, b, 1, iparm, dparm)
+
+
+def test_pastix_personal_ordering_grid():
+    N = 12
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm0, invp0 = sy.order_grid(N, N, N)
+    perm, invp = perm0 + 1, invp0 + 1            # same base as the CSC (kass.c:143-156)
+    b = np.random.default_rng(5).random(n)
+    rhs = b.copy()
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LLT
+    iparm[px.IPARM["ORDERING"]] = px.API_ORDER_PERSONAL
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK["SOLVE"]
+    pd = px.pastix(None, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    A = _sym_matvec(n, cp, r, v)
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-12
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
+    px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
