@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- factorization GFLOP/s of the MI355X sopalin path on BASELINE.json's headline config.
+
+A step = one pass of the hot path over one synthetic matrix: device re-fill of the panels (zero +
+scatter of the CSC values, inputs already resident in HBM) followed by the numerical factorization.
+Workload at N=1: 3-D 7-point Laplacian 200^3, double LLt (the configuration the metric is quoted on;
+~140 GB of panels, fits one 288 GB MI355X).  --grid overrides the size (e.g. 100 = configs[1]).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : dominant kernel k_update (GEMM + scatter), MFMA-bound; achieved = algorithmic update
+                 flops / time inside k_update launches, both measured live with HIP events on the
+                 engine's own stream.
+  cpu_baseline : the REAL reference (oracle/_ref, PaStiX 5.2.2.16 CPU sopalin + OpenBLAS) timed on this
+                 box's host cores on a bounded sample (smaller grid of the same stencil), rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F64_PEAK = 78.6e12   # dense fp64 matrix peak of MI355X (vendor); tools/probe_mfma_f64 measures 77.5e12
+
+
+def cpu_baseline(sample_grid, threads):
+    """Time the real reference on host cores; fall back to the oracle port when oracle/_ref is absent."""
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1", MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="1")
+    for exe, blas in (("ref_harness_d_ob", "OpenBLAS"), ("ref_harness_d", "MKL")):
+        path = os.path.join(ROOT, "oracle", "_ref", exe)
+        if not os.path.exists(path):
+            continue
+        try:
+            out = subprocess.run([path, "time", "lap3d", str(sample_grid), "llt", str(threads), "/dev/null"], env=env,
+                                 capture_output=True, text=True, timeout=600)
+            line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            return {"value": round(d["gflops"], 2), "unit": "GFLOP/s", "cores": threads, "kind": "reference",
+                    "sample": "PaStiX 5.2.2.16 CPU sopalin (%s, %d threads), 3-D Laplacian %d^3 dLLt, "
+                              "%.3e flop in %.2f s" % (blas, threads, sample_grid, d["flops"], d["time"])}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("cpu_baseline: %s failed: %r\n" % (exe, e))
+    # scalar port (the oracle), one core
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from pastix_amd import symbolic as sy
+    from pastix_amd import fact_flops
+    N = 30
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm)
+    L0, _ = oracle_lib.fill(0, 1, n, cp, r, v, s["perm"], s["cblk4"], s["blok4"])
+    t = time.time()
+    oracle_lib.sopalin(0, s["cblk4"], s["blok4"], L0, None, 1e-14)
+    dt = time.time() - t
+    fl = fact_flops(s["cblk4"], s["blok4"], 0)
+    return {"value": round(fl / dt * 1e-9, 2), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": "oracle restatement (plain C, no BLAS), 3-D Laplacian %d^3 dLLt" % N}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=int(os.environ.get("PASTIX_AMD_BENCH_GRID", "200")))
+    ap.add_argument("--blocksize", type=int, default=128)
+    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--cpu-sample-grid", type=int, default=70)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pastix_amd import Plan, fact_flops
+    from pastix_amd import symbolic as sy
+    if world > 1:
+        from pastix_amd import dist as pdist
+        res = pdist.bench_distributed(a, rank, world, local)
+    else:
+        N = a.grid
+        t0 = time.time()
+        n, cp, r, v = sy.laplacian_3d(N)
+        perm, _ = sy.order_grid(N, N, N)
+        s = sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
+        c4, b4 = s["cblk4"], s["blok4"]
+        flops = fact_flops(c4, b4, 0)
+        t_sym = time.time() - t0
+        t0 = time.time()
+        plan = Plan(c4, b4, 0, device=local, lookahead=a.chunk)
+        t_plan = time.time() - t0
+        crit = 6.0 * 2 * np.sqrt(1e-31)
+        t0 = time.time()
+        plan.fill_csc(1, n, cp, r, v, s["perm"])
+        t_fill = time.time() - t0
+        for _ in range(a.warmup):
+            plan.refill()
+            plan.factorize(crit)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        ft = ut = 0.0
+        st = None
+        for _ in range(a.steps):
+            plan.refill()
+            st = plan.factorize(crit)
+            ft += st["fact_time"]
+            ut += st["update_time"]
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+        # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
+        rng = np.random.default_rng(1)
+        b = rng.random(n)
+        bp = np.empty(n)
+        bp[s["perm"]] = b
+        x = plan.solve(bp)[s["perm"]]
+        import scipy.sparse as sp
+        A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+        resid = float(np.linalg.norm(A @ x + sp.tril(A, -1).T @ x - b) / np.linalg.norm(b))
+        ps = plan.stats()
+        res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_flops=ps["update_flops"],
+                   nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
+                   blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
+                   ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu")
+        plan.close()
+
+    if rank == 0:
+        K = a.steps
+        value = res["flops"] * K / res["wall"] * 1e-9
+        upd_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
+        out = {
+            "metric": "factorization GFLOP/s, 3D 7-point Laplacian %d^3 dLLt" % a.grid,
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": a.gpus, "steps": K, "warmup": a.warmup,
+            "ms_per_step": round(res["wall"] / K * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D 7-point Laplacian %d^3 (n=%d), double LLt, geometric ND, max blocksize %d"
+                                   % (a.grid, res["n"], a.blocksize),
+                       "cblknbr": res["cblk"], "bloknbr": res["blok"], "nnzL": res["nnzl"],
+                       "fact_flops": res["flops"], "parallelism": res["parallelism"],
+                       "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * a.gpus) * 100, 2),
+                       "fact_time_s_per_step": round(res["fact_time"] / K, 4),
+                       "residual": res["resid"], "static_pivots": res["nbpivot"],
+                       "analysis_s": {"symbolic": round(res["t_sym"], 2), "plan": round(res["t_plan"], 2),
+                                      "fill_prepare": round(res["t_fill"], 2)}},
+            "roofline": {"bound": "mfma", "kernel": "k_update", "achieved": round(upd_rate * 1e-12, 3),
+                         "peak": MFMA_F64_PEAK * 1e-12, "unit": "TFLOP/s",
+                         "frac": round(upd_rate / MFMA_F64_PEAK, 4), "traffic": None,
+                         "launches_per_step": res["nlaunch"],
+                         "avg_launch_ms": round(res["update_time"] / K / max(res["nlaunch"], 1) * 1e3, 4),
+                         "flops_per_launch": res["update_flops"] / max(res["nlaunch"], 1)},
+        }
+        if a.gpus == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample_grid, min(os.cpu_count() or 1, 64))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
