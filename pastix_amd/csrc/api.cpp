@@ -18,8 +18,8 @@ void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n
                      long long* nbpivot, int* errflag);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
-void launch_solve(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t n, const DevBlok* bl,
-                  double* x);
+void launch_solve_level(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t ntask,
+                        const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* x);
 }  // namespace pastix_amd
 
 using namespace pastix_amd;
@@ -41,7 +41,8 @@ struct pastix_amd_plan_s {
   // cached coefficient fill (destinations + values) so that a re-fill is device-only
   int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
-  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr;
+  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk* dChunk = nullptr;
+  std::vector<int64_t> lvl_chunk_ptr;
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};
@@ -146,7 +147,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
-  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok);
+  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -368,17 +369,28 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);
-    for (int64_t q = 0; q < H.cblknbr; q++) {
-      const int32_t k = H.lvl_cblk[q];
-      st[q] = SolveTask{H.poff[k], (int32_t)H.cblk[k].stride, (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1),
-                        (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum};
+    std::vector<SolveChunk> ch;
+    p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
+    for (int l = 0; l < H.nlevels; l++) {
+      p->lvl_chunk_ptr[l] = (int64_t)ch.size();
+      for (int64_t q = H.lvl_cblk_ptr[l]; q < H.lvl_cblk_ptr[l + 1]; q++) {
+        const int32_t k = H.lvl_cblk[q];
+        const int32_t w = (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1), sd = (int32_t)H.cblk[k].stride;
+        st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                          (int32_t)H.cblk[k + 1].bloknum};
+        for (int32_t r = w; r < sd; r += 256)
+          ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                  (int32_t)H.cblk[k + 1].bloknum, r, std::min(256, sd - r)});
+      }
     }
+    p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
     std::vector<DevBlok> bl((size_t)H.bloknbr);
     for (int64_t b = 0; b < H.bloknbr; b++)
       bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
     int r;
     if ((r = to_device(&p->dSolve, st))) return r;
     if ((r = to_device(&p->dBlok, bl))) return r;
+    if ((r = to_device(&p->dChunk, ch))) return r;
   }
   double* dx = nullptr;
   HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * sizeof(double)));
@@ -386,11 +398,11 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   for (int64_t j = 0; j < nrhs; j++) {
     HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * sizeof(double), hipMemcpyHostToDevice, p->stream));
     for (int l = 0; l < H.nlevels; l++)
-      launch_solve(p->stream, true, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
-                   p->dBlok, dx);
+      launch_solve_level(p->stream, true, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                         p->dChunk + p->lvl_chunk_ptr[l], p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
     for (int l = H.nlevels - 1; l >= 0; l--)
-      launch_solve(p->stream, false, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
-                   p->dBlok, dx);
+      launch_solve_level(p->stream, false, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                         p->dChunk + p->lvl_chunk_ptr[l], p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
     HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
   }

@@ -454,15 +454,17 @@ __device__ __forceinline__ int panel_row_to_global(const DevBlok* __restrict__ b
   return bl[lo].frow + (p - bl[lo].coefind);
 }
 
-__global__ __launch_bounds__(256) void k_solve_fwd(const double* __restrict__ L, const SolveTask* __restrict__ tasks,
-                                                   const DevBlok* __restrict__ bl, double* __restrict__ x) {
+// forward, step 1: x_k := L_kk^-1 x_k (one workgroup per cblk)
+__global__ __launch_bounds__(256) void k_solve_diag_fwd(const double* __restrict__ L,
+                                                        const SolveTask* __restrict__ tasks,
+                                                        double* __restrict__ x) {
   __shared__ double xs[MAXW];
   const SolveTask tk = tasks[blockIdx.x];
   const double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
   for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
   __syncthreads();
-  for (int c = 0; c < w; c++) {            // diagonal blok: column-oriented forward substitution
+  for (int c = 0; c < w; c++) {            // column-oriented forward substitution
     const double xc = xs[c] / A[c + (int64_t)c * ld];
     __syncthreads();
     if (tid == 0) xs[c] = xc;
@@ -470,30 +472,59 @@ __global__ __launch_bounds__(256) void k_solve_fwd(const double* __restrict__ L,
     __syncthreads();
   }
   for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
-  for (int p = w + tid; p < ld; p += 256) { // off-diagonal rows: x[row] -= L[row,:] . x_k
+}
+
+// forward, step 2: x[row] -= L[row, :] . x_k for 256 panel rows per workgroup (one row per thread)
+__global__ __launch_bounds__(256) void k_solve_off_fwd(const double* __restrict__ L,
+                                                       const SolveChunk* __restrict__ chunks,
+                                                       const DevBlok* __restrict__ bl, double* __restrict__ x) {
+  __shared__ double xs[MAXW];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* A = L + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x;
+  for (int c = tid; c < w; c += 256) xs[c] = x[ck.fcol + c];
+  __syncthreads();
+  const int p = ck.row0 + tid;
+  if (tid < ck.nrows) {
     double s = 0;
     for (int c = 0; c < w; c++) s += A[p + (int64_t)c * ld] * xs[c];
-    unsafeAtomicAdd(&x[panel_row_to_global(bl, tk.fblok, tk.lblok, p)], -s);
+    unsafeAtomicAdd(&x[panel_row_to_global(bl, ck.fblok, ck.lblok, p)], -s);
   }
 }
 
-__global__ __launch_bounds__(256) void k_solve_bwd(const double* __restrict__ L, const SolveTask* __restrict__ tasks,
-                                                   const DevBlok* __restrict__ bl, double* __restrict__ x) {
+// backward, step 1: x_k[c] -= sum over 256 panel rows of L[row, c] * x[row]
+__global__ __launch_bounds__(256) void k_solve_off_bwd(const double* __restrict__ L,
+                                                       const SolveChunk* __restrict__ chunks,
+                                                       const DevBlok* __restrict__ bl, double* __restrict__ x) {
+  __shared__ double part[4][MAXW];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* A = L + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = ck.row0 + tid;
+  const bool valid = tid < ck.nrows;
+  const double xr = valid ? x[panel_row_to_global(bl, ck.fblok, ck.lblok, min(p, ld - 1))] : 0.0;
+  const double* Ap = A + min(p, ld - 1);
+  for (int c = 0; c < w; c++) {
+    double s = valid ? Ap[(int64_t)c * ld] * xr : 0.0;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) part[wave][c] = s;
+  }
+  __syncthreads();
+  for (int c = tid; c < w; c += 256)
+    unsafeAtomicAdd(&x[ck.fcol + c], -(part[0][c] + part[1][c] + part[2][c] + part[3][c]));
+}
+
+// backward, step 2: L_kk^T x_k = rhs
+__global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict__ L,
+                                                        const SolveTask* __restrict__ tasks,
+                                                        double* __restrict__ x) {
   __shared__ double xs[MAXW];
   const SolveTask tk = tasks[blockIdx.x];
   const double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
   for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
   __syncthreads();
-  for (int c = wave; c < w; c += 4) {       // x_k[c] -= sum_rows L[row,c] * x[row]
-    double s = 0;
-    for (int p = w + lane; p < ld; p += 64)
-      s += A[p + (int64_t)c * ld] * x[panel_row_to_global(bl, tk.fblok, tk.lblok, p)];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if (lane == 0) xs[c] -= s;
-  }
-  __syncthreads();
-  for (int c = w - 1; c >= 0; c--) {        // L_kk^T x_k = rhs : row-oriented backward substitution
+  for (int c = w - 1; c >= 0; c--) {        // row-oriented backward substitution
     const double xc = xs[c] / A[c + (int64_t)c * ld];
     __syncthreads();
     if (tid == 0) xs[c] = xc;
@@ -529,11 +560,15 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
     hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
 }
 
-void launch_solve(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t n, const DevBlok* bl,
-                  double* x) {
-  if (n <= 0) return;
-  if (fwd) hipLaunchKernelGGL(k_solve_fwd, dim3((unsigned)n), dim3(256), 0, s, L, tasks, bl, x);
-  else     hipLaunchKernelGGL(k_solve_bwd, dim3((unsigned)n), dim3(256), 0, s, L, tasks, bl, x);
+void launch_solve_level(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t ntask,
+                        const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* x) {
+  if (fwd) {
+    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
+    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
+  } else {
+    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
+    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
+  }
 }
 
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n) {

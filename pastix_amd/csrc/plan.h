@@ -61,6 +61,11 @@ struct SolveTask {
   int32_t fblok, lblok;        // blok range [fblok, lblok) in the device blok table (fblok = diagonal)
 };
 struct DevBlok { int32_t frow, lrow, coefind; };
+struct SolveChunk {            // 256 off-diagonal panel rows of one cblk
+  int64_t off;
+  int32_t stride, width, fcol, fblok, lblok;
+  int32_t row0, nrows;
+};
 
 
 struct Plan {
