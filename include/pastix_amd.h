@@ -69,7 +69,9 @@ typedef struct pastix_amd_options_s {
                             value; 1 = every source separately (right-looking), huge = once per tile
                             (left-looking); <=0 = default 512 */
   int verbose;
-  int reserved[13];
+  int external_arena;    /* 1: do not allocate the panel arena; the caller provides device memory with
+                            pastix_amd_plan_set_arena (e.g. a torch tensor used with torch.distributed) */
+  int reserved[12];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */
@@ -81,8 +83,9 @@ typedef struct pastix_amd_stats_s {
   pastix_amd_int_t nbpivot;  /* static pivots (IPARM_STATIC_PIVOTING) */
   pastix_amd_int_t coefnbr;  /* panel elements (one of L/U) */
   pastix_amd_int_t nlevels, ntasks, npieces, nupdate_launches;
-  double update_flops;     /* 2*m*n*k summed over update pieces actually issued (incl. MFMA tile padding excluded) */
-  double reserved[6];
+  double update_flops;     /* 2*m*n*k summed over the update pieces of this plan */
+  double local_flops;      /* fact_flops restricted to the cblks this plan owns (== fact_flops on one GPU) */
+  double reserved[5];
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;
@@ -121,6 +124,29 @@ int pastix_amd_refill(pastix_amd_plan_t *plan);
 
 /* numerical factorization of the device-resident panels (the hot path). */
 int pastix_amd_factorize(pastix_amd_plan_t *plan, double critere, pastix_amd_stats_t *stats);
+
+/* ---- multi-GPU: one plan per rank over the same layout ------------------------------
+ * owner[k] = rank that factorizes cblk k.  The plan holds the owned panels plus zero-initialised
+ * "shadow" panels for remote cblks that receive contributions from owned ones: the fan-in buffers of
+ * add_contrib_target (sopalin_compute.c:600-733).  Contributions are SUBTRACTED into the shadow; the
+ * caller ships each shadow to its owner (RCCL point-to-point) before the owner reaches that cblk's
+ * level, and the owner ADDS it into its panel (recv_handle_fanin, sopalin_sendrecv.c:384-389).
+ * The level-stepped calls let the caller interleave that exchange:
+ *   begin; for l in levels: factorize_level(l,1); <exchange+add shadows of level l>; factorize_level(l,2); end. */
+int pastix_amd_plan_create_dist(const pastix_amd_layout_t *layout, int factotype, int floattype,
+                                const pastix_amd_options_t *opts, const int32_t *owner, int32_t myrank,
+                                pastix_amd_plan_t **plan);
+/* poff[cblknbr+1]: arena offset of every panel (absent cblks have size 0); level[cblknbr];
+ * role[cblknbr]: 1 owned, 2 shadow, 0 absent.  Any pointer may be NULL. */
+int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *poff, int32_t *level,
+                                int8_t *role);
+int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);   /* with opts.external_arena */
+int pastix_amd_plan_set_stream(pastix_amd_plan_t *plan, void *hip_stream);     /* run on the caller's stream */
+int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
+/* phase 0: contributions of slot `level` then the owned cblks of `level`; 1: contributions only;
+ * 2: cblks only (the fan-in exchange for cblks of `level` goes between phase 1 and phase 2) */
+int pastix_amd_factorize_level(pastix_amd_plan_t *plan, int level, int phase);
+int pastix_amd_factorize_end(pastix_amd_plan_t *plan, pastix_amd_stats_t *stats);
 
 /* triangular solves on the device-resident factors, x (permuted numbering, n x nrhs, ld n) in place */
 int pastix_amd_solve(pastix_amd_plan_t *plan, void *x, pastix_amd_int_t nrhs);

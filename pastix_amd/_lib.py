@@ -30,7 +30,7 @@ class Layout(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
-                ("reserved", ctypes.c_int * 13)]
+                ("external_arena", ctypes.c_int), ("reserved", ctypes.c_int * 12)]
 
 
 class Stats(ctypes.Structure):
@@ -38,7 +38,8 @@ class Stats(ctypes.Structure):
                 ("update_time", ctypes.c_double), ("h2d_time", ctypes.c_double),
                 ("d2h_time", ctypes.c_double), ("nbpivot", i64), ("coefnbr", i64),
                 ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64),
-                ("update_flops", ctypes.c_double), ("reserved", ctypes.c_double * 6)]
+                ("update_flops", ctypes.c_double), ("local_flops", ctypes.c_double),
+                ("reserved", ctypes.c_double * 5)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -63,6 +64,9 @@ EXPORTS = [
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
     "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve",
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
+    "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena",
+    "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
+    "pastix_amd_factorize_end",
 ]
 # include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
 EXPORTS_HOST = [

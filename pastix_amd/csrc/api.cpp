@@ -28,6 +28,9 @@ struct pastix_amd_plan_s {
   Plan host;
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true, own_arena = true, distributed = false;
+  int nupd_run = 0;
+  double crit_run = 0;
   double* dL = nullptr;
   double* dU = nullptr;
   double* dDinv = nullptr;
@@ -78,15 +81,16 @@ double pastix_amd_fact_flops(const pastix_amd_layout_t* layout, int factotype, i
   return fact_flops(layout, factotype, floattype);
 }
 
-int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int floattype,
-                           const pastix_amd_options_t* opts, pastix_amd_plan_t** out) {
+static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, int floattype,
+                              const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank,
+                              pastix_amd_plan_t** out) {
   if (!out) return PASTIX_AMD_ERR_BADPARAMETER;
   *out = nullptr;
   pastix_amd_plan_s* p = new (std::nothrow) pastix_amd_plan_s();
   if (!p) return PASTIX_AMD_ERR_ALLOC;
   int rc;
   try {
-    rc = build_plan(layout, factotype, floattype, opts, p->host);
+    rc = build_plan(layout, factotype, floattype, opts, owner, myrank, p->host);
   } catch (const std::bad_alloc&) {
     rc = PASTIX_AMD_ERR_ALLOC;
   }
@@ -104,9 +108,13 @@ int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int
   auto body = [&]() -> int {
     HIPCHK(hipSetDevice(p->device));
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void**)&p->dL, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
-    if (H.factotype != PASTIX_AMD_FACT_LLT)
-      HIPCHK(hipMalloc((void**)&p->dU, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+    p->distributed = owner != nullptr;
+    p->own_arena = !(opts && opts->external_arena);
+    if (p->own_arena) {
+      HIPCHK(hipMalloc((void**)&p->dL, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+      if (H.factotype != PASTIX_AMD_FACT_LLT)
+        HIPCHK(hipMalloc((void**)&p->dU, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+    }
     HIPCHK(hipMalloc((void**)&p->dDinv, std::max<int64_t>(H.dinv_ws, 256) * sizeof(double)));
     int r;
     if ((r = to_device(&p->dTasks, H.tasks))) return r;
@@ -127,6 +135,7 @@ int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int
     p->maxw = std::max<int>(p->maxw, (int)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1));
   pastix_amd_stats_t& S = p->stats;
   S.fact_flops = H.fact_flops;
+  S.local_flops = H.local_flops;
   S.coefnbr = H.coefnbr;
   S.nlevels = H.nlevels;
   S.ntasks = (int64_t)H.tasks.size();
@@ -139,11 +148,48 @@ int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int
   return PASTIX_AMD_OK;
 }
 
+int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int floattype,
+                           const pastix_amd_options_t* opts, pastix_amd_plan_t** out) {
+  return plan_create_common(layout, factotype, floattype, opts, nullptr, 0, out);
+}
+
+int pastix_amd_plan_create_dist(const pastix_amd_layout_t* layout, int factotype, int floattype,
+                                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank,
+                                pastix_amd_plan_t** out) {
+  if (!owner) return PASTIX_AMD_ERR_BADPARAMETER;
+  return plan_create_common(layout, factotype, floattype, opts, owner, myrank, out);
+}
+
+int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU) {
+  if (!p || !dL || p->own_arena) return PASTIX_AMD_ERR_BADPARAMETER;
+  p->dL = (double*)dL;
+  p->dU = (double*)dU;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_plan_set_stream(pastix_amd_plan_t* p, void* stream) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (p->own_stream && p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+  p->stream = (hipStream_t)stream;
+  p->own_stream = false;
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_plan_layout_info(const pastix_amd_plan_t* p, pastix_amd_int_t* poff, int32_t* level, int8_t* role) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  if (poff) std::memcpy(poff, H.poff.data(), (size_t)(H.cblknbr + 1) * sizeof(int64_t));
+  if (level) std::memcpy(level, H.level.data(), (size_t)H.cblknbr * sizeof(int32_t));
+  if (role) std::memcpy(role, H.role.data(), (size_t)H.cblknbr);
+  return PASTIX_AMD_OK;
+}
+
 void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  (void)hipFree(p->dL); (void)hipFree(p->dU); (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
+  if (p->own_arena) { (void)hipFree(p->dL); (void)hipFree(p->dU); }
+  (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
@@ -151,7 +197,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
 
@@ -196,6 +242,7 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
   double t0 = now_s();
   for (int64_t k = 0; k < H.cblknbr; k++) {
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
     HIPCHK(hipMemcpyAsync(p->dL + H.poff[k], coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
@@ -213,6 +260,7 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
   double t0 = now_s();
   for (int64_t k = 0; k < H.cblknbr; k++) {
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
     HIPCHK(hipMemcpyAsync(coeftab[k], p->dL + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
@@ -245,7 +293,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   valL.reserve((size_t)nnz * (sym ? 2 : 1));
   auto locate = [&](int64_t pr, int64_t pc, bool offdiag_only) -> int64_t {
     const int64_t kc = col2cblk[pc];
-    if (pr < H.cblk[kc].fcolnum) return -1;
+    if (H.role[kc] != 1 || pr < H.cblk[kc].fcolnum) return -1;   // only owned panels are filled
     int64_t lo = H.cblk[kc].bloknum, hi = H.cblk[kc + 1].bloknum - 1, fb = lo;
     while (lo < hi) {
       int64_t mid = (lo + hi + 1) >> 1;
@@ -289,7 +337,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
 
 // Re-apply the cached coefficient fill (device only): zero the panels, scatter the values.
 int pastix_amd_refill(pastix_amd_plan_t* p) {
-  if (!p || !p->dFillIdxL) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (!p || (!p->dFillIdxL && p->nFillL != 0) || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
@@ -300,33 +348,42 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   return PASTIX_AMD_OK;
 }
 
-// The device replacement of sopalin_smp's task loop (sopalin3d.c:790-1025): for every dependency
-// level s: apply the contributions scheduled into slot s (k_update), then factorize the cblks of
-// level s (k_diag + k_trsm).  Time is measured like DPARM_FACT_TIME: panels resident, first launch
-// to last completion (sopalin3d.c:775,1031,1125-1132).
-int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
-  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
-  const Plan& H = p->host;
+int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
+  if (!p || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   HIPCHK(hipMemsetAsync(p->dNbpivot, 0, sizeof(long long), s));
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
-  HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipEventRecord(p->ev0, s));
-  int nupd = 0;
-  for (int l = 0; l < H.nlevels; l++) {
-    const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
-    if (t1 > t0) {
-      HIPCHK(hipEventRecord(p->ev[2 * nupd], s));
-      launch_update(s, p->dL, p->dU, p->dTasks + t0, p->dPieces, t1 - t0);
-      HIPCHK(hipEventRecord(p->ev[2 * nupd + 1], s));
-      nupd++;
-    }
-    launch_diag_llt(s, p->dL, p->dPanel + H.lvl_panel_ptr[l], H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l],
-                    p->dDinv, critere, p->dNbpivot, p->dErr);
-    launch_trsm_llt(s, p->dL, p->dTrsm + H.lvl_trsm_ptr[l], H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l],
-                    p->dDinv, p->maxw);
+  p->nupd_run = 0;
+  p->crit_run = critere;
+  return PASTIX_AMD_OK;
+}
+
+// one dependency level: contributions scheduled into slot l, then the owned cblks of level l
+int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
+  if (!p || l < 0 || l >= p->host.nlevels) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  hipStream_t s = p->stream;
+  const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
+  if (t1 > t0 && phase != 2) {
+    HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
+    launch_update(s, p->dL, p->dU, p->dTasks + t0, p->dPieces, t1 - t0);
+    HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
+    p->nupd_run++;
   }
+  if (phase == 1) return PASTIX_AMD_OK;
+  launch_diag_llt(s, p->dL, p->dPanel + H.lvl_panel_ptr[l], H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l],
+                  p->dDinv, p->crit_run, p->dNbpivot, p->dErr);
+  launch_trsm_llt(s, p->dL, p->dTrsm + H.lvl_trsm_ptr[l], H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l],
+                  p->dDinv, p->maxw);
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  hipStream_t s = p->stream;
   HIPCHK(hipEventRecord(p->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
@@ -351,7 +408,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     }
   }
   p->stats.update_time = upd;
-  p->stats.nupdate_launches = nupd;
+  p->stats.nupdate_launches = p->nupd_run;
   long long nb = 0;
   int err = 0;
   HIPCHK(hipMemcpy(&nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
@@ -361,11 +418,25 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   return err ? PASTIX_AMD_ERR_NUMERIC : PASTIX_AMD_OK;
 }
 
+// The device replacement of sopalin_smp's task loop (sopalin3d.c:790-1025): for every dependency
+// level s: apply the contributions scheduled into slot s (k_update), then factorize the cblks of
+// level s (k_diag + k_trsm).  Time is measured like DPARM_FACT_TIME: panels resident, first launch
+// to last completion (sopalin3d.c:775,1031,1125-1132).
+int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
+  int rc = pastix_amd_factorize_begin(p, critere);
+  if (rc) return rc;
+  for (int l = 0; l < p->host.nlevels; l++)
+    if ((rc = pastix_amd_factorize_level(p, l, 0))) return rc;
+  return pastix_amd_factorize_end(p, stats);
+}
+
 // Forward / backward substitution on the device-resident factors (LLt), x in permuted numbering.
 int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
-  if (H.factotype != PASTIX_AMD_FACT_LLT) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (H.factotype != PASTIX_AMD_FACT_LLT || p->distributed) return PASTIX_AMD_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);

@@ -85,7 +85,7 @@ static int check_layout(const pastix_amd_layout_t* L) {
 }
 
 int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
-               const pastix_amd_options_t* opts, Plan& P) {
+               const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& P) {
   int rc = check_layout(L);
   if (rc) return rc;
   if (floattype != PASTIX_AMD_REALDOUBLE) return PASTIX_AMD_ERR_UNSUPPORTED;
@@ -105,17 +105,39 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.bloknbr = L->bloknbr;
   P.cblk.assign(L->cblktab, L->cblktab + nc + 1);
   P.blok.assign(L->bloktab, L->bloktab + L->bloknbr);
+  // ownership (multi-GPU fan-in): owned cblks are factorized here; a remote cblk that
+  // receives contributions from an owned source gets a zero-initialised shadow panel in which the
+  // (negated) local contributions are accumulated (add_contrib_target, sopalin_compute.c:600-733)
+  P.role.assign(nc, owner ? 0 : 1);
+  if (owner) {
+    for (int64_t k = 0; k < nc; k++) if (owner[k] == myrank) P.role[k] = 1;
+    for (int64_t k = 0; k < nc; k++) {
+      if (P.role[k] != 1) continue;
+      for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
+        if (P.role[P.blok[b].cblknum] == 0) P.role[P.blok[b].cblknum] = 2;
+    }
+  }
   P.poff.resize(nc + 1);
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
     int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
     if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
-    P.poff[k + 1] = P.poff[k] + P.cblk[k].stride * w;
+    P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.cblk[k].stride * w : 0);
   }
   P.coefnbr = P.poff[nc];
   P.ncol = P.cblk[nc - 1].lcolnum + 1;
   P.fact_flops = fact_flops(L, factotype, floattype);
+  P.local_flops = 0;
+  for (int64_t k = 0; k < nc; k++) {
+    if (P.role[k] != 1) continue;
+    pastix_amd_cblk_t two[2] = {P.cblk[k], P.cblk[k + 1]};
+    two[0].fcolnum = 0; two[0].lcolnum = P.cblk[k].lcolnum - P.cblk[k].fcolnum;
+    const int64_t b0 = two[0].bloknum;
+    two[0].bloknum = 0; two[1].bloknum -= b0;
+    pastix_amd_layout_t one{1, two[1].bloknum, two, P.blok.data() + b0};
+    P.local_flops += fact_flops(&one, factotype, floattype);
+  }
 
   // ---- dependency levels -----------------------------------------------------------------
   P.level.assign(nc, 0);
@@ -129,18 +151,19 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
 
   // cblks by level
   P.lvl_cblk_ptr.assign(NL + 1, 0);
-  for (int64_t k = 0; k < nc; k++) P.lvl_cblk_ptr[P.level[k] + 1]++;
+  for (int64_t k = 0; k < nc; k++) if (P.role[k] == 1) P.lvl_cblk_ptr[P.level[k] + 1]++;
   for (int l = 0; l < NL; l++) P.lvl_cblk_ptr[l + 1] += P.lvl_cblk_ptr[l];
-  P.lvl_cblk.resize(nc);
+  const int64_t nowned = P.lvl_cblk_ptr[NL];
+  P.lvl_cblk.resize(nowned);
   {
     std::vector<int64_t> pos(P.lvl_cblk_ptr.begin(), P.lvl_cblk_ptr.end() - 1);
-    for (int64_t k = 0; k < nc; k++) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
+    for (int64_t k = 0; k < nc; k++) if (P.role[k] == 1) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
   }
 
   // ---- panel / trsm tasks per level ------------------------------------------------------------
   P.lvl_panel_ptr.assign(NL + 1, 0);
   P.lvl_trsm_ptr.assign(NL + 1, 0);
-  P.panel_tasks.resize(nc);
+  P.panel_tasks.resize(nowned);
   P.dinv_ws = 0;
   for (int l = 0; l < NL; l++) {
     int64_t ws = 0;
@@ -166,7 +189,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
     P.dinv_ws = std::max(P.dinv_ws, ws);
   }
-  P.lvl_panel_ptr[NL] = nc;
+  P.lvl_panel_ptr[NL] = nowned;
   P.lvl_trsm_ptr[NL] = (int64_t)P.trsm_tasks.size();
 
   // ---- update pieces -----------------------------------------------------------------------------
@@ -215,6 +238,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   };
 
   for (int64_t k = 0; k < nc; k++) {
+    if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
     const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
     for (int64_t i = fb + 1; i < lb; i++) {
       const int64_t t = P.blok[i].cblknum;

@@ -74,7 +74,10 @@ struct Plan {
   int64_t cblknbr = 0, bloknbr = 0, coefnbr = 0, ncol = 0;
   std::vector<pastix_amd_cblk_t> cblk;   // [cblknbr+1]
   std::vector<pastix_amd_blok_t> blok;
-  std::vector<int64_t> poff;             // panel offsets [cblknbr+1]
+  std::vector<int64_t> poff;             // panel offsets [cblknbr+1] (absent cblks have size 0)
+  std::vector<int8_t> role;              // per cblk: 1 owned (factorized here), 2 shadow (fan-in
+                                         // accumulator for a remote cblk), 0 absent
+  double local_flops = 0;                // fact_flops restricted to owned cblks
   std::vector<int32_t> level;            // dependency level of each cblk
   int32_t nlevels = 0;
 
@@ -103,7 +106,7 @@ struct Plan {
 
 // Build the host plan. Returns PASTIX_AMD_OK or an error code.
 int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
-               const pastix_amd_options_t* opts, Plan& plan);
+               const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
 

@@ -1,0 +1,313 @@
+"""Multi-GPU factorization: elimination-tree subtrees mapped one per GPU, fan-in of aggregated
+contributions over point-to-point messages.
+
+Reference model: proportional mapping + fan-in of PaStiX (`FanInTarget`, src/blend/src/ftgt.h:67-113;
+`add_contrib_target`, src/sopalin/src/sopalin_compute.c:600-733: local contributions are SUBTRACTED into a
+zero-initialised buffer; `recv_handle_fanin`, src/sopalin/src/sopalin_sendrecv.c:384-389: the owner ADDS
+the received block).  Here every rank holds one plan over the same layout
+(`pastix_amd_plan_create_dist`): its owned panels plus "shadow" panels for the remote cblks it
+contributes to.  All ranks walk the dependency levels in lockstep:
+
+    for l in levels:
+        update(l)                      # contributions scheduled into slot l (into owned or shadow panels)
+        exchange shadows of the cblks of level l  (one message per (sender, cblk), RCCL send/recv)
+        owner adds the received blocks
+        panels(l)                      # diagonal factor + panel solve of the owned cblks of level l
+
+There is no collective on the data path.  The orchestration is engine-agnostic (GPU engine below; the
+CPU tests drive the same code with a numpy engine over gloo).
+"""
+import ctypes
+import heapq
+
+import numpy as np
+
+from . import _lib
+from ._lib import LayoutArrays, Options, Stats, check
+
+
+# ------------------------------------------------------------------------------------------------
+# partition
+# ------------------------------------------------------------------------------------------------
+def cblk_flops(cblk4, blok4):
+    """Per-cblk share of DPARM_FACT_FLOPS for LLt (blend_symbol_cost.c:382-430)."""
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    nc = len(c4) - 1
+    N = (c4[:-1, 1] - c4[:-1, 0] + 1).astype(np.float64)
+    S = c4[:-1, 3].astype(np.float64)
+    M = S - N
+    fl = N * (((1. / 6.) * N + 0.5) * N + (1. / 3.)) + N * (((1. / 6.) * N) * N - (1. / 6.)) + M * N * (N + 1.)
+    owner_of_blok = np.repeat(np.arange(nc), np.diff(c4[:, 2]))
+    h = (b4[:, 1] - b4[:, 0] + 1).astype(np.float64)
+    offd = b4[:, 3] > 0                         # off-diagonal bloks (coefind > 0)
+    rem = S[owner_of_blok] - b4[:, 3]
+    g = 2.0 * rem * h * N[owner_of_blok] * offd
+    fl += np.bincount(owner_of_blok, weights=g, minlength=nc)
+    return fl
+
+
+def partition(cblk4, blok4, world, split=6):
+    """owner[k] for every cblk: disjoint subtrees of the (cblk) elimination tree go to one rank each
+    (largest first onto the least loaded rank); the cblks above the cut are dealt out by their own work.
+    The heaviest subtree is split until it is lighter than total/(split*world)."""
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    nc = len(c4) - 1
+    owner = np.zeros(nc, dtype=np.int32)
+    if world <= 1:
+        return owner
+    fl = cblk_flops(c4, b4)
+    nb = np.diff(c4[:, 2])
+    parent = np.full(nc, -1, dtype=np.int64)
+    has = nb > 1
+    parent[has] = b4[c4[:-1, 2][has] + 1, 2]
+    sub = fl.copy()
+    kids = [[] for _ in range(nc)]
+    for k in range(nc):
+        p = parent[k]
+        if p >= 0:
+            sub[p] += sub[k]
+            kids[p].append(k)
+    total = float(fl.sum())
+    heap = [(-sub[k], k) for k in range(nc) if parent[k] < 0]
+    heapq.heapify(heap)
+    top = []
+    limit = total / (split * world)
+    while heap and (-heap[0][0] > limit or len(heap) < world) and len(heap) < 64 * world:
+        _, r = heapq.heappop(heap)
+        top.append(r)
+        for c in kids[r]:
+            heapq.heappush(heap, (-sub[c], c))
+    load = np.zeros(world)
+    owner[:] = -1
+    for negf, r in sorted(heap):
+        q = int(np.argmin(load))
+        owner[r] = q
+        load[q] += -negf
+    in_top = np.zeros(nc, dtype=bool)
+    in_top[top] = True
+    for k in range(nc - 1, -1, -1):              # parents have larger indices than their children
+        if owner[k] < 0 and not in_top[k]:
+            owner[k] = owner[parent[k]]
+    for k in sorted(top, key=lambda t: -fl[t]):
+        q = int(np.argmin(load))
+        owner[k] = q
+        load[q] += fl[k]
+    assert (owner >= 0).all()
+    return owner
+
+
+def levels_of(cblk4, blok4):
+    """Dependency level of every cblk (same rule as plan.cpp)."""
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    nc = len(c4) - 1
+    level = np.zeros(nc, dtype=np.int32)
+    src = np.repeat(np.arange(nc), np.diff(c4[:, 2]))
+    offd = b4[:, 3] > 0
+    s, t = src[offd], b4[offd, 2]
+    for k, f in zip(s.tolist(), t.tolist()):     # sources in increasing order => one pass suffices
+        if level[f] < level[k] + 1:
+            level[f] = level[k] + 1
+    return level
+
+
+def fanin_pairs(cblk4, blok4, owner):
+    """All (sender rank, cblk) pairs: rank r owns a cblk with a blok facing cblk t owned by another rank."""
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    nc = len(c4) - 1
+    src = np.repeat(np.arange(nc), np.diff(c4[:, 2]))
+    offd = b4[:, 3] > 0
+    r = owner[src[offd]].astype(np.int64)
+    t = b4[offd, 2]
+    m = r != owner[t]
+    return np.unique(np.stack([r[m], t[m]], axis=1), axis=0)
+
+
+class Exchange:
+    """Per-level send / receive lists of one rank (deterministic order on every rank)."""
+
+    def __init__(self, cblk4, blok4, owner, level, rank):
+        pairs = fanin_pairs(cblk4, blok4, owner)
+        nlev = int(level.max()) + 1
+        self.sends = [[] for _ in range(nlev)]      # (cblk, destination rank)
+        self.recvs = [[] for _ in range(nlev)]      # (cblk, source rank)
+        for r, t in pairs.tolist():
+            if r == rank:
+                self.sends[level[t]].append((t, int(owner[t])))
+            elif owner[t] == rank:
+                self.recvs[level[t]].append((t, r))
+        self.nlevels = nlev
+
+
+def factorize_levels(engine, exch, transport):
+    """The lockstep level loop.  engine: update(l), panels(l), panel(k) -> 1-D view;
+    transport.exchange(sends=[(view, dst)], recvs=[(cblk, src, numel)]) -> list of received 1-D buffers
+    (same order as recvs)."""
+    for l in range(exch.nlevels):
+        engine.update(l)
+        if exch.sends[l] or exch.recvs[l]:
+            sends = [(engine.panel(t), dst) for t, dst in exch.sends[l]]
+            recvs = [(t, src, engine.panel(t).numel() if hasattr(engine.panel(t), "numel") else engine.panel(t).size)
+                     for t, src in exch.recvs[l]]
+            bufs = transport.exchange(sends, recvs)
+            for (t, _src, _n), buf in zip(recvs, bufs):
+                engine.add(t, buf)                 # recv_handle_fanin: owner ADDS the aggregated block
+        engine.panels(l)
+
+
+class TorchTransport:
+    """RCCL / gloo point-to-point through torch.distributed (one grouped batch per level)."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = device
+
+    def exchange(self, sends, recvs):
+        import torch.distributed as dist
+        torch = self.torch
+        ops, bufs = [], []
+        for t, src, n in recvs:
+            b = torch.empty(n, dtype=torch.float64, device=self.device)
+            bufs.append(b)
+            ops.append(dist.P2POp(dist.irecv, b, src))
+        for view, dst in sends:
+            ops.append(dist.P2POp(dist.isend, view, dst))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return bufs
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU engine (the C ABI) -- panels live in a torch tensor so that torch.distributed can ship them
+# ------------------------------------------------------------------------------------------------
+class GpuEngine:
+    def __init__(self, cblk4, blok4, owner, rank, device_index, chunk=0):
+        import torch
+        self.torch = torch
+        self.layout = LayoutArrays(cblk4, blok4)
+        self.rank = rank
+        opts = Options()
+        opts.device = device_index
+        opts.lookahead = chunk
+        opts.external_arena = 1
+        self._h = ctypes.c_void_p()
+        own = np.ascontiguousarray(owner, dtype=np.int32)
+        check(_lib.lib().pastix_amd_plan_create_dist(ctypes.byref(self.layout.c), 0, 1, ctypes.byref(opts),
+                                                     _lib.ptr(own), ctypes.c_int32(rank), ctypes.byref(self._h)),
+              "pastix_amd_plan_create_dist")
+        nc = self.layout.cblknbr
+        self.poff = np.zeros(nc + 1, dtype=np.int64)
+        self.level = np.zeros(nc, dtype=np.int32)
+        self.role = np.zeros(nc, dtype=np.int8)
+        check(_lib.lib().pastix_amd_plan_layout_info(self._h, _lib.ptr(self.poff), _lib.ptr(self.level),
+                                                     _lib.ptr(self.role)), "pastix_amd_plan_layout_info")
+        self.device = torch.device("cuda", device_index)
+        self.arena = torch.zeros(max(int(self.poff[-1]), 1), dtype=torch.float64, device=self.device)
+        check(_lib.lib().pastix_amd_plan_set_arena(self._h, ctypes.c_void_p(self.arena.data_ptr()), None),
+              "pastix_amd_plan_set_arena")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.lib().pastix_amd_plan_set_stream(self._h, ctypes.c_void_p(stream)), "pastix_amd_plan_set_stream")
+
+    def close(self):
+        if self._h:
+            _lib.lib().pastix_amd_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def stats(self):
+        s = Stats()
+        check(_lib.lib().pastix_amd_plan_stats(self._h, ctypes.byref(s)), "pastix_amd_plan_stats")
+        return s.as_dict()
+
+    def fill_csc(self, sym, n, colptr, rows, vals, perm):
+        colptr, rows, perm = _lib.as_i64(colptr), _lib.as_i64(rows), _lib.as_i64(perm)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        check(_lib.lib().pastix_amd_fill_csc(self._h, int(sym), ctypes.c_int64(n), _lib.ptr(colptr), _lib.ptr(rows),
+                                             _lib.ptr(vals), _lib.ptr(perm)), "pastix_amd_fill_csc")
+
+    def refill(self):
+        check(_lib.lib().pastix_amd_refill(self._h), "pastix_amd_refill")
+
+    def begin(self, critere):
+        check(_lib.lib().pastix_amd_factorize_begin(self._h, ctypes.c_double(critere)), "pastix_amd_factorize_begin")
+
+    def update(self, l):
+        check(_lib.lib().pastix_amd_factorize_level(self._h, int(l), 1), "pastix_amd_factorize_level")
+
+    def panels(self, l):
+        check(_lib.lib().pastix_amd_factorize_level(self._h, int(l), 2), "pastix_amd_factorize_level")
+
+    def end(self):
+        s = Stats()
+        check(_lib.lib().pastix_amd_factorize_end(self._h, ctypes.byref(s)), "pastix_amd_factorize_end")
+        return s.as_dict()
+
+    def panel(self, k):
+        return self.arena[int(self.poff[k]):int(self.poff[k + 1])]
+
+    def add(self, k, buf):
+        self.panel(k).add_(buf)
+
+
+def bench_distributed(a, rank, world, local):
+    """bench.py's N>1 leg: every rank analyses the same matrix, owns a share of the elimination tree."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import fact_flops
+    from . import symbolic as sy
+    N = a.grid
+    t0 = time.time()
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
+    c4, b4 = s["cblk4"], s["blok4"]
+    flops = fact_flops(c4, b4, 0)
+    owner = partition(c4, b4, world)
+    level = levels_of(c4, b4)
+    exch = Exchange(c4, b4, owner, level, rank)
+    t_sym = time.time() - t0
+    t0 = time.time()
+    eng = GpuEngine(c4, b4, owner, rank, local, chunk=a.chunk)
+    t_plan = time.time() - t0
+    tr = TorchTransport(eng.device)
+    crit = 6.0 * 2 * np.sqrt(1e-31)
+    t0 = time.time()
+    eng.fill_csc(1, n, cp, r, v, s["perm"])
+    t_fill = time.time() - t0
+
+    def step():
+        eng.refill()
+        eng.begin(crit)
+        factorize_levels(eng, exch, tr)
+        return eng.end()
+
+    for _ in range(a.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ft = ut = 0.0
+    st = None
+    for _ in range(a.steps):
+        st = step()
+        ft += st["fact_time"]
+        ut += st["update_time"]
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.time() - t0
+    ps = eng.stats()
+    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"]], dtype=torch.float64, device=eng.device)
+    mx = tw.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    sm = tw.clone()
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    nsend = sum(len(x) for x in exch.sends)
+    res = dict(wall=float(mx[0]), flops=flops, fact_time=ft, update_time=float(sm[1]) / world,
+               update_flops=float(sm[2]) / world, nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
+               n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
+               t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
+               parallelism="subtree-per-gpu fan-in x%d (rank0 owns %.1f%% of flops, %d fan-in sends/rank0)"
+                           % (world, 100.0 * ps["local_flops"] / flops, nsend))
+    eng.close()
+    return res

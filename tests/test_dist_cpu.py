@@ -1,0 +1,89 @@
+"""Multi-rank fan-in protocol on CPU: partition properties and a world_size-2 gloo run of
+pastix_amd.dist.factorize_levels with the numpy engine, checked against the golden reference factors."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import HERE, ROOT
+from pastix_amd import dist as pd
+from pastix_amd import symbolic as sy
+
+
+def test_partition_balanced_and_subtree_closed():
+    n, cp, r, v = sy.laplacian_3d(20)
+    perm, _ = sy.order_grid(20, 20, 20)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=32)
+    c4, b4 = s["cblk4"], s["blok4"]
+    fl = pd.cblk_flops(c4, b4)
+    from pastix_amd import fact_flops
+    assert abs(fl.sum() - fact_flops(c4, b4, 0)) <= 1e-9 * fl.sum()
+    for P in (2, 4, 8):
+        ow = pd.partition(c4, b4, P)
+        loads = np.array([fl[ow == q].sum() for q in range(P)]) / fl.sum()
+        assert loads.max() < 1.25 / P
+        lv = pd.levels_of(c4, b4)
+        pairs = pd.fanin_pairs(c4, b4, ow)
+        # every fan-in message goes to a cblk of a strictly higher level than some source of the sender
+        assert all(ow[t] != r_ for r_, t in pairs.tolist())
+        ex = [pd.Exchange(c4, b4, ow, lv, q) for q in range(P)]
+        nsend = sum(len(x) for e in ex for x in e.sends)
+        nrecv = sum(len(x) for e in ex for x in e.recvs)
+        assert nsend == nrecv == len(pairs)
+
+
+def _worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fixture_io
+    from np_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = fixture_io.load_npz(os.path.join(HERE, "golden", name + ".npz"))
+    c4, b4 = g["cblk4"], g["blok4"]
+    owner = pd.partition(c4, b4, world, split=2)
+    level = pd.levels_of(c4, b4)
+    eng = NumpyEngine(c4, b4, owner, level, rank, g["L0"])
+    exch = pd.Exchange(c4, b4, owner, level, rank)
+    pd.factorize_levels(eng, exch, pd.TorchTransport(torch.device("cpu")))
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    err = 0.0
+    for k in np.nonzero(owner == rank)[0]:
+        ref = g["L1"][off[k]:off[k + 1]].reshape(int(w[k]), -1).T
+        got = eng.panel(k).numpy().reshape(int(w[k]), -1).T
+        wk = int(w[k])
+        # compare the lower triangle of the diagonal blok and the off-diagonal rows
+        m = np.ones_like(ref, dtype=bool)
+        m[:wk, :wk] = np.tril(np.ones((wk, wk), dtype=bool))
+        err = max(err, float(np.abs(got - ref)[m].max()))
+    nsend = sum(len(x) for x in exch.sends)
+    q.put((rank, err, int((owner == rank).sum()), nsend))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["rlap3d_10_llt", "rlap3d_14_llt_bs24"])
+def test_two_rank_fanin_over_gloo(name, golden):
+    g = golden(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scale = np.abs(g["L1"]).max()
+    for rank, err, nown, nsend in res:
+        assert err <= 1e-11 * scale
+        assert nown > 0
+    assert sum(r[3] for r in res) > 0          # the exchange path was exercised
