@@ -141,6 +141,12 @@ int pastix_amd_plan_create_dist(const pastix_amd_layout_t *layout, int factotype
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *poff, int32_t *level,
                                 int8_t *role);
 int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);   /* with opts.external_arena */
+/* host-only schedule statistics of one rank (no device needed): per launch slot the update flops, the
+ * largest task (multiply-adds), the task count, and per level the panel (diag+trsm) flops */
+int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
+                            const int32_t *owner, int32_t myrank, pastix_amd_int_t maxlevels, double *slot_flops,
+                            double *slot_maxwork, pastix_amd_int_t *slot_tasks, double *level_panel_flops,
+                            pastix_amd_int_t *nlevels);
 int pastix_amd_plan_set_stream(pastix_amd_plan_t *plan, void *hip_stream);     /* run on the caller's stream */
 int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
 /* phase 0: contributions of slot `level` then the owned cblks of `level`; 1: contributions only;

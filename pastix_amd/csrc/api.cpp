@@ -160,6 +160,39 @@ int pastix_amd_plan_create_dist(const pastix_amd_layout_t* layout, int factotype
   return plan_create_common(layout, factotype, floattype, opts, owner, myrank, out);
 }
 
+// Host-only: build the schedule of one rank and report per-slot update flops / largest task / task
+// count (capacity-planning aid for the multi-GPU partition; needs no device).
+int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, const pastix_amd_options_t* opts,
+                            const int32_t* owner, int32_t myrank, pastix_amd_int_t maxlevels, double* slot_flops,
+                            double* slot_maxwork, pastix_amd_int_t* slot_tasks, double* level_panel_flops,
+                            pastix_amd_int_t* nlevels) {
+  if (!layout || !nlevels) return PASTIX_AMD_ERR_BADPARAMETER;
+  Plan P;
+  int rc;
+  try {
+    rc = build_plan(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, owner, myrank, P);
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  if (rc) return rc;
+  *nlevels = P.nlevels;
+  for (int l = 0; l < P.nlevels && l < maxlevels; l++) {
+    if (slot_flops) slot_flops[l] = P.slot_flops[l];
+    if (slot_maxwork) slot_maxwork[l] = P.slot_maxwork[l];
+    if (slot_tasks) slot_tasks[l] = P.slot_task_ptr[l + 1] - P.slot_task_ptr[l];
+    if (level_panel_flops) {
+      double f = 0;
+      for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
+        const int32_t k = P.lvl_cblk[q];
+        const double N = double(P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1), M = double(P.cblk[k].stride) - N;
+        f += N * N * N / 3.0 + M * N * (N + 1.0);
+      }
+      level_panel_flops[l] = f;
+    }
+  }
+  return PASTIX_AMD_OK;
+}
+
 int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU) {
   if (!p || !dL || p->own_arena) return PASTIX_AMD_ERR_BADPARAMETER;
   p->dL = (double*)dL;

@@ -103,6 +103,28 @@ __device__ __forceinline__ bool piece_full(const Piece& pc) {
   return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && (pc.k & (KC - 1)) == 0;
 }
 
+// Epilogue variant for tiles that several workgroups update in the same launch (split piece lists of
+// the multi-GPU fan-in schedule): accumulate with f64 atomics instead of an exclusive read-modify-write.
+template <int MI, int NI>
+__device__ __forceinline__ void epilogue_atomic(double* C, const d4 (&acc)[MI][NI], unsigned touched, int row0,
+                                                int col0, int l15, int g, int tm1, int tn1, int ldc) {
+#pragma unroll
+  for (int mi = 0; mi < MI; mi++) {
+    if (!((touched >> mi) & 1u)) continue;
+    const int r = row0 + mi * 16 + l15;
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++) {
+      if (!((touched >> (4 + ni)) & 1u)) continue;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = col0 + ni * 16 + g + 4 * q;
+        if (r <= tm1 && c <= tn1) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -acc[mi][ni][q]);
+      }
+    }
+  }
+}
+
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__ L, double* __restrict__ U,
                                                            const Task* __restrict__ tasks,
@@ -215,6 +237,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__
   // 16-row band are issued together from clamped addresses (one latency per band, not per element).
   double* C = ((tk.flags & 1) ? U : L) + tk.c_off;
   const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
+  if (tk.flags & 2) {
+    epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
     if (!((touched >> mi) & 1u)) continue;

@@ -53,6 +53,7 @@ struct RawPiece {
   int64_t tile;   // target tile id (+ntile for the U arena)
   int32_t lvl;    // level of the source cblk
   uint8_t carena; // 0: L arena, 1: U arena
+  uint8_t shared; // target receives contributions from several ranks (windowed schedule)
   Piece p;
 };
 }  // namespace
@@ -117,6 +118,15 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         if (P.role[P.blok[b].cblknum] == 0) P.role[P.blok[b].cblknum] = 2;
     }
   }
+  // cblks that receive contributions from more than one rank ("shared"): their contributions are
+  // scheduled left-looking with a window (see below) so that every rank works on the same target at
+  // the same level and the fan-in exchange never waits for a rank's bulk trailing update
+  std::vector<uint8_t> shared(nc, 0);
+  if (owner)
+    for (int64_t k = 0; k < nc; k++)
+      for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
+        if (owner[k] != owner[P.blok[b].cblknum]) shared[P.blok[b].cblknum] = 1;
+  const int window = getenv("PASTIX_AMD_WINDOW") ? atoi(getenv("PASTIX_AMD_WINDOW")) : 0;
   P.poff.resize(nc + 1);
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
@@ -220,8 +230,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         RawPiece rp;
         int64_t tile = tile_base[t] + rt * nct + ct + (carena ? ntile : 0);
         rp.tile = tile;
-        rp.lvl = P.level[k];
+        // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
+        // targets: not before `window` levels ahead of the target's own level.
+        rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
         rp.carena = carena;
+        rp.shared = shared[t];
         rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
         rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
         rp.p.lda = (int32_t)sk;
@@ -321,6 +334,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       // close the chunk once enough work is gathered, but never split pieces of one source level
       // (many small pieces are flushed early by count: each costs a latency-bound pass, and keeping
       // them for the tile's last chunk would put them on the critical path of the dependency chain)
+      if (raw[q].shared) {
+        // shared tile: every slot gets its own tasks; a long list is cut into several tasks that run
+        // concurrently and combine with f64 atomics (split-K), so that the few tiles of one target
+        // cblk still fill the chip
+        if (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl ||
+            work >= chunk_work || (int)(e - q) >= max_pieces) break;
+        continue;
+      }
       if ((work >= chunk_work || (int)(e - q) >= max_pieces) &&
           (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
     }
@@ -338,7 +359,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);
-    tk.flags = carena;
+    tk.flags = carena | (raw[q].shared ? 2u : 0u);
     P.tasks.push_back(tk);
     task_work.push_back(work + 4096.0 * double(e - q));
     task_slot.push_back(slot);
