@@ -18,6 +18,14 @@ void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n
                      long long* nbpivot, int* errflag);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
+void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                      long long* nbpivot);
+void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
+                    double critere, long long* nbpivot);
+void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                      int maxw);
+void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                    int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t ntask,
                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* x);
 }  // namespace pastix_amd
@@ -95,7 +103,6 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     rc = PASTIX_AMD_ERR_ALLOC;
   }
   if (rc) { delete p; return rc; }
-  if (factotype != PASTIX_AMD_FACT_LLT) { delete p; return PASTIX_AMD_ERR_UNSUPPORTED; }
   Plan& H = p->host;
   p->device = H.opts.device;
   int ndev = 0;
@@ -382,7 +389,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
 }
 
 int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
-  if (!p || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (!p || !p->dL || (p->host.factotype != PASTIX_AMD_FACT_LLT && !p->dU)) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   HIPCHK(hipMemsetAsync(p->dNbpivot, 0, sizeof(long long), s));
@@ -406,10 +413,20 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
     p->nupd_run++;
   }
   if (phase == 1) return PASTIX_AMD_OK;
-  launch_diag_llt(s, p->dL, p->dPanel + H.lvl_panel_ptr[l], H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l],
-                  p->dDinv, p->crit_run, p->dNbpivot, p->dErr);
-  launch_trsm_llt(s, p->dL, p->dTrsm + H.lvl_trsm_ptr[l], H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l],
-                  p->dDinv, p->maxw);
+  const PanelTask* pt = p->dPanel + H.lvl_panel_ptr[l];
+  const int64_t npt = H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l];
+  const TrsmTask* tt = p->dTrsm + H.lvl_trsm_ptr[l];
+  const int64_t ntt = H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l];
+  if (H.factotype == PASTIX_AMD_FACT_LLT) {
+    launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr);
+    launch_trsm_llt(s, p->dL, tt, ntt, p->dDinv, p->maxw);
+  } else if (H.factotype == PASTIX_AMD_FACT_LDLT) {
+    launch_diag_ldlt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
+    launch_trsm_ldlt(s, p->dL, p->dU, tt, ntt, p->dDinv, p->maxw);
+  } else {
+    launch_diag_lu(s, p->dL, p->dU, pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
+    launch_trsm_lu(s, p->dL, p->dU, tt, ntt, p->dDinv, p->maxw);
+  }
   return PASTIX_AMD_OK;
 }
 

@@ -1,0 +1,380 @@
+// kernels_var.hip -- diagonal-block and panel-solve kernels of the LDLt (sy) and LU (ge) variants.
+// Same structure as k_diag_llt / k_trsm_llt in kernels.hip; the update kernel k_update is shared by all
+// variants (the plan tags every piece with the arena of its A, B and C operands).
+//
+//   LDLt  factor_diag  = PASTIX_sytrf_block   compute_diag.c:262-307  (unit L below, D on the diagonal)
+//         factor_trsm1d = kernel_trsm (sy)     compute_trsm.c:84-113   (TRSM "R","L","T","U" -> L*D, kept in the
+//                                              second arena for the updates; then columns scaled by 1/d)
+//   LU    factor_diag  = PASTIX_getrf_block + DimTrans   compute_diag.c:486-532,564-567 (no row pivoting)
+//         factor_trsm1d = kernel_trsm (ge)     compute_trsm.c:58-67    (L_off = A U_d^-1 ; U_off^T = A' L_d^-T unit)
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace pastix_amd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// forward substitution for the inverse of a 16x16 lower-triangular tile held in LDS (identity padding
+// beyond nb); thread c computes column c.  lower(i,p) is read through the functor.
+template <class F>
+__device__ __forceinline__ void tile_inverse(F lower, bool unit, int nb, int c, double (*Ti)[17], double* dst) {
+  for (int i = 0; i < 16; i++) {
+    double x;
+    if (i >= nb || c >= nb) x = (i == c) ? 1.0 : 0.0;
+    else if (i < c) x = 0.0;
+    else {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int p = c; p < i; p++) s -= lower(i, p) * Ti[p][c];
+      x = unit ? s : s / lower(i, i);
+    }
+    Ti[i][c] = x;
+  }
+  for (int i = 0; i < 16; i++) dst[i + 16 * c] = Ti[i][c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDLt diagonal blok
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                   double* __restrict__ dinv_ws, double critere,
+                                                   long long* __restrict__ nbpivot) {
+  __shared__ double Ts[16][17];
+  __shared__ double Lo[16][17];
+  __shared__ double Ti[16][17];
+  __shared__ double Xs[16][244];   // L  rows below the tile (scaled)
+  __shared__ double Ws[16][244];   // L*D rows below the tile
+  const PanelTask tk = tasks[blockIdx.x];
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
+  int npiv = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    if (ti < nb && tc < nb && ti >= tc) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
+    for (int j = 0; j < nb; j++) {                       // PASTIX_sytrf, compute_diag.c:223-242
+      __syncthreads();
+      double d = Ts[j][j];
+      if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
+      const double inv = 1.0 / d;
+      if (ti < nb && tc < nb) {
+        if (tc == j) {
+          if (ti == j) Lo[j][j] = d;
+          else if (ti > j) Lo[ti][j] = Ts[ti][j] * inv;
+        } else if (tc > j && ti >= tc) {
+          Ts[ti][tc] -= (Ts[ti][j] * inv) * (d * (Ts[tc][j] * inv));   // SYR alpha = -d
+        }
+      }
+    }
+    __syncthreads();
+    if (ti < nb && tc < nb && ti >= tc) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
+    if (tid < 16) {
+      tile_inverse([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
+                   dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256);
+    } else if (tid - 16 < rem) {
+      // TRSM "R","L","T","U" gives L*D (compute_diag.c:284-288), then scale by 1/d (:289-298)
+      const int rr = tid - 16;
+      double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) x[c] = ap[(int64_t)min(c, nb - 1) * ld];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          double s = x[c];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < c) s -= x[p] * Lo[c][p];
+          x[c] = s;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const double v = (c < nb) ? x[c] : 0.0;
+        const double sc = (c < nb) ? v * (1.0 / Lo[min(c, nb - 1)][min(c, nb - 1)]) : 0.0;
+        Ws[c][rr] = v;
+        Xs[c][rr] = sc;
+        if (c < nb) ap[(int64_t)c * ld] = sc;
+      }
+    }
+    __syncthreads();
+    if (rem > 0) {                                       // A22 -= (L D) L^T, lower part
+      const int nt = (rem + 3) >> 2;
+      double* Cb = A + (kb + nb) + (int64_t)(kb + nb) * ld;
+      for (int id = tid; id < nt * nt; id += 256) {
+        const int tr = id % nt, tcc = id / nt;
+        if (tr < tcc) continue;
+        double c[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
+        for (int p = 0; p < nb; p++) {
+          double xa[4], xb[4];
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            xa[a] = Ws[p][min(4 * tr + a, 243)];
+            xb[a] = Xs[p][min(4 * tcc + a, 243)];
+          }
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            const int r = 4 * tr + a, cc = 4 * tcc + b;
+            if (r < rem && cc < rem && r >= cc) Cb[r + (int64_t)cc * ld] -= c[a][b];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LU diagonal blok (full w x w square in the L arena; transposed copy into the U arena at the end)
+// workspace: [nbk blocks: inverse of (U tile)^T, lower non-unit][nbk blocks: inverse of the unit L tile]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double* __restrict__ U,
+                                                 const PanelTask* __restrict__ tasks, double* __restrict__ dinv_ws,
+                                                 double critere, long long* __restrict__ nbpivot) {
+  __shared__ double Ts[16][17];
+  __shared__ double Lo[16][17];    // tile after getrf: unit L strictly below, U on and above the diagonal
+  __shared__ double Ti[16][17];
+  __shared__ double Xs[16][244];   // L rows below the tile   Xs[p][r] = L[r][p]
+  __shared__ double Ys[16][244];   // U columns right of tile Ys[p][c] = U[p][c]
+  const PanelTask tk = tasks[blockIdx.x];
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
+  const int nbk = (w + 15) >> 4;
+  int npiv = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    if (ti < nb && tc < nb) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
+    for (int j = 0; j < nb; j++) {                       // PASTIX_getrf, compute_diag.c:432-469
+      __syncthreads();
+      double d = Ts[j][j];
+      if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
+      const double inv = 1.0 / d;
+      if (ti < nb && tc < nb) {
+        if (ti == j && tc >= j) Lo[j][tc] = (tc == j) ? d : Ts[j][tc];          // row j of U
+        else if (tc == j && ti > j) Lo[ti][j] = Ts[ti][j] * inv;                // column j of L
+        else if (ti > j && tc > j) Ts[ti][tc] -= (Ts[ti][j] * inv) * Ts[j][tc]; // GER
+      }
+    }
+    __syncthreads();
+    if (ti < nb && tc < nb) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
+    if (tid < 16) {
+      // inverse of (U tile)^T : lower, non-unit, element (i,p) = U[p][i]
+      tile_inverse([&](int i, int p) { return Lo[p][i]; }, false, nb, tid, Ti,
+                   dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256);
+    } else if (tid - 16 < rem) {
+      // rows below: X = A U_T^-1  (TRSM inside getrf_block's panel, compute_diag.c:496-499 via getrf on m rows)
+      const int rr = tid - 16;
+      double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) x[c] = ap[(int64_t)min(c, nb - 1) * ld];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          double s = x[c];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < c) s -= x[p] * Lo[p][c];
+          x[c] = s / Lo[c][c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        Xs[c][rr] = (c < nb) ? x[c] : 0.0;
+        if (c < nb) ap[(int64_t)c * ld] = x[c];
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      // inverse of the unit-lower L tile
+      tile_inverse([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
+                   dinv_ws + tk.dinv_off + (int64_t)(nbk + (kb >> 4)) * 256);
+    } else if (tid - 16 < rem) {
+      // columns right of the tile: Y = L_T^-1 B  (TRSM "L","L","N","U", compute_diag.c:505-508)
+      const int cc = tid - 16;
+      double* bp = A + kb + (int64_t)(kb + nb + cc) * ld;
+      double y[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) y[r] = bp[min(r, nb - 1)];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (r < nb) {
+          double s = y[r];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < r) s -= Lo[r][p] * y[p];
+          y[r] = s;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        Ys[r][cc] = (r < nb) ? y[r] : 0.0;
+        if (r < nb) bp[r] = y[r];
+      }
+    }
+    __syncthreads();
+    if (rem > 0) {                                       // A22 -= L21 U12 (full square, compute_diag.c:510-511)
+      const int nt = (rem + 3) >> 2;
+      double* Cb = A + (kb + nb) + (int64_t)(kb + nb) * ld;
+      for (int id = tid; id < nt * nt; id += 256) {
+        const int tr = id % nt, tcc = id / nt;
+        double c[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
+        for (int p = 0; p < nb; p++) {
+          double xa[4], xb[4];
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            xa[a] = Xs[p][min(4 * tr + a, 243)];
+            xb[a] = Ys[p][min(4 * tcc + a, 243)];
+          }
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+            const int r = 4 * tr + a, cc = 4 * tcc + b;
+            if (r < rem && cc < rem) Cb[r + (int64_t)cc * ld] -= c[a][b];
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // DimTrans (compute_diag.c:521-532, :564-567): U arena diagonal blok = transpose of the factored blok
+  double* Ud = U + tk.off;
+  for (int id = tid; id < w * w; id += 256) {
+    const int a = id % w, b = id / w;
+    Ud[b + (int64_t)a * ld] = A[a + (int64_t)b * ld];
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generalized panel solve  X^T[ct] = Tinv[ct] (A^T[ct] - sum_{p<ct} T[ct,p] X^T[p])   (see k_trsm_llt)
+//   MODE 1 (LDLt):  T = unit-lower L_d, in/out = L arena; writes L*D to the U arena and L = (L*D) D^-1 to L
+//   MODE 2 (LU, L): T(i,c) = U_d[c][i] (transposed access of the factored blok), in/out = L arena
+//   MODE 3 (LU, U): T = unit-lower L_d (from the L arena), in/out = U arena
+// ------------------------------------------------------------------------------------------------
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void k_trsm_var(double* __restrict__ L, double* __restrict__ U,
+                                                  const TrsmTask* __restrict__ tasks,
+                                                  const double* __restrict__ dinv_ws) {
+  const TrsmTask tk = tasks[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int nbk = (w + 15) >> 4;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  double* X = (MODE == 3 ? U : L) + tk.off + tk.row0;
+  double* Xp = X + rloc;
+  const double* Xpc = X + min(rloc, tk.nrows - 1);
+  const double* Td = L + tk.off;                       // factored diagonal blok (always in the L arena)
+  const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)nbk * 256 : 0);
+
+  d4 acc[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const double v = Xpc[(int64_t)min(col, w - 1) * ld];
+      acc[ct][q] = (rvalid && col < w) ? v : 0.0;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+    if (ct < nbk) {
+      const int li = ct * 16 + l15;
+      const int lic = min(li, w - 1);
+#pragma unroll
+      for (int p = 0; p < ct; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int lc = p * 16 + g + 4 * q;
+          const double tv = (MODE == 2) ? Td[lc + (int64_t)lic * ld] : Td[lic + (int64_t)lc * ld];
+          const double a = (li < w) ? -tv : 0.0;
+          acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[p][q], acc[ct], 0, 0, 0);
+        }
+      }
+      d4 t = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double a = Ti[ct * 256 + l15 + 16 * (g + 4 * q)];
+        t = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[ct][q], t, 0, 0, 0);
+      }
+      acc[ct] = t;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      if (MODE == 1) {
+        const double dv = Td[min(col, w - 1) * (int64_t)(ld + 1)];
+        if (rvalid && col < w) {
+          (U + tk.off + tk.row0 + rloc)[(int64_t)col * ld] = acc[ct][q];           // L*D (compute_trsm.c:108-109)
+          Xp[(int64_t)col * ld] = acc[ct][q] * (1.0 / dv);                        // L   (:110)
+        }
+      } else {
+        if (rvalid && col < w) Xp[(int64_t)col * ld] = acc[ct][q];
+      }
+    }
+  }
+}
+
+void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                      long long* nbpivot) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_diag_ldlt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
+}
+
+void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
+                    double critere, long long* nbpivot) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_diag_lu, dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv, critere, nbpivot);
+}
+
+template <int MODE>
+static void launch_trsm_mode(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n,
+                             const double* dinv, int maxw) {
+  if (maxw <= 128)
+    hipLaunchKernelGGL((k_trsm_var<8, MODE>), dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv);
+  else
+    hipLaunchKernelGGL((k_trsm_var<16, MODE>), dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv);
+}
+
+void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                      int maxw) {
+  if (n <= 0) return;
+  launch_trsm_mode<1>(s, L, U, tasks, n, dinv, maxw);
+}
+
+void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                    int maxw) {
+  if (n <= 0) return;
+  launch_trsm_mode<2>(s, L, U, tasks, n, dinv, maxw);
+  launch_trsm_mode<3>(s, L, U, tasks, n, dinv, maxw);
+}
+
+}  // namespace pastix_amd

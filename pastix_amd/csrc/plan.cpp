@@ -195,7 +195,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         TrsmTask tt{P.poff[k], s, w, r, std::min(64, s - r), ws};
         P.trsm_tasks.push_back(tt);
       }
-      ws += (int64_t)((w + 15) / 16) * 256;
+      ws += (int64_t)((w + 15) / 16) * 256 * (factotype == PASTIX_AMD_FACT_LU ? 2 : 1);
     }
     P.dinv_ws = std::max(P.dinv_ws, ws);
   }

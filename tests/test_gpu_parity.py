@@ -61,3 +61,54 @@ def test_static_pivot_clamp_matches_oracle(golden):
     assert nbo >= 10 and st["nbpivot"] == nbo
     assert np.isfinite(Lo).all()
     assert np.abs(L1 - Lo).max() <= TOL * np.abs(Lo).max()
+
+
+def _lower_mask(c4):
+    """True where a panel entry is meaningful for LDLt: everything except the strict upper triangle
+    of the diagonal bloks (the reference's blocked sytrf leaves GEMM by-products there)."""
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    parts = []
+    for k in range(len(w)):
+        s, wk = int(c4[k, 3]), int(w[k])
+        m = np.ones((wk, s), dtype=bool)           # [col][row]
+        for c in range(wk):
+            m[c, :c] = False
+        parts.append(m.ravel())
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("lookahead", [1, 0])
+@pytest.mark.parametrize("name", golden_names("ldlt"))
+def test_ldlt_matches_reference_golden(name, lookahead, golden):
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], lookahead=lookahead) as p:
+        p.upload(g["L0"])
+        st = p.factorize(g["critere"])
+        L1, _ = p.download()
+    m = _lower_mask(g["cblk4"])
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("lookahead", [1, 0])
+@pytest.mark.parametrize("name", golden_names("lu"))
+def test_lu_matches_reference_golden(name, lookahead, golden):
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], lookahead=lookahead) as p:
+        p.upload(g["L0"], g["U0"])
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+    scale = max(np.abs(g["L1"]).max(), np.abs(g["U1"]).max())
+    assert np.abs(L1 - g["L1"]).max() <= TOL * scale
+    assert np.abs(U1 - g["U1"]).max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", golden_names("lu"))
+def test_lu_device_fill_matches_reference(name, golden):
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        L0, U0 = p.download()
+    assert np.array_equal(L0, g["L0"]) and np.array_equal(U0, g["U0"])
