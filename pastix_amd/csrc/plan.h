@@ -93,6 +93,8 @@ struct Plan {
   std::vector<Task> tasks;
   std::vector<Piece> pieces;
   double update_flops = 0;
+  double update_bytes = 0;               // algorithmic bytes of the update kernel: operands read once per
+                                         // piece (8k(m+n)) + one read-modify-write of the tile per task (16 tm tn)
   std::vector<double> slot_flops;        // [nlevels] update flops per slot
   std::vector<int64_t> slot_pieces;      // [nlevels]
   std::vector<int32_t> slot_maxpn;       // [nlevels] longest piece list of a task in the slot

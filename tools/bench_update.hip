@@ -15,7 +15,8 @@ int main(int argc, char** argv) {
   double *d; CK(hipMalloc(&d, (src_elems + c_elems) * 8));
   std::vector<double> h(src_elems + c_elems);
   std::mt19937_64 rng(1); std::uniform_real_distribution<double> u(-1, 1);
-  for (auto& v : h) v = u(rng);
+  const char* fillmode = getenv("FILL");
+  for (auto& v : h) v = (fillmode && fillmode[0] == 'z') ? 0.0 : (fillmode && fillmode[0] == 'c') ? 1.25 : u(rng);
   CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   std::vector<Task> tasks(ntask); std::vector<Piece> pieces((size_t)ntask * P);
   for (int t = 0; t < ntask; t++) {
