@@ -135,6 +135,7 @@ def main():
             resid = float(np.linalg.norm(A @ x + sp.tril(A, -1).T @ x - b) / np.linalg.norm(b))
         ps = plan.stats()
         res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_flops=ps["update_flops"],
+                   update_bytes=ps["update_bytes"],
                    nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
                    blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
                    ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu")
@@ -143,6 +144,13 @@ def main():
     if rank == 0:
         K = a.steps
         value = res["flops"] * K / res["wall"] * 1e-9
+        traffic = None
+        try:   # PMC-measured bytes per k_update launch for this workload (profiles/r01, see its _doc)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic_k_update.json")))
+            if a.gpus == 1 and a.facto == "llt" and a.blocksize == 128 and str(a.grid) in tj:
+                traffic = tj[str(a.grid)]["bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         upd_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
         out = {
             "metric": "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
@@ -160,7 +168,8 @@ def main():
                                       "fill_prepare": round(res["t_fill"], 2)}},
             "roofline": {"bound": "mfma", "kernel": "k_update", "achieved": round(upd_rate * 1e-12, 3),
                          "peak": MFMA_F64_PEAK * 1e-12, "unit": "TFLOP/s",
-                         "frac": round(upd_rate / MFMA_F64_PEAK, 4), "traffic": None,
+                         "frac": round(upd_rate / MFMA_F64_PEAK, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) / max(res["nlaunch"], 1),
                          "launches_per_step": res["nlaunch"],
                          "avg_launch_ms": round(res["update_time"] / K / max(res["nlaunch"], 1) * 1e3, 4),
                          "flops_per_launch": res["update_flops"] / max(res["nlaunch"], 1)},
