@@ -33,7 +33,7 @@ if [ "$BLAS" = openblas ]; then
 fi
 mkdir -p "$OBJ"
 S="$REF/src"
-INC="-I$S/common/src -I$S/symbol/src -I$S/order/src -I$S/fax/src -I$S/kass/src -I$S/blend/src -I$S/sopalin/src -I$S/perf/src -I$S/perf/src/num_recipes -I$S/sparse-matrix/src -I$S/matrix_drivers/src"
+INC="-I$S/common/src -I$S/symbol/src -I$S/order/src -I$S/fax/src -I$S/kass/src -I$S/blend/src -I$S/sopalin/src -I$S/perf/src -I$S/sparse-matrix/src -I$S/matrix_drivers/src"
 DEFS="-DFORCE_NOMPI -DPREC_DOUBLE -DINTSIZE32 -DVERSION=\"ref\" -DX_ARCHi686_pc_linux -DDOF_CONSTANT -DFORCE_NO_CUDA"
 [ "$PREC" = z ] && DEFS="$DEFS -DTYPE_COMPLEX"
 DEFS="$DEFS $RENAMES"

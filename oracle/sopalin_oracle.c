@@ -27,7 +27,9 @@ typedef int64_t i64;
 #define CONJ(x) (x)
 #define ABS(x) fabs(x)
 #define SQRT(x) sqrt(x)
+#define SYR_FULL 0
 #include "sopalin_oracle_impl.h"
+#undef SYR_FULL
 #undef T
 #undef NAME
 #undef CONJ
@@ -39,7 +41,9 @@ typedef int64_t i64;
 #define CONJ(x) conj(x)
 #define ABS(x) cabs(x)
 #define SQRT(x) csqrt(x)
+#define SYR_FULL 1
 #include "sopalin_oracle_impl.h"
+#undef SYR_FULL
 #undef T
 #undef NAME
 #undef CONJ

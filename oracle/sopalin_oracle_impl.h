@@ -10,7 +10,7 @@
  * at poff[k] + coefind(b) + (r-frownum(b)) + j*stride(k)   (SURVEY 8a row a1,
  * src/blend/src/solver.h:94-117).
  *
- * Requires: T, NAME(x), CONJ(x), ABS(x), SQRT(x), IS_HERM (he variant conjugates)
+ * Requires: T, NAME(x), CONJ(x), ABS(x), SQRT(x), SYR_FULL (1 in complex builds)
  */
 
 /* ---- PASTIX_potrf: unblocked LLt, compute_diag.c:124-153 ------------------------------ */
@@ -23,11 +23,12 @@ static void NAME(potrf)(T *A, i64 n, i64 ld, i64 *nbpivot, double critere)
     *d = SQRT(*d);                                                /* :140-142 */
     { T inv = (T)1.0 / *d;                                        /* SCAL :150 */
       for (i = 1; i < n - k; i++) d[i] *= inv; }
-    /* SYR "L" (x x^T, no conjugation: sopalin_compute.h:549-562), :151 */
+    /* SYR "L" :151.  In complex builds SOPALIN_SYR is GER(x, x^T): the FULL square is updated,
+     * no conjugation (sopalin_compute.h:549-562); in real builds dsyr "L" touches the lower part */
     for (j = 1; j < n - k; j++) {
       T xj = d[j];
       T *c = d + j * ld;
-      for (i = j; i < n - k; i++) c[i] -= d[i] * xj;
+      for (i = SYR_FULL ? 1 : j; i < n - k; i++) c[i] -= d[i] * xj;
     }
   }
 }
@@ -86,12 +87,13 @@ static void NAME(sytrf)(T *A, i64 n, i64 ld, i64 *nbpivot, double critere, int h
     if (ABS(*d) < critere) { *d = (T)critere; (*nbpivot)++; }
     { T inv = (T)1.0 / *d;
       for (i = 1; i < n - k; i++) d[i] *= inv; }
-    /* SYR/HER "L" with alpha = -d_k : A -= d_k x x^T (or x x^H) */
+    /* SYR/HER "L" with alpha = -d_k : A -= d_k x x^T (or x x^H).  Complex symmetric: GER, full
+     * square (sopalin_compute.h:549-562); Hermitian: zher "L" */
     for (j = 1; j < n - k; j++) {
       T xj = herm ? CONJ(d[j]) : d[j];
       T *c = d + j * ld;
       T s = (*d) * xj;
-      for (i = j; i < n - k; i++) c[i] -= d[i] * s;
+      for (i = (SYR_FULL && !herm) ? 1 : j; i < n - k; i++) c[i] -= d[i] * s;
     }
   }
 }

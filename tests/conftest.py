@@ -14,11 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names(facto=None):
+def golden_names(facto=None, prec="d"):
+    """Fixture names; prec 'd' = real double, 'z' = complex double (names start with 'z'), None = all."""
     import glob
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "golden", "*.npz")))
     if facto:
         names = [n for n in names if n.split("_")[2] == facto]
+    if prec == "d":
+        names = [n for n in names if not n.startswith("z")]
+    elif prec == "z":
+        names = [n for n in names if n.startswith("z")]
     return names
 
 

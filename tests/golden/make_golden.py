@@ -27,12 +27,19 @@ CASES = [
     ("rlap3d_12_ldlt", "d", "rlap3d", "12", "ldlt", []),
     ("rlap3d_8_lu", "d", "rlap3d", "8", "lu", []),
     ("rlap3d_12_lu", "d", "rlap3d", "12", "lu", []),
+    # complex double (BASELINE config 5 family): complex SYMMETRIC values, LDLt without conjugation
+    ("zrlap3d_8_ldlt", "z", "rlap3d", "8", "ldlt", []),
+    ("zrlap3d_8_lu", "z", "rlap3d", "8", "lu", []),
+    ("zyoung4c_841_ldlt", "z", "mtx", "/root/reference/src/matrix/young4c.mtx", "ldlt", []),   # the reference's own fixture
 ]
 
 
 def main():
+    only = sys.argv[1:]
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
     for name, prec, kind, arg, facto, extra in CASES:
+        if only and name not in only:
+            continue
         exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_" + prec)
         raw = "/tmp/%s.bin" % name
         out = subprocess.run([exe, "dump", kind, arg, facto, "1", raw] + extra, env=env,

@@ -9,7 +9,7 @@ from conftest import golden_names
 TOL = 1e-12  # per entry, relative to max|L_ref| (SURVEY 8d parity tolerance for d)
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(prec=None))
 def test_fill_matches_reference(name, golden):
     g = golden(name)
     L0, U0 = oracle_lib.fill(g["facto"], g["sym"], g["n"], g["colptr"], g["rows"], g["vals"],
@@ -19,7 +19,7 @@ def test_fill_matches_reference(name, golden):
         assert np.array_equal(U0, g["U0"])
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(prec=None))
 def test_factor_matches_reference(name, golden):
     g = golden(name)
     L1, U1, nbpiv = oracle_lib.sopalin(g["facto"], g["cblk4"], g["blok4"], g["L0"], g["U0"], g["critere"])
@@ -30,14 +30,14 @@ def test_factor_matches_reference(name, golden):
     assert nbpiv == g["nbpivot"]
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(prec=None))
 def test_flops_match_reference(name, golden):
     g = golden(name)
     f = oracle_lib.fact_flops(g["facto"], g["prec"], g["cblk4"], g["blok4"])
     assert abs(f - g["flops"]) <= 1e-9 * g["flops"]
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(prec=None))
 def test_solve_matches_reference(name, golden):
     g = golden(name)
     bp = np.empty_like(g["b"])
