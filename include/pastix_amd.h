@@ -25,7 +25,7 @@ typedef int64_t pastix_amd_int_t;
 
 /* IPARM_FACTORIZATION values (src/common/src/api.h:381-384) */
 enum { PASTIX_AMD_FACT_LLT = 0, PASTIX_AMD_FACT_LDLT = 1, PASTIX_AMD_FACT_LU = 2, PASTIX_AMD_FACT_LDLH = 3 };
-/* IPARM_FLOAT values (api.h:522-525): only double real is built in round 1 */
+/* IPARM_FLOAT values (api.h:522-525): built: REALDOUBLE (LLt, LDLt, LU) and COMPLEXDOUBLE (symmetric LDLt) */
 enum { PASTIX_AMD_REALSINGLE = 0, PASTIX_AMD_REALDOUBLE = 1, PASTIX_AMD_COMPLEXSINGLE = 2, PASTIX_AMD_COMPLEXDOUBLE = 3 };
 
 enum {
@@ -101,6 +101,11 @@ int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t *layout, double *const *co
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab, double *const *ucoeftab,
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+
+/* complex double, complex-SYMMETRIC LDLt (Z_sy_sopalin_thread): coeftab[k] is the reference's interleaved
+ * `double complex` panel.  Other complex variants (po, he, ge) return PASTIX_AMD_ERR_UNSUPPORTED. */
+int pastix_amd_z_sy_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 
 /* ---- staged API (analysis once, many factorizations; panels may stay on the device) -------- */
 int pastix_amd_plan_create(const pastix_amd_layout_t *layout, int factotype, int floattype,

@@ -13,7 +13,12 @@
 #include "plan.h"
 
 namespace pastix_amd {
-void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks);
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks);
+void launch_diag_zsy(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot);
+void launch_trsm_zsy(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv);
+void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n);
+void launch_merge(hipStream_t s, double* z, const double* re, const double* im, int64_t n);
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
@@ -39,8 +44,12 @@ struct pastix_amd_plan_s {
   bool own_stream = true, own_arena = true, distributed = false;
   int nupd_run = 0;
   double crit_run = 0;
-  double* dL = nullptr;
-  double* dU = nullptr;
+  double* dL = nullptr;      // L  (real part)
+  double* dU = nullptr;      // U / L*D (real part)
+  double* dLi = nullptr;     // imaginary planes (complex double only)
+  double* dUi = nullptr;
+  bool cplx = false;
+  Arenas arenas() const { return Arenas{{dL, dU, dLi, dUi}}; }
   double* dDinv = nullptr;
   Task* dTasks = nullptr;
   Piece* dPieces = nullptr;
@@ -51,6 +60,7 @@ struct pastix_amd_plan_s {
   int maxw = 0;
   // cached coefficient fill (destinations + values) so that a re-fill is device-only
   int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
+  double* dFillValLi = nullptr;   // imaginary parts (complex)
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk* dChunk = nullptr;
   std::vector<int64_t> lvl_chunk_ptr;
@@ -117,10 +127,16 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     p->distributed = owner != nullptr;
     p->own_arena = !(opts && opts->external_arena);
+    p->cplx = H.floattype == PASTIX_AMD_COMPLEXDOUBLE;
+    if (p->cplx && !p->own_arena) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (p->own_arena) {
-      HIPCHK(hipMalloc((void**)&p->dL, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
-      if (H.factotype != PASTIX_AMD_FACT_LLT)
-        HIPCHK(hipMalloc((void**)&p->dU, std::max<int64_t>(H.coefnbr, 1) * sizeof(double)));
+      const size_t bytes = std::max<int64_t>(H.coefnbr, 1) * sizeof(double);
+      HIPCHK(hipMalloc((void**)&p->dL, bytes));
+      if (H.factotype != PASTIX_AMD_FACT_LLT) HIPCHK(hipMalloc((void**)&p->dU, bytes));
+      if (p->cplx) {
+        HIPCHK(hipMalloc((void**)&p->dLi, bytes));
+        if (H.factotype != PASTIX_AMD_FACT_LLT) HIPCHK(hipMalloc((void**)&p->dUi, bytes));
+      }
     }
     HIPCHK(hipMalloc((void**)&p->dDinv, std::max<int64_t>(H.dinv_ws, 256) * sizeof(double)));
     int r;
@@ -229,11 +245,11 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  if (p->own_arena) { (void)hipFree(p->dL); (void)hipFree(p->dU); }
+  if (p->own_arena) { (void)hipFree(p->dL); (void)hipFree(p->dU); (void)hipFree(p->dLi); (void)hipFree(p->dUi); }
   (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
-  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
+  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
   (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -255,12 +271,42 @@ int pastix_amd_device_arenas(pastix_amd_plan_t* p, void** dL, void** dU) {
   return PASTIX_AMD_OK;
 }
 
+// complex: the host side is interleaved (re,im) like the reference's `double complex` panels; the device
+// keeps split planes.  Conversion goes through a bounded staging buffer.
+static int z_transfer(pastix_amd_plan_t* p, bool to_device, void* host, double* re, double* im, int64_t off, int64_t n) {
+  const int64_t CH = 1 << 24;   // elements per chunk (256 MiB of interleaved data)
+  double* stage = nullptr;
+  HIPCHK(hipMalloc((void**)&stage, std::min(CH, std::max<int64_t>(n, 1)) * 2 * sizeof(double)));
+  for (int64_t c = 0; c < n; c += CH) {
+    const int64_t m = std::min(CH, n - c);
+    double* h = (double*)host + 2 * c;
+    if (to_device) {
+      HIPCHK(hipMemcpyAsync(stage, h, m * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+      launch_split(p->stream, stage, re + off + c, im + off + c, m);
+    } else {
+      launch_merge(p->stream, stage, re + off + c, im + off + c, m);
+      HIPCHK(hipMemcpyAsync(h, stage, m * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+  }
+  HIPCHK(hipFree(stage));
+  return 0;
+}
+
 int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U) {
   if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   double t0 = now_s();
-  HIPCHK(hipMemcpy(p->dL, L, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
-  if (p->dU && U) HIPCHK(hipMemcpy(p->dU, U, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+  if (p->cplx) {
+    int r = z_transfer(p, true, (void*)L, p->dL, p->dLi, 0, p->host.coefnbr);
+    if (r) return r;
+    if (p->dU) {   // second arena (L*D / U) starts from zeros unless provided
+      if (U) { if ((r = z_transfer(p, true, (void*)U, p->dU, p->dUi, 0, p->host.coefnbr))) return r; }
+    }
+  } else {
+    HIPCHK(hipMemcpy(p->dL, L, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+    if (p->dU && U) HIPCHK(hipMemcpy(p->dU, U, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+  }
   p->stats.h2d_time = now_s() - t0;
   return PASTIX_AMD_OK;
 }
@@ -270,8 +316,14 @@ int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
   HIPCHK(hipSetDevice(p->device));
   double t0 = now_s();
   HIPCHK(hipStreamSynchronize(p->stream));
-  HIPCHK(hipMemcpy(L, p->dL, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
-  if (p->dU && U) HIPCHK(hipMemcpy(U, p->dU, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+  if (p->cplx) {
+    int r = z_transfer(p, false, L, p->dL, p->dLi, 0, p->host.coefnbr);
+    if (r) return r;
+    if (p->dU && U && (r = z_transfer(p, false, U, p->dU, p->dUi, 0, p->host.coefnbr))) return r;
+  } else {
+    HIPCHK(hipMemcpy(L, p->dL, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+    if (p->dU && U) HIPCHK(hipMemcpy(U, p->dU, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+  }
   p->stats.d2h_time = now_s() - t0;
   return PASTIX_AMD_OK;
 }
@@ -285,6 +337,11 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
     if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
+    if (p->cplx) {
+      int r = z_transfer(p, true, coeftab[k], p->dL, p->dLi, H.poff[k], H.poff[k + 1] - H.poff[k]);
+      if (r) return r;
+      continue;
+    }
     HIPCHK(hipMemcpyAsync(p->dL + H.poff[k], coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
       HIPCHK(hipMemcpyAsync(p->dU + H.poff[k], ucoeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
@@ -303,6 +360,11 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
     if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
+    if (p->cplx) {
+      int r = z_transfer(p, false, coeftab[k], p->dL, p->dLi, H.poff[k], H.poff[k + 1] - H.poff[k]);
+      if (r) return r;
+      continue;
+    }
     HIPCHK(hipMemcpyAsync(coeftab[k], p->dL + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
       HIPCHK(hipMemcpyAsync(ucoeftab[k], p->dU + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
@@ -322,7 +384,9 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   if (!p || !colptr || !rows || !vals_ || !perm) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
-  const double* vals = (const double*)vals_;
+  const double* vals = (const double*)vals_;   // complex: interleaved (re,im)
+  const int vs = p->cplx ? 2 : 1;
+  std::vector<double> valLi;
   HIPCHK(hipSetDevice(p->device));
   std::vector<int32_t> col2cblk((size_t)n);
   for (int64_t k = 0; k < H.cblknbr; k++)
@@ -353,10 +417,10 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
       for (int pass = 0; pass < npass; pass++) {
         const int64_t pr = perm[pass ? j : i], pc = perm[pass ? i : j];
         int64_t d = locate(pr, pc, false);
-        if (d >= 0) { idxL.push_back(d); valL.push_back(vals[q]); }
+        if (d >= 0) { idxL.push_back(d); valL.push_back(vals[vs * q]); if (p->cplx) valLi.push_back(vals[2 * q + 1]); }
         if (lu) {
           d = locate(pc, pr, true);
-          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[q]); }
+          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[vs * q]); }
         }
       }
     }
@@ -373,6 +437,14 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   int r;
   if ((r = cache(idxL, valL, &p->dFillIdxL, &p->dFillValL, &p->nFillL))) return r;
   if ((r = cache(idxU, valU, &p->dFillIdxU, &p->dFillValU, &p->nFillU))) return r;
+  if (p->cplx) {
+    (void)hipFree(p->dFillValLi);
+    p->dFillValLi = nullptr;
+    if (!valLi.empty()) {
+      HIPCHK(hipMalloc((void**)&p->dFillValLi, valLi.size() * sizeof(double)));
+      HIPCHK(hipMemcpy(p->dFillValLi, valLi.data(), valLi.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   return pastix_amd_refill(p);
 }
 
@@ -383,7 +455,10 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
   if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->dLi) HIPCHK(hipMemsetAsync(p->dLi, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->dUi) HIPCHK(hipMemsetAsync(p->dUi, 0, H.coefnbr * sizeof(double), p->stream));
   launch_scatter(p->stream, p->dL, p->dFillIdxL, p->dFillValL, p->nFillL);
+  if (p->cplx && p->dFillValLi) launch_scatter(p->stream, p->dLi, p->dFillIdxL, p->dFillValLi, p->nFillL);
   if (p->dU && p->nFillU) launch_scatter(p->stream, p->dU, p->dFillIdxU, p->dFillValU, p->nFillU);
   HIPCHK(hipStreamSynchronize(p->stream));
   return PASTIX_AMD_OK;
@@ -409,7 +484,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
   if (t1 > t0 && phase != 2) {
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
-    launch_update(s, p->dL, p->dU, p->dTasks + t0, p->dPieces, t1 - t0);
+    launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, t1 - t0);
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
     p->nupd_run++;
   }
@@ -418,7 +493,10 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   const int64_t npt = H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l];
   const TrsmTask* tt = p->dTrsm + H.lvl_trsm_ptr[l];
   const int64_t ntt = H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l];
-  if (H.factotype == PASTIX_AMD_FACT_LLT) {
+  if (p->cplx) {
+    launch_diag_zsy(s, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
+    launch_trsm_zsy(s, p->arenas(), tt, ntt, p->dDinv);
+  } else if (H.factotype == PASTIX_AMD_FACT_LLT) {
     launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr);
     launch_trsm_llt(s, p->dL, tt, ntt, p->dDinv, p->maxw);
   } else if (H.factotype == PASTIX_AMD_FACT_LDLT) {
@@ -535,9 +613,9 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
 
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
-                    pastix_amd_stats_t* stats) {
+                    pastix_amd_stats_t* stats, int floattype = PASTIX_AMD_REALDOUBLE) {
   pastix_amd_plan_t* plan = nullptr;
-  int rc = pastix_amd_plan_create(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, &plan);
+  int rc = pastix_amd_plan_create(layout, factotype, floattype, opts, &plan);
   if (rc) return rc;
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
@@ -556,6 +634,11 @@ int pastix_amd_d_po_sopalin(const pastix_amd_layout_t* layout, double* const* co
 int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double critere,
                             const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
   return one_shot(PASTIX_AMD_FACT_LDLT, layout, coeftab, nullptr, critere, opts, stats);
+}
+int pastix_amd_z_sy_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LDLT, layout, (double* const*)coeftab, nullptr, critere, opts, stats,
+                  PASTIX_AMD_COMPLEXDOUBLE);
 }
 int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double* const* ucoeftab,
                             double critere, const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {

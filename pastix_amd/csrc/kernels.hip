@@ -80,11 +80,12 @@ __device__ __forceinline__ void stage_store(const Stage<NW>& st, double* sA, dou
                                             int tid, bool full) {
   constexpr int KS = 64 * NW / 128;
   const int row = tid & 127, k0 = tid >> 7;
+  const double sgn = (pc.flags & 16) ? -1.0 : 1.0;   // "+=" pieces (complex cross terms): negate B
   if (full) {
 #pragma unroll
     for (int q = 0; q < Stage<NW>::NLD; q++) {
       sA[(k0 + KS * q) * SLD + row] = st.a[q];
-      sB[(k0 + KS * q) * SLD + row] = st.b[q];
+      sB[(k0 + KS * q) * SLD + row] = sgn * st.b[q];
     }
   } else {
     const int ra = row - (int)pc.dr, rb = row - (int)pc.dc;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void stage_store(const Stage<NW>& st, double* sA, dou
     for (int q = 0; q < Stage<NW>::NLD; q++) {
       const bool kv = kc + k0 + KS * q <= klast;
       sA[(k0 + KS * q) * SLD + row] = (va && kv) ? st.a[q] : 0.0;
-      sB[(k0 + KS * q) * SLD + row] = (vb && kv) ? st.b[q] : 0.0;
+      sB[(k0 + KS * q) * SLD + row] = (vb && kv) ? sgn * st.b[q] : 0.0;
     }
   }
 }
@@ -126,7 +127,7 @@ __device__ __forceinline__ void epilogue_atomic(double* C, const d4 (&acc)[MI][N
 
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__ L, double* __restrict__ U,
+__global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
                                                            const Task* __restrict__ tasks,
                                                            const Piece* __restrict__ pieces) {
   constexpr int WRN = NW / 2;                   // wave grid: WRN rows x 2 cols
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
   Stage<NW> st;
   {
-    const double* Ab = ((cur.flags & 1) ? U : L) + cur.a_off;
-    const double* Bb = ((cur.flags & 2) ? U : L) + cur.b_off;
+    const double* Ab = ar.p[cur.flags & 3] + cur.a_off;
+    const double* Bb = ar.p[(cur.flags >> 2) & 3] + cur.b_off;
     const bool full = piece_full(cur);
     stage_load<NW>(st, Ab, Bb, cur, 0, tid, full);
     stage_store<NW>(st, sh[0][0], sh[0][1], cur, 0, tid, full);
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__
     const bool has_next = npi < pend;
     const bool nfull = piece_full(nxt);
     if (has_next) {
-      const double* Ab = ((nxt.flags & 1) ? U : L) + nxt.a_off;
-      const double* Bb = ((nxt.flags & 2) ? U : L) + nxt.b_off;
+      const double* Ab = ar.p[nxt.flags & 3] + nxt.a_off;
+      const double* Bb = ar.p[(nxt.flags >> 2) & 3] + nxt.b_off;
       stage_load<NW>(st, Ab, Bb, nxt, nkc, tid, nfull);
     }
     if (adv) nextp = pieces[min(npi + 1, pend - 1)];
@@ -235,9 +236,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(double* __restrict__
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column).  Loads of one
   // 16-row band are issued together from clamped addresses (one latency per band, not per element).
-  double* C = ((tk.flags & 1) ? U : L) + tk.c_off;
+  double* C = ar.p[tk.flags & 3] + tk.c_off;
   const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
-  if (tk.flags & 2) {
+  if (tk.flags & 4) {
     epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
     return;
   }
@@ -563,13 +564,13 @@ __global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
-void launch_update(hipStream_t s, double* L, double* U, const Task* tasks, const Piece* pieces, int64_t ntasks) {
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks) {
   if (ntasks <= 0) return;
   static const int nw = getenv("PASTIX_AMD_UPDATE_WAVES") ? atoi(getenv("PASTIX_AMD_UPDATE_WAVES")) : 8;
   if (nw == 4)
-    hipLaunchKernelGGL(k_update<4>, dim3((unsigned)ntasks), dim3(256), 0, s, L, U, tasks, pieces);
+    hipLaunchKernelGGL(k_update<4>, dim3((unsigned)ntasks), dim3(256), 0, s, ar, tasks, pieces);
   else
-    hipLaunchKernelGGL(k_update<8>, dim3((unsigned)ntasks), dim3(512), 0, s, L, U, tasks, pieces);
+    hipLaunchKernelGGL(k_update<8>, dim3((unsigned)ntasks), dim3(512), 0, s, ar, tasks, pieces);
 }
 
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,

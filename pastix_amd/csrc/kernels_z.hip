@@ -1,0 +1,278 @@
+// kernels_z.hip -- complex double, complex-SYMMETRIC LDLt (the reference's z `sy` variant: SYR is x x^T,
+// TRSM/GEMM use "T", no conjugation anywhere: sopalin_compute.h:549-562, compute_diag.c:223-307,
+// compute_trsm.c:84-113).  Panels are kept as split planes on the device (arena 0/2 = Re/Im of L,
+// arena 1/3 = Re/Im of L*D), so the update kernel k_update stays a real fp64 MFMA kernel: every complex
+// piece is four real pieces (plan.cpp).  Only the diagonal-blok kernel and the panel solve need complex
+// arithmetic; they mirror k_diag_ldlt / k_trsm_var<.,1> of kernels_var.hip.
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+
+namespace pastix_amd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct cz {
+  double re, im;
+};
+__device__ __forceinline__ cz cmul(cz a, cz b) { return cz{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cz csub(cz a, cz b) { return cz{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cz cinv(cz a) {
+  // 1/a, scaled (Smith) to stay finite for large/small |a|
+  if (fabs(a.re) >= fabs(a.im)) {
+    const double r = a.im / a.re, d = a.re + a.im * r;
+    return cz{1.0 / d, -r / d};
+  }
+  const double r = a.re / a.im, d = a.re * r + a.im;
+  return cz{r / d, -1.0 / d};
+}
+
+__global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTask* __restrict__ tasks,
+                                                  double* __restrict__ dinv_ws, double critere,
+                                                  long long* __restrict__ nbpivot) {
+  __shared__ cz Ts[16][17];
+  __shared__ cz Lo[16][17];
+  __shared__ cz Ti[16][17];
+  __shared__ cz Xs[16][132];   // L   rows below the tile
+  __shared__ cz Ws[16][132];   // L*D rows below the tile
+  const PanelTask tk = tasks[blockIdx.x];
+  double* Ar = ar.p[0] + tk.off;
+  double* Ai = ar.p[2] + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
+  int npiv = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    if (ti < nb && tc < nb && ti >= tc) {
+      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
+      Ts[ti][tc] = cz{Ar[o], Ai[o]};
+    }
+    for (int j = 0; j < nb; j++) {                       // PASTIX_sytrf, compute_diag.c:223-242
+      __syncthreads();
+      cz d = Ts[j][j];
+      if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // ABS_FLOAT = cabs
+      const cz inv = cinv(d);
+      if (ti < nb && tc < nb) {
+        if (tc == j) {
+          if (ti == j) Lo[j][j] = d;
+          else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
+        } else if (tc > j && ti >= tc) {
+          const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tc][j], inv);
+          Ts[ti][tc] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));    // GER with alpha = -d (x x^T)
+        }
+      }
+    }
+    __syncthreads();
+    if (ti < nb && tc < nb && ti >= tc) {
+      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
+      Ar[o] = Lo[ti][tc].re;
+      Ai[o] = Lo[ti][tc].im;
+    }
+    if (tid < 16) {
+      // inverse of the unit-lower tile (complex), column c by forward substitution
+      const int c = tid;
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512;   // [256 re][256 im] per block
+      for (int i = 0; i < 16; i++) {
+        cz x;
+        if (i >= nb || c >= nb) x = cz{(i == c) ? 1.0 : 0.0, 0.0};
+        else if (i < c) x = cz{0.0, 0.0};
+        else {
+          cz s = cz{(i == c) ? 1.0 : 0.0, 0.0};
+          for (int p = c; p < i; p++) s = csub(s, cmul(Lo[i][p], Ti[p][c]));
+          x = s;
+        }
+        Ti[i][c] = x;
+      }
+      for (int i = 0; i < 16; i++) { dst[i + 16 * c] = Ti[i][c].re; dst[256 + i + 16 * c] = Ti[i][c].im; }
+    } else if (tid - 16 < rem) {
+      const int rr = tid - 16;
+      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
+      cz x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const int64_t o = o0 + (int64_t)min(c, nb - 1) * ld;
+        x[c] = cz{Ar[o], Ai[o]};
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          cz s = x[c];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < c) s = csub(s, cmul(x[p], Lo[c][p]));
+          x[c] = s;                                        // L*D  (TRSM "R","L","T","U")
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const cz v = (c < nb) ? x[c] : cz{0.0, 0.0};
+        const cz sc = (c < nb) ? cmul(v, cinv(Lo[min(c, nb - 1)][min(c, nb - 1)])) : cz{0.0, 0.0};
+        Ws[c][rr] = v;
+        Xs[c][rr] = sc;
+        if (c < nb) {
+          Ar[o0 + (int64_t)c * ld] = sc.re;
+          Ai[o0 + (int64_t)c * ld] = sc.im;
+        }
+      }
+    }
+    __syncthreads();
+    if (rem > 0) {                                         // A22 -= (L D) L^T, lower part
+      const int nt = (rem + 1) >> 1;                       // 2x2 register tiles (complex)
+      const int64_t ob = (kb + nb) + (int64_t)(kb + nb) * ld;
+      for (int id = tid; id < nt * nt; id += 256) {
+        const int tr = id % nt, tcc = id / nt;
+        if (tr < tcc) continue;
+        cz c[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) c[a][b] = cz{0.0, 0.0};
+        for (int p = 0; p < nb; p++) {
+          cz xa[2], xb[2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            xa[a] = Ws[p][min(2 * tr + a, 131)];
+            xb[a] = Xs[p][min(2 * tcc + a, 131)];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const cz m = cmul(xa[a], xb[b]);
+              c[a][b].re += m.re;
+              c[a][b].im += m.im;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            const int r = 2 * tr + a, cc = 2 * tcc + b;
+            if (r < rem && cc < rem && r >= cc) {
+              const int64_t o = ob + r + (int64_t)cc * ld;
+              Ar[o] -= c[a][b].re;
+              Ai[o] -= c[a][b].im;
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
+// Panel solve Y = A L_d^-T (unit lower, complex symmetric), L = Y D^-1; Y^T tiles (re, im) live in MFMA
+// accumulators; complex products are four real MFMAs.  w <= 128 (NT = 8).
+__global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTask* __restrict__ tasks,
+                                                  const double* __restrict__ dinv_ws) {
+  constexpr int NT = 8;
+  const TrsmTask tk = tasks[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int nbk = (w + 15) >> 4;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  const int64_t xo = tk.off + tk.row0 + min(rloc, tk.nrows - 1);
+  const double* Tr = ar.p[0] + tk.off;
+  const double* Tim = ar.p[2] + tk.off;
+  const double* Ti = dinv_ws + tk.dinv_off;
+
+  d4 yr[NT], yi[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const int64_t o = xo + (int64_t)min(col, w - 1) * ld;
+      const double vr = ar.p[0][o], vi = ar.p[2][o];
+      yr[ct][q] = (rvalid && col < w) ? vr : 0.0;
+      yi[ct][q] = (rvalid && col < w) ? vi : 0.0;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+    if (ct < nbk) {
+      const int li = ct * 16 + l15;
+      const int lic = min(li, w - 1);
+#pragma unroll
+      for (int p = 0; p < ct; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int lc = p * 16 + g + 4 * q;
+          const int64_t o = lic + (int64_t)lc * ld;
+          const double tr = (li < w) ? Tr[o] : 0.0, tim = (li < w) ? Tim[o] : 0.0;
+          // y[ct] -= t * y[p]
+          yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr, yr[p][q], yr[ct], 0, 0, 0);
+          yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(tim, yi[p][q], yr[ct], 0, 0, 0);
+          yi[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr, yi[p][q], yi[ct], 0, 0, 0);
+          yi[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tim, yr[p][q], yi[ct], 0, 0, 0);
+        }
+      }
+      d4 nr = d4{0, 0, 0, 0}, ni = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double ar_ = Ti[ct * 512 + l15 + 16 * (g + 4 * q)];
+        const double ai_ = Ti[ct * 512 + 256 + l15 + 16 * (g + 4 * q)];
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yr[ct][q], nr, 0, 0, 0);
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai_, yi[ct][q], nr, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yi[ct][q], ni, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ai_, yr[ct][q], ni, 0, 0, 0);
+      }
+      yr[ct] = nr;
+      yi[ct] = ni;
+    }
+  }
+  const int64_t so = tk.off + tk.row0 + rloc;
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const int64_t dd = (int64_t)min(col, w - 1) * (ld + 1);
+      const cz dinv = cinv(cz{Tr[dd], Tim[dd]});
+      if (rvalid && col < w) {
+        const int64_t o = so + (int64_t)col * ld;
+        const cz y = cz{yr[ct][q], yi[ct][q]};
+        const cz l = cmul(y, dinv);
+        ar.p[1][o] = y.re;                 // L*D (compute_trsm.c:108-109)
+        ar.p[3][o] = y.im;
+        ar.p[0][o] = l.re;                 // L   (:110)
+        ar.p[2][o] = l.im;
+      }
+    }
+  }
+}
+
+// interleaved complex <-> split planes
+__global__ void k_split(const double* __restrict__ z, double* __restrict__ re, double* __restrict__ im, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { re[i] = z[2 * i]; im[i] = z[2 * i + 1]; }
+}
+__global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, const double* __restrict__ im, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) { z[2 * i] = re[i]; z[2 * i + 1] = im[i]; }
+}
+
+void launch_diag_zsy(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_diag_zsy, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
+}
+void launch_trsm_zsy(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_trsm_zsy, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv);
+}
+void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_split, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, z, re, im, n);
+}
+void launch_merge(hipStream_t s, double* z, const double* re, const double* im, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_merge, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, z, re, im, n);
+}
+
+}  // namespace pastix_amd

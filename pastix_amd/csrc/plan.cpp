@@ -49,10 +49,11 @@ double fact_flops(const pastix_amd_layout_t* L, int factotype, int floattype) {
 }
 
 namespace {
+constexpr uint16_t AB(int a, int b) { return (uint16_t)(a | (b << 2)); }   // piece flags: arenas of A and B
 struct RawPiece {
   int64_t tile;   // target tile id (+ntile for the U arena)
   int32_t lvl;    // level of the source cblk
-  uint8_t carena; // 0: L arena, 1: U arena
+  uint8_t carena; // arena (plane) of the target: 0 L, 1 U, 2/3 their imaginary planes
   uint8_t shared; // target receives contributions from several ranks (windowed schedule)
   Piece p;
 };
@@ -89,9 +90,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& P) {
   int rc = check_layout(L);
   if (rc) return rc;
-  if (floattype != PASTIX_AMD_REALDOUBLE) return PASTIX_AMD_ERR_UNSUPPORTED;
+  const bool cplx = floattype == PASTIX_AMD_COMPLEXDOUBLE;
+  if (floattype != PASTIX_AMD_REALDOUBLE && !cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
   if (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT && factotype != PASTIX_AMD_FACT_LU)
     return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (cplx && factotype != PASTIX_AMD_FACT_LDLT) return PASTIX_AMD_ERR_UNSUPPORTED;   // z: complex symmetric LDLt only
   P.factotype = factotype;
   P.floattype = floattype;
   if (opts) P.opts = *opts;
@@ -131,7 +134,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
     int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-    if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
+    if (w > (cplx ? 128 : MAXW)) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
     P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.cblk[k].stride * w : 0);
   }
@@ -195,7 +198,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         TrsmTask tt{P.poff[k], s, w, r, std::min(64, s - r), ws};
         P.trsm_tasks.push_back(tt);
       }
-      ws += (int64_t)((w + 15) / 16) * 256 * (factotype == PASTIX_AMD_FACT_LU ? 2 : 1);
+      ws += (int64_t)((w + 15) / 16) * 256 * (factotype == PASTIX_AMD_FACT_LU ? 2 : 1) * (cplx ? 2 : 1);
     }
     P.dinv_ws = std::max(P.dinv_ws, ws);
   }
@@ -227,26 +230,38 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
       for (int64_t ct = tcol / TN; ct * TN < tcol + ncols; ct++) {
         int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
-        RawPiece rp;
-        int64_t tile = tile_base[t] + rt * nct + ct + (carena ? ntile : 0);
-        rp.tile = tile;
-        // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
-        // targets: not before `window` levels ahead of the target's own level.
-        rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
-        rp.carena = carena;
-        rp.shared = shared[t];
-        rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
-        rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
-        rp.p.lda = (int32_t)sk;
-        rp.p.k = (uint16_t)wk;
-        rp.p.dr = (uint16_t)(r0 - rt * TM);
-        rp.p.m = (uint16_t)(r1 - r0);
-        rp.p.dc = (uint16_t)(c0 - ct * TN);
-        rp.p.n = (uint16_t)(c1 - c0);
-        rp.p.flags = flags;
-        raw.push_back(rp);
-        uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
-        ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
+        auto push = [&](uint16_t fl, uint8_t ca) {
+          RawPiece rp;
+          rp.tile = tile_base[t] + rt * nct + ct + (int64_t)ca * ntile;
+          // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
+          // targets: not before `window` levels ahead of the target's own level.
+          rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
+          rp.carena = ca;
+          rp.shared = shared[t];
+          rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
+          rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
+          rp.p.lda = (int32_t)sk;
+          rp.p.k = (uint16_t)wk;
+          rp.p.dr = (uint16_t)(r0 - rt * TM);
+          rp.p.m = (uint16_t)(r1 - r0);
+          rp.p.dc = (uint16_t)(c0 - ct * TN);
+          rp.p.n = (uint16_t)(c1 - c0);
+          rp.p.flags = fl;
+          raw.push_back(rp);
+          uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
+          ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
+        };
+        if (!cplx) {
+          push(flags, carena);
+        } else {
+          // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
+          //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T
+          const int a = flags & 3, b = (flags >> 2) & 3;
+          push(AB(a, b), carena);
+          push((uint16_t)(AB(a + 2, b + 2) | 16), carena);
+          push(AB(a, b + 2), (uint8_t)(carena + 2));
+          push(AB(a + 2, b), (uint8_t)(carena + 2));
+        }
       }
     }
   };
@@ -268,13 +283,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         if (run_len <= 0) return;
         if (!lu) {
           // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? 2 : 0, 0);
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? AB(0, 1) : AB(0, 0), 0);
         } else if (!run_diag) {
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // L U^T -> L arena
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 1, 1);   // U L^T -> U arena
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // L U^T -> L arena
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(1, 0), 1);   // U L^T -> U arena
         } else {
           // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, 2, 0);   // lower/diag part
+          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // lower/diag part
         }
         run_len = 0;
       };
@@ -296,7 +311,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           if (j != i) {
             // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
             // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
-            emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, 2, 0);
+            emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, AB(0, 1), 0);
           }
         }
       }
@@ -349,7 +364,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     int slot = raw[e - 1].lvl + 1;
     int64_t tile = raw[q].tile;
     uint8_t carena = raw[q].carena;
-    if (carena) tile -= ntile;
+    tile -= (int64_t)carena * ntile;
     int64_t t = std::upper_bound(tile_base.begin(), tile_base.end(), tile) - tile_base.begin() - 1;
     int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1, nct = (w_t + TN - 1) / TN;
     int64_t rt = (tile - tile_base[t]) / nct, ct = (tile - tile_base[t]) % nct;
@@ -360,7 +375,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);
-    tk.flags = carena | (raw[q].shared ? 2u : 0u);
+    tk.flags = carena | (raw[q].shared ? 4u : 0u);
     P.tasks.push_back(tk);
     task_work.push_back(work + 4096.0 * double(e - q));
     task_slot.push_back(slot);

@@ -27,7 +27,8 @@ struct Piece {
   uint16_t k;         // source cblk width
   uint16_t dr, m;     // destination rows inside the tile
   uint16_t dc, n;     // destination cols inside the tile
-  uint16_t flags;     // bit0: A in U arena, bit1: B in U arena
+  uint16_t flags;     // bits 0-1: arena of A, bits 2-3: arena of B, bit 4: contribution is ADDED
+                      // arenas: 0 = L (real part), 1 = U / L*D (real part), 2/3 = their imaginary planes
 };
 static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 
@@ -36,10 +37,12 @@ struct Task {
   int32_t ldc;
   uint16_t tm, tn;    // valid extent of the tile (<= TM, TN)
   int32_t p0, pn;     // piece range
-  uint32_t flags;     // bit0: C in U arena
+  uint32_t flags;     // bits 0-1: arena of C, bit 2: combine with atomics (tile shared by several tasks)
   uint32_t pad;
 };
 static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
+
+struct Arenas { double* p[4]; };   // device base pointers of the (up to) four planes
 
 struct PanelTask {    // one cblk for the diagonal-block kernel
   int64_t off;        // arena offset of the panel

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import LayoutArrays, Options, Stats, check
 
 FACT_LLT, FACT_LDLT, FACT_LU, FACT_LDLH = 0, 1, 2, 3
-REALDOUBLE = 1
+REALDOUBLE, COMPLEXDOUBLE = 1, 3
 
 
 def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
@@ -24,6 +24,7 @@ class Plan:
     def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
+        self.dtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float64
         self._h = ctypes.c_void_p()
         opts = Options()
         opts.device = device
@@ -60,20 +61,20 @@ class Plan:
         return s.as_dict()
 
     def upload(self, L, U=None):
-        L = np.ascontiguousarray(L, dtype=np.float64)
+        L = np.ascontiguousarray(L, dtype=self.dtype)
         assert L.size == self.coefnbr
-        U = np.ascontiguousarray(U, dtype=np.float64) if U is not None else None
+        U = np.ascontiguousarray(U, dtype=self.dtype) if U is not None else None
         check(_lib.lib().pastix_amd_upload_packed(self._h, _lib.ptr(L), _lib.ptr(U)), "pastix_amd_upload_packed")
 
     def download(self):
-        L = np.empty(self.coefnbr, dtype=np.float64)
-        U = np.empty(self.coefnbr, dtype=np.float64) if self.factotype == FACT_LU else None
+        L = np.empty(self.coefnbr, dtype=self.dtype)
+        U = np.empty(self.coefnbr, dtype=self.dtype) if self.factotype == FACT_LU else None
         check(_lib.lib().pastix_amd_download_packed(self._h, _lib.ptr(L), _lib.ptr(U)), "pastix_amd_download_packed")
         return L, U
 
     def fill_csc(self, sym, n, colptr, rows, vals, perm):
         colptr, rows, perm = _lib.as_i64(colptr), _lib.as_i64(rows), _lib.as_i64(perm)
-        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        vals = np.ascontiguousarray(vals, dtype=self.dtype)
         check(_lib.lib().pastix_amd_fill_csc(self._h, int(sym), ctypes.c_int64(n), _lib.ptr(colptr),
                                              _lib.ptr(rows), _lib.ptr(vals), _lib.ptr(perm)),
               "pastix_amd_fill_csc")

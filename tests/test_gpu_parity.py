@@ -112,3 +112,29 @@ def test_lu_device_fill_matches_reference(name, golden):
         p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
         L0, U0 = p.download()
     assert np.array_equal(L0, g["L0"]) and np.array_equal(U0, g["U0"])
+
+
+@pytest.mark.parametrize("name", golden_names("ldlt", prec="z"))
+def test_z_ldlt_matches_reference_golden(name, golden):
+    """BASELINE config 5 family: complex double, complex-symmetric LDLt (incl. the reference's own
+    young4c.mtx fixture, 120-wide cblks)."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE) as p:
+        p.upload(g["L0"])
+        st = p.factorize(g["critere"])
+        L1, _ = p.download()
+    m = _lower_mask(g["cblk4"])
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", golden_names("ldlt", prec="z"))
+def test_z_device_fill_matches_reference(name, golden):
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        L0, _ = p.download()
+    assert np.array_equal(L0, g["L0"])
