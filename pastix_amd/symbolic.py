@@ -75,3 +75,49 @@ def laplacian_3d(nx, ny=None, nz=None, full=False):
     np.add.at(colptr, cols + 1, 1)
     colptr = np.cumsum(colptr) + 1
     return n, colptr, rws + 1, vals
+
+
+def elasticity_3d(N, dof=3, seed=12345):
+    """BASELINE config 5 matrix: 3 dof per node on an N^3 grid with 7-point node coupling, every node
+    pair coupled by a full dof x dof block; values complex SYMMETRIC (not Hermitian), off-diagonal
+    entries (u + i v), u,v ~ U(-1,1) (seeded), diagonal = 1 + sum |off-diagonals of the row| (real).
+    Returns (n, colptr, rows, vals, node_of_dof): lower-triangular CSC, 1-based, complex128."""
+    rng = np.random.default_rng(seed)
+    nn = N * N * N
+    ids = np.arange(nn, dtype=np.int64)
+    x, y, z = ids % N, (ids // N) % N, ids // (N * N)
+    pairs_i, pairs_j = [ids], [ids]                 # node pairs (i >= j): self + 3 forward neighbours
+    for m, d in ((x < N - 1, 1), (y < N - 1, N), (z < N - 1, N * N)):
+        pairs_i.append(ids[m] + d)
+        pairs_j.append(ids[m])
+    pi, pj = np.concatenate(pairs_i), np.concatenate(pairs_j)
+    rows, cols = [], []
+    for a in range(dof):
+        for b in range(dof):
+            r_, c_ = pi * dof + a, pj * dof + b
+            keep = r_ >= c_                          # lower triangle (drops the upper part of self blocks)
+            rows.append(r_[keep])
+            cols.append(c_[keep])
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    order = np.lexsort((rows, cols))
+    rows, cols = rows[order], cols[order]
+    n = nn * dof
+    vals = rng.uniform(-1, 1, len(rows)) + 1j * rng.uniform(-1, 1, len(rows))
+    offd = rows != cols
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, rows[offd], np.abs(vals[offd]))
+    np.add.at(rowsum, cols[offd], np.abs(vals[offd]))
+    vals[~offd] = rowsum[rows[~offd]] + 1.0
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(colptr, cols + 1, 1)
+    colptr = np.cumsum(colptr) + 1
+    return n, colptr, rows + 1, vals.astype(np.complex128), np.arange(n) // dof
+
+
+def order_grid_dof(N, dof, leaf=8):
+    """Geometric ND of the node grid, expanded to dofs (all dofs of a node stay adjacent)."""
+    pn, _ = order_grid(N, N, N, leaf=leaf)
+    perm = (pn[:, None] * dof + np.arange(dof)[None, :]).reshape(-1)
+    invp = np.empty_like(perm)
+    invp[perm] = np.arange(len(perm))
+    return perm, invp

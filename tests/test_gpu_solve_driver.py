@@ -152,3 +152,39 @@ def test_distributed_plans_emulated_on_one_gpu(world, golden):
         assert np.abs(got - g["L1"][off[k]:off[k + 1]]).max() <= 1e-12 * scale
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("N", [5, 8])
+def test_config5_z_ldlt_elasticity_pattern(N):
+    """BASELINE config 5: complex double LDLt on a 3-dof elasticity-pattern matrix (complex symmetric),
+    GPU (split-plane zgemm on MFMA) vs the CPU oracle; tolerance 1e-12 * max|L|."""
+    from pastix_amd import COMPLEXDOUBLE
+    n, cp, r, v, _ = sy.elasticity_3d(N)
+    perm, _ = sy.order_grid_dof(N, 3)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=96)
+    c4, b4 = s["cblk4"], s["blok4"]
+    L0, _ = oracle_lib.fill(1, 1, n, cp, r, v, s["perm"], c4, b4)
+    crit = 1e-12
+    Lo, _, nbo = oracle_lib.sopalin(1, c4, b4, L0, None, crit)
+    with Plan(c4, b4, 1, floattype=COMPLEXDOUBLE) as p:
+        p.fill_csc(1, n, cp, r, v, s["perm"])
+        Ld, _ = p.download()
+        assert np.array_equal(Ld, L0)
+        st = p.factorize(crit)
+        L1, _ = p.download()
+    assert st["nbpivot"] == nbo == 0
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    m = np.ones(len(L1), dtype=bool)
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    for k in range(len(w)):
+        for c in range(int(w[k])):
+            m[off[k] + c * c4[k, 3]: off[k] + c * c4[k, 3] + c] = False
+    assert np.abs(L1 - Lo)[m].max() <= 1e-12 * np.abs(Lo[m]).max()
+    # end-to-end: solve with the oracle's substitution on the GPU factors
+    b = np.random.default_rng(2).random(n) + 0j
+    bp = np.empty(n, dtype=np.complex128)
+    bp[s["perm"]] = b
+    x = oracle_lib.solve(1, c4, b4, L1, None, bp)[s["perm"]]
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    A = A + sp.tril(A, -1).T
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
