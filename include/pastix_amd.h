@@ -83,6 +83,7 @@ typedef struct pastix_amd_stats_s {
   pastix_amd_int_t nbpivot;  /* static pivots (IPARM_STATIC_PIVOTING) */
   pastix_amd_int_t coefnbr;  /* panel elements (one of L/U) */
   pastix_amd_int_t nlevels, ntasks, npieces, nupdate_launches;
+  pastix_amd_int_t inertia;  /* IPARM_INERTIA: positive D entries (real LDLt), -1 otherwise */
   double update_flops;     /* 2*m*n*k summed over the update pieces of this plan */
   double local_flops;      /* fact_flops restricted to the cblks this plan owns (== fact_flops on one GPU) */
   double update_bytes;     /* algorithmic bytes of the update kernel: 8k(m+n) per piece + 16*tm*tn per task */

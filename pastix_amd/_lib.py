@@ -37,7 +37,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("fact_flops", ctypes.c_double), ("fact_time", ctypes.c_double),
                 ("update_time", ctypes.c_double), ("h2d_time", ctypes.c_double),
                 ("d2h_time", ctypes.c_double), ("nbpivot", i64), ("coefnbr", i64),
-                ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64),
+                ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64), ("inertia", i64),
                 ("update_flops", ctypes.c_double), ("local_flops", ctypes.c_double),
                 ("update_bytes", ctypes.c_double), ("reserved", ctypes.c_double * 4)]
 

@@ -31,8 +31,10 @@ void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks
                       int maxw);
 void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
                     int maxw);
-void launch_solve_level(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t ntask,
-                        const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* x);
+void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const DevBlok* bl, double* x);
+void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
 }  // namespace pastix_amd
 
 using namespace pastix_amd;
@@ -144,7 +146,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     if ((r = to_device(&p->dPieces, H.pieces))) return r;
     if ((r = to_device(&p->dPanel, H.panel_tasks))) return r;
     if ((r = to_device(&p->dTrsm, H.trsm_tasks))) return r;
-    HIPCHK(hipMalloc((void**)&p->dNbpivot, sizeof(long long)));
+    HIPCHK(hipMalloc((void**)&p->dNbpivot, 2 * sizeof(long long)));   // [static pivots, positive D entries]
     HIPCHK(hipMalloc((void**)&p->dErr, sizeof(int)));
     HIPCHK(hipEventCreate(&p->ev0));
     HIPCHK(hipEventCreate(&p->ev1));
@@ -468,7 +470,7 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   if (!p || !p->dL || (p->host.factotype != PASTIX_AMD_FACT_LLT && !p->dU)) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = p->stream;
-  HIPCHK(hipMemsetAsync(p->dNbpivot, 0, sizeof(long long), s));
+  HIPCHK(hipMemsetAsync(p->dNbpivot, 0, 2 * sizeof(long long), s));
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
   p->nupd_run = 0;
@@ -538,11 +540,13 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   }
   p->stats.update_time = upd;
   p->stats.nupdate_launches = p->nupd_run;
-  long long nb = 0;
+  long long nb[2] = {0, 0};
   int err = 0;
-  HIPCHK(hipMemcpy(&nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&err, p->dErr, sizeof(err), hipMemcpyDeviceToHost));
-  p->stats.nbpivot = nb;
+  p->stats.nbpivot = nb[0];
+  // IPARM_INERTIA: number of positive D entries, real LDLt only, else -1 (sopalin3d.c:1144-1160)
+  p->stats.inertia = (H.factotype == PASTIX_AMD_FACT_LDLT && !p->cplx) ? nb[1] : -1;
   if (stats) *stats = p->stats;
   return err ? PASTIX_AMD_ERR_NUMERIC : PASTIX_AMD_OK;
 }
@@ -561,11 +565,12 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   return pastix_amd_factorize_end(p, stats);
 }
 
-// Forward / backward substitution on the device-resident factors (LLt), x in permuted numbering.
+// Forward / (diagonal) / backward substitution on the device-resident factors (real LLt, LDLt, LU; the data
+// flow of up_down_smp, updo.c:114), x in permuted numbering.
 int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
-  if (H.factotype != PASTIX_AMD_FACT_LLT || p->distributed) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (p->distributed || p->cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);
@@ -598,11 +603,14 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   for (int64_t j = 0; j < nrhs; j++) {
     HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * sizeof(double), hipMemcpyHostToDevice, p->stream));
     for (int l = 0; l < H.nlevels; l++)
-      launch_solve_level(p->stream, true, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
-                         p->dChunk + p->lvl_chunk_ptr[l], p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
+      launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
+    if (H.factotype == PASTIX_AMD_FACT_LDLT) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx);
     for (int l = H.nlevels - 1; l >= 0; l--)
-      launch_solve_level(p->stream, false, p->dL, p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
-                         p->dChunk + p->lvl_chunk_ptr[l], p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
+      launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
     HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
   }

@@ -169,6 +169,7 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         rc = pastix_amd_factorize(D->plan, critere, &st);
         dparm[DPARM_FACT_TIME] = st.fact_time;           // sopalin3d.c:1125-1132
         iparm[IPARM_STATIC_PIVOTING] = st.nbpivot;        // pastix.c:3853
+        iparm[IPARM_INERTIA] = st.inertia;
         if (rc) FAIL(rc);
         D->factorized = true;
         break;

@@ -482,9 +482,10 @@ __device__ __forceinline__ int panel_row_to_global(const DevBlok* __restrict__ b
 }
 
 // forward, step 1: x_k := L_kk^-1 x_k (one workgroup per cblk)
+// unit: LDLt and LU (unit-lower L); else LLt
 __global__ __launch_bounds__(256) void k_solve_diag_fwd(const double* __restrict__ L,
                                                         const SolveTask* __restrict__ tasks,
-                                                        double* __restrict__ x) {
+                                                        double* __restrict__ x, int unit) {
   __shared__ double xs[MAXW];
   const SolveTask tk = tasks[blockIdx.x];
   const double* A = L + tk.off;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256) void k_solve_diag_fwd(const double* __restrict
   for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
   __syncthreads();
   for (int c = 0; c < w; c++) {            // column-oriented forward substitution
-    const double xc = xs[c] / A[c + (int64_t)c * ld];
+    const double xc = unit ? xs[c] : xs[c] / A[c + (int64_t)c * ld];
     __syncthreads();
     if (tid == 0) xs[c] = xc;
     for (int r = c + 1 + tid; r < w; r += 256) xs[r] -= A[r + (int64_t)c * ld] * xc;
@@ -541,10 +542,19 @@ __global__ __launch_bounds__(256) void k_solve_off_bwd(const double* __restrict_
     unsafeAtomicAdd(&x[ck.fcol + c], -(part[0][c] + part[1][c] + part[2][c] + part[3][c]));
 }
 
+// LDLt: x_k := D_k^-1 x_k between the forward and the backward sweep
+__global__ __launch_bounds__(256) void k_solve_dscale(const double* __restrict__ L,
+                                                      const SolveTask* __restrict__ tasks, double* __restrict__ x) {
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  for (int c = threadIdx.x; c < tk.width; c += 256) x[tk.fcol + c] /= A[c + (int64_t)c * tk.stride];
+}
+
 // backward, step 2: L_kk^T x_k = rhs
+// mode 0: L^T non-unit (LLt); 1: L^T unit (LDLt); 2: U = upper triangle of the factored blok (LU)
 __global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict__ L,
                                                         const SolveTask* __restrict__ tasks,
-                                                        double* __restrict__ x) {
+                                                        double* __restrict__ x, int mode) {
   __shared__ double xs[MAXW];
   const SolveTask tk = tasks[blockIdx.x];
   const double* A = L + tk.off;
@@ -552,10 +562,11 @@ __global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict
   for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
   __syncthreads();
   for (int c = w - 1; c >= 0; c--) {        // row-oriented backward substitution
-    const double xc = xs[c] / A[c + (int64_t)c * ld];
+    const double xc = (mode == 1) ? xs[c] : xs[c] / A[c + (int64_t)c * ld];
     __syncthreads();
     if (tid == 0) xs[c] = xc;
-    for (int r = tid; r < c; r += 256) xs[r] -= A[c + (int64_t)r * ld] * xc;
+    for (int r = tid; r < c; r += 256)
+      xs[r] -= (mode == 2 ? A[r + (int64_t)c * ld] : A[c + (int64_t)r * ld]) * xc;
     __syncthreads();
   }
   for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
@@ -587,15 +598,24 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
     hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
 }
 
-void launch_solve_level(hipStream_t s, bool fwd, const double* L, const SolveTask* tasks, int64_t ntask,
-                        const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* x) {
+// fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
+void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const DevBlok* bl, double* x) {
+  const int unit = factotype != PASTIX_AMD_FACT_LLT;
   if (fwd) {
-    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
+    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
     if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
   } else {
-    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
-    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
+    const double* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
+    const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
+    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, bl, x);
+    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, mode);
   }
+}
+
+void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {
+  if (ntask > 0) hipLaunchKernelGGL(k_solve_dscale, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
 }
 
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n) {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
   const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
-  int npiv = 0;
+  int npiv = 0, npos = 0;
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
     if (ti < nb && tc < nb && ti >= tc) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
       __syncthreads();
       double d = Ts[j][j];
       if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
+      if (tid == 0 && d > 0.0) npos++;                     // inertia (sopalin3d.c:1144-1160)
       const double inv = 1.0 / d;
       if (ti < nb && tc < nb) {
         if (tc == j) {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
     __syncthreads();
   }
   if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+  if (tid == 0 && npos) atomicAdd((unsigned long long*)nbpivot + 1, (unsigned long long)npos);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -89,6 +89,7 @@ def test_ldlt_matches_reference_golden(name, lookahead, golden):
     scale = np.abs(g["L1"][m]).max()
     assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
     assert st["nbpivot"] == g["nbpivot"]
+    assert st["inertia"] == g["inertia"] == g["n"]       # SPD input: all D positive (IPARM_INERTIA)
 
 
 @pytest.mark.parametrize("lookahead", [1, 0])

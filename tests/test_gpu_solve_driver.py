@@ -28,6 +28,18 @@ def test_solve_matches_oracle(golden):
     assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
 
 
+@pytest.mark.parametrize("name", ["rlap3d_12_ldlt", "rlap3d_12_lu", "rlap3d_8_lu"])
+def test_solve_ldlt_lu_matches_reference(name, golden):
+    g = golden(name)
+    bp = np.empty_like(g["b"])
+    bp[g["perm"]] = g["b"]
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.upload(g["L0"], g["U0"])
+        p.factorize(g["critere"])
+        x = p.solve(bp)[g["perm"]]
+    assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
+
+
 def test_refill_is_idempotent_and_refactor_is_deterministic(golden):
     g = golden("rlap3d_10_llt")
     with Plan(g["cblk4"], g["blok4"], 0) as p:
