@@ -147,12 +147,90 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
 
-  int pi = tk.p0;
+  unsigned touched = 0;                         // union of active (mi | ni<<4) masks
+  if (tk.nfull > 0) {
+    // ---- leading pieces that cover the whole tile with K % 16 == 0 (the bulk of the flops in the
+    // dense parts of the elimination tree): minimal per-chunk bookkeeping, pointer-bumped loads
+    constexpr int KS = 64 * NW / 128;
+    constexpr int NLD = Stage<NW>::NLD;
+    const int row = tid & 127, k0 = tid >> 7;
+    int pi = tk.p0;
+    const int pend = tk.p0 + (int)tk.nfull;
+    Piece cur = pieces[pi];
+    Piece nextp = pieces[min(pi + 1, pend - 1)];
+    int64_t lda = cur.lda;
+    const double* pa = ar.p[cur.flags & 3] + cur.a_off + row + (int64_t)k0 * lda;
+    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + row + (int64_t)k0 * lda;
+    int left = (int)cur.k / KC;                   // chunks left in the current piece (incl. the staged one)
+    double sgn = (cur.flags & 16) ? -1.0 : 1.0;
+    double sa[NLD], sb[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; q++) { sa[q] = pa[(int64_t)q * KS * lda]; sb[q] = pb[(int64_t)q * KS * lda]; }
+    {
+      double* dA = sh[0][0] + k0 * SLD + row;
+      double* dB = sh[0][1] + k0 * SLD + row;
+#pragma unroll
+      for (int q = 0; q < NLD; q++) { dA[q * KS * SLD] = sa[q]; dB[q * KS * SLD] = sgn * sb[q]; }
+    }
+    __syncthreads();
+    int buf = 0;
+    touched = MALL | (0xFu << 4);
+    const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
+    const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+    while (true) {
+      bool has_next = true;
+      if (--left == 0) {
+        if (++pi < pend) {
+          cur = nextp;
+          lda = cur.lda;
+          pa = ar.p[cur.flags & 3] + cur.a_off + row + (int64_t)k0 * lda;
+          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + row + (int64_t)k0 * lda;
+          left = (int)cur.k / KC;
+          sgn = (cur.flags & 16) ? -1.0 : 1.0;
+          nextp = pieces[min(pi + 1, pend - 1)];
+        } else {
+          has_next = false;
+        }
+      } else {
+        pa += (int64_t)KC * lda;
+        pb += (int64_t)KC * lda;
+      }
+      if (has_next) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) { sa[q] = pa[(int64_t)q * KS * lda]; sb[q] = pb[(int64_t)q * KS * lda]; }
+      }
+      const double* sA = sAw + buf * (2 * KC * SLD);
+      const double* sB = sBw + buf * (2 * KC * SLD);
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ks++) {
+        double bm[MI], an_[NI];
+#pragma unroll
+        for (int s = 0; s < MI; s++) bm[s] = sA[ks * 4 * SLD + s * 16];
+#pragma unroll
+        for (int s = 0; s < NI; s++) an_[s] = sB[ks * 4 * SLD + s * 16];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
+      }
+      if (has_next) {
+        double* dA = sh[buf ^ 1][0] + k0 * SLD + row;
+        double* dB = sh[buf ^ 1][1] + k0 * SLD + row;
+#pragma unroll
+        for (int q = 0; q < NLD; q++) { dA[q * KS * SLD] = sa[q]; dB[q * KS * SLD] = sgn * sb[q]; }
+      }
+      __syncthreads();
+      if (!has_next) break;
+      buf ^= 1;
+    }
+  }
+  if ((int)tk.nfull < tk.pn) {
+  int pi = tk.p0 + (int)tk.nfull;
   const int pend = tk.p0 + tk.pn;
   Piece cur = pieces[pi];
   Piece nextp = pieces[min(pi + 1, pend - 1)];  // descriptor prefetched one piece ahead
   int kc = 0, buf = 0;
-  unsigned touched = 0;                         // union of active (mi | ni<<4) masks
   Stage<NW> st;
   {
     const double* Ab = ar.p[cur.flags & 3] + cur.a_off;
@@ -232,6 +310,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     pi = npi;
     kc = nkc;
     buf ^= 1;
+  }
+
   }
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column).  Loads of one

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   std::vector<Task> tasks(ntask); std::vector<Piece> pieces((size_t)ntask * P);
   for (int t = 0; t < ntask; t++) {
-    tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, 0};
+    tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, (unsigned)(getenv("NOFAST") ? 0 : P)};
     for (int p = 0; p < P; p++) {
       int s = (t * 7 + p * 13) % pool; int ra = ((t * 31 + p) % (rows / 128)) * 128, rb = ((t * 17 + 3 * p) % (rows / 128)) * 128;
       pieces[(size_t)t * P + p] = Piece{(int64_t)s * rows * K + ra, (int64_t)s * rows * K + rb, rows, (uint16_t)K, 0, 128, 0, 128, 0};
@@ -30,9 +30,9 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
   CK(hipMemcpy(dp, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  launch_update(0, d, d, dt, dp, ntask); CK(hipDeviceSynchronize());
+  launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask); CK(hipDeviceSynchronize());
   int reps = 5; CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; r++) launch_update(0, d, d, dt, dp, ntask);
+  for (int r = 0; r < reps; r++) launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double fl = 2.0 * 128 * 128 * K * (double)P * ntask * reps;
   printf("tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,
