@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=int(os.environ.get("PASTIX_AMD_BENCH_GRID", "200")))
     ap.add_argument("--blocksize", type=int, default=128)
-    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=0, help="update-schedule chunk (0 = engine default)")
     ap.add_argument("--facto", choices=["llt", "ldlt", "lu"], default="llt")
     ap.add_argument("--cpu-sample-grid", type=int, default=70)
     ap.add_argument("--no-cpu-baseline", action="store_true")
