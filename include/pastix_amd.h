@@ -87,7 +87,8 @@ typedef struct pastix_amd_stats_s {
   double update_flops;     /* 2*m*n*k summed over the update pieces of this plan */
   double local_flops;      /* fact_flops restricted to the cblks this plan owns (== fact_flops on one GPU) */
   double update_bytes;     /* algorithmic bytes of the update kernel: 8k(m+n) per piece + 16*tm*tn per task */
-  double reserved[4];
+  double full_flops;       /* part of update_flops carried by full 128x128 pieces */
+  double reserved[3];
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;

@@ -39,7 +39,8 @@ class Stats(ctypes.Structure):
                 ("d2h_time", ctypes.c_double), ("nbpivot", i64), ("coefnbr", i64),
                 ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64), ("inertia", i64),
                 ("update_flops", ctypes.c_double), ("local_flops", ctypes.c_double),
-                ("update_bytes", ctypes.c_double), ("reserved", ctypes.c_double * 4)]
+                ("update_bytes", ctypes.c_double), ("full_flops", ctypes.c_double),
+                ("reserved", ctypes.c_double * 3)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -167,6 +167,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.npieces = (int64_t)H.pieces.size();
   S.update_flops = H.update_flops;
   S.update_bytes = H.update_bytes;
+  S.full_flops = H.full_flops;
   // the piece/task tables now live on the device; keep only what the host driver reads
   std::vector<Piece>().swap(H.pieces);
   std::vector<Task>().swap(H.tasks);

@@ -380,13 +380,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);
     tk.flags = carena | (raw[q].shared ? 4u : 0u);
-    {   // full pieces (whole tile, K a multiple of the staging chunk) first: the kernel runs them
+    {   // full pieces (whole 128x128 tile, K a multiple of the staging chunk) first: the kernel runs them
         // through its specialized loop; tk.nfull = how many
       auto isfull = [](const Piece& pc) {
-        return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && (pc.k % 16) == 0 && pc.k > 0;
+        return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && pc.k > 0 && pc.k % 16 == 0;
       };
       auto mid = std::stable_partition(P.pieces.begin() + q, P.pieces.begin() + e, isfull);
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
+      for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
     }
     P.tasks.push_back(tk);
     task_work.push_back(work + 4096.0 * double(e - q));

@@ -15,7 +15,7 @@ ap.add_argument("-n", type=int, default=60)
 ap.add_argument("--leaf", type=int, default=8)
 ap.add_argument("--amalg", type=int, default=5)
 ap.add_argument("--bs", type=int, default=128)
-ap.add_argument("--look", type=int, default=4)
+ap.add_argument("--look", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--verbose", type=int, default=0)
@@ -31,8 +31,9 @@ print("N=%d cblk=%d blok=%d nnzl=%.3e flops=%.4e  symbolic %.1fs" % (N, len(c4) 
 t = time.time()
 p = Plan(c4, b4, 0, lookahead=a.look, verbose=a.verbose)
 st = p.stats()
-print("plan %.1fs: levels=%d tasks=%d pieces=%d update_flops=%.4e (%.3f of total)" % (
-    time.time() - t, st["nlevels"], st["ntasks"], st["npieces"], st["update_flops"], st["update_flops"] / fl), flush=True)
+print("plan %.1fs: levels=%d tasks=%d pieces=%d update_flops=%.4e (%.3f of total), in full pieces %.3f" % (
+    time.time() - t, st["nlevels"], st["ntasks"], st["npieces"], st["update_flops"], st["update_flops"] / fl,
+    st["full_flops"] / max(st["update_flops"], 1)), flush=True)
 crit = 1e-14
 for rep in range(a.reps):
     t = time.time()
