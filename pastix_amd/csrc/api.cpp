@@ -20,7 +20,7 @@ void launch_trsm_zsy(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int
 void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n);
 void launch_merge(hipStream_t s, double* z, const double* re, const double* im, int64_t n);
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
-                     long long* nbpivot, int* errflag);
+                     long long* nbpivot, int* errflag, int maxw);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
 void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
@@ -500,7 +500,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
     launch_diag_zsy(s, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
     launch_trsm_zsy(s, p->arenas(), tt, ntt, p->dDinv);
   } else if (H.factotype == PASTIX_AMD_FACT_LLT) {
-    launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr);
+    launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr, p->maxw);
     launch_trsm_llt(s, p->dL, tt, ntt, p->dDinv, p->maxw);
   } else if (H.factotype == PASTIX_AMD_FACT_LDLT) {
     launch_diag_ldlt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot);

@@ -1,0 +1,29 @@
+// devmath.h -- device-only scalar helpers (include after <hip/hip_runtime.h>)
+#pragma once
+
+namespace pastix_amd {
+
+// Latency-critical scalar math of the diagonal-blok kernels: hardware estimate (v_rcp_f64 / v_rsq_f64)
+// refined by two Newton steps in FMA arithmetic (<= 2 ulp), instead of the ~40-instruction correctly
+// rounded software sequences hipcc emits for 1.0/x and sqrt(x): the per-column chain of the diagonal
+// factorization is serial, so instruction latency, not throughput, is what a dependency level waits for.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+// returns sqrt(x) and 1/sqrt(x) for x > 0
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+  double y = __builtin_amdgcn_rsq(x);
+  double h = 0.5 * y;
+  y = __builtin_fma(h, __builtin_fma(-x * y, y, 1.0), y);
+  h = 0.5 * y;
+  y = __builtin_fma(h, __builtin_fma(-x * y, y, 1.0), y);
+  double r = x * y;
+  r = __builtin_fma(__builtin_fma(-r, r, x), 0.5 * y, r);   // one correction of the root
+  s = r;
+  rs = y;
+}
+
+}  // namespace pastix_amd

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "plan.h"
+#include "devmath.h"
 
 namespace pastix_amd {
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
       double d = Ts[j][j];
       if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
       if (tid == 0 && d > 0.0) npos++;                     // inertia (sopalin3d.c:1144-1160)
-      const double inv = 1.0 / d;
+      const double inv = fast_rcp(d);
       if (ti < nb && tc < nb) {
         if (tc == j) {
           if (ti == j) Lo[j][j] = d;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
 #pragma unroll
       for (int c = 0; c < 16; c++) {
         const double v = (c < nb) ? x[c] : 0.0;
-        const double sc = (c < nb) ? v * (1.0 / Lo[min(c, nb - 1)][min(c, nb - 1)]) : 0.0;
+        const double sc = (c < nb) ? v * fast_rcp(Lo[min(c, nb - 1)][min(c, nb - 1)]) : 0.0;
         Ws[c][rr] = v;
         Xs[c][rr] = sc;
         if (c < nb) ap[(int64_t)c * ld] = sc;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
       __syncthreads();
       double d = Ts[j][j];
       if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
-      const double inv = 1.0 / d;
+      const double inv = fast_rcp(d);
       if (ti < nb && tc < nb) {
         if (ti == j && tc >= j) Lo[j][tc] = (tc == j) ? d : Ts[j][tc];          // row j of U
         else if (tc == j && ti > j) Lo[ti][j] = Ts[ti][j] * inv;                // column j of L
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
 #pragma unroll
           for (int p = 0; p < 16; p++)
             if (p < c) s -= x[p] * Lo[p][c];
-          x[c] = s / Lo[c][c];
+          x[c] = s * fast_rcp(Lo[c][c]);
         }
       }
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void k_trsm_var(double* __restrict__ L, double
         const double dv = Td[min(col, w - 1) * (int64_t)(ld + 1)];
         if (rvalid && col < w) {
           (U + tk.off + tk.row0 + rloc)[(int64_t)col * ld] = acc[ct][q];           // L*D (compute_trsm.c:108-109)
-          Xp[(int64_t)col * ld] = acc[ct][q] * (1.0 / dv);                        // L   (:110)
+          Xp[(int64_t)col * ld] = acc[ct][q] * fast_rcp(dv);                      // L   (:110)
         }
       } else {
         if (rvalid && col < w) Xp[(int64_t)col * ld] = acc[ct][q];

@@ -42,7 +42,8 @@ struct Task {
 };
 static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
 
-struct Arenas { double* p[4]; };   // device base pointers of the (up to) four planes
+struct Arenas { double* p[4]; };
+   // device base pointers of the (up to) four planes
 
 struct PanelTask {    // one cblk for the diagonal-block kernel
   int64_t off;        // arena offset of the panel
