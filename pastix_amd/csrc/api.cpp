@@ -43,7 +43,11 @@ struct pastix_amd_plan_s {
   Plan host;
   int device = 0;
   hipStream_t stream = nullptr;
-  bool own_stream = true, own_arena = true, distributed = false;
+  hipStream_t stream2 = nullptr;      // second stream: non-urgent contributions overlap the panel kernels
+  std::vector<hipEvent_t> evP, evB;   // per level: panels done (stream), bulk contributions done (stream2)
+  std::vector<hipEvent_t> evT;        // timing pairs of the bulk launches
+  int nupdB_run = 0;
+  bool own_stream = true, own_arena = true, distributed = false, overlapped = false;
   int nupd_run = 0;
   double crit_run = 0;
   double* dL = nullptr;      // L  (real part)
@@ -126,7 +130,12 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
 #define CHK(x) do { int r_ = (x); if (r_) { pastix_amd_plan_destroy(p); return r_; } } while (0)
   auto body = [&]() -> int {
     HIPCHK(hipSetDevice(p->device));
-    HIPCHK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically smallest = highest priority
+      HIPCHK(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
+      HIPCHK(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, lo));
+    }
     p->distributed = owner != nullptr;
     p->own_arena = !(opts && opts->external_arena);
     p->cplx = H.floattype == PASTIX_AMD_COMPLEXDOUBLE;
@@ -152,6 +161,12 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     HIPCHK(hipEventCreate(&p->ev1));
     p->ev.resize(2 * (size_t)H.nlevels);
     for (auto& e : p->ev) HIPCHK(hipEventCreate(&e));
+    p->evT.resize(2 * (size_t)H.nlevels);
+    for (auto& e : p->evT) HIPCHK(hipEventCreate(&e));
+    p->evP.resize((size_t)H.nlevels);
+    p->evB.resize((size_t)H.nlevels);
+    for (auto& e : p->evP) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : p->evB) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
   };
   CHK(body());
@@ -255,6 +270,10 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
   (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : p->evT) if (e) (void)hipEventDestroy(e);
+  for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
+  for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
+  if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -475,11 +494,14 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
   p->nupd_run = 0;
+  p->nupdB_run = 0;
   p->crit_run = critere;
   return PASTIX_AMD_OK;
 }
 
 // one dependency level: contributions scheduled into slot l, then the owned cblks of level l
+static int launch_panels(pastix_amd_plan_t* p, int l);
+
 int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   if (!p || l < 0 || l >= p->host.nlevels) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
@@ -492,6 +514,12 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
     p->nupd_run++;
   }
   if (phase == 1) return PASTIX_AMD_OK;
+  return launch_panels(p, l);
+}
+
+static int launch_panels(pastix_amd_plan_t* p, int l) {
+  const Plan& H = p->host;
+  hipStream_t s = p->stream;
   const PanelTask* pt = p->dPanel + H.lvl_panel_ptr[l];
   const int64_t npt = H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l];
   const TrsmTask* tt = p->dTrsm + H.lvl_trsm_ptr[l];
@@ -525,8 +553,8 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   double upd = 0;
   {
     int i = 0;
-    for (int l = 0; l < H.nlevels; l++) {
-      const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
+    for (int l = 0; l < H.nlevels && i < p->nupd_run; l++) {
+      const int64_t t0 = H.slot_task_ptr[l], t1 = p->overlapped ? H.slot_urgent_end[l] : H.slot_task_ptr[l + 1];
       if (t1 <= t0) continue;
       float m2 = 0;
       HIPCHK(hipEventElapsedTime(&m2, p->ev[2 * i], p->ev[2 * i + 1]));
@@ -539,8 +567,33 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
       i++;
     }
   }
+  if (p->nupdB_run > 0) {
+    // the launches of the two streams overlap: count the time at least one of them was in flight
+    std::vector<std::pair<float, float>> iv;
+    for (int i = 0; i < p->nupd_run; i++) {
+      float a = 0, b = 0;
+      HIPCHK(hipEventElapsedTime(&a, p->ev0, p->ev[2 * i]));
+      HIPCHK(hipEventElapsedTime(&b, p->ev0, p->ev[2 * i + 1]));
+      iv.emplace_back(a, b);
+    }
+    for (int i = 0; i < p->nupdB_run; i++) {
+      float a = 0, b = 0;
+      HIPCHK(hipEventElapsedTime(&a, p->ev0, p->evT[2 * i]));
+      HIPCHK(hipEventElapsedTime(&b, p->ev0, p->evT[2 * i + 1]));
+      iv.emplace_back(a, b);
+    }
+    std::sort(iv.begin(), iv.end());
+    double tot = 0;
+    float cs = 0, ce = -1;
+    for (auto& q : iv) {
+      if (ce < 0 || q.first > ce) { if (ce >= 0) tot += ce - cs; cs = q.first; ce = q.second; }
+      else ce = std::max(ce, q.second);
+    }
+    if (ce >= 0) tot += ce - cs;
+    upd = tot * 1e-3;
+  }
   p->stats.update_time = upd;
-  p->stats.nupdate_launches = p->nupd_run;
+  p->stats.nupdate_launches = p->nupd_run + p->nupdB_run;
   long long nb[2] = {0, 0};
   int err = 0;
   HIPCHK(hipMemcpy(nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
@@ -559,10 +612,54 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
+  // Overlap pays where the panel kernels are a visible share of the run (small problems); big ones keep
+  // one stream (per-launch timings stay exclusive).  PASTIX_AMD_OVERLAP=0|1 forces.
+  static const char* ov_env = getenv("PASTIX_AMD_OVERLAP");
+  const bool want = ov_env ? atoi(ov_env) != 0 : p->host.fact_flops < 5e13;
+  p->overlapped = p->own_stream && p->stream2 && want;
   int rc = pastix_amd_factorize_begin(p, critere);
   if (rc) return rc;
-  for (int l = 0; l < p->host.nlevels; l++)
-    if ((rc = pastix_amd_factorize_level(p, l, 0))) return rc;
+  if (!p->overlapped) {
+    for (int l = 0; l < p->host.nlevels; l++)
+      if ((rc = pastix_amd_factorize_level(p, l, 0))) return rc;
+    return pastix_amd_factorize_end(p, stats);
+  }
+  // Two streams.  stream (high priority): contributions of slot l to level l (A), then the panel kernels
+  // of level l (P).  stream2: the rest of slot l, whose sources are of level <= l-1 and whose targets are of
+  // level l+1 or later (B); it runs beside A(l) and P(l).  Orders kept: B(l) after P(l-1); A(l+1) after
+  // B(l): all writers of a tile stay ordered, results do not depend on timing.
+  const Plan& H = p->host;
+  hipStream_t s1 = p->stream, s2 = p->stream2;
+  int lastN = -1;
+  bool s2_used = false;
+  for (int l = 0; l < H.nlevels; l++) {
+    const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
+    if (lastN >= 0) { HIPCHK(hipStreamWaitEvent(s1, p->evB[lastN], 0)); lastN = -1; }
+    if (tu > t0) {
+      HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s1));
+      launch_update(s1, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0);
+      HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s1));
+      p->nupd_run++;
+    }
+    if ((rc = launch_panels(p, l))) return rc;
+    HIPCHK(hipEventRecord(p->evP[l], s1));
+    if (t1 > tu) {
+      if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
+      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
+      // one launch; inside it the tasks for level l+1 (N) come first.  (Launching N and R separately so
+      // that A(l+1) waits for N only was measured slower: smaller launches, same chain.)
+      launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu);
+      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
+      HIPCHK(hipEventRecord(p->evB[l], s2));
+      lastN = l;
+      p->nupdB_run++;
+      s2_used = true;
+    }
+  }
+  if (s2_used) {
+    HIPCHK(hipEventRecord(p->evB[0], s2));
+    HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
+  }
   return pastix_amd_factorize_end(p, stats);
 }
 

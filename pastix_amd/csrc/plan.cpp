@@ -340,6 +340,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_task_ptr.assign(NL + 1, 0);
   std::vector<double> task_work;
   std::vector<int32_t> task_slot;
+  std::vector<uint8_t> task_urgent;
   P.slot_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
@@ -392,6 +393,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.tasks.push_back(tk);
     task_work.push_back(work + 4096.0 * double(e - q));
     task_slot.push_back(slot);
+    task_urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
     P.slot_task_ptr[slot + 1]++;
     ubytes += 16.0 * double(tk.tm) * double(tk.tn);
     P.slot_flops[slot] += 2.0 * work;
@@ -415,9 +417,19 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     std::iota(idx.begin(), idx.end(), 0);
     std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
       if (task_slot[a] != task_slot[b]) return task_slot[a] < task_slot[b];
+      if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];   // urgent tasks first
       if (order_mode == 0) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
       return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
     });
+    P.slot_urgent_end.assign(NL, 0);
+    P.slot_next_end.assign(NL, 0);
+    for (int sl = 0; sl < NL; sl++) {
+      int64_t q = P.slot_task_ptr[sl];
+      while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 2) q++;
+      P.slot_urgent_end[sl] = q;
+      while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 1) q++;
+      P.slot_next_end[sl] = q;
+    }
     std::vector<Task> sorted(P.tasks.size());
     if (order_mode == 0) {
       for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];

@@ -94,6 +94,10 @@ struct Plan {
 
   // per slot (slot s runs right before level s is factorized)
   std::vector<int64_t> slot_task_ptr;    // [nlevels+1]
+  std::vector<int64_t> slot_next_end;    // [nlevels] then, up to here, tasks whose targets are of level s+1
+  std::vector<int64_t> slot_urgent_end;  // [nlevels] tasks [slot_task_ptr[s], slot_urgent_end[s]) target cblks of
+                                         // level s itself (needed by this level's panel kernels); the rest of the
+                                         // slot only feeds later levels and may overlap with the panel kernels
   std::vector<Task> tasks;
   std::vector<Piece> pieces;
   double update_flops = 0;
