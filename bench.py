@@ -81,10 +81,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # PASTIX_AMD_DIST_TEST=1 (validation on a 1-GPU box only): ranks share the visible GPUs and the fan-in
+    # messages go through gloo (host staged) -- everything but the RCCL calls themselves is exercised.
+    dist_test = os.environ.get("PASTIX_AMD_DIST_TEST") == "1"
+    if dist_test:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if dist_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from pastix_amd import Plan, fact_flops
     from pastix_amd import symbolic as sy
@@ -147,7 +155,7 @@ def main():
         try:   # PMC-measured bytes per k_update launch for this workload (profiles/r01, see its _doc)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic_k_update.json")))
             if a.gpus == 1 and a.facto == "llt" and a.blocksize == 128 and str(a.grid) in tj:
-                traffic = tj[str(a.grid)]["bytes_per_launch"]
+                traffic = tj[str(a.grid)]["bytes_per_factorization"]
         except Exception:  # noqa: BLE001
             traffic = None
         upd_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
@@ -167,7 +175,8 @@ def main():
                                       "fill_prepare": round(res["t_fill"], 2)}},
             "roofline": {"bound": "mfma", "kernel": "k_update", "achieved": round(upd_rate * 1e-12, 3),
                          "peak": MFMA_F64_PEAK * 1e-12, "unit": "TFLOP/s",
-                         "frac": round(upd_rate / MFMA_F64_PEAK, 4), "traffic": traffic,
+                         "frac": round(upd_rate / MFMA_F64_PEAK, 4),
+                         "traffic": None if traffic is None else traffic / max(res["nlaunch"], 1),
                          "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) / max(res["nlaunch"], 1),
                          "launches_per_step": res["nlaunch"],
                          "avg_launch_ms": round(res["update_time"] / K / max(res["nlaunch"], 1) * 1e3, 4),

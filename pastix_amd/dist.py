@@ -183,17 +183,20 @@ class TorchTransport:
     def exchange(self, sends, recvs):
         import torch.distributed as dist
         torch = self.torch
+        # gloo moves host memory only: stage through the host (CPU tests, 1-GPU validation runs)
+        staged = dist.get_backend() == "gloo" and self.device.type != "cpu"
+        dev = "cpu" if staged else self.device
         ops, bufs = [], []
         for t, src, n in recvs:
-            b = torch.empty(n, dtype=torch.float64, device=self.device)
+            b = torch.empty(n, dtype=torch.float64, device=dev)
             bufs.append(b)
             ops.append(dist.P2POp(dist.irecv, b, src))
         for view, dst in sends:
-            ops.append(dist.P2POp(dist.isend, view, dst))
+            ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, dst))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return bufs
+        return [b.to(self.device) for b in bufs] if staged else bufs
 
 
 # ------------------------------------------------------------------------------------------------
@@ -315,14 +318,15 @@ def bench_distributed(a, rank, world, local):
     dist.barrier()
     wall = time.time() - t0
     ps = eng.stats()
-    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"]], dtype=torch.float64, device=eng.device)
+    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"]], dtype=torch.float64,
+                      device="cpu" if dist.get_backend() == "gloo" else eng.device)
     mx = tw.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = tw.clone()
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     nsend = sum(len(x) for x in exch.sends)
     res = dict(wall=float(mx[0]), flops=flops, fact_time=ft, update_time=float(sm[1]) / world,
-               update_flops=float(sm[2]) / world, nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
+               update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
                n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
                t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
                parallelism="subtree-per-gpu fan-in x%d (rank0 owns %.1f%% of flops, %d fan-in sends/rank0)"

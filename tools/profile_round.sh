@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run ON THE GPU BOX (gpurun -- 'bash tools/profile_round.sh 200'): kernel-trace statistics and the two HBM
+# traffic passes (FETCH_SIZE, WRITE_SIZE; separate --pmc runs, no other tracing) of one bench.py step.
+# Outputs under gpurun_out/profile_<grid>/ ; copy the summaries into profiles/rNN/.
+G=${1:-200}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/profile_$G
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --grid $G"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ARGS > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  python3 tools/pmc_sum.py $OUT/pmc_$c k_update > $OUT/sum_$c.json
+  rm -rf $OUT/pmc_$c
+done
+rm -rf $OUT/stats
+cat $OUT/sum_*.json
+head -8 $OUT/kernel_stats.csv
+tail -1 $OUT/bench_under_rocprof.json
