@@ -104,10 +104,19 @@ int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t *layout, double *const *co
 int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab, double *const *ucoeftab,
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 
-/* complex double, complex-SYMMETRIC LDLt (Z_sy_sopalin_thread): coeftab[k] is the reference's interleaved
- * `double complex` panel.  Other complex variants (po, he, ge) return PASTIX_AMD_ERR_UNSUPPORTED. */
+/* complex double: coeftab[k] / ucoeftab[k] are the reference's interleaved `double complex` panels.
+ *   z_sy = Z_sy_sopalin_thread, complex-SYMMETRIC LDLt (no conjugation: sopalin_compute.h:549-562)
+ *   z_he = Z_he_sopalin_thread, Hermitian LDL^H (-DHERMITIAN: compute_diag.c:326-410, compute_trsm.c:91-95)
+ *   z_ge = Z_ge_sopalin_thread, LU with static pivoting (compute_diag.c:432-532)
+ * The complex `po` variant of the reference mixes symmetric and Hermitian BLAS calls (csqrt/geru/TRSM "T" in
+ * compute_diag.c:124-203 with zherk and GEMM "N","C" in sopalin_compute.c:326-332); it is not offered:
+ * plan_create(LLT, COMPLEXDOUBLE) returns PASTIX_AMD_ERR_UNSUPPORTED. */
 int pastix_amd_z_sy_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, double critere,
                             const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_z_he_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_z_ge_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, void *const *ucoeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 
 /* ---- staged API (analysis once, many factorizations; panels may stay on the device) -------- */
 int pastix_amd_plan_create(const pastix_amd_layout_t *layout, int factotype, int floattype,

@@ -317,7 +317,7 @@ int main(int argc, char **argv)
   pastix(&pd, 0, n, A.colptr, A.rows, A.vals, perm, invp, b, 1, iparm, dparm);
   /* (2) parameters (SURVEY 8c harness sequence) */
   iparm[IPARM_THREAD_NBR] = nthr;
-  iparm[IPARM_SYM] = A.sym ? API_SYM_YES : API_SYM_NO;
+  iparm[IPARM_SYM] = A.sym ? (facto == API_FACT_LDLH ? API_SYM_HER : API_SYM_YES) : API_SYM_NO;
   iparm[IPARM_FACTORIZATION] = facto;
   iparm[IPARM_MATRIX_VERIFICATION] = API_NO;
   iparm[IPARM_ORDERING] = API_ORDER_PERSONAL;
@@ -449,7 +449,11 @@ int main(int argc, char **argv)
         for (p = A.colptr[j] - 1; p < A.colptr[j + 1] - 1; p++) {
           long ii = A.rows[p] - 1;
           r[ii] += A.vals[p] * b[j];
+#ifdef TYPE_COMPLEX
+          if (A.sym && ii != j) r[j] += (facto == API_FACT_LDLH ? conj(A.vals[p]) : A.vals[p]) * b[ii];
+#else
           if (A.sym && ii != j) r[j] += A.vals[p] * b[ii];
+#endif
         }
       for (j = 0; j < n; j++) {
         double d = ABS_FLOAT(r[j] - bsave[j]), e = ABS_FLOAT(bsave[j]);

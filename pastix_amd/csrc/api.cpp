@@ -14,9 +14,13 @@
 
 namespace pastix_amd {
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks);
-void launch_diag_zsy(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
-                     long long* nbpivot);
-void launch_trsm_zsy(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv);
+void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int maxw);
+void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int maxw);
+void launch_trsm_zlu(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
+void launch_trsm_zsy(hipStream_t s, bool herm, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv,
+                     int maxw);
 void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n);
 void launch_merge(hipStream_t s, double* z, const double* re, const double* im, int64_t n);
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
@@ -67,6 +71,7 @@ struct pastix_amd_plan_s {
   // cached coefficient fill (destinations + values) so that a re-fill is device-only
   int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
   double* dFillValLi = nullptr;   // imaginary parts (complex)
+  double* dFillValUi = nullptr;
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk* dChunk = nullptr;
   std::vector<int64_t> lvl_chunk_ptr;
@@ -267,7 +272,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
-  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
+  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
   (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evT) if (e) (void)hipEventDestroy(e);
@@ -362,6 +367,9 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
     if (p->cplx) {
       int r = z_transfer(p, true, coeftab[k], p->dL, p->dLi, H.poff[k], H.poff[k + 1] - H.poff[k]);
       if (r) return r;
+      if (p->dU && ucoeftab && ucoeftab[k] &&
+          (r = z_transfer(p, true, ucoeftab[k], p->dU, p->dUi, H.poff[k], H.poff[k + 1] - H.poff[k])))
+        return r;
       continue;
     }
     HIPCHK(hipMemcpyAsync(p->dL + H.poff[k], coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
@@ -385,6 +393,9 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
     if (p->cplx) {
       int r = z_transfer(p, false, coeftab[k], p->dL, p->dLi, H.poff[k], H.poff[k + 1] - H.poff[k]);
       if (r) return r;
+      if (p->dU && ucoeftab && ucoeftab[k] &&
+          (r = z_transfer(p, false, ucoeftab[k], p->dU, p->dUi, H.poff[k], H.poff[k + 1] - H.poff[k])))
+        return r;
       continue;
     }
     HIPCHK(hipMemcpyAsync(coeftab[k], p->dL + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
@@ -408,7 +419,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
   const double* vals = (const double*)vals_;   // complex: interleaved (re,im)
   const int vs = p->cplx ? 2 : 1;
-  std::vector<double> valLi;
+  std::vector<double> valLi, valUi;
   HIPCHK(hipSetDevice(p->device));
   std::vector<int32_t> col2cblk((size_t)n);
   for (int64_t k = 0; k < H.cblknbr; k++)
@@ -439,10 +450,15 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
       for (int pass = 0; pass < npass; pass++) {
         const int64_t pr = perm[pass ? j : i], pc = perm[pass ? i : j];
         int64_t d = locate(pr, pc, false);
-        if (d >= 0) { idxL.push_back(d); valL.push_back(vals[vs * q]); if (p->cplx) valLi.push_back(vals[2 * q + 1]); }
+        if (d >= 0) {
+          idxL.push_back(d);
+          valL.push_back(vals[vs * q]);
+          // Hermitian input: the mirrored entry is the conjugate (CscOrdistrib type 'H', pastix.c:3309)
+          if (p->cplx) valLi.push_back((pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1]);
+        }
         if (lu) {
           d = locate(pc, pr, true);
-          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[vs * q]); }
+          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[vs * q]); if (p->cplx) valUi.push_back(vals[2 * q + 1]); }
         }
       }
     }
@@ -466,6 +482,12 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
       HIPCHK(hipMalloc((void**)&p->dFillValLi, valLi.size() * sizeof(double)));
       HIPCHK(hipMemcpy(p->dFillValLi, valLi.data(), valLi.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    (void)hipFree(p->dFillValUi);
+    p->dFillValUi = nullptr;
+    if (!valUi.empty()) {
+      HIPCHK(hipMalloc((void**)&p->dFillValUi, valUi.size() * sizeof(double)));
+      HIPCHK(hipMemcpy(p->dFillValUi, valUi.data(), valUi.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
   }
   return pastix_amd_refill(p);
 }
@@ -482,6 +504,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   launch_scatter(p->stream, p->dL, p->dFillIdxL, p->dFillValL, p->nFillL);
   if (p->cplx && p->dFillValLi) launch_scatter(p->stream, p->dLi, p->dFillIdxL, p->dFillValLi, p->nFillL);
   if (p->dU && p->nFillU) launch_scatter(p->stream, p->dU, p->dFillIdxU, p->dFillValU, p->nFillU);
+  if (p->dUi && p->nFillU && p->dFillValUi) launch_scatter(p->stream, p->dUi, p->dFillIdxU, p->dFillValUi, p->nFillU);
   HIPCHK(hipStreamSynchronize(p->stream));
   return PASTIX_AMD_OK;
 }
@@ -525,8 +548,14 @@ static int launch_panels(pastix_amd_plan_t* p, int l) {
   const TrsmTask* tt = p->dTrsm + H.lvl_trsm_ptr[l];
   const int64_t ntt = H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l];
   if (p->cplx) {
-    launch_diag_zsy(s, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
-    launch_trsm_zsy(s, p->arenas(), tt, ntt, p->dDinv);
+    if (H.factotype == PASTIX_AMD_FACT_LU) {
+      launch_diag_zlu(s, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->maxw);
+      launch_trsm_zlu(s, p->arenas(), tt, ntt, p->dDinv, p->maxw);
+      return PASTIX_AMD_OK;
+    }
+    const bool herm = H.factotype == PASTIX_AMD_FACT_LDLH;
+    launch_diag_zsy(s, herm, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->maxw);
+    launch_trsm_zsy(s, herm, p->arenas(), tt, ntt, p->dDinv, p->maxw);
   } else if (H.factotype == PASTIX_AMD_FACT_LLT) {
     launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr, p->maxw);
     launch_trsm_llt(s, p->dL, tt, ntt, p->dDinv, p->maxw);
@@ -744,6 +773,16 @@ int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t* layout, double* const* co
 int pastix_amd_z_sy_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, double critere,
                             const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
   return one_shot(PASTIX_AMD_FACT_LDLT, layout, (double* const*)coeftab, nullptr, critere, opts, stats,
+                  PASTIX_AMD_COMPLEXDOUBLE);
+}
+int pastix_amd_z_he_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LDLH, layout, (double* const*)coeftab, nullptr, critere, opts, stats,
+                  PASTIX_AMD_COMPLEXDOUBLE);
+}
+int pastix_amd_z_ge_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, void* const* ucoeftab,
+                            double critere, const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot(PASTIX_AMD_FACT_LU, layout, (double* const*)coeftab, (double* const*)ucoeftab, critere, opts, stats,
                   PASTIX_AMD_COMPLEXDOUBLE);
 }
 int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* coeftab, double* const* ucoeftab,

@@ -1,6 +1,7 @@
-// kernels_z.hip -- complex double, complex-SYMMETRIC LDLt (the reference's z `sy` variant: SYR is x x^T,
-// TRSM/GEMM use "T", no conjugation anywhere: sopalin_compute.h:549-562, compute_diag.c:223-307,
-// compute_trsm.c:84-113).  Panels are kept as split planes on the device (arena 0/2 = Re/Im of L,
+// kernels_z.hip -- complex double LDLt.  HERM = false: complex-SYMMETRIC (the reference's z `sy` variant: SYR
+// is x x^T, TRSM/GEMM use "T", no conjugation anywhere: sopalin_compute.h:549-562, compute_diag.c:223-307,
+// compute_trsm.c:84-113).  HERM = true: Hermitian LDL^H (z `he`: zher with the real part of d and a real
+// diagonal, TRSM "C", GEMM "N","C": compute_diag.c:326-410, compute_trsm.c:91-95).  Panels are kept as split planes on the device (arena 0/2 = Re/Im of L,
 // arena 1/3 = Re/Im of L*D), so the update kernel k_update stays a real fp64 MFMA kernel: every complex
 // piece is four real pieces (plan.cpp).  Only the diagonal-blok kernel and the panel solve need complex
 // arithmetic; they mirror k_diag_ldlt / k_trsm_var<.,1> of kernels_var.hip.
@@ -17,6 +18,8 @@ struct cz {
 };
 __device__ __forceinline__ cz cmul(cz a, cz b) { return cz{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cz csub(cz a, cz b) { return cz{a.re - b.re, a.im - b.im}; }
+template <bool C>
+__device__ __forceinline__ cz cj(cz a) { return C ? cz{a.re, -a.im} : a; }
 __device__ __forceinline__ cz cinv(cz a) {
   // 1/a, scaled (Smith) to stay finite for large/small |a|
   if (fabs(a.re) >= fabs(a.im)) {
@@ -27,14 +30,15 @@ __device__ __forceinline__ cz cinv(cz a) {
   return cz{r / d, -1.0 / d};
 }
 
+template <bool HERM, int XR>
 __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                   double* __restrict__ dinv_ws, double critere,
                                                   long long* __restrict__ nbpivot) {
   __shared__ cz Ts[16][17];
   __shared__ cz Lo[16][17];
   __shared__ cz Ti[16][17];
-  __shared__ cz Xs[16][132];   // L   rows below the tile
-  __shared__ cz Ws[16][132];   // L*D rows below the tile
+  __shared__ cz Xs[16][XR];    // L   rows below the tile (XR >= widest cblk - 16)
+  __shared__ cz Ws[16][XR];    // L*D rows below the tile
   const PanelTask tk = tasks[blockIdx.x];
   double* Ar = ar.p[0] + tk.off;
   double* Ai = ar.p[2] + tk.off;
@@ -58,7 +62,12 @@ __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTa
           else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
         } else if (tc > j && ti >= tc) {
           const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tc][j], inv);
-          Ts[ti][tc] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));    // GER with alpha = -d (x x^T)
+          if (!HERM) Ts[ti][tc] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));    // GER with alpha = -d (x x^T)
+          else {                                                               // zher: alpha = -Re(d), x x^H,
+            cz v = csub(Ts[ti][tc], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));   // diagonal kept real
+            if (ti == tc) v.im = 0.0;
+            Ts[ti][tc] = v;
+          }
         }
       }
     }
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTa
           cz s = x[c];
 #pragma unroll
           for (int p = 0; p < 16; p++)
-            if (p < c) s = csub(s, cmul(x[p], Lo[c][p]));
-          x[c] = s;                                        // L*D  (TRSM "R","L","T","U")
+            if (p < c) s = csub(s, cmul(x[p], cj<HERM>(Lo[c][p])));
+          x[c] = s;                                        // L*D  (TRSM "R","L","T"|"C","U")
         }
       }
 #pragma unroll
@@ -131,14 +140,14 @@ __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTa
           cz xa[2], xb[2];
 #pragma unroll
           for (int a = 0; a < 2; a++) {
-            xa[a] = Ws[p][min(2 * tr + a, 131)];
-            xb[a] = Xs[p][min(2 * tcc + a, 131)];
+            xa[a] = Ws[p][min(2 * tr + a, XR - 1)];
+            xb[a] = Xs[p][min(2 * tcc + a, XR - 1)];
           }
 #pragma unroll
           for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int b = 0; b < 2; b++) {
-              const cz m = cmul(xa[a], xb[b]);
+              const cz m = cmul(xa[a], cj<HERM>(xb[b]));
               c[a][b].re += m.re;
               c[a][b].im += m.im;
             }
@@ -162,10 +171,10 @@ __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTa
 }
 
 // Panel solve Y = A L_d^-T (unit lower, complex symmetric), L = Y D^-1; Y^T tiles (re, im) live in MFMA
-// accumulators; complex products are four real MFMAs.  w <= 128 (NT = 8).
+// accumulators; complex products are four real MFMAs.  w <= 16 NT.
+template <int NT, bool HERM>
 __global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
-  constexpr int NT = 8;
   const TrsmTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTas
         for (int q = 0; q < 4; q++) {
           const int lc = p * 16 + g + 4 * q;
           const int64_t o = lic + (int64_t)lc * ld;
-          const double tr = (li < w) ? Tr[o] : 0.0, tim = (li < w) ? Tim[o] : 0.0;
+          const double tr = (li < w) ? Tr[o] : 0.0, tim = (li < w) ? (HERM ? -Tim[o] : Tim[o]) : 0.0;
           // y[ct] -= t * y[p]
           yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr, yr[p][q], yr[ct], 0, 0, 0);
           yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(tim, yi[p][q], yr[ct], 0, 0, 0);
@@ -214,7 +223,8 @@ __global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTas
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const double ar_ = Ti[ct * 512 + l15 + 16 * (g + 4 * q)];
-        const double ai_ = Ti[ct * 512 + 256 + l15 + 16 * (g + 4 * q)];
+        const double ai0 = Ti[ct * 512 + 256 + l15 + 16 * (g + 4 * q)];
+        const double ai_ = HERM ? -ai0 : ai0;                  // (conj L)^-1 = conj(L^-1)
         nr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yr[ct][q], nr, 0, 0, 0);
         nr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai_, yi[ct][q], nr, 0, 0, 0);
         ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yi[ct][q], ni, 0, 0, 0);
@@ -245,6 +255,265 @@ __global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTas
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// complex LU without row pivoting (z `ge`: PASTIX_getrf_block + DimTrans, compute_diag.c:432-532,564-567;
+// no conjugation anywhere, "N"/"T" only).  Mirrors k_diag_lu / k_trsm_var<.,2|3> of kernels_var.hip on split
+// planes: arena 0/2 = Re/Im of L (and of the factored diagonal blok), arena 1/3 = Re/Im of the U panel (stored
+// transposed, as a lower panel).
+// ------------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ void ztile_inverse(F M, bool unit, int nb, int c, cz (*Ti)[17], double* dst) {
+  // column c of the inverse of the lower-triangular 16x16 tile M (identity-padded beyond nb)
+  for (int i = 0; i < 16; i++) {
+    cz x;
+    if (i >= nb || c >= nb) x = cz{(i == c) ? 1.0 : 0.0, 0.0};
+    else if (i < c) x = cz{0.0, 0.0};
+    else {
+      cz s = cz{(i == c) ? 1.0 : 0.0, 0.0};
+      for (int p = c; p < i; p++) s = csub(s, cmul(M(i, p), Ti[p][c]));
+      x = unit ? s : cmul(s, cinv(M(i, i)));
+    }
+    Ti[i][c] = x;
+  }
+  for (int i = 0; i < 16; i++) { dst[i + 16 * c] = Ti[i][c].re; dst[256 + i + 16 * c] = Ti[i][c].im; }
+}
+
+template <int XR>
+__global__ __launch_bounds__(256) void k_diag_zlu(const Arenas ar, const PanelTask* __restrict__ tasks,
+                                                  double* __restrict__ dinv_ws, double critere,
+                                                  long long* __restrict__ nbpivot) {
+  __shared__ cz Ts[16][17];
+  __shared__ cz Lo[16][17];
+  __shared__ cz Ti[16][17];
+  __shared__ cz Xs[16][XR];    // L rows below the tile   Xs[p][r] = L[r][p]
+  __shared__ cz Ys[16][XR];    // U columns right of tile Ys[p][c] = U[p][c]
+  const PanelTask tk = tasks[blockIdx.x];
+  double* Ar = ar.p[0] + tk.off;
+  double* Ai = ar.p[2] + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
+  const int nbk = (w + 15) >> 4;
+  int npiv = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    if (ti < nb && tc < nb) {
+      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
+      Ts[ti][tc] = cz{Ar[o], Ai[o]};
+    }
+    for (int j = 0; j < nb; j++) {                       // PASTIX_getrf, compute_diag.c:432-469
+      __syncthreads();
+      cz d = Ts[j][j];
+      if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }
+      const cz inv = cinv(d);
+      if (ti < nb && tc < nb) {
+        if (ti == j && tc >= j) Lo[j][tc] = (tc == j) ? d : Ts[j][tc];                         // row j of U
+        else if (tc == j && ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);                           // column j of L
+        else if (ti > j && tc > j) Ts[ti][tc] = csub(Ts[ti][tc], cmul(cmul(Ts[ti][j], inv), Ts[j][tc]));   // GERU
+      }
+    }
+    __syncthreads();
+    if (ti < nb && tc < nb) {
+      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
+      Ar[o] = Lo[ti][tc].re;
+      Ai[o] = Lo[ti][tc].im;
+    }
+    if (tid < 16) {
+      // inverse of (U tile)^T : lower, non-unit, element (i,p) = U[p][i]
+      ztile_inverse([&](int i, int p) { return Lo[p][i]; }, false, nb, tid, Ti,
+                    dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512);
+    } else if (tid - 16 < rem) {
+      // rows below: X = A U_T^-1
+      const int rr = tid - 16;
+      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
+      cz x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const int64_t o = o0 + (int64_t)min(c, nb - 1) * ld;
+        x[c] = cz{Ar[o], Ai[o]};
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          cz s = x[c];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < c) s = csub(s, cmul(x[p], Lo[p][c]));
+          x[c] = cmul(s, cinv(Lo[c][c]));
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        Xs[c][rr] = (c < nb) ? x[c] : cz{0.0, 0.0};
+        if (c < nb) {
+          Ar[o0 + (int64_t)c * ld] = x[c].re;
+          Ai[o0 + (int64_t)c * ld] = x[c].im;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      // inverse of the unit-lower L tile
+      ztile_inverse([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
+                    dinv_ws + tk.dinv_off + (int64_t)(nbk + (kb >> 4)) * 512);
+    } else if (tid - 16 < rem) {
+      // columns right of the tile: Y = L_T^-1 B  (TRSM "L","L","N","U", compute_diag.c:505-508)
+      const int cc = tid - 16;
+      const int64_t o0 = kb + (int64_t)(kb + nb + cc) * ld;
+      cz y[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t o = o0 + min(r, nb - 1);
+        y[r] = cz{Ar[o], Ai[o]};
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (r < nb) {
+          cz s = y[r];
+#pragma unroll
+          for (int p = 0; p < 16; p++)
+            if (p < r) s = csub(s, cmul(Lo[r][p], y[p]));
+          y[r] = s;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        Ys[r][cc] = (r < nb) ? y[r] : cz{0.0, 0.0};
+        if (r < nb) {
+          Ar[o0 + r] = y[r].re;
+          Ai[o0 + r] = y[r].im;
+        }
+      }
+    }
+    __syncthreads();
+    if (rem > 0) {                                       // A22 -= L21 U12 (full square, compute_diag.c:510-511)
+      const int nt = (rem + 1) >> 1;
+      const int64_t ob = (kb + nb) + (int64_t)(kb + nb) * ld;
+      for (int id = tid; id < nt * nt; id += 256) {
+        const int tr = id % nt, tcc = id / nt;
+        cz c[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) c[a][b] = cz{0.0, 0.0};
+        for (int p = 0; p < nb; p++) {
+          cz xa[2], xb[2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            xa[a] = Xs[p][min(2 * tr + a, XR - 1)];
+            xb[a] = Ys[p][min(2 * tcc + a, XR - 1)];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const cz m = cmul(xa[a], xb[b]);
+              c[a][b].re += m.re;
+              c[a][b].im += m.im;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            const int r = 2 * tr + a, cc = 2 * tcc + b;
+            if (r < rem && cc < rem) {
+              const int64_t o = ob + r + (int64_t)cc * ld;
+              Ar[o] -= c[a][b].re;
+              Ai[o] -= c[a][b].im;
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // DimTrans (compute_diag.c:521-532, :564-567): U arena diagonal blok = transpose of the factored blok
+  double* Ur = ar.p[1] + tk.off;
+  double* Ui = ar.p[3] + tk.off;
+  for (int id = tid; id < w * w; id += 256) {
+    const int a = id % w, b = id / w;
+    Ur[b + (int64_t)a * ld] = Ar[a + (int64_t)b * ld];
+    Ui[b + (int64_t)a * ld] = Ai[a + (int64_t)b * ld];
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
+// MODE 2: L panel, T(i,c) = U_d[c][i];  MODE 3: U panel, T = unit-lower L_d.  See k_trsm_var.
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void k_trsm_zlu(const Arenas ar, const TrsmTask* __restrict__ tasks,
+                                                  const double* __restrict__ dinv_ws) {
+  const TrsmTask tk = tasks[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int nbk = (w + 15) >> 4;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  double* Xr = ar.p[MODE == 3 ? 1 : 0];
+  double* Xi = ar.p[MODE == 3 ? 3 : 2];
+  const int64_t xo = tk.off + tk.row0 + min(rloc, tk.nrows - 1);
+  const double* Tr = ar.p[0] + tk.off;                 // factored diagonal blok (always in the L arenas)
+  const double* Tim = ar.p[2] + tk.off;
+  const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)nbk * 512 : 0);
+
+  d4 yr[NT], yi[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const int64_t o = xo + (int64_t)min(col, w - 1) * ld;
+      const double vr = Xr[o], vi = Xi[o];
+      yr[ct][q] = (rvalid && col < w) ? vr : 0.0;
+      yi[ct][q] = (rvalid && col < w) ? vi : 0.0;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+    if (ct < nbk) {
+      const int li = ct * 16 + l15;
+      const int lic = min(li, w - 1);
+#pragma unroll
+      for (int p = 0; p < ct; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int lc = p * 16 + g + 4 * q;
+          const int64_t o = (MODE == 2) ? lc + (int64_t)lic * ld : lic + (int64_t)lc * ld;
+          const double tr = (li < w) ? Tr[o] : 0.0, tim = (li < w) ? Tim[o] : 0.0;
+          yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr, yr[p][q], yr[ct], 0, 0, 0);
+          yr[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(tim, yi[p][q], yr[ct], 0, 0, 0);
+          yi[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr, yi[p][q], yi[ct], 0, 0, 0);
+          yi[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-tim, yr[p][q], yi[ct], 0, 0, 0);
+        }
+      }
+      d4 nr = d4{0, 0, 0, 0}, ni = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double ar_ = Ti[ct * 512 + l15 + 16 * (g + 4 * q)];
+        const double ai_ = Ti[ct * 512 + 256 + l15 + 16 * (g + 4 * q)];
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yr[ct][q], nr, 0, 0, 0);
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai_, yi[ct][q], nr, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yi[ct][q], ni, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ai_, yr[ct][q], ni, 0, 0, 0);
+      }
+      yr[ct] = nr;
+      yi[ct] = ni;
+    }
+  }
+  const int64_t so = tk.off + tk.row0 + rloc;
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      if (rvalid && col < w) {
+        Xr[so + (int64_t)col * ld] = yr[ct][q];
+        Xi[so + (int64_t)col * ld] = yi[ct][q];
+      }
+    }
+  }
+}
+
 // interleaved complex <-> split planes
 __global__ void k_split(const double* __restrict__ z, double* __restrict__ re, double* __restrict__ im, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,14 +526,46 @@ __global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, c
   for (; i < n; i += stride) { z[2 * i] = re[i]; z[2 * i + 1] = im[i]; }
 }
 
-void launch_diag_zsy(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
-                     long long* nbpivot) {
+void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv,
+                     double critere, long long* nbpivot, int maxw) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_diag_zsy, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
+  const dim3 g((unsigned)n), b(256);
+  if (maxw <= 128) {
+    if (herm) hipLaunchKernelGGL((k_diag_zsy<true, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+    else hipLaunchKernelGGL((k_diag_zsy<false, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+  } else {
+    if (herm) hipLaunchKernelGGL((k_diag_zsy<true, 244>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+    else hipLaunchKernelGGL((k_diag_zsy<false, 244>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+  }
 }
-void launch_trsm_zsy(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv) {
+void launch_trsm_zsy(hipStream_t s, bool herm, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv,
+                     int maxw) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_trsm_zsy, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv);
+  const dim3 g((unsigned)n), b(256);
+  if (maxw <= 128) {
+    if (herm) hipLaunchKernelGGL((k_trsm_zsy<8, true>), g, b, 0, s, ar, tasks, dinv);
+    else hipLaunchKernelGGL((k_trsm_zsy<8, false>), g, b, 0, s, ar, tasks, dinv);
+  } else {
+    if (herm) hipLaunchKernelGGL((k_trsm_zsy<16, true>), g, b, 0, s, ar, tasks, dinv);
+    else hipLaunchKernelGGL((k_trsm_zsy<16, false>), g, b, 0, s, ar, tasks, dinv);
+  }
+}
+void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int maxw) {
+  if (n <= 0) return;
+  if (maxw <= 128) hipLaunchKernelGGL(k_diag_zlu<116>, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
+  else hipLaunchKernelGGL(k_diag_zlu<244>, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
+}
+void launch_trsm_zlu(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw) {
+  if (n <= 0) return;
+  const dim3 g((unsigned)n), b(256);
+  if (maxw <= 128) {
+    hipLaunchKernelGGL((k_trsm_zlu<8, 2>), g, b, 0, s, ar, tasks, dinv);
+    hipLaunchKernelGGL((k_trsm_zlu<8, 3>), g, b, 0, s, ar, tasks, dinv);
+  } else {
+    hipLaunchKernelGGL((k_trsm_zlu<16, 2>), g, b, 0, s, ar, tasks, dinv);
+    hipLaunchKernelGGL((k_trsm_zlu<16, 3>), g, b, 0, s, ar, tasks, dinv);
+  }
 }
 void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n) {
   if (n <= 0) return;

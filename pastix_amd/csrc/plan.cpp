@@ -92,9 +92,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   if (rc) return rc;
   const bool cplx = floattype == PASTIX_AMD_COMPLEXDOUBLE;
   if (floattype != PASTIX_AMD_REALDOUBLE && !cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
-  if (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT && factotype != PASTIX_AMD_FACT_LU)
+  if (factotype == PASTIX_AMD_FACT_LDLH && !cplx) factotype = PASTIX_AMD_FACT_LDLT;   // real `he` is `sy`
+  if (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT && factotype != PASTIX_AMD_FACT_LU &&
+      factotype != PASTIX_AMD_FACT_LDLH)
     return PASTIX_AMD_ERR_UNSUPPORTED;
-  if (cplx && factotype != PASTIX_AMD_FACT_LDLT) return PASTIX_AMD_ERR_UNSUPPORTED;   // z: complex symmetric LDLt only
+  // z: complex symmetric LDLt (`sy`), Hermitian LDLh (`he`) and LU (`ge`).  The reference's complex `po` mixes
+  // symmetric (csqrt, geru, TRSM "T") and Hermitian (zherk, GEMM "N","C") kernels and is not reproduced.
+  if (cplx && factotype == PASTIX_AMD_FACT_LLT) return PASTIX_AMD_ERR_UNSUPPORTED;
   P.factotype = factotype;
   P.floattype = floattype;
   if (opts) P.opts = *opts;
@@ -138,7 +142,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
     int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-    if (w > (cplx ? 128 : MAXW)) return PASTIX_AMD_ERR_UNSUPPORTED;
+    if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
     P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.cblk[k].stride * w : 0);
   }
@@ -218,7 +222,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }
   const int64_t ntile = tile_base[nc];
   const bool lu = factotype == PASTIX_AMD_FACT_LU;
-  const bool ldlt = factotype == PASTIX_AMD_FACT_LDLT;
+  const bool ldlt = factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH;
+  const bool herm = factotype == PASTIX_AMD_FACT_LDLH;
   std::vector<RawPiece> raw;
   raw.reserve((size_t)P.bloknbr * 8);
   double uflops = 0, ubytes = 0;
@@ -257,6 +262,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         };
         if (!cplx) {
           push(flags, carena);
+        } else if (herm) {
+          // Hermitian product on split planes (SOPALIN_GEMM "N","C": the B operand, L D, is conjugated):
+          //   C_re -= A_re B_re^T + A_im B_im^T ;  C_im -= A_im B_re^T - A_re B_im^T
+          const int a = flags & 3, b = (flags >> 2) & 3;
+          push(AB(a, b), carena);
+          push(AB(a + 2, b + 2), carena);
+          push(AB(a + 2, b), (uint8_t)(carena + 2));
+          push((uint16_t)(AB(a, b + 2) | 16), (uint8_t)(carena + 2));
         } else {
           // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
           //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T

@@ -100,8 +100,8 @@ class Plan:
 
 
 def sopalin_tabs(factotype, cblk4, blok4, coeftab, ucoeftab=None, critere=0.0, lookahead=0):
-    """One-shot drop-in call {po,sy,ge}_sopalin with the reference's per-cblk host buffers
-    (lists of 1-D float64 arrays, factorized in place)."""
+    """One-shot drop-in call {po,sy,ge,he}_sopalin with the reference's per-cblk host buffers
+    (lists of 1-D float64 arrays -- D_ variants -- or complex128 arrays -- Z_ variants --, factorized in place)."""
     la = LayoutArrays(cblk4, blok4)
     n = la.cblknbr
     arr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in coeftab])
@@ -109,6 +109,19 @@ def sopalin_tabs(factotype, cblk4, blok4, coeftab, ucoeftab=None, critere=0.0, l
     opts.lookahead = lookahead
     s = Stats()
     L = _lib.lib()
+    if coeftab and coeftab[0].dtype == np.complex128:
+        cr = ctypes.c_double(critere)
+        if factotype == FACT_LU:
+            uarr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in ucoeftab])
+            rc = L.pastix_amd_z_ge_sopalin(ctypes.byref(la.c), arr, uarr, cr, ctypes.byref(opts), ctypes.byref(s))
+        elif factotype == FACT_LDLT:
+            rc = L.pastix_amd_z_sy_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+        elif factotype == 3:
+            rc = L.pastix_amd_z_he_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+        else:
+            rc = -5
+        check(rc, "pastix_amd_z_*_sopalin")
+        return s.as_dict()
     if factotype == FACT_LLT:
         rc = L.pastix_amd_d_po_sopalin(ctypes.byref(la.c), arr, ctypes.c_double(critere), ctypes.byref(opts), ctypes.byref(s))
     elif factotype == FACT_LDLT:

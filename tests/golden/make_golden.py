@@ -30,6 +30,11 @@ CASES = [
     # complex double (BASELINE config 5 family): complex SYMMETRIC values, LDLt without conjugation
     ("zrlap3d_8_ldlt", "z", "rlap3d", "8", "ldlt", []),
     ("zrlap3d_8_lu", "z", "rlap3d", "8", "lu", []),
+    ("zrlap3d_12_ldlt", "z", "rlap3d", "12", "ldlt", []),   # 144-wide root cblk: the wide-cblk complex kernels
+    ("zrlap3d_12_lu", "z", "rlap3d", "12", "lu", []),
+    # complex HERMITIAN values (real diagonal), LDLh: zher / TRSM "C" / GEMM "N","C"
+    ("zrlap3d_8_ldlh", "z", "rlap3d", "8", "ldlh", []),
+    ("zrlap3d_12_ldlh", "z", "rlap3d", "12", "ldlh", []),
     ("zyoung4c_841_ldlt", "z", "mtx", "/root/reference/src/matrix/young4c.mtx", "ldlt", []),   # the reference's own fixture
 ]
 

@@ -139,3 +139,64 @@ def test_z_device_fill_matches_reference(name, golden):
         p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
         L0, _ = p.download()
     assert np.array_equal(L0, g["L0"])
+
+
+@pytest.mark.parametrize("name", golden_names("ldlh", prec="z"))
+def test_z_ldlh_matches_reference_golden(name, golden):
+    """z `he`: Hermitian LDL^H (reference built with -DHERMITIAN)."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    assert g["facto"] == 3
+    with Plan(g["cblk4"], g["blok4"], 3, floattype=COMPLEXDOUBLE) as p:
+        p.upload(g["L0"])
+        st = p.factorize(g["critere"])
+        L1, _ = p.download()
+    m = _lower_mask(g["cblk4"])
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", golden_names("ldlh", prec="z") + golden_names("lu", prec="z"))
+def test_z_device_fill_he_ge_matches_reference(name, golden):
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        L0, U0 = p.download()
+    assert np.array_equal(L0, g["L0"])
+    if g["facto"] == 2:
+        assert np.array_equal(U0, g["U0"])
+
+
+@pytest.mark.parametrize("name", golden_names("lu", prec="z"))
+def test_z_lu_matches_reference_golden(name, golden):
+    """z `ge`: complex LU with static pivoting, no conjugation."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], 2, floattype=COMPLEXDOUBLE) as p:
+        p.upload(g["L0"], g["U0"])
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+    scale = max(np.abs(g["L1"]).max(), np.abs(g["U1"]).max())
+    assert np.abs(L1 - g["L1"]).max() <= TOL * scale
+    assert np.abs(U1 - g["U1"]).max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", ["zrlap3d_8_ldlh", "zrlap3d_8_lu", "zrlap3d_8_ldlt"])
+def test_z_one_shot_tabs(name, golden):
+    """Z_{he,ge,sy}_sopalin_thread drop-ins with the reference's per-cblk interleaved complex buffers."""
+    from pastix_amd.solver import sopalin_tabs
+    g = golden(name)
+    c4 = g["cblk4"]
+    poff = np.concatenate([[0], np.cumsum(c4[:-1, 3] * (c4[:-1, 1] - c4[:-1, 0] + 1))])
+    tabs = [g["L0"][poff[k]:poff[k + 1]].copy() for k in range(len(c4) - 1)]
+    utabs = [g["U0"][poff[k]:poff[k + 1]].copy() for k in range(len(c4) - 1)] if g["facto"] == 2 else None
+    st = sopalin_tabs(g["facto"], c4, g["blok4"], tabs, utabs, critere=g["critere"])
+    L1 = np.concatenate(tabs)
+    m = _lower_mask(c4) if g["facto"] != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * np.abs(g["L1"]).max()
+    if utabs is not None:
+        assert np.abs(np.concatenate(utabs) - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()
+    assert st["nbpivot"] == g["nbpivot"]
