@@ -127,6 +127,14 @@ __device__ __forceinline__ void epilogue_atomic(double* C, const d4 (&acc)[MI][N
 }
 
 
+// 1 KiB of zeros: the DMA source of k-lines beyond a piece's K (the last chunk of a piece with K % 16 != 0)
+__device__ double g_zero_line[128];
+
+// LDS-DMA helper: one wave-instruction copies 64 lanes x 16 B = one 128-row k-line straight into LDS (no VGPRs).
+#define PASTIX_AMD_GLDS(gptr, lptr)                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
                                                            const Task* __restrict__ tasks,
@@ -150,44 +158,54 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
   if (tk.nfull > 0) {
-    // ---- leading pieces that cover the whole tile with K % 16 == 0 (the bulk of the flops in the
-    // dense parts of the elimination tree): minimal per-chunk bookkeeping, pointer-bumped loads
-    constexpr int KS = 64 * NW / 128;
-    constexpr int NLD = Stage<NW>::NLD;
-    const int row = tid & 127, k0 = tid >> 7;
+    // ---- leading full pieces, LDS-DMA version: every wave copies KC/NW k-lines of A and of B per chunk with
+    // global_load_lds_dwordx4 (no staging registers, no ds_write), the MFMA operands are double-buffered in
+    // registers so that the ds_reads of k-step s+1 are in flight under the MFMAs of k-step s, and the chunk
+    // barrier sits in front of the LAST k-step's MFMAs (operands already in registers), so no wave leaves
+    // the barrier without matrix work.  Order: DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+barrier |
+    // read (i+1, ks0) | MFMA ks3.  RAW: own vmcnt(0), then the barrier, then the read.  WAR: buffer i is
+    // re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired.
+    constexpr int NL = KC / NW;                    // k-lines per wave per operand per chunk
     int pi = tk.p0;
     const int pend = tk.p0 + (int)tk.nfull;
     Piece cur = pieces[pi];
     Piece nextp = pieces[min(pi + 1, pend - 1)];
     int64_t lda = cur.lda;
-    const double* pa = ar.p[cur.flags & 3] + cur.a_off + row + (int64_t)k0 * lda;
-    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + row + (int64_t)k0 * lda;
-    int left = (int)cur.k / KC;                   // chunks left in the current piece (incl. the staged one)
-    double sgn = (cur.flags & 16) ? -1.0 : 1.0;
-    double sa[NLD], sb[NLD];
+    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda + 2 * lane;
+    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda + 2 * lane;
+    int left = ((int)cur.k + KC - 1) / KC;
+    int krem = (int)cur.k;                          // k-lines of the piece not yet issued
+    bool negn = (cur.flags & 16) != 0, negc = negn;
+    const double* zl = g_zero_line + 2 * lane;
 #pragma unroll
-    for (int q = 0; q < NLD; q++) { sa[q] = pa[(int64_t)q * KS * lda]; sb[q] = pb[(int64_t)q * KS * lda]; }
-    {
-      double* dA = sh[0][0] + k0 * SLD + row;
-      double* dB = sh[0][1] + k0 * SLD + row;
-#pragma unroll
-      for (int q = 0; q < NLD; q++) { dA[q * KS * SLD] = sa[q]; dB[q * KS * SLD] = sgn * sb[q]; }
+    for (int q = 0; q < NL; q++) {
+      const bool kv = wave + NW * q < krem;        // wave-uniform
+      PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, sh[0][0] + (wave + NW * q) * SLD);
+      PASTIX_AMD_GLDS(kv ? pb + (int64_t)q * NW * lda : zl, sh[0][1] + (wave + NW * q) * SLD);
     }
-    __syncthreads();
-    int buf = 0;
+    krem -= KC;
     touched = MALL | (0xFu << 4);
     const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
     const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+    double bm0[MI], an0[NI], bm1[MI], an1[NI];
+    __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm0[s] = sAw[s * 16];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an0[s] = sBw[s * 16];
+    int buf = 0;
     while (true) {
       bool has_next = true;
+      negc = negn;
       if (--left == 0) {
         if (++pi < pend) {
           cur = nextp;
           lda = cur.lda;
-          pa = ar.p[cur.flags & 3] + cur.a_off + row + (int64_t)k0 * lda;
-          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + row + (int64_t)k0 * lda;
-          left = (int)cur.k / KC;
-          sgn = (cur.flags & 16) ? -1.0 : 1.0;
+          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda + 2 * lane;
+          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda + 2 * lane;
+          left = ((int)cur.k + KC - 1) / KC;
+          krem = (int)cur.k;
+          negn = (cur.flags & 16) != 0;
           nextp = pieces[min(pi + 1, pend - 1)];
         } else {
           has_next = false;
@@ -197,34 +215,85 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         pb += (int64_t)KC * lda;
       }
       if (has_next) {
+        double* dA = sh[buf ^ 1][0] + wave * SLD;
+        double* dB = sh[buf ^ 1][1] + wave * SLD;
 #pragma unroll
-        for (int q = 0; q < NLD; q++) { sa[q] = pa[(int64_t)q * KS * lda]; sb[q] = pb[(int64_t)q * KS * lda]; }
+        for (int q = 0; q < NL; q++) {
+          const bool kv = wave + NW * q < krem;
+          PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS(kv ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+        }
+        krem -= KC;
       }
       const double* sA = sAw + buf * (2 * KC * SLD);
       const double* sB = sBw + buf * (2 * KC * SLD);
+      if (negc) {
 #pragma unroll
-      for (int ks = 0; ks < KC / 4; ks++) {
-        double bm[MI], an_[NI];
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm[s] = sA[ks * 4 * SLD + s * 16];
-#pragma unroll
-        for (int s = 0; s < NI; s++) an_[s] = sB[ks * 4 * SLD + s * 16];
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
+        for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
       }
-      if (has_next) {
-        double* dA = sh[buf ^ 1][0] + k0 * SLD + row;
-        double* dB = sh[buf ^ 1][1] + k0 * SLD + row;
+      // ks0 (operands in *0), prefetch ks1 into *1
 #pragma unroll
-        for (int q = 0; q < NLD; q++) { dA[q * KS * SLD] = sa[q]; dB[q * KS * SLD] = sgn * sb[q]; }
+      for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * 16];
+#pragma unroll
+      for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * 16];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      if (negc) {
+#pragma unroll
+        for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
       }
-      __syncthreads();
+      // ks1, prefetch ks2 into *0
+#pragma unroll
+      for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * 16];
+#pragma unroll
+      for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * 16];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+      if (negc) {
+#pragma unroll
+        for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
+      }
+      // ks2, prefetch ks3 into *1
+#pragma unroll
+      for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * 16];
+#pragma unroll
+      for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * 16];
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      if (negc) {
+#pragma unroll
+        for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
+      }
+      __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+      {
+        // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
+        const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
+        const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
+#pragma unroll
+        for (int s = 0; s < MI; s++) bm0[s] = nA[s * 16];
+#pragma unroll
+        for (int s = 0; s < NI; s++) an0[s] = nB[s * 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
+      // ks3 from registers
+#pragma unroll
+      for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
       if (!has_next) break;
       buf ^= 1;
     }
+    __syncthreads();         // the general loop below restarts on buffer 0
   }
   if ((int)tk.nfull < tk.pn) {
   int pi = tk.p0 + (int)tk.nfull;

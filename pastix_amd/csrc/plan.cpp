@@ -394,14 +394,32 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);
     tk.flags = carena | (raw[q].shared ? 4u : 0u);
-    {   // full pieces (whole 128x128 tile, K a multiple of the staging chunk) first: the kernel runs them
+    {   // full pieces (whole 128x128 tile, any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
         // through its specialized loop; tk.nfull = how many
       auto isfull = [](const Piece& pc) {
-        return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && pc.k > 0 && pc.k % 16 == 0;
+        return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && pc.k > 0;
       };
       auto mid = std::stable_partition(P.pieces.begin() + q, P.pieces.begin() + e, isfull);
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
       for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
+      static const bool hist = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
+      if (hist) {   // diagnostic: flops of the non-full pieces by reason
+        static double cat[6] = {0, 0, 0, 0, 0, 0};
+        static int64_t calls = 0;
+        for (auto it = mid; it != P.pieces.begin() + e; ++it) {
+          const double f = 2.0 * it->m * (double)it->n * it->k;
+          const bool whole = it->dr == 0 && it->dc == 0 && it->m == TM && it->n == TN;
+          const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
+          const bool tiny = (int)it->m * (int)it->n < 64 * 64;
+          int c = whole ? 0 : (tiny ? 1 : (even ? 2 : 3));
+          cat[c] += f;
+          if (it->k % 16) cat[4] += f;
+          cat[5] += 2.0 * TM * (double)TN * ((it->k + 15) / 16 * 16);   // what the MFMA loop actually executes
+        }
+        if ((++calls % 200000) == 0 || getenv("PASTIX_AMD_PIECE_HIST")[0] == 'v')
+          fprintf(stderr, "[piece hist] non-full flops: whole-tile(K%%16!=0) %.3e  tiny(<64x64) %.3e  partial-even %.3e  partial-odd %.3e | K%%16!=0 %.3e | executed(padded) %.3e | full %.3e\n",
+                  cat[0], cat[1], cat[2], cat[3], cat[4], cat[5], P.full_flops);
+      }
     }
     P.tasks.push_back(tk);
     task_work.push_back(work + 4096.0 * double(e - q));
