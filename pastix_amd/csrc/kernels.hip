@@ -109,17 +109,17 @@ __device__ __forceinline__ bool piece_full(const Piece& pc) {
 // the multi-GPU fan-in schedule): accumulate with f64 atomics instead of an exclusive read-modify-write.
 template <int MI, int NI>
 __device__ __forceinline__ void epilogue_atomic(double* C, const d4 (&acc)[MI][NI], unsigned touched, int row0,
-                                                int col0, int l15, int g, int tm1, int tn1, int ldc) {
+                                                int col0, int RS, int CS, int l15, int g, int tm1, int tn1, int ldc) {
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
     if (!((touched >> mi) & 1u)) continue;
-    const int r = row0 + mi * 16 + l15;
+    const int r = row0 + mi * RS + l15;
 #pragma unroll
     for (int ni = 0; ni < NI; ni++) {
       if (!((touched >> (4 + ni)) & 1u)) continue;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = col0 + ni * 16 + g + 4 * q;
+        const int c = col0 + ni * CS + g + 4 * q;
         if (r <= tm1 && c <= tn1) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -acc[mi][ni][q]);
       }
     }
@@ -148,7 +148,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*16*MI.., cols wc*64..
   const int l15 = lane & 15, g = lane >> 4;
-  const int row0 = wr * 16 * MI, col0 = wc * 64;
+  // cyclic sub-tile ownership: wave (wr, wc) owns the 16-row bands wr, wr + WRN, ... and the 16-col bands
+  // wc, wc + 2, ...: a piece that covers only part of the tile still spreads over all waves
+  constexpr int RS = 16 * WRN, CS = 32;          // distance between a wave's consecutive row / col bands
+  const int row0 = wr * 16, col0 = wc * 16;
 
   d4 acc[MI][NI];
 #pragma unroll
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     double bm0[MI], an0[NI], bm1[MI], an1[NI];
     __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
 #pragma unroll
-    for (int s = 0; s < MI; s++) bm0[s] = sAw[s * 16];
+    for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
 #pragma unroll
-    for (int s = 0; s < NI; s++) an0[s] = sBw[s * 16];
+    for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
     int buf = 0;
     while (true) {
       bool has_next = true;
@@ -233,9 +236,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       }
       // ks0 (operands in *0), prefetch ks1 into *1
 #pragma unroll
-      for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * 16];
+      for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
 #pragma unroll
-      for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * 16];
+      for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -247,9 +250,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       }
       // ks1, prefetch ks2 into *0
 #pragma unroll
-      for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * 16];
+      for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
 #pragma unroll
-      for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * 16];
+      for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -261,9 +264,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       }
       // ks2, prefetch ks3 into *1
 #pragma unroll
-      for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * 16];
+      for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
 #pragma unroll
-      for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * 16];
+      for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
 #pragma unroll
       for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
         const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
 #pragma unroll
-        for (int s = 0; s < MI; s++) bm0[s] = nA[s * 16];
+        for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
 #pragma unroll
-        for (int s = 0; s < NI; s++) an0[s] = nB[s * 16];
+        for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
       }
       __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
       // ks3 from registers
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       unsigned am = 0, an = 0;                  // wave-uniform sub-tile activity
 #pragma unroll
       for (int s = 0; s < MI; s++) {
-        const int r0 = row0 + s * 16;
+        const int r0 = row0 + s * RS;
         if (r0 < (int)cur.dr + (int)cur.m && r0 + 16 > (int)cur.dr) am |= 1u << s;
       }
 #pragma unroll
       for (int s = 0; s < NI; s++) {
-        const int c0 = col0 + s * 16;
+        const int c0 = col0 + s * CS;
         if (c0 < (int)cur.dc + (int)cur.n && c0 + 16 > (int)cur.dc) an |= 1u << s;
       }
       if (am && an) {
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
             const int kk = (ks * 4 + g) * SLD;
             double bm[MI], an_[NI];
 #pragma unroll
-            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * 16];    // rows -> MFMA B operand
+            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * RS];    // rows -> MFMA B operand
 #pragma unroll
-            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * 16];   // cols -> MFMA A operand
+            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * CS];   // cols -> MFMA A operand
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -360,9 +363,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
             const int kk = (ks * 4 + g) * SLD;
             double bm[MI], an_[NI];
 #pragma unroll
-            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * 16];
+            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * RS];
 #pragma unroll
-            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * 16];
+            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * CS];
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
 #pragma unroll
@@ -389,20 +392,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
   double* C = ar.p[tk.flags & 3] + tk.c_off;
   const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
   if (tk.flags & 4) {
-    epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, RS, CS, l15, g, tm1, tn1, tk.ldc);
     return;
   }
 #pragma unroll
   for (int mi = 0; mi < MI; mi++) {
     if (!((touched >> mi) & 1u)) continue;
-    const int r = row0 + mi * 16 + l15;
+    const int r = row0 + mi * RS + l15;
     const int rc = min(r, tm1);
     double cv[NI][4];
 #pragma unroll
     for (int ni = 0; ni < NI; ni++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = min(col0 + ni * 16 + g + 4 * q, tn1);
+        const int c = min(col0 + ni * CS + g + 4 * q, tn1);
         cv[ni][q] = C[rc + (int64_t)c * tk.ldc];
       }
 #pragma unroll
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       if (!((touched >> (4 + ni)) & 1u)) continue;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = col0 + ni * 16 + g + 4 * q;
+        const int c = col0 + ni * CS + g + 4 * q;
         if (r <= tm1 && c <= tn1) C[r + (int64_t)c * tk.ldc] = cv[ni][q] - acc[mi][ni][q];
       }
     }

@@ -354,6 +354,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<double> task_work;
   std::vector<int32_t> task_slot;
   std::vector<uint8_t> task_urgent;
+  const bool hist_on = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
+  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0;
+  int64_t hist_c[3][3] = {{0}};
   P.slot_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
@@ -402,23 +405,37 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       auto mid = std::stable_partition(P.pieces.begin() + q, P.pieces.begin() + e, isfull);
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
       for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
-      static const bool hist = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
-      if (hist) {   // diagnostic: flops of the non-full pieces by reason
-        static double cat[6] = {0, 0, 0, 0, 0, 0};
-        static int64_t calls = 0;
+      if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
         for (auto it = mid; it != P.pieces.begin() + e; ++it) {
           const double f = 2.0 * it->m * (double)it->n * it->k;
-          const bool whole = it->dr == 0 && it->dc == 0 && it->m == TM && it->n == TN;
           const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
-          const bool tiny = (int)it->m * (int)it->n < 64 * 64;
-          int c = whole ? 0 : (tiny ? 1 : (even ? 2 : 3));
-          cat[c] += f;
-          if (it->k % 16) cat[4] += f;
-          cat[5] += 2.0 * TM * (double)TN * ((it->k + 15) / 16 * 16);   // what the MFMA loop actually executes
+          const int cm = it->m >= 96 ? 2 : it->m >= 32 ? 1 : 0, cn = it->n >= 96 ? 2 : it->n >= 32 ? 1 : 0;
+          hist_f[cm][cn] += f;
+          hist_c[cm][cn] += 1;
+          if (!even) hist_odd += f;
+          // 16x16 sub-tiles the piece touches x chunks of 16: what the MFMA pipe executes for it
+          const int rs = (it->dr + it->m + 15) / 16 - it->dr / 16, cs = (it->dc + it->n + 15) / 16 - it->dc / 16;
+          hist_exec += 2.0 * 256.0 * rs * cs * ((it->k + 15) / 16 * 16);
+          // time-like: the busiest wave (32x64 wave tiles) x 8 waves
+          int mx = 0;
+          for (int wr = 0; wr < 4; wr++)
+            for (int wc = 0; wc < 2; wc++) {
+              int r = 0, c = 0;
+              for (int t = 0; t < 2; t++) { int lo = wr * 32 + t * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
+              for (int t = 0; t < 4; t++) { int lo = wc * 64 + t * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
+              mx = std::max(mx, r * c);
+            }
+          hist_wave += 2.0 * 256.0 * mx * 8 * ((it->k + 15) / 16 * 16);
+          int mxc = 0;   // cyclic sub-tile ownership: wave (wr,wc) owns row sub-tiles wr, wr+4 and col sub-tiles wc, wc+2, wc+4, wc+6
+          for (int wr = 0; wr < 4; wr++)
+            for (int wc = 0; wc < 2; wc++) {
+              int r = 0, c = 0;
+              for (int t = 0; t < 2; t++) { int lo = (wr + 4 * t) * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
+              for (int t = 0; t < 4; t++) { int lo = (wc + 2 * t) * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
+              mxc = std::max(mxc, r * c);
+            }
+          hist_cyc += 2.0 * 256.0 * mxc * 8 * ((it->k + 15) / 16 * 16);
         }
-        if ((++calls % 200000) == 0 || getenv("PASTIX_AMD_PIECE_HIST")[0] == 'v')
-          fprintf(stderr, "[piece hist] non-full flops: whole-tile(K%%16!=0) %.3e  tiny(<64x64) %.3e  partial-even %.3e  partial-odd %.3e | K%%16!=0 %.3e | executed(padded) %.3e | full %.3e\n",
-                  cat[0], cat[1], cat[2], cat[3], cat[4], cat[5], P.full_flops);
       }
     }
     P.tasks.push_back(tk);
@@ -452,6 +469,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       if (order_mode == 0) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
       return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
     });
+    if (hist_on) {
+      fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
+      for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
+      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n", hist_odd, hist_exec, hist_wave, hist_cyc);
+    }
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);
     for (int sl = 0; sl < NL; sl++) {
