@@ -157,7 +157,10 @@ int pastix_amd_plan_create_dist(const pastix_amd_layout_t *layout, int factotype
  * role[cblknbr]: 1 owned, 2 shadow, 0 absent.  Any pointer may be NULL. */
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *poff, int32_t *level,
                                 int8_t *role);
-int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);   /* with opts.external_arena */
+/* with opts.external_arena.  The memory must be readable 16 bytes beyond both ends of the coefnbr doubles (allocate
+ * 2 x 16 bytes more and pass base + 16): the update kernel's 16-byte DMA lanes touch the neighbouring element
+ * when a contribution starts or ends on an odd row. */
+int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);
 /* host-only schedule statistics of one rank (no device needed): per launch slot the update flops, the
  * largest task (multiply-adds), the task count, and per level the panel (diag+trsm) flops */
 int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,

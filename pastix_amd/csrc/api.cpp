@@ -43,6 +43,8 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
 
 using namespace pastix_amd;
 
+static constexpr size_t ARENA_PAD = 256;
+
 struct pastix_amd_plan_s {
   Plan host;
   int device = 0;
@@ -147,11 +149,22 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     if (p->cplx && !p->own_arena) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (p->own_arena) {
       const size_t bytes = std::max<int64_t>(H.coefnbr, 1) * sizeof(double);
-      HIPCHK(hipMalloc((void**)&p->dL, bytes));
-      if (H.factotype != PASTIX_AMD_FACT_LLT) HIPCHK(hipMalloc((void**)&p->dU, bytes));
+      // 256 B of slack on both sides: the update kernel's 16-byte DMA lanes may touch the element just
+      // before / after a panel when a contribution starts or ends on an odd row (kernels.hip, k_update)
+      auto alloc = [&](double** out) -> int {
+        char* raw = nullptr;
+        HIPCHK(hipMalloc((void**)&raw, bytes + 2 * ARENA_PAD));
+        HIPCHK(hipMemset(raw, 0, ARENA_PAD));
+        HIPCHK(hipMemset(raw + ARENA_PAD + bytes, 0, ARENA_PAD));
+        *out = (double*)(raw + ARENA_PAD);
+        return 0;
+      };
+      int ra;
+      if ((ra = alloc(&p->dL))) return ra;
+      if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = alloc(&p->dU))) return ra;
       if (p->cplx) {
-        HIPCHK(hipMalloc((void**)&p->dLi, bytes));
-        if (H.factotype != PASTIX_AMD_FACT_LLT) HIPCHK(hipMalloc((void**)&p->dUi, bytes));
+        if ((ra = alloc(&p->dLi))) return ra;
+        if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = alloc(&p->dUi))) return ra;
       }
     }
     HIPCHK(hipMalloc((void**)&p->dDinv, std::max<int64_t>(H.dinv_ws, 256) * sizeof(double)));
@@ -268,7 +281,9 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  if (p->own_arena) { (void)hipFree(p->dL); (void)hipFree(p->dU); (void)hipFree(p->dLi); (void)hipFree(p->dUi); }
+  if (p->own_arena)
+    for (double* a : {p->dL, p->dU, p->dLi, p->dUi})
+      if (a) (void)hipFree((char*)a - ARENA_PAD);
   (void)hipFree(p->dDinv); (void)hipFree(p->dTasks);
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);

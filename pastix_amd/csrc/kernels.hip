@@ -144,6 +144,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
   constexpr int NI = 4;                         // 16-col sub-tiles per wave
   constexpr unsigned MALL = (1u << MI) - 1u;
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+#ifdef PASTIX_AMD_DESYNC_BIT
+  if ((blockIdx.x >> PASTIX_AMD_DESYNC_BIT) & 1) { __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); }
+#endif
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*16*MI.., cols wc*64..
@@ -217,17 +220,26 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         pa += (int64_t)KC * lda;
         pb += (int64_t)KC * lda;
       }
+#ifndef EXP_NO_DMA
       if (has_next) {
         double* dA = sh[buf ^ 1][0] + wave * SLD;
         double* dB = sh[buf ^ 1][1] + wave * SLD;
 #pragma unroll
         for (int q = 0; q < NL; q++) {
           const bool kv = wave + NW * q < krem;
+#if defined(EXP_DMA_ZERO)
+          PASTIX_AMD_GLDS(zl, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS(zl, dB + NW * q * SLD);
+#elif defined(EXP_DMA_HALF)
+          PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+#else
           PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
           PASTIX_AMD_GLDS(kv ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+#endif
         }
         krem -= KC;
       }
+#endif
       const double* sA = sAw + buf * (2 * KC * SLD);
       const double* sB = sBw + buf * (2 * KC * SLD);
       if (negc) {
@@ -276,7 +288,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #pragma unroll
         for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
       }
+#ifndef EXP_NO_BARRIER
       __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+#endif
       {
         // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
         const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);

@@ -224,7 +224,10 @@ class GpuEngine:
         check(_lib.lib().pastix_amd_plan_layout_info(self._h, _lib.ptr(self.poff), _lib.ptr(self.level),
                                                      _lib.ptr(self.role)), "pastix_amd_plan_layout_info")
         self.device = torch.device("cuda", device_index)
-        self.arena = torch.zeros(max(int(self.poff[-1]), 1), dtype=torch.float64, device=self.device)
+        # 32 doubles of slack on both sides (pastix_amd_plan_set_arena: the update kernel's DMA lanes may touch
+        # the element next to a panel); self.arena is the view the panels live in
+        self._arena_store = torch.zeros(max(int(self.poff[-1]), 1) + 64, dtype=torch.float64, device=self.device)
+        self.arena = self._arena_store[32:-32]
         check(_lib.lib().pastix_amd_plan_set_arena(self._h, ctypes.c_void_p(self.arena.data_ptr()), None),
               "pastix_amd_plan_set_arena")
         stream = torch.cuda.current_stream(self.device).cuda_stream

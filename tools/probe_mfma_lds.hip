@@ -17,7 +17,7 @@ __global__ __launch_bounds__(BLK) void k(double* out, int iters, double seed) {
   double a = seed * threadIdx.x * 1e-3, b = seed * (1.0 + threadIdx.x * 1e-4);
   d4 c[8];
   for (int i = 0; i < 8; i++) c[i] = d4{0, 0, 0, 0};
-  double r[6] = {0, 0, 0, 0, 0, 0};
+  double r[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const double* p = sh + (threadIdx.x & 63);
   for (int it = 0; it < iters; it++) {
     const double* q = p + ((it & 31) * 144);
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(BLK) void k(double* out, int iters, double seed) {
 template <int R, bool USE>
 void run(const char* name, double seed) {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
-  int cus = p.multiProcessorCount, iters = 20000;
+  int cus = p.multiProcessorCount, iters = 100000;
   double* dout; CK(hipMalloc(&dout, (size_t)cus * 1024 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   k<R, USE><<<cus * (1024 / BLK), BLK>>>(dout, 1000, seed); CK(hipDeviceSynchronize());
@@ -52,6 +52,8 @@ int main() {
     run<3, false>("8 MFMA + 3 ds_read (unused)", seed);
     run<6, false>("8 MFMA + 6 ds_read (unused)", seed);
     run<6, true>("8 MFMA + 6 ds_read (operands)", seed);
+    run<2, false>("8 MFMA + 2 ds_read (unused)", seed);
+    run<12, false>("8 MFMA + 12 ds_read (unused)", seed);
   }
   return 0;
 }
