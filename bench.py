@@ -121,13 +121,14 @@ def main():
             plan.factorize(crit)
         torch.cuda.synchronize()
         t0 = time.time()
-        ft = ut = 0.0
+        ft = ut = uts = 0.0
         st = None
         for _ in range(a.steps):
             plan.refill()
             st = plan.factorize(crit)
             ft += st["fact_time"]
             ut += st["update_time"]
+            uts += st["update_time_sum"]
         torch.cuda.synchronize()
         wall = time.time() - t0
         # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
@@ -141,7 +142,7 @@ def main():
         Ax = A @ x if facto == 2 else A @ x + sp.tril(A, -1).T @ x
         resid = float(np.linalg.norm(Ax - b) / np.linalg.norm(b))
         ps = plan.stats()
-        res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_flops=ps["update_flops"],
+        res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_time_sum=uts, update_flops=ps["update_flops"],
                    update_bytes=ps["update_bytes"],
                    nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
                    blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
@@ -158,7 +159,12 @@ def main():
                 traffic = tj[str(a.grid)]["bytes_per_factorization"]
         except Exception:  # noqa: BLE001
             traffic = None
-        upd_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
+        # per-launch flops / average launch duration (HIP events around every k_update launch).  The engine runs
+        # the urgent and the bulk launches of a level on two streams, so launches overlap: the sum of their
+        # durations (what rocprofv3's per-kernel average is made of) exceeds the time k_update occupies the chip.
+        ut_sum = res.get("update_time_sum", res["update_time"])
+        upd_rate = res["update_flops"] * K / max(ut_sum, 1e-12)
+        busy_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
         out = {
             "metric": "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": a.gpus, "steps": K, "warmup": a.warmup,
@@ -179,7 +185,8 @@ def main():
                          "traffic": None if traffic is None else traffic / max(res["nlaunch"], 1),
                          "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) / max(res["nlaunch"], 1),
                          "launches_per_step": res["nlaunch"],
-                         "avg_launch_ms": round(res["update_time"] / K / max(res["nlaunch"], 1) * 1e3, 4),
+                         "avg_launch_ms": round(ut_sum / K / max(res["nlaunch"], 1) * 1e3, 4),
+                         "achieved_while_in_flight": round(busy_rate * 1e-12, 3),
                          "flops_per_launch": res["update_flops"] / max(res["nlaunch"], 1)},
         }
         if a.gpus == 1 and not a.no_cpu_baseline:

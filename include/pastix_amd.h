@@ -78,7 +78,8 @@ typedef struct pastix_amd_options_s {
 typedef struct pastix_amd_stats_s {
   double fact_flops;       /* DPARM_FACT_FLOPS definition (blend_symbol_cost.c:52-88) on this layout */
   double fact_time;        /* seconds, first kernel launch -> last kernel done (DPARM_FACT_TIME semantics) */
-  double update_time;      /* seconds inside the update (GEMM+scatter) kernel, from HIP events */
+  double update_time;      /* seconds during which at least one launch of the update (GEMM+scatter) kernel was in
+                              flight, from HIP events (the launches of the two streams may overlap) */
   double h2d_time, d2h_time;
   pastix_amd_int_t nbpivot;  /* static pivots (IPARM_STATIC_PIVOTING) */
   pastix_amd_int_t coefnbr;  /* panel elements (one of L/U) */
@@ -88,7 +89,8 @@ typedef struct pastix_amd_stats_s {
   double local_flops;      /* fact_flops restricted to the cblks this plan owns (== fact_flops on one GPU) */
   double update_bytes;     /* algorithmic bytes of the update kernel: 8k(m+n) per piece + 16*tm*tn per task */
   double full_flops;       /* part of update_flops carried by full 128x128 pieces */
-  double reserved[3];
+  double update_time_sum;  /* sum of the update launches' own durations (== update_time when none overlap) */
+  double reserved[2];
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;

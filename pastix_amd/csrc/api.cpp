@@ -54,6 +54,7 @@ struct pastix_amd_plan_s {
   std::vector<hipEvent_t> evT;        // timing pairs of the bulk launches
   int nupdB_run = 0;
   bool own_stream = true, own_arena = true, distributed = false, overlapped = false;
+  int overlap_mode = 0;
   int nupd_run = 0;
   double crit_run = 0;
   double* dL = nullptr;      // L  (real part)
@@ -626,6 +627,9 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
       HIPCHK(hipEventElapsedTime(&b, p->ev0, p->evT[2 * i + 1]));
       iv.emplace_back(a, b);
     }
+    double sum = 0;
+    for (auto& q : iv) sum += q.second - q.first;
+    p->stats.update_time_sum = sum * 1e-3;
     std::sort(iv.begin(), iv.end());
     double tot = 0;
     float cs = 0, ce = -1;
@@ -636,6 +640,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
     if (ce >= 0) tot += ce - cs;
     upd = tot * 1e-3;
   }
+  if (p->nupdB_run == 0) p->stats.update_time_sum = upd;
   p->stats.update_time = upd;
   p->stats.nupdate_launches = p->nupd_run + p->nupdB_run;
   long long nb[2] = {0, 0};
@@ -656,11 +661,14 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
-  // Overlap pays where the panel kernels are a visible share of the run (small problems); big ones keep
-  // one stream (per-launch timings stay exclusive).  PASTIX_AMD_OVERLAP=0|1 forces.
+  // Two streams where the panel kernels are a visible share of the run (below 5e13 flop; measured: 100^3 +8 %,
+  // 160^3 +3 %, 200^3 +1 %): mode 1 below.  Bigger factorizations keep one stream, so that every k_update launch
+  // has the chip to itself and its HIP-event duration is what a profiler reports for it.  PASTIX_AMD_OVERLAP=0|1|2
+  // forces a mode.
   static const char* ov_env = getenv("PASTIX_AMD_OVERLAP");
-  const bool want = ov_env ? atoi(ov_env) != 0 : p->host.fact_flops < 5e13;
-  p->overlapped = p->own_stream && p->stream2 && want;
+  const int want = ov_env ? atoi(ov_env) : (p->host.fact_flops < 5e13 ? 1 : 0);
+  p->overlap_mode = want;
+  p->overlapped = p->own_stream && p->stream2 && want != 0;
   int rc = pastix_amd_factorize_begin(p, critere);
   if (rc) return rc;
   if (!p->overlapped) {
@@ -668,12 +676,43 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       if ((rc = pastix_amd_factorize_level(p, l, 0))) return rc;
     return pastix_amd_factorize_end(p, stats);
   }
-  // Two streams.  stream (high priority): contributions of slot l to level l (A), then the panel kernels
+  const Plan& H = p->host;
+  hipStream_t s1 = p->stream, s2 = p->stream2;
+  if (p->overlap_mode == 2) {
+    // Two streams, update launches never beside each other.  stream2 carries every contribution launch in
+    // order: A(l) (slot l's tasks that target level l), then B(l) (the rest of slot l: sources of level <= l-1,
+    // targets of later levels).  stream carries the panel kernels P(l), which start when A(l) is done and run
+    // beside B(l); A(l+1) waits for P(l).  P(l) touches level-l panels only, B(l) never does.
+    HIPCHK(hipEventRecord(p->evP[0], s1));                 // begin()'s resets precede everything on stream2
+    HIPCHK(hipStreamWaitEvent(s2, p->evP[0], 0));
+    for (int l = 0; l < H.nlevels; l++) {
+      const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
+      if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
+      if (tu > t0) {
+        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s2));
+        launch_update(s2, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0);
+        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s2));
+        p->nupd_run++;
+      }
+      HIPCHK(hipEventRecord(p->evB[l], s2));               // level l's panels have every contribution
+      HIPCHK(hipStreamWaitEvent(s1, p->evB[l], 0));
+      if ((rc = launch_panels(p, l))) return rc;
+      HIPCHK(hipEventRecord(p->evP[l], s1));
+      if (t1 > tu) {
+        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
+        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu);
+        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
+        p->nupdB_run++;
+      }
+    }
+    HIPCHK(hipEventRecord(p->evB[0], s2));
+    HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
+    return pastix_amd_factorize_end(p, stats);
+  }
+  // Mode 1.  stream (high priority): contributions of slot l to level l (A), then the panel kernels
   // of level l (P).  stream2: the rest of slot l, whose sources are of level <= l-1 and whose targets are of
   // level l+1 or later (B); it runs beside A(l) and P(l).  Orders kept: B(l) after P(l-1); A(l+1) after
   // B(l): all writers of a tile stay ordered, results do not depend on timing.
-  const Plan& H = p->host;
-  hipStream_t s1 = p->stream, s2 = p->stream2;
   int lastN = -1;
   bool s2_used = false;
   for (int l = 0; l < H.nlevels; l++) {

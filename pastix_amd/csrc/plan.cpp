@@ -361,9 +361,18 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
+  // (only where the two-stream driver is the default, see pastix_amd_factorize: it costs one more pass over the tile)
+  const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
+                                                               : (!big && owner == nullptr);
   for (size_t q = 0; q < raw.size();) {
     size_t e = q;
     double work = 0;
+    int tlev;
+    {
+      const int64_t tile0 = raw[q].tile - (int64_t)raw[q].carena * ntile;
+      const int64_t tt = std::upper_bound(tile_base.begin(), tile_base.end(), tile0) - tile_base.begin() - 1;
+      tlev = P.level[tt];
+    }
     while (e < raw.size() && raw[e].tile == raw[q].tile) {
       P.pieces[e] = raw[e].p;
       work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
@@ -381,6 +390,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       }
       if ((work >= chunk_work || (int)(e - q) >= max_pieces) &&
           (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
+      // contributions from the level right below the target's are the only ones that cannot be computed
+      // before that level's panel kernels: keep them in tasks of their own (the urgent set of their slot) and
+      // flush everything older one slot earlier, where it overlaps with the panel kernels (api.cpp, two streams)
+      if (urgent_split && e < raw.size() && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
+          raw[e - 1].lvl < tlev - 1) break;
     }
     int slot = raw[e - 1].lvl + 1;
     int64_t tile = raw[q].tile;

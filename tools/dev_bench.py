@@ -42,7 +42,7 @@ for rep in range(a.reps):
     st = p.factorize(crit)
     print("rep %d: fill %.2fs fact %.4fs = %.1f GFLOP/s (%.1f%% of 78.6T) | update kernels %.4fs (%.1f GF/s on update flops) launches=%d nbpivot=%d" % (
         rep, tf, st["fact_time"], fl / st["fact_time"] * 1e-9, fl / st["fact_time"] / 78.6e12 * 100,
-        st["update_time"], st["update_flops"] / max(st["update_time"], 1e-9) * 1e-9, st["nupdate_launches"], st["nbpivot"]), flush=True)
+        st["update_time"], st["update_flops"] / max(st["update_time"], 1e-9) * 1e-9, st["nupdate_launches"], st["nbpivot"]), "sum %.4fs" % st["update_time_sum"], flush=True)
 if a.check:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     import oracle_lib
