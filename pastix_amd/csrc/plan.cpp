@@ -355,7 +355,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<int32_t> task_slot;
   std::vector<uint8_t> task_urgent;
   const bool hist_on = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
-  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0;
+  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0, hist_merged = 0;
+  int64_t hist_groups = 0, hist_nonfull = 0;
   int64_t hist_c[3][3] = {{0}};
   P.slot_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
@@ -420,6 +421,32 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
       for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
       if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
+        {   // how many non-full pieces share (tile, source cblk): candidates for multi-segment merged pieces
+          int64_t lastk = -1;
+          int rs_lo = 999, rs_hi = -1, cs_lo = 999, cs_hi = -1, kk = 0;
+          auto flushg = [&]() {
+            if (lastk < 0) return;
+            hist_groups++;
+            // merged piece: bounding sub-tile box, busiest-wave model with cyclic ownership
+            int mx = 0;
+            for (int wr = 0; wr < 4; wr++)
+              for (int wc = 0; wc < 2; wc++) {
+                int r = 0, c = 0;
+                for (int t = 0; t < 2; t++) { int b = wr + 4 * t; if (b >= rs_lo && b <= rs_hi) r++; }
+                for (int t = 0; t < 4; t++) { int b = wc + 2 * t; if (b >= cs_lo && b <= cs_hi) c++; }
+                mx = std::max(mx, r * c);
+              }
+            hist_merged += 2.0 * 256.0 * mx * 8 * ((kk + 15) / 16 * 16);
+          };
+          for (auto it = mid; it != P.pieces.begin() + e; ++it) {
+            const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), it->a_off) - P.poff.begin() - 1;
+            if (k != lastk) { flushg(); lastk = k; rs_lo = cs_lo = 999; rs_hi = cs_hi = -1; kk = it->k; }
+            rs_lo = std::min(rs_lo, it->dr / 16); rs_hi = std::max(rs_hi, (it->dr + it->m - 1) / 16);
+            cs_lo = std::min(cs_lo, it->dc / 16); cs_hi = std::max(cs_hi, (it->dc + it->n - 1) / 16);
+            hist_nonfull++;
+          }
+          flushg();
+        }
         for (auto it = mid; it != P.pieces.begin() + e; ++it) {
           const double f = 2.0 * it->m * (double)it->n * it->k;
           const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
@@ -486,7 +513,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     if (hist_on) {
       fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
-      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n", hist_odd, hist_exec, hist_wave, hist_cyc);
+      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n   non-full pieces %lld in %lld (tile, source cblk) groups; merged-piece bound %.3e\n", hist_odd, hist_exec, hist_wave, hist_cyc, (long long)hist_nonfull, (long long)hist_groups, hist_merged);
     }
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);

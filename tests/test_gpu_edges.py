@@ -1,0 +1,133 @@
+"""Edge cases of the HIP path (hand-made layouts): smallest problems, single dense cblks of every width class,
+one-column cblks, error codes.  The CPU oracle (pinned against the reference, test_oracle_golden.py) is the checker."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from pastix_amd import Plan
+from pastix_amd._lib import PastixAmdError
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def dense_layout(widths):
+    """Dense lower-triangular block structure: cblk k has a diagonal blok and one blok facing every later cblk."""
+    first = np.concatenate([[0], np.cumsum(widths)]).astype(np.int64)
+    n = int(first[-1])
+    nc = len(widths)
+    cblk, blok = [], []
+    for k in range(nc):
+        off = 0
+        cblk.append([first[k], first[k + 1] - 1, len(blok), n - first[k]])
+        for t in range(k, nc):
+            blok.append([first[t], first[t + 1] - 1, t, off])
+            off += widths[t]
+    cblk.append([n, n, len(blok), 0])
+    return np.array(cblk, dtype=np.int64), np.array(blok, dtype=np.int64), n
+
+
+def panels_of(A, c4):
+    """Pack the lower part of dense A (rows >= first column of the cblk) into the panel arena."""
+    out = []
+    for k in range(len(c4) - 1):
+        f, l = int(c4[k, 0]), int(c4[k, 1])
+        out.append(A[f:, f:l + 1].flatten(order="F"))
+    return np.concatenate(out)
+
+
+def lower_mask(c4):
+    m = []
+    for k in range(len(c4) - 1):
+        w, s = int(c4[k, 1] - c4[k, 0] + 1), int(c4[k, 3])
+        blk = np.ones((s, w), dtype=bool)
+        blk[:w, :w] = np.tril(np.ones((w, w), dtype=bool))
+        m.append(blk.flatten(order="F"))
+    return np.concatenate(m)
+
+
+def spd(n, seed):
+    rng = np.random.default_rng(seed)
+    B = rng.standard_normal((n, n))
+    return B @ B.T + n * np.eye(n)
+
+
+@pytest.mark.parametrize("facto", [0, 1, 2])
+def test_one_by_one(facto):
+    c4, b4, n = dense_layout([1])
+    L0 = np.array([4.0])
+    U0 = np.array([4.0]) if facto == 2 else None
+    with Plan(c4, b4, facto) as p:
+        p.upload(L0, U0)
+        st = p.factorize(1e-30)
+        L1, U1 = p.download()
+    assert st["nbpivot"] == 0
+    assert L1[0] == (2.0 if facto == 0 else 4.0)
+    if facto == 2:
+        assert U1[0] == 4.0
+
+
+@pytest.mark.parametrize("widths", [[7], [16], [17], [64], [100], [128], [129], [200], [256],
+                                     [1, 1, 1], [5, 1, 130, 1], [128, 128, 3], [256, 40]])
+@pytest.mark.parametrize("facto", [0, 1, 2])
+def test_dense_blocks_match_oracle(widths, facto):
+    c4, b4, n = dense_layout(widths)
+    A = spd(n, 11 + n)
+    if facto == 2:
+        A = A + np.triu(np.random.default_rng(5).standard_normal((n, n)), 1) * 0.1     # unsymmetric values
+    L0 = panels_of(A, c4)
+    U0 = panels_of(A.T, c4) if facto == 2 else None
+    Lo, Uo, nbo = oracle_lib.sopalin(facto, c4, b4, L0, U0, 1e-30)
+    with Plan(c4, b4, facto) as p:
+        p.upload(L0, U0)
+        st = p.factorize(1e-30)
+        L1, U1 = p.download()
+    assert st["nbpivot"] == nbo == 0
+    m = lower_mask(c4) if facto != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
+    if facto == 2:
+        assert np.abs(U1 - Uo).max() <= TOL * np.abs(Uo).max()
+    if facto == 0 and len(widths) == 1:      # independent check: dense Cholesky
+        C = np.linalg.cholesky(A)
+        assert np.abs(L1.reshape(n, n, order="F") - C)[np.tril_indices(n)].max() <= 1e-11 * np.abs(C).max()
+
+
+def test_wider_than_256_is_unsupported():
+    c4, b4, n = dense_layout([257])
+    with pytest.raises(PastixAmdError) as e:
+        Plan(c4, b4, 0)
+    assert e.value.code == -5
+
+
+def test_bad_layout_is_rejected():
+    c4, b4, n = dense_layout([8, 8])
+    b4 = b4.copy()
+    b4[1, 2] = 0                       # off-diagonal blok facing its own cblk
+    with pytest.raises(PastixAmdError) as e:
+        Plan(c4, b4, 0)
+    assert e.value.code in (-6, -1)
+
+
+def test_indefinite_llt_reports_numeric_error():
+    """The reference's check after sqrt is ineffective (compute_diag.c:143, NaNs propagate); here a non-finite
+    pivot is reported as PASTIX_AMD_ERR_NUMERIC."""
+    c4, b4, n = dense_layout([40, 24])
+    A = spd(n, 3)
+    A[10, 10] = -50.0
+    with Plan(c4, b4, 0) as p:
+        p.upload(panels_of(A, c4))
+        st = p.factorize(1e-30, allow_numeric_error=True)
+    assert st["rc"] == -4
+
+
+def test_all_pivots_clamped():
+    """Zero matrix: every pivot is below critere and is replaced by it (compute_diag.c:133-137)."""
+    c4, b4, n = dense_layout([20, 12])
+    L0 = np.zeros(int(((c4[:-1, 1] - c4[:-1, 0] + 1) * c4[:-1, 3]).sum()))
+    Lo, _, nbo = oracle_lib.sopalin(0, c4, b4, L0, None, 0.5)
+    with Plan(c4, b4, 0) as p:
+        p.upload(L0)
+        st = p.factorize(0.5)
+        L1, _ = p.download()
+    assert st["nbpivot"] == nbo == n
+    assert np.abs(L1 - Lo)[lower_mask(c4)].max() <= TOL
