@@ -176,7 +176,8 @@ def main():
                        "fact_flops": res["flops"], "parallelism": res["parallelism"],
                        "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * a.gpus) * 100, 2),
                        "fact_time_s_per_step": round(res["fact_time"] / K, 4),
-                       "residual": res["resid"], "static_pivots": res["nbpivot"],
+                       "residual": res["resid"], "logdet_rel_err": res.get("logdet_rel_err"),
+                       "static_pivots": res["nbpivot"],
                        "analysis_s": {"symbolic": round(res["t_sym"], 2), "plan": round(res["t_plan"], 2),
                                       "fill_prepare": round(res["t_fill"], 2)}},
             "roofline": {"bound": "mfma", "kernel": "k_update", "achieved": round(upd_rate * 1e-12, 3),

@@ -155,7 +155,16 @@ int pastix_amd_factorize(pastix_amd_plan_t *plan, double critere, pastix_amd_sta
 int pastix_amd_plan_create_dist(const pastix_amd_layout_t *layout, int factotype, int floattype,
                                 const pastix_amd_options_t *opts, const int32_t *owner, int32_t myrank,
                                 pastix_amd_plan_t **plan);
-/* poff[cblknbr+1]: arena offset of every panel (absent cblks have size 0); level[cblknbr];
+/* Fan-in regions (the reference's FanInTarget, ftgt.h:67-113, at blok granularity; host only): bit r of
+ * mask[b] (b < bloknbr, r < 64) is set when rank r contributes into blok b of a cblk it does not own.  A rank's
+ * shadow panel of a remote cblk holds exactly its marked bloks, in blok order, column-major with leading dimension
+ * = the sum of their heights; sender and receiver both derive it from (layout, owner). */
+int pastix_amd_fanin_touched(const pastix_amd_layout_t *layout, const int32_t *owner, uint64_t *mask);
+/* owner side of the fan-in (recv_handle_fanin, sopalin_sendrecv.c:384-404): panel(cblk)[rows[r], c] += src[r + c*nrows]
+ * for r < nrows, c < width(cblk); src and rows are device pointers, the add runs on the plan's stream. */
+int pastix_amd_plan_fanin_add(pastix_amd_plan_t *plan, pastix_amd_int_t cblk, const void *src, const int32_t *rows,
+                              pastix_amd_int_t nrows);
+/* poff[cblknbr+1]: arena offset of every panel (absent cblks have size 0, shadows are compact); level[cblknbr];
  * role[cblknbr]: 1 owned, 2 shadow, 0 absent.  Any pointer may be NULL. */
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *poff, int32_t *level,
                                 int8_t *role);

@@ -68,7 +68,7 @@ EXPORTS = [
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
     "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena",
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
-    "pastix_amd_factorize_end", "pastix_amd_plan_profile",
+    "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add",
 ]
 # include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
 EXPORTS_HOST = [

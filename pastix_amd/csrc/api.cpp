@@ -16,6 +16,8 @@ namespace pastix_amd {
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
+void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
+                      int64_t ncols);
 void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_trsm_zlu(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
@@ -251,6 +253,23 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
       level_panel_flops[l] = f;
     }
   }
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask) {
+  if (!layout || !owner || !mask) return PASTIX_AMD_ERR_BADPARAMETER;
+  return fanin_touched(layout, owner, mask);
+}
+
+int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const void* src, const int32_t* rows,
+                              pastix_amd_int_t nrows) {
+  if (!p || !src || !rows || cblk < 0 || cblk >= p->host.cblknbr || nrows < 0) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  if (H.role[cblk] != 1 || p->cplx || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  const int64_t w = H.cblk[cblk].lcolnum - H.cblk[cblk].fcolnum + 1;
+  launch_fanin_add(p->stream, p->dL + H.poff[cblk], H.cblk[cblk].stride, (const double*)src, rows, nrows, w);
+  HIPCHK(hipGetLastError());
   return PASTIX_AMD_OK;
 }
 

@@ -875,6 +875,25 @@ __global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
+// fan-in receive: dst[rows[r] + c*ldd] += src[r + c*nrows]  (recv_handle_fanin, sopalin_sendrecv.c:384-404: the owner
+// ADDS the aggregated block; here the block is the sender's compact shadow panel)
+__global__ void k_fanin_add(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src,
+                            const int32_t* __restrict__ rows, int64_t nrows, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int64_t c = i / nrows, r = i - c * nrows;
+    dst[rows[r] + c * ldd] += src[i];
+  }
+}
+void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
+                      int64_t ncols) {
+  const int64_t total = nrows * ncols;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(k_fanin_add, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s, dst,
+                     ldd, src, rows, nrows, total);
+}
+
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks) {
   if (ntasks <= 0) return;
   static const int nw = getenv("PASTIX_AMD_UPDATE_WAVES") ? atoi(getenv("PASTIX_AMD_UPDATE_WAVES")) : 8;

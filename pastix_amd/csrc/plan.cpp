@@ -86,6 +86,33 @@ static int check_layout(const pastix_amd_layout_t* L) {
   return PASTIX_AMD_OK;
 }
 
+// Which ranks contribute into which target blok (the reference's FanInTarget regions, ftgt.h:67-113, at blok
+// granularity): bit r of mask[b] is set when a cblk owned by rank r != owner(cblk of b) has a blok pair (i, j >= i)
+// whose rows land in blok b.  Deterministic from (layout, owner): sender and receiver derive the same compact
+// fan-in buffers from it.
+int fanin_touched(const pastix_amd_layout_t* L, const int32_t* owner, uint64_t* mask) {
+  const int64_t nc = L->cblknbr;
+  for (int64_t b = 0; b < L->bloknbr; b++) mask[b] = 0;
+  for (int64_t k = 0; k < nc; k++) {
+    const int32_t r = owner[k];
+    if (r < 0 || r >= 64) return PASTIX_AMD_ERR_UNSUPPORTED;
+    const int64_t fb = L->cblktab[k].bloknum, lb = L->cblktab[k + 1].bloknum;
+    for (int64_t i = fb + 1; i < lb; i++) {
+      const int64_t t = L->bloktab[i].cblknum;
+      if (owner[t] == r) continue;
+      const int64_t tlb = L->cblktab[t + 1].bloknum;
+      int64_t b3 = L->cblktab[t].bloknum;
+      for (int64_t j = i; j < lb; j++) {
+        const int64_t fj = L->bloktab[j].frownum, lj = L->bloktab[j].lrownum;
+        while (b3 < tlb && !(fj >= L->bloktab[b3].frownum && lj <= L->bloktab[b3].lrownum)) b3++;
+        if (b3 >= tlb) return PASTIX_AMD_ERR_LAYOUT;
+        mask[b3] |= 1ull << r;
+      }
+    }
+  }
+  return PASTIX_AMD_OK;
+}
+
 int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& P) {
   int rc = check_layout(L);
@@ -138,13 +165,32 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
         if (owner[k] != owner[P.blok[b].cblknum]) shared[P.blok[b].cblknum] = 1;
   const int window = getenv("PASTIX_AMD_WINDOW") ? atoi(getenv("PASTIX_AMD_WINDOW")) : 0;
+  // target-side layout: owned panels as given; shadow panels COMPACT -- only the bloks this rank contributes
+  // into (fanin_touched), packed in blok order with their own leading dimension
+  P.tstride.resize(nc);
+  P.tcoef.resize(P.bloknbr);
+  for (int64_t k = 0; k < nc; k++) P.tstride[k] = P.cblk[k].stride;
+  for (int64_t b = 0; b < P.bloknbr; b++) P.tcoef[b] = P.blok[b].coefind;
+  if (owner) {
+    std::vector<uint64_t> mask((size_t)P.bloknbr);
+    if ((rc = fanin_touched(L, owner, mask.data()))) return rc;
+    for (int64_t t = 0; t < nc; t++) {
+      if (P.role[t] != 2) continue;
+      int64_t off = 0;
+      for (int64_t b = P.cblk[t].bloknum; b < P.cblk[t + 1].bloknum; b++) {
+        if ((mask[b] >> myrank) & 1ull) { P.tcoef[b] = off; off += P.blok[b].lrownum - P.blok[b].frownum + 1; }
+        else P.tcoef[b] = -1;
+      }
+      P.tstride[t] = off;
+    }
+  }
   P.poff.resize(nc + 1);
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
     int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
     if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
-    P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.cblk[k].stride * w : 0);
+    P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.tstride[k] * w : 0);
   }
   P.coefnbr = P.poff[nc];
   P.ncol = P.cblk[nc - 1].lcolnum + 1;
@@ -218,7 +264,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<int64_t> tile_base(nc + 1, 0);
   for (int64_t t = 0; t < nc; t++) {
     int64_t w = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
-    tile_base[t + 1] = tile_base[t] + ((P.cblk[t].stride + TM - 1) / TM) * ((w + TN - 1) / TN);
+    tile_base[t + 1] = tile_base[t] + ((P.tstride[t] + TM - 1) / TM) * ((w + TN - 1) / TN);
   }
   const int64_t ntile = tile_base[nc];
   const bool lu = factotype == PASTIX_AMD_FACT_LU;
@@ -314,7 +360,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         const int64_t fj = P.blok[j].frownum, lj = P.blok[j].lrownum, hj = lj - fj + 1;
         while (b3 < tlb && !(fj >= P.blok[b3].frownum && lj <= P.blok[b3].lrownum)) b3++;
         if (b3 >= tlb) return PASTIX_AMD_ERR_LAYOUT;   // containment (sopalin_compute.c:558-559)
-        const int64_t dst = P.blok[b3].coefind + (fj - P.blok[b3].frownum);
+        if (P.tcoef[b3] < 0) return PASTIX_AMD_ERR_LAYOUT;   // (cannot happen: fanin_touched marks exactly these)
+        const int64_t dst = P.tcoef[b3] + (fj - P.blok[b3].frownum);
         const bool diag = (b3 == tfb);
         if (run_len > 0 && dst == run_dst + run_len && diag == run_diag && !(lu && diag)) {
           run_len += hj;
@@ -405,9 +452,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1, nct = (w_t + TN - 1) / TN;
     int64_t rt = (tile - tile_base[t]) / nct, ct = (tile - tile_base[t]) % nct;
     Task tk{};
-    tk.c_off = P.poff[t] + rt * TM + ct * TN * P.cblk[t].stride;
-    tk.ldc = (int32_t)P.cblk[t].stride;
-    tk.tm = (uint16_t)std::min<int64_t>(TM, P.cblk[t].stride - rt * TM);
+    tk.c_off = P.poff[t] + rt * TM + ct * TN * P.tstride[t];
+    tk.ldc = (int32_t)P.tstride[t];
+    tk.tm = (uint16_t)std::min<int64_t>(TM, P.tstride[t] - rt * TM);
     tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);

@@ -93,6 +93,9 @@ struct Plan {
   int64_t dinv_ws = 0;                   // doubles needed for the Tinv workspace
 
   // per slot (slot s runs right before level s is factorized)
+  std::vector<int64_t> tstride;          // [cblknbr] leading dimension of the panel as a contribution TARGET here
+  std::vector<int64_t> tcoef;            // [bloknbr] row offset of the blok in that panel (-1: not present in a
+                                         // compact shadow); equal to stride / coefind except for shadow cblks
   std::vector<int64_t> slot_task_ptr;    // [nlevels+1]
   std::vector<int64_t> slot_next_end;    // [nlevels] then, up to here, tasks whose targets are of level s+1
   std::vector<int64_t> slot_urgent_end;  // [nlevels] tasks [slot_task_ptr[s], slot_urgent_end[s]) target cblks of
@@ -120,5 +123,6 @@ int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
+int fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask);
 
 }  // namespace pastix_amd

@@ -46,52 +46,105 @@ def cblk_flops(cblk4, blok4):
     return fl
 
 
-def partition(cblk4, blok4, world, split=6):
-    """owner[k] for every cblk: disjoint subtrees of the (cblk) elimination tree go to one rank each
-    (largest first onto the least loaded rank); the cblks above the cut are dealt out by their own work.
-    The heaviest subtree is split until it is lighter than total/(split*world)."""
-    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+def _etree(c4, b4):
     nc = len(c4) - 1
-    owner = np.zeros(nc, dtype=np.int32)
-    if world <= 1:
-        return owner
-    fl = cblk_flops(c4, b4)
     nb = np.diff(c4[:, 2])
     parent = np.full(nc, -1, dtype=np.int64)
     has = nb > 1
-    parent[has] = b4[c4[:-1, 2][has] + 1, 2]
+    parent[has] = b4[c4[:-1, 2][has] + 1, 2]       # facing cblk of the first off-diagonal blok
+    return parent
+
+
+def partition(cblk4, blok4, world, split=6, light=0.05):
+    """owner[k] for every cblk by proportional mapping (the idea of PaStiX's blend, splitpart.c:752-1012, on the
+    cblk elimination tree): a subtree is given a SET of ranks; the chain of cblks at its top (the split cblks of
+    one separator) is dealt over that set, longest first onto the least loaded rank; where the tree branches the
+    set is divided among the heavy children in proportion to their work; a subtree with one rank goes to it
+    whole.  Light side subtrees (< `light` of their parent's work) go whole to the least loaded rank of the set.
+    Fan-in traffic therefore stays inside the rank set of the enclosing subtree: a rank only contributes to
+    separators on its own path to the root.  `split` is kept for callers of the earlier interface (unused)."""
+    del split
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    nc = len(c4) - 1
+    owner = np.full(nc, -1, dtype=np.int32)
+    if world <= 1:
+        owner[:] = 0
+        return owner
+    fl = cblk_flops(c4, b4)
+    parent = _etree(c4, b4)
     sub = fl.copy()
     kids = [[] for _ in range(nc)]
-    for k in range(nc):
-        p = parent[k]
-        if p >= 0:
-            sub[p] += sub[k]
-            kids[p].append(k)
-    total = float(fl.sum())
-    heap = [(-sub[k], k) for k in range(nc) if parent[k] < 0]
-    heapq.heapify(heap)
-    top = []
-    limit = total / (split * world)
-    while heap and (-heap[0][0] > limit or len(heap) < world) and len(heap) < 64 * world:
-        _, r = heapq.heappop(heap)
-        top.append(r)
-        for c in kids[r]:
-            heapq.heappush(heap, (-sub[c], c))
+    for k in range(nc):                           # children have smaller indices than their parents
+        q = parent[k]
+        if q >= 0:
+            sub[q] += sub[k]
+            kids[q].append(k)
     load = np.zeros(world)
-    owner[:] = -1
-    for negf, r in sorted(heap):
-        q = int(np.argmin(load))
-        owner[r] = q
-        load[q] += -negf
-    in_top = np.zeros(nc, dtype=bool)
-    in_top[top] = True
-    for k in range(nc - 1, -1, -1):              # parents have larger indices than their children
-        if owner[k] < 0 and not in_top[k]:
+    whole = []                                    # (subtree root, rank): everything below goes to the rank
+
+    def give_whole(root, ranks):
+        q = min(ranks, key=lambda r_: load[r_])
+        whole.append((root, q))
+        load[q] += sub[root]
+
+    def split_ranks(ranks, weights):
+        """Divide the rank list among len(weights) <= len(ranks) children, proportionally, at least one each."""
+        m, tot = len(ranks), float(sum(weights))
+        cnt = [max(1, int(round(m * w_ / tot))) for w_ in weights]
+        while sum(cnt) > m:
+            i = max(range(len(cnt)), key=lambda j: (cnt[j] > 1, cnt[j] - m * weights[j] / tot))
+            cnt[i] -= 1
+        while sum(cnt) < m:
+            i = max(range(len(cnt)), key=lambda j: m * weights[j] / tot - cnt[j])
+            cnt[i] += 1
+        out, pos = [], 0
+        for c_ in cnt:
+            out.append(ranks[pos:pos + c_])
+            pos += c_
+        return out
+
+    stack = [(r_, list(range(world))) for r_ in range(nc) if parent[r_] < 0]
+    if len(stack) > 1:                            # a forest: treat the roots as children of a virtual node
+        roots = sorted((r_ for r_, _ in stack), key=lambda r_: -sub[r_])
+        stack = []
+        heavy = roots[:world]
+        for r_, rk in zip(heavy, split_ranks(list(range(world)), [sub[r_] for r_ in heavy])):
+            stack.append((r_, rk))
+        for r_ in roots[world:]:
+            give_whole(r_, list(range(world)))
+    while stack:
+        node, ranks = stack.pop()
+        if len(ranks) == 1:
+            whole.append((node, ranks[0]))
+            load[ranks[0]] += sub[node]
+            continue
+        chain = []
+        while True:                               # walk down the separator chain to the branching point
+            chain.append(node)
+            ch = sorted(kids[node], key=lambda c_: -sub[c_])
+            heavy = [c_ for c_ in ch if sub[c_] >= light * sub[node]]
+            for c_ in ch[len(heavy):]:
+                give_whole(c_, ranks)
+            if len(heavy) != 1:
+                break
+            node = heavy[0]
+        for k in sorted(chain, key=lambda c_: -fl[c_]):
+            q = min(ranks, key=lambda r_: load[r_])
+            owner[k] = q
+            load[q] += fl[k]
+        if not heavy:
+            continue
+        if len(heavy) > len(ranks):               # more heavy children than ranks: the lightest go whole
+            for c_ in heavy[len(ranks):]:
+                give_whole(c_, ranks)
+            heavy = heavy[:len(ranks)]
+        for c_, rk in zip(heavy, split_ranks(ranks, [sub[c_] for c_ in heavy])):
+            stack.append((c_, rk))
+    for root, q in whole:
+        owner[root] = q
+    for k in range(nc - 1, -1, -1):               # parents have larger indices than their children
+        if owner[k] < 0:
             owner[k] = owner[parent[k]]
-    for k in sorted(top, key=lambda t: -fl[t]):
-        q = int(np.argmin(load))
-        owner[k] = q
-        load[q] += fl[k]
     assert (owner >= 0).all()
     return owner
 
@@ -120,6 +173,30 @@ def fanin_pairs(cblk4, blok4, owner):
     t = b4[offd, 2]
     m = r != owner[t]
     return np.unique(np.stack([r[m], t[m]], axis=1), axis=0)
+
+
+def fanin_touched(cblk4, blok4, owner):
+    """uint64 mask per blok: bit r set when rank r contributes into that blok of a cblk it does not own
+    (pastix_amd_fanin_touched; the reference's FanInTarget regions at blok granularity)."""
+    la = LayoutArrays(cblk4, blok4)
+    own = np.ascontiguousarray(owner, dtype=np.int32)
+    mask = np.zeros(len(np.asarray(blok4)), dtype=np.uint64)
+    check(_lib.lib().pastix_amd_fanin_touched(ctypes.byref(la.c), _lib.ptr(own), _lib.ptr(mask)),
+          "pastix_amd_fanin_touched")
+    return mask
+
+
+def fanin_rows(cblk4, blok4, mask, src, t):
+    """Rows (0-based, inside the full panel of cblk t) of the compact block rank `src` sends for cblk t."""
+    c4, b4 = np.asarray(cblk4, dtype=np.int64), np.asarray(blok4, dtype=np.int64)
+    fb, lb = int(c4[t, 2]), int(c4[t + 1, 2])
+    sel = np.nonzero((mask[fb:lb] >> np.uint64(src)) & np.uint64(1))[0] + fb
+    if len(sel) == 0:
+        return np.zeros(0, dtype=np.int32)
+    h = (b4[sel, 1] - b4[sel, 0] + 1).astype(np.int64)
+    start = np.repeat(b4[sel, 3], h)
+    within = np.arange(int(h.sum()), dtype=np.int64) - np.repeat(np.cumsum(h) - h, h)
+    return (start + within).astype(np.int32)
 
 
 def plan_profile(cblk4, blok4, owner, rank, chunk=0, maxlevels=100000):
@@ -157,18 +234,18 @@ class Exchange:
 
 
 def factorize_levels(engine, exch, transport):
-    """The lockstep level loop.  engine: update(l), panels(l), panel(k) -> 1-D view;
-    transport.exchange(sends=[(view, dst)], recvs=[(cblk, src, numel)]) -> list of received 1-D buffers
-    (same order as recvs)."""
+    """The lockstep level loop.  engine: update(l), panels(l), panel(k) -> 1-D view of what this rank holds for
+    cblk k (for a remote cblk: its fan-in buffer), recv_numel(k, src) -> elements rank src sends for cblk k,
+    add(k, buf, src).  transport.exchange(sends=[(view, dst)], recvs=[(cblk, src, numel)]) -> list of received 1-D
+    buffers (same order as recvs)."""
     for l in range(exch.nlevels):
         engine.update(l)
         if exch.sends[l] or exch.recvs[l]:
             sends = [(engine.panel(t), dst) for t, dst in exch.sends[l]]
-            recvs = [(t, src, engine.panel(t).numel() if hasattr(engine.panel(t), "numel") else engine.panel(t).size)
-                     for t, src in exch.recvs[l]]
+            recvs = [(t, src, engine.recv_numel(t, src)) for t, src in exch.recvs[l]]
             bufs = transport.exchange(sends, recvs)
-            for (t, _src, _n), buf in zip(recvs, bufs):
-                engine.add(t, buf)                 # recv_handle_fanin: owner ADDS the aggregated block
+            for (t, src, _n), buf in zip(recvs, bufs):
+                engine.add(t, buf, src)            # recv_handle_fanin: owner ADDS the aggregated block
         engine.panels(l)
 
 
@@ -232,6 +309,14 @@ class GpuEngine:
               "pastix_amd_plan_set_arena")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(_lib.lib().pastix_amd_plan_set_stream(self._h, ctypes.c_void_p(stream)), "pastix_amd_plan_set_stream")
+        # receive side of the fan-in: row map of every (cblk owned here, sending rank) block, on the device
+        self._c4 = np.asarray(cblk4, dtype=np.int64)
+        self._width = (self._c4[:-1, 1] - self._c4[:-1, 0] + 1).astype(np.int64)
+        mask = fanin_touched(cblk4, blok4, owner)
+        self._rows = {}
+        for src, t in fanin_pairs(cblk4, blok4, np.asarray(owner)).tolist():
+            if owner[t] == rank:
+                self._rows[(t, src)] = torch.from_numpy(fanin_rows(cblk4, blok4, mask, src, t)).to(self.device)
 
     def close(self):
         if self._h:
@@ -269,8 +354,16 @@ class GpuEngine:
     def panel(self, k):
         return self.arena[int(self.poff[k]):int(self.poff[k + 1])]
 
-    def add(self, k, buf):
-        self.panel(k).add_(buf)
+    def recv_numel(self, k, src):
+        return int(self._rows[(k, src)].numel() * self._width[k])
+
+    def add(self, k, buf, src):
+        rows = self._rows[(k, src)]
+        if buf.device != self.device:
+            buf = buf.to(self.device)
+        check(_lib.lib().pastix_amd_plan_fanin_add(self._h, ctypes.c_int64(int(k)), ctypes.c_void_p(buf.data_ptr()),
+                                                    ctypes.c_void_p(rows.data_ptr()), ctypes.c_int64(rows.numel())),
+              "pastix_amd_plan_fanin_add")
 
 
 def bench_distributed(a, rank, world, local):
@@ -321,18 +414,35 @@ def bench_distributed(a, rank, world, local):
     dist.barrier()
     wall = time.time() - t0
     ps = eng.stats()
-    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"]], dtype=torch.float64,
+    # size-independent check of the distributed factors (no solve across ranks here): log det A = 2 sum log L_kk
+    # over the owned cblks of all ranks, against the analytic spectrum of the 7-point Dirichlet Laplacian
+    # (eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)))
+    wid = (c4[:-1, 1] - c4[:-1, 0] + 1).astype(np.int64)
+    own = np.nonzero(eng.role == 1)[0]
+    rep = np.repeat(own, wid[own])
+    col = np.arange(len(rep), dtype=np.int64) - np.repeat(np.cumsum(wid[own]) - wid[own], wid[own])
+    didx = eng.poff[rep] + col * (c4[rep, 3] + 1)
+    dvals = eng.arena[torch.from_numpy(didx).to(eng.device)]
+    ld_local = float(2.0 * torch.log(dvals).sum().item()) if len(didx) else 0.0
+    cs = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
+    ld_exact = float(np.log(6.0 - cs[:, None, None] - cs[None, :, None] - cs[None, None, :]).sum())
+    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"], ld_local], dtype=torch.float64,
                       device="cpu" if dist.get_backend() == "gloo" else eng.device)
     mx = tw.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = tw.clone()
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     nsend = sum(len(x) for x in exch.sends)
-    res = dict(wall=float(mx[0]), flops=flops, fact_time=ft, update_time=float(sm[1]) / world,
+    ld_err = abs(float(sm[4]) - ld_exact) / abs(ld_exact)
+    if not ld_err < 1e-9:
+        raise RuntimeError("distributed factorization failed its log-det check: %.15g vs %.15g" % (float(sm[4]), ld_exact))
+    res = dict(wall=float(mx[0]), flops=flops, logdet_rel_err=ld_err, fact_time=ft, update_time=float(sm[1]) / world,
                update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
                n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
                t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
-               parallelism="subtree-per-gpu fan-in x%d (rank0 owns %.1f%% of flops, %d fan-in sends/rank0)"
-                           % (world, 100.0 * ps["local_flops"] / flops, nsend))
+               parallelism="subtree-per-gpu fan-in x%d (rank0 owns %.1f%% of flops, %d fan-in sends/rank0, "
+                           "rank0 arena %.1f GB of which fan-in buffers %.1f GB)"
+                           % (world, 100.0 * ps["local_flops"] / flops, nsend, 8e-9 * float(eng.poff[-1]),
+                              8e-9 * float(sum(int(eng.poff[k + 1] - eng.poff[k]) for k in np.nonzero(eng.role == 2)[0]))))
     eng.close()
     return res

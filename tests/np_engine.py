@@ -31,7 +31,10 @@ class NumpyEngine:
     def _mat(self, k):
         return self.panels_[k].numpy().reshape(int(self.w[k]), int(self.c4[k, 3])).T   # stride x width view
 
-    def add(self, k, buf):
+    def recv_numel(self, k, src):
+        return int(self.panels_[k].numel())          # this test engine keeps full-size fan-in buffers
+
+    def add(self, k, buf, src):
         self.panels_[k].add_(buf)
 
     def update(self, l):

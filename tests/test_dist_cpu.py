@@ -87,3 +87,27 @@ def test_two_rank_fanin_over_gloo(name, golden):
         assert err <= 1e-11 * scale
         assert nown > 0
     assert sum(r[3] for r in res) > 0          # the exchange path was exercised
+
+
+def test_fanin_touched_regions(golden):
+    """pastix_amd_fanin_touched (host only): a rank is marked on a blok only if it owns a source cblk facing the
+    blok's cblk and does not own that cblk; the rows a sender packs are rows of exactly those bloks."""
+    from pastix_amd import dist as pd
+    g = golden("rlap3d_14_llt_bs24")
+    c4, b4 = g["cblk4"], g["blok4"]
+    for world in (2, 3, 4):
+        owner = pd.partition(c4, b4, world, split=2)
+        mask = pd.fanin_touched(c4, b4, owner)
+        pairs = {(int(r), int(t)) for r, t in pd.fanin_pairs(c4, b4, owner)}
+        cb = np.repeat(np.arange(len(c4) - 1), np.diff(c4[:, 2]))        # cblk of every blok
+        seen = set()
+        for b in np.nonzero(mask)[0]:
+            t = int(cb[b])
+            for r in range(world):
+                if (int(mask[b]) >> r) & 1:
+                    assert r != owner[t] and (r, t) in pairs
+                    seen.add((r, t))
+        assert seen == pairs                      # every sender/cblk pair has at least one region
+        for r, t in sorted(pairs)[:50]:
+            rows = pd.fanin_rows(c4, b4, mask, r, t)
+            assert len(rows) > 0 and len(np.unique(rows)) == len(rows) and rows.max() < c4[t, 3]

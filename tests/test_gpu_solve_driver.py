@@ -152,7 +152,8 @@ def test_distributed_plans_emulated_on_one_gpu(world, golden):
             e.update(l)
         for r in range(world):
             for t, dst in exch[r].sends[l]:
-                engs[dst].add(t, engs[r].panel(t))
+                assert engs[r].panel(t).numel() == engs[dst].recv_numel(t, r)
+                engs[dst].add(t, engs[r].panel(t).clone(), r)
         for e in engs:
             e.panels(l)
     nb = sum(e.end()["nbpivot"] for e in engs)
