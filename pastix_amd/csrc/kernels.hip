@@ -691,6 +691,181 @@ __global__ __launch_bounds__(256) void k_diag_llt_lds(double* __restrict__ L, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_diag_llt_w : wave-synchronous version of k_diag_llt_lds (w <= 128).  Per 16-column block step:
+//   (A) wave 0 factors the 16x16 tile in registers, row i in lane i, columns broadcast with v_readlane
+//       (no barrier per column), and keeps the rows for (B');
+//   (B) waves 1-3: thread-per-row solve of the rows below against the tile (in LDS);
+//   (B') wave 0, meanwhile: the tile's inverse for k_trsm, again from registers;
+//   (C) all waves: trailing update of the resident blok on the MFMA pipe, 16x16 tiles of the lower part.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                    double* __restrict__ dinv_ws, double critere,
+                                                    long long* __restrict__ nbpivot, int* __restrict__ errflag) {
+  __shared__ double D[128 * DLD];      // D[c * DLD + r]; everything outside the lower w x w part is zero
+  __shared__ double Ri[16];            // reciprocals of the tile's diagonal
+  const PanelTask tk = tasks[blockIdx.x];
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  {
+    // blok -> LDS: thread = (row r, column parity); 32 columns per pass, loads issued before the stores
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c0 = 0; c0 < 128; c0 += 64) {
+      double v[32];
+#pragma unroll
+      for (int q = 0; q < 32; q++) {                     // unconditional loads from clamped addresses
+        const int c = min(c0 + ch + 2 * q, w - 1);
+        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      }
+#pragma unroll
+      for (int q = 0; q < 32; q++) {
+        const int c = c0 + ch + 2 * q;
+        D[c * DLD + r] = (r < w && c <= r) ? v[q] : 0.0;
+      }
+    }
+  }
+#ifdef DIAG_PROFILE
+  long long st[6] = {0, 0, 0, 0, 0, 0};
+  long long t_prev = __builtin_readcyclecounter();
+#define STAMP(i) { __syncthreads(); long long t_now = __builtin_readcyclecounter(); st[i] += t_now - t_prev; t_prev = t_now; }
+#else
+#define STAMP(i)
+#endif
+  STAMP(0)
+  int npiv = 0;
+  bool bad = false;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    double* T = D + kb * DLD + kb;                       // tile element (i,c) at T[c * DLD + i]
+    __syncthreads();
+    double a[16];                                        // wave 0: row l15 of the tile
+    double ri[16];                                       // (uniform) reciprocals of the diagonal
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = T[c * DLD + l15];
+#pragma unroll
+      for (int j = 0; j < 16; j++) {                     // PASTIX_potrf (compute_diag.c:124-153)
+        if (j < nb) {
+          double d = readlane_f64(a[j], j);
+          if (fabs(d) < critere) { d = critere; npiv++; }
+          if (!(d > 0.0)) bad = true;
+          double inv;
+          fast_sqrt_rsqrt(d, d, inv);
+          ri[j] = inv;
+          a[j] = (l15 == j) ? d : a[j] * inv;            // (lanes above the diagonal carry zeros)
+#pragma unroll
+          for (int k = j + 1; k < 16; k++) {
+            const double lkj = readlane_f64(a[j], k);
+            a[k] = __builtin_fma(-a[j], lkj, a[k]);     // row i, column k: only i >= k is meaningful
+          }
+        } else {
+          ri[j] = 1.0;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+          if (c <= l15) T[c * DLD + l15] = a[c];
+        double rmine = 1.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) if (c == l15) rmine = ri[c];
+        Ri[l15] = rmine;
+      }
+    }
+    STAMP(1)
+    __syncthreads();
+    if (wave == 0) {
+      // (B') column c = l15 of inv(tile) by forward substitution; L(i,p) comes from lane i's registers
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double sacc = (i == l15) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p2 = 0; p2 < 16; p2++)
+          if (p2 < i) {
+            const double lip = (i < nb) ? readlane_f64(a[p2], i) : 0.0;
+            sacc = __builtin_fma(-lip, x[p2], sacc);
+          }
+        x[i] = (i < nb && l15 < nb) ? ((i >= l15) ? sacc * ri[i] : 0.0) : ((i == l15) ? 1.0 : 0.0);
+      }
+      if (lane < 16) {
+        double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+      }
+    } else if (tid - 64 < rem) {
+      // (B) rows below the tile: x = A21 L11^-T, one thread per row (TRSM "R","L","T","N", compute_diag.c:191-195)
+      const int rr = kb + nb + tid - 64;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) x[c] = D[(kb + c) * DLD + rr];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          double sacc = x[c];
+#pragma unroll
+          for (int p2 = 0; p2 < 16; p2++)
+            if (p2 < c) sacc = __builtin_fma(-x[p2], T[p2 * DLD + c], sacc);
+          x[c] = sacc * Ri[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c < nb) D[(kb + c) * DLD + rr] = x[c];
+    }
+    STAMP(2)
+    __syncthreads();
+    if (rem > 0) {
+      // (C) A22 -= X X^T on the lower 16x16 tiles (SYRK "L","N", compute_diag.c:197-200); MFMA "i" = column,
+      // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros
+      const int nbd = (rem + 15) >> 4, r0 = kb + nb;
+      const int ntile = nbd * (nbd + 1) / 2;
+      for (int t = wave; t < ntile; t += 4) {
+        int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
+        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
+        const int bi = bj + rest;
+        const int rb = r0 + bi * 16, cb = r0 + bj * 16;
+        d4 c;
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = D[(cb + g + 4 * q) * DLD + rb + l15];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          const double xc = D[(kb + 4 * ks + g) * DLD + cb + l15];
+          const double xr = D[(kb + 4 * ks + g) * DLD + rb + l15];
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc, xr, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) D[(cb + g + 4 * q) * DLD + rb + l15] = c[q];
+      }
+    }
+    STAMP(3)
+  }
+  STAMP(4)
+  __syncthreads();
+  {
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c = ch; c < w; c += 2)
+      if (r < w && r >= c) A[r + (int64_t)c * ld] = D[c * DLD + r];
+  }
+  STAMP(5)
+#ifdef DIAG_PROFILE
+  if (tid == 0) for (int i = 0; i < 6; i++) dinv_ws[8192 + i] = (double)st[i];
+#endif
+  if (wave == 0 && lane == 0) {
+    if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+    if (bad) atomicOr(errflag, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_trsm : X = A * L_d^-T for 64 panel rows per workgroup (one wave per 16 rows), X^T tiles live in
 // MFMA accumulators: X^T[ct] = Tinv[ct] * (A^T[ct] - sum_{p<ct} L[ct,p] X^T[p]).  The accumulator of
 // tile p (register q = rows g+4q of X^T[p]) is used directly as the B operand of k-step q; the A
@@ -906,7 +1081,10 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag, int maxw) {
   if (n <= 0) return;
-  if (maxw <= 128)
+  static const int diag_v = getenv("PASTIX_AMD_DIAG_KERNEL") ? atoi(getenv("PASTIX_AMD_DIAG_KERNEL")) : 2;
+  if (maxw <= 128 && diag_v == 2)
+    hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
+  else if (maxw <= 128)
     hipLaunchKernelGGL(k_diag_llt_lds, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
   else
     hipLaunchKernelGGL(k_diag_llt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
