@@ -250,12 +250,18 @@ def factorize_levels(engine, exch, transport):
 
 
 class TorchTransport:
-    """RCCL / gloo point-to-point through torch.distributed (one grouped batch per level)."""
+    """RCCL / gloo point-to-point through torch.distributed (one grouped batch per level).
+
+    A level's batch is waited for only by a rank that RECEIVES in it: a pure sender's later work does not depend
+    on the send (its fan-in buffer is not written again before the next refill), so it runs ahead instead of
+    idling until the owner has posted its receives.  `drain()` retires the pending sends; call it before the
+    buffers are reused (end of a factorization)."""
 
     def __init__(self, device):
         import torch
         self.torch = torch
         self.device = device
+        self._pending = []
 
     def exchange(self, sends, recvs):
         import torch.distributed as dist
@@ -263,17 +269,29 @@ class TorchTransport:
         # gloo moves host memory only: stage through the host (CPU tests, 1-GPU validation runs)
         staged = dist.get_backend() == "gloo" and self.device.type != "cpu"
         dev = "cpu" if staged else self.device
-        ops, bufs = [], []
+        ops, bufs, keep = [], [], []
         for t, src, n in recvs:
             b = torch.empty(n, dtype=torch.float64, device=dev)
             bufs.append(b)
             ops.append(dist.P2POp(dist.irecv, b, src))
         for view, dst in sends:
-            ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, dst))
+            v = view.cpu() if staged else view
+            keep.append(v)
+            ops.append(dist.P2POp(dist.isend, v, dst))
         if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+            works = dist.batch_isend_irecv(ops)
+            if recvs:
+                for w in works:
+                    w.wait()
+            else:
+                self._pending.append((works, keep))
         return [b.to(self.device) for b in bufs] if staged else bufs
+
+    def drain(self):
+        for works, _keep in self._pending:
+            for w in works:
+                w.wait()
+        self._pending = []
 
 
 # ------------------------------------------------------------------------------------------------
@@ -397,6 +415,7 @@ def bench_distributed(a, rank, world, local):
         eng.refill()
         eng.begin(crit)
         factorize_levels(eng, exch, tr)
+        tr.drain()                                  # pending fan-in sends, before the buffers are zeroed again
         return eng.end()
 
     for _ in range(a.warmup):

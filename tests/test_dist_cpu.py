@@ -51,7 +51,9 @@ def _worker(rank, world, port, name, q):
     level = pd.levels_of(c4, b4)
     eng = NumpyEngine(c4, b4, owner, level, rank, g["L0"])
     exch = pd.Exchange(c4, b4, owner, level, rank)
-    pd.factorize_levels(eng, exch, pd.TorchTransport(torch.device("cpu")))
+    tr = pd.TorchTransport(torch.device("cpu"))
+    pd.factorize_levels(eng, exch, tr)
+    tr.drain()
     w = c4[:-1, 1] - c4[:-1, 0] + 1
     off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
     err = 0.0
