@@ -89,7 +89,12 @@ typedef struct pastix_amd_stats_s {
   double local_flops;      /* fact_flops restricted to the cblks this plan owns (== fact_flops on one GPU) */
   double update_bytes;     /* algorithmic bytes of the update kernel: 8k(m+n) per piece + 16*tm*tn per task */
   double full_flops;       /* part of update_flops carried by full 128x128 pieces */
-  double update_time_sum;  /* sum of the update launches' own durations (== update_time when none overlap) */
+  double update_time_sum;  /* sum of the durations of the bulk update launches (kernel k_update<.,0>), nupdate_launches
+                              of them, carrying update_flops - urgent_flops */
+  double urgent_flops;     /* part of update_flops done by the urgent launches of the two-stream driver (kernel
+                              k_update<.,1>; 0 with one stream) */
+  double urgent_time_sum;  /* sum of their durations */
+  pastix_amd_int_t nurgent_launches;
   double reserved[2];
 } pastix_amd_stats_t;
 

@@ -40,7 +40,9 @@ class Stats(ctypes.Structure):
                 ("nlevels", i64), ("ntasks", i64), ("npieces", i64), ("nupdate_launches", i64), ("inertia", i64),
                 ("update_flops", ctypes.c_double), ("local_flops", ctypes.c_double),
                 ("update_bytes", ctypes.c_double), ("full_flops", ctypes.c_double),
-                ("update_time_sum", ctypes.c_double), ("reserved", ctypes.c_double * 2)]
+                ("update_time_sum", ctypes.c_double), ("urgent_flops", ctypes.c_double),
+                ("urgent_time_sum", ctypes.c_double), ("nurgent_launches", ctypes.c_int64),
+                ("reserved", ctypes.c_double * 2)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -13,7 +13,8 @@
 #include "plan.h"
 
 namespace pastix_amd {
-void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks);
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
+                   bool urgent);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
@@ -204,6 +205,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.update_flops = H.update_flops;
   S.update_bytes = H.update_bytes;
   S.full_flops = H.full_flops;
+  S.urgent_flops = H.urgent_flops;
   // the piece/task tables now live on the device; keep only what the host driver reads
   std::vector<Piece>().swap(H.pieces);
   std::vector<Task>().swap(H.tasks);
@@ -567,7 +569,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
   if (t1 > t0 && phase != 2) {
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
-    launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, t1 - t0);
+    launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, t1 - t0, false);
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
     p->nupd_run++;
   }
@@ -646,9 +648,15 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
       HIPCHK(hipEventElapsedTime(&b, p->ev0, p->evT[2 * i + 1]));
       iv.emplace_back(a, b);
     }
-    double sum = 0;
-    for (auto& q : iv) sum += q.second - q.first;
-    p->stats.update_time_sum = sum * 1e-3;
+    double sumA = 0, sumB = 0;
+    for (int i = 0; i < (int)iv.size(); i++) (i < p->nupd_run ? sumA : sumB) += iv[i].second - iv[i].first;
+    if (p->overlap_mode == 1) {           // ev[] = urgent launches (k_update<.,1>), evT[] = bulk launches
+      p->stats.update_time_sum = sumB * 1e-3;
+      p->stats.urgent_time_sum = sumA * 1e-3;
+    } else {
+      p->stats.update_time_sum = (sumA + sumB) * 1e-3;
+      p->stats.urgent_time_sum = 0;
+    }
     std::sort(iv.begin(), iv.end());
     double tot = 0;
     float cs = 0, ce = -1;
@@ -659,9 +667,12 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
     if (ce >= 0) tot += ce - cs;
     upd = tot * 1e-3;
   }
-  if (p->nupdB_run == 0) p->stats.update_time_sum = upd;
+  if (p->nupdB_run == 0) { p->stats.update_time_sum = upd; p->stats.urgent_time_sum = 0; }
   p->stats.update_time = upd;
-  p->stats.nupdate_launches = p->nupd_run + p->nupdB_run;
+  const bool two_kernels = p->nupdB_run > 0 && p->overlap_mode == 1;
+  p->stats.nupdate_launches = two_kernels ? p->nupdB_run : p->nupd_run + p->nupdB_run;
+  p->stats.nurgent_launches = two_kernels ? p->nupd_run : 0;
+  p->stats.urgent_flops = two_kernels ? p->host.urgent_flops : 0.0;
   long long nb[2] = {0, 0};
   int err = 0;
   HIPCHK(hipMemcpy(nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
@@ -680,12 +691,10 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
-  // Two streams where the panel kernels are a visible share of the run (below 5e13 flop; measured: 100^3 +8 %,
-  // 160^3 +3 %, 200^3 +1 %): mode 1 below.  Bigger factorizations keep one stream, so that every k_update launch
-  // has the chip to itself and its HIP-event duration is what a profiler reports for it.  PASTIX_AMD_OVERLAP=0|1|2
-  // forces a mode.
+  // Two streams (mode 1 below) unless PASTIX_AMD_OVERLAP=0 (one stream) or =2.  Measured gain over one stream:
+  // 60^3 +25 %, 100^3 +8 %, 160^3 +3 %, 200^3 +1 %.
   static const char* ov_env = getenv("PASTIX_AMD_OVERLAP");
-  const int want = ov_env ? atoi(ov_env) : (p->host.fact_flops < 5e13 ? 1 : 0);
+  const int want = ov_env ? atoi(ov_env) : 1;
   p->overlap_mode = want;
   p->overlapped = p->own_stream && p->stream2 && want != 0;
   int rc = pastix_amd_factorize_begin(p, critere);
@@ -709,7 +718,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
       if (tu > t0) {
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s2));
-        launch_update(s2, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0);
+        launch_update(s2, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, false);
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s2));
         p->nupd_run++;
       }
@@ -719,7 +728,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       HIPCHK(hipEventRecord(p->evP[l], s1));
       if (t1 > tu) {
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu);
+        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
         p->nupdB_run++;
       }
@@ -739,7 +748,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     if (lastN >= 0) { HIPCHK(hipStreamWaitEvent(s1, p->evB[lastN], 0)); lastN = -1; }
     if (tu > t0) {
       HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s1));
-      launch_update(s1, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0);
+      launch_update(s1, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, true);
       HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s1));
       p->nupd_run++;
     }
@@ -750,7 +759,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
       // one launch; inside it the tasks for level l+1 (N) come first.  (Launching N and R separately so
       // that A(l+1) waits for N only was measured slower: smaller launches, same chain.)
-      launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu);
+      launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
       HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
       HIPCHK(hipEventRecord(p->evB[l], s2));
       lastN = l;

@@ -135,7 +135,10 @@ __device__ double g_zero_line[128];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int NW>
+// KIND 0: the bulk launches.  KIND 1 (`k_update_urgent` in profiles): the same code for the few latency-critical
+// tasks of a level that the two-stream driver runs beside the bulk launch of the previous slot; a separate
+// instantiation so that per-kernel profiles of the two do not mix.
+template <int NW, int KIND>
 __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
                                                            const Task* __restrict__ tasks,
                                                            const Piece* __restrict__ pieces) {
@@ -1069,13 +1072,18 @@ void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src
                      ldd, src, rows, nrows, total);
 }
 
-void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks) {
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
+                   bool urgent) {
   if (ntasks <= 0) return;
   static const int nw = getenv("PASTIX_AMD_UPDATE_WAVES") ? atoi(getenv("PASTIX_AMD_UPDATE_WAVES")) : 8;
-  if (nw == 4)
-    hipLaunchKernelGGL(k_update<4>, dim3((unsigned)ntasks), dim3(256), 0, s, ar, tasks, pieces);
-  else
-    hipLaunchKernelGGL(k_update<8>, dim3((unsigned)ntasks), dim3(512), 0, s, ar, tasks, pieces);
+  const dim3 g((unsigned)ntasks);
+  if (nw == 4) {
+    if (urgent) hipLaunchKernelGGL((k_update<4, 1>), g, dim3(256), 0, s, ar, tasks, pieces);
+    else hipLaunchKernelGGL((k_update<4, 0>), g, dim3(256), 0, s, ar, tasks, pieces);
+  } else {
+    if (urgent) hipLaunchKernelGGL((k_update<8, 1>), g, dim3(512), 0, s, ar, tasks, pieces);
+    else hipLaunchKernelGGL((k_update<8, 0>), g, dim3(512), 0, s, ar, tasks, pieces);
+  }
 }
 
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,

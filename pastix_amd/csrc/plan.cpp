@@ -409,9 +409,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
-  // (only where the two-stream driver is the default, see pastix_amd_factorize: it costs one more pass over the tile)
+  // (single-GPU plans: the two-stream driver of pastix_amd_factorize; it costs one more pass over the tile)
   const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
-                                                               : (!big && owner == nullptr);
+                                                               : (owner == nullptr);
   for (size_t q = 0; q < raw.size();) {
     size_t e = q;
     double work = 0;
@@ -530,6 +530,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     task_work.push_back(work + 4096.0 * double(e - q));
     task_slot.push_back(slot);
     task_urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
+    if (P.level[t] == slot) P.urgent_flops += 2.0 * work;
     P.slot_task_ptr[slot + 1]++;
     ubytes += 16.0 * double(tk.tm) * double(tk.tn);
     P.slot_flops[slot] += 2.0 * work;

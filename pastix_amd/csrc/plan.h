@@ -105,6 +105,7 @@ struct Plan {
   std::vector<Piece> pieces;
   double update_flops = 0;
   double full_flops = 0;                 // part of update_flops in full 128x128 pieces (specialized loop)
+  double urgent_flops = 0;               // part of update_flops in the urgent tasks of their slots
   double update_bytes = 0;               // algorithmic bytes of the update kernel: operands read once per
                                          // piece (8k(m+n)) + one read-modify-write of the tile per task (16 tm tn)
   std::vector<double> slot_flops;        // [nlevels] update flops per slot

@@ -30,9 +30,9 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
   CK(hipMemcpy(dp, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask); CK(hipDeviceSynchronize());
+  launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask, false); CK(hipDeviceSynchronize());
   int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5; CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; r++) launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask);
+  for (int r = 0; r < reps; r++) launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask, false);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double fl = 2.0 * 128 * 128 * K * (double)P * ntask * reps;
   printf("tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,

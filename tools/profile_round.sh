@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $A
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $ARGS > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
-  python3 tools/pmc_sum.py $OUT/pmc_$c k_update > $OUT/sum_$c.json
+  python3 tools/pmc_sum.py $OUT/pmc_$c "k_update<8, 0>" > $OUT/sum_$c.json
   rm -rf $OUT/pmc_$c
 done
 rm -rf $OUT/stats
