@@ -711,7 +711,11 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
                                                     double* __restrict__ dinv_ws, double critere,
                                                     long long* __restrict__ nbpivot, int* __restrict__ errflag) {
-  __shared__ double D[128 * DLD];      // D[c * DLD + r]; everything outside the lower w x w part is zero
+  // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
+  // only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
+  // size fits beside one k_update workgroup.  Entries outside the w x w part are zero.
+  __shared__ double D[128 * 129 / 2];
+#define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
   __shared__ double Ri[16];            // reciprocals of the tile's diagonal
   const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
 #pragma unroll
       for (int q = 0; q < 32; q++) {
         const int c = c0 + ch + 2 * q;
-        D[c * DLD + r] = (r < w && c <= r) ? v[q] : 0.0;
+        if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
       }
     }
   }
@@ -747,13 +751,12 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
   bool bad = false;
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
-    double* T = D + kb * DLD + kb;                       // tile element (i,c) at T[c * DLD + i]
     __syncthreads();
     double a[16];                                        // wave 0: row l15 of the tile
     double ri[16];                                       // (uniform) reciprocals of the diagonal
     if (wave == 0) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = T[c * DLD + l15];
+      for (int c = 0; c < 16; c++) a[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
 #pragma unroll
       for (int j = 0; j < 16; j++) {                     // PASTIX_potrf (compute_diag.c:124-153)
         if (j < nb) {
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
       if (lane < 16) {
 #pragma unroll
         for (int c = 0; c < 16; c++)
-          if (c <= l15) T[c * DLD + l15] = a[c];
+          if (c <= l15) DP(kb + c, kb + l15) = a[c];
         double rmine = 1.0;
 #pragma unroll
         for (int c = 0; c < 16; c++) if (c == l15) rmine = ri[c];
@@ -809,20 +812,20 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
       const int rr = kb + nb + tid - 64;
       double x[16];
 #pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = D[(kb + c) * DLD + rr];
+      for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
 #pragma unroll
       for (int c = 0; c < 16; c++) {
         if (c < nb) {
           double sacc = x[c];
 #pragma unroll
           for (int p2 = 0; p2 < 16; p2++)
-            if (p2 < c) sacc = __builtin_fma(-x[p2], T[p2 * DLD + c], sacc);
+            if (p2 < c) sacc = __builtin_fma(-x[p2], DP(kb + p2, kb + c), sacc);
           x[c] = sacc * Ri[c];
         }
       }
 #pragma unroll
       for (int c = 0; c < 16; c++)
-        if (c < nb) D[(kb + c) * DLD + rr] = x[c];
+        if (c < nb) DP(kb + c, rr) = x[c];
     }
     STAMP(2)
     __syncthreads();
@@ -837,16 +840,23 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
         const int bi = bj + rest;
         const int rb = r0 + bi * 16, cb = r0 + bj * 16;
         d4 c;
+        const int row = rb + l15;
 #pragma unroll
-        for (int q = 0; q < 4; q++) c[q] = D[(cb + g + 4 * q) * DLD + rb + l15];
+        for (int q = 0; q < 4; q++) {
+          const int col = cb + g + 4 * q;
+          c[q] = (row >= col) ? DP(col, row) : 0.0;          // (diagonal tiles: the upper part is not stored)
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
-          const double xc = D[(kb + 4 * ks + g) * DLD + cb + l15];
-          const double xr = D[(kb + 4 * ks + g) * DLD + rb + l15];
+          const double xc = DP(kb + 4 * ks + g, cb + l15);
+          const double xr = DP(kb + 4 * ks + g, rb + l15);
           c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc, xr, c, 0, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) D[(cb + g + 4 * q) * DLD + rb + l15] = c[q];
+        for (int q = 0; q < 4; q++) {
+          const int col = cb + g + 4 * q;
+          if (row >= col) DP(col, row) = c[q];
+        }
       }
     }
     STAMP(3)
@@ -856,7 +866,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 2)
-      if (r < w && r >= c) A[r + (int64_t)c * ld] = D[c * DLD + r];
+      if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
   }
   STAMP(5)
 #ifdef DIAG_PROFILE
@@ -867,6 +877,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
     if (bad) atomicOr(errflag, 1);
   }
 }
+#undef DP
 
 // ------------------------------------------------------------------------------------------------
 // k_trsm : X = A * L_d^-T for 64 panel rows per workgroup (one wave per 16 rows), X^T tiles live in
