@@ -13,6 +13,7 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -206,6 +207,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.local_flops += fact_flops(&one, factotype, floattype);
   }
 
+  const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tph = tnow();
+  auto phase = [&](const char* name) { if (ptime) { double t = tnow(); fprintf(stderr, "[plan] %-28s %.2f s\n", name, t - tph); tph = t; } };
   // ---- dependency levels -----------------------------------------------------------------
   P.level.assign(nc, 0);
   for (int64_t k = 0; k < nc; k++)
@@ -259,6 +264,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.lvl_panel_ptr[NL] = nowned;
   P.lvl_trsm_ptr[NL] = (int64_t)P.trsm_tasks.size();
 
+  phase("setup, levels, panel tasks");
   // ---- update pieces -----------------------------------------------------------------------------
   // tile numbering: tile_base[t] + rt * nct(t) + ct, times 2 arenas for LU
   std::vector<int64_t> tile_base(nc + 1, 0);
@@ -384,6 +390,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }
   P.update_flops = uflops;
 
+  phase("piece generation");
   // ---- group into tasks --------------------------------------------------------------------------
   // Per target tile the contributions are ordered by source level and cut into chunks of about
   // chunk_work multiply-adds; a chunk is launched in the slot right after its last source level, so
@@ -395,6 +402,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     if (a.p.a_off != b.p.a_off) return a.p.a_off < b.p.a_off;   // deterministic accumulation order
     return a.p.b_off < b.p.b_off;
   });
+  phase("piece sort");
   P.pieces.resize(raw.size());
   P.tasks.clear();
   P.slot_task_ptr.assign(NL + 1, 0);
@@ -410,6 +418,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
   // (single-GPU plans: the two-stream driver of pastix_amd_factorize; it costs one more pass over the tile)
+  std::vector<Piece> part_tmp;
   const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
                                                                : (owner == nullptr);
   for (size_t q = 0; q < raw.size();) {
@@ -464,7 +473,15 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       auto isfull = [](const Piece& pc) {
         return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && pc.k > 0;
       };
-      auto mid = std::stable_partition(P.pieces.begin() + q, P.pieces.begin() + e, isfull);
+      // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
+      part_tmp.clear();
+      size_t wpos = q;
+      for (size_t z = q; z < e; z++) {
+        if (isfull(P.pieces[z])) P.pieces[wpos++] = P.pieces[z];
+        else part_tmp.push_back(P.pieces[z]);
+      }
+      std::copy(part_tmp.begin(), part_tmp.end(), P.pieces.begin() + wpos);
+      auto mid = P.pieces.begin() + wpos;
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
       for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
       if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
@@ -563,6 +580,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
       fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n   non-full pieces %lld in %lld (tile, source cblk) groups; merged-piece bound %.3e\n", hist_odd, hist_exec, hist_wave, hist_cyc, (long long)hist_nonfull, (long long)hist_groups, hist_merged);
     }
+    phase("task grouping");
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);
     for (int sl = 0; sl < NL; sl++) {
@@ -588,6 +606,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
     P.tasks.swap(sorted);
   }
+  phase("task ordering");
   return PASTIX_AMD_OK;
 }
 

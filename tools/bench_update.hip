@@ -9,6 +9,8 @@ using namespace pastix_amd;
 int main(int argc, char** argv) {
   int ntask = argc > 1 ? atoi(argv[1]) : 2048, P = argc > 2 ? atoi(argv[2]) : 8, K = argc > 3 ? atoi(argv[3]) : 128;
   int pool = argc > 4 ? atoi(argv[4]) : 64;        // number of distinct source panels
+  const int pm = getenv("PM") ? atoi(getenv("PM")) : 128, pn = getenv("PN") ? atoi(getenv("PN")) : 128;   // piece extents
+  const int pdr = getenv("PDR") ? atoi(getenv("PDR")) : 0, pdc = getenv("PDC") ? atoi(getenv("PDC")) : 0;
   int rows = 4096;                                 // rows per source panel
   int64_t src_elems = (int64_t)pool * rows * K;
   int64_t c_elems = (int64_t)ntask * 128 * 128;
@@ -20,10 +22,10 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   std::vector<Task> tasks(ntask); std::vector<Piece> pieces((size_t)ntask * P);
   for (int t = 0; t < ntask; t++) {
-    tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, (unsigned)(getenv("NOFAST") ? 0 : P)};
+    tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, (unsigned)((getenv("NOFAST") || pm != 128 || pn != 128) ? 0 : P)};
     for (int p = 0; p < P; p++) {
       int s = (t * 7 + p * 13) % pool; int ra = ((t * 31 + p) % (rows / 128)) * 128, rb = ((t * 17 + 3 * p) % (rows / 128)) * 128;
-      pieces[(size_t)t * P + p] = Piece{(int64_t)s * rows * K + ra, (int64_t)s * rows * K + rb, rows, (uint16_t)K, 0, 128, 0, 128, 0};
+      pieces[(size_t)t * P + p] = Piece{(int64_t)s * rows * K + ra, (int64_t)s * rows * K + rb, rows, (uint16_t)K, (uint16_t)pdr, (uint16_t)pm, (uint16_t)pdc, (uint16_t)pn, 0};
     }
   }
   Task* dt; Piece* dp; CK(hipMalloc(&dt, tasks.size() * sizeof(Task))); CK(hipMalloc(&dp, pieces.size() * sizeof(Piece)));
@@ -34,7 +36,7 @@ int main(int argc, char** argv) {
   int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5; CK(hipEventRecord(e0));
   for (int r = 0; r < reps; r++) launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask, false);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  double fl = 2.0 * 128 * 128 * K * (double)P * ntask * reps;
+  double fl = 2.0 * pm * pn * K * (double)P * ntask * reps;
   printf("tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,
          fl / (ms * 1e-3) * 1e-12, fl / (ms * 1e-3) / 78.6e12 * 100);
   return 0;
