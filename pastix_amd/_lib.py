@@ -80,12 +80,33 @@ EXPORTS_HOST = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  If this library pulls in the system copy first and
+    torch is imported later, the process ends up with two HIP runtimes and torch reports "No HIP GPUs are
+    available".  Loading torch's copy first (without importing torch) makes both use one runtime, whatever the
+    import order; without torch installed nothing happens and the system runtime is used."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001  (best effort: the system runtime still works on its own)
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("pastix_amd: %s is missing; run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         L.pastix_amd_fact_flops.restype = ctypes.c_double
         L.pastix_amd_version.restype = ctypes.c_char_p

@@ -202,3 +202,91 @@ def test_config5_z_ldlt_elasticity_pattern(N):
     A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
     A = A + sp.tril(A, -1).T
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
+
+
+def _run_tasks(pd, first, last, n, cp, r, v, perm, invp, b, nrhs, iparm, dparm):
+    iparm[px.IPARM["START_TASK"]] = px.API_TASK[first]
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK[last]
+    pd = px.pastix(pd, n, cp, r, v, perm, invp, b, nrhs, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    return pd
+
+
+def test_pastix_step_by_step_multi_rhs_and_refactorization():
+    """The call sequences of the reference's examples step-by-step.c and multi-rhs.c: every task on its own,
+    several right-hand sides in one solve, then new values with the analysis kept (NUMFACT .. REFINE again)."""
+    N = 10
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LLT
+    pd = px.PastixData()
+    pd.set_grid(N, N, N)
+    nrhs = 3
+    B = np.asfortranarray(np.random.default_rng(8).random((n, nrhs)))
+    b = B.reshape(-1, order="F").copy()
+    for task in ("ORDERING", "SYMBFACT", "ANALYSE", "NUMFACT", "SOLVE", "REFINE"):
+        pd = _run_tasks(pd, task, task, n, cp, r, v, perm, invp, b, nrhs, iparm, dparm)
+    A = _sym_matvec(n, cp, r, v)
+    X = b.reshape(n, nrhs, order="F")
+    assert np.linalg.norm(A @ X - B) / np.linalg.norm(B) < 1e-12
+    assert sorted(perm.tolist()) == list(range(1, n + 1)) and np.array_equal(perm[invp - 1], np.arange(1, n + 1))
+    # second factorization on the same analysis with other values
+    v2 = v.copy()
+    v2[v2 > 0] *= 1.5
+    b2 = np.random.default_rng(9).random(n)
+    rhs2 = b2.copy()
+    pd = _run_tasks(pd, "NUMFACT", "REFINE", n, cp, r, v2, perm, invp, b2, 1, iparm, dparm)
+    A2 = _sym_matvec(n, cp, r, v2)
+    assert np.linalg.norm(A2 @ b2 - rhs2) / np.linalg.norm(rhs2) < 1e-12
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v2, perm, invp, b2, 1, iparm, dparm)
+
+
+def test_pastix_reentrant_two_instances():
+    """reentrant.c: two independent pastix_data handles alive at once, tasks interleaved."""
+    out = []
+    for N, seed in ((8, 1), (9, 2)):
+        n, cp, r, v = sy.laplacian_3d(N)
+        iparm, dparm = px.init_param()
+        iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LLT
+        pd = px.PastixData()
+        pd.set_grid(N, N, N)
+        b = np.random.default_rng(seed).random(n)
+        out.append(dict(N=N, n=n, cp=cp, r=r, v=v, iparm=iparm, dparm=dparm, pd=pd, b=b, rhs=b.copy(),
+                        perm=np.zeros(n, dtype=np.int64), invp=np.zeros(n, dtype=np.int64)))
+    for first, last in (("ORDERING", "ANALYSE"), ("NUMFACT", "NUMFACT"), ("SOLVE", "SOLVE")):
+        for o in out:
+            o["pd"] = _run_tasks(o["pd"], first, last, o["n"], o["cp"], o["r"], o["v"], o["perm"], o["invp"], o["b"], 1,
+                                 o["iparm"], o["dparm"])
+    for o in out:
+        A = _sym_matvec(o["n"], o["cp"], o["r"], o["v"])
+        assert np.linalg.norm(A @ o["b"] - o["rhs"]) / np.linalg.norm(o["rhs"]) < 1e-12
+        _run_tasks(o["pd"], "CLEAN", "CLEAN", o["n"], o["cp"], o["r"], o["v"], o["perm"], o["invp"], o["b"], 1,
+                   o["iparm"], o["dparm"])
+
+
+@pytest.mark.parametrize("facto", ["LDLT", "LU"])
+def test_pastix_ldlt_and_lu_through_the_entry_point(facto):
+    N = 9
+    full = facto == "LU"
+    n, cp, r, v = sy.laplacian_3d(N, full=full)
+    if full:                                   # unsymmetric values on the symmetric pattern
+        v = v * (1.0 + 0.1 * np.random.default_rng(4).random(len(v)))
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LU if full else px.API_FACT_LDLT
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if full else px.API_SYM_YES
+    pd = px.PastixData()
+    pd.set_grid(N, N, N)
+    b = np.random.default_rng(6).random(n)
+    rhs = b.copy()
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    pd = _run_tasks(pd, "ORDERING", "REFINE", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    if not full:
+        A = A + sp.tril(A, -1).T
+        assert iparm[px.IPARM["INERTIA"]] == n            # SPD: every D entry positive (sopalin3d.c:1144-1160)
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-12
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
