@@ -21,7 +21,8 @@ enum {
   IPARM_ITERMAX = 5, IPARM_MATRIX_VERIFICATION = 6, IPARM_NBITER = 10, IPARM_AMALGAMATION_LEVEL = 13,
   IPARM_ORDERING = 14, IPARM_STATIC_PIVOTING = 20, IPARM_NNZEROS = 22, IPARM_BASEVAL = 24,
   IPARM_MIN_BLOCKSIZE = 25, IPARM_MAX_BLOCKSIZE = 26, IPARM_FACTORIZATION = 30, IPARM_THREAD_NBR = 34,
-  IPARM_LEVEL_OF_FILL = 36, IPARM_RHS_MAKING = 38, IPARM_REFINEMENT = 39, IPARM_SYM = 40, IPARM_INERTIA = 54,
+  IPARM_LEVEL_OF_FILL = 36, IPARM_RHS_MAKING = 38, IPARM_REFINEMENT = 39, IPARM_SYM = 40, IPARM_GMRES_IM = 44,
+  IPARM_INERTIA = 54,
   IPARM_ESP_NBTASKS = 55, IPARM_FLOAT = 61, IPARM_ERROR_NUMBER = 63, IPARM_CUDA_NBR = 64
 };
 /* DPARM_ACCESS (api.h:219-234) */
@@ -35,6 +36,8 @@ enum { API_TASK_INIT = 0, API_TASK_ORDERING = 1, API_TASK_SYMBFACT = 2, API_TASK
        API_TASK_NUMFACT = 4, API_TASK_SOLVE = 5, API_TASK_REFINE = 6, API_TASK_CLEAN = 7 };
 enum { API_NO = 0, API_YES = 1 };
 enum { API_SYM_YES = 0, API_SYM_NO = 1, API_SYM_HER = 2 };
+/* refinement modes, IPARM_REFINEMENT (api.h:353-365) */
+enum { API_RAF_GMRES = 0, API_RAF_GRAD = 1, API_RAF_PIVOT = 2, API_RAF_BICGSTAB = 3 };
 enum { API_ORDER_SCOTCH = 0, API_ORDER_METIS = 1, API_ORDER_PERSONAL = 2, API_ORDER_LOAD = 3 };
 
 typedef struct pastix_amd_data_s pastix_amd_data_t;

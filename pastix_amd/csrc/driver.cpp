@@ -8,8 +8,9 @@
 // dparm slots and enum values of api.h:124-234) so that the reference's example call sequence
 // (src/example/src/simple.c:59-256) runs unchanged on a box without PaStiX: ordering and symbolic
 // steps use this repo's producer (symbolic.cpp), the numerical factorization and the solves run on
-// the device.  Refinement is plain iterative refinement (the reference's API_RAF_PIVOT family); its
-// Krylov refiners are out of scope.
+// the device.  Refinement: GMRES(m), conjugate gradient and plain iterative refinement, all
+// preconditioned by the device solve; vectors and SpMV on the host.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +53,8 @@ static void init_param(pastix_amd_int_t* iparm, double* dparm) {   // pastix_ini
   iparm[IPARM_CUDA_NBR] = 0;
   iparm[IPARM_LEVEL_OF_FILL] = 1;
   iparm[IPARM_RHS_MAKING] = 0;
-  iparm[IPARM_REFINEMENT] = 0;
+  iparm[IPARM_REFINEMENT] = API_RAF_GMRES;
+  iparm[IPARM_GMRES_IM] = 25;
   iparm[IPARM_SYM] = API_SYM_YES;
   iparm[IPARM_INERTIA] = -1;
   iparm[IPARM_ESP_NBTASKS] = -1;
@@ -188,35 +190,122 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         break;
       }
       case API_TASK_REFINE: {
-        // plain iterative refinement x += A^-1 (b - A x) until ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT
+        // pastix_task_raff (pastix.c:4300-4500) picks the refiner from IPARM_REFINEMENT (api.h:353-365): GMRES
+        // (raff_gmres.c), conjugate gradient for the symmetric factorizations (raff_grad.c), plain iterative
+        // refinement (raff_pivot.c).  All three are preconditioned by the device solve with the factors and stop at
+        // ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT or after IPARM_ITERMAX iterations; BICGSTAB requests run
+        // GMRES.  The vectors and the SpMV stay on the host (the matrix is the caller's CSC).
         if (!D->factorized || !b || !avals || (int64_t)D->rhs.size() != n * rhs) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
-        std::vector<double> r((size_t)n), d((size_t)n);
+        const double eps = dparm[DPARM_EPSILON_REFINEMENT];
+        const int64_t itermax = iparm[IPARM_ITERMAX];
+        int mode = (int)iparm[IPARM_REFINEMENT];
+        if (mode == API_RAF_BICGSTAB) mode = API_RAF_GMRES;
+        if (mode == API_RAF_GRAD && facto == PASTIX_AMD_FACT_LU) mode = API_RAF_GMRES;
+        auto ax = [&](const double* x, double* y) {           // y = A x  (symmetric input: lower triangle stored)
+          for (int64_t i = 0; i < n; i++) y[i] = 0.0;
+          for (int64_t j = 0; j < n; j++)
+            for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+              const int64_t i = row[q] - 1;
+              y[i] += avals[q] * x[j];
+              if (sym && i != j) y[j] += avals[q] * x[i];
+            }
+        };
+        std::vector<double> pbuf((size_t)n);
+        auto precond = [&](const double* r, double* z) -> int {   // z = (factors)^-1 r
+          for (int64_t i = 0; i < n; i++) pbuf[D->perm[i]] = r[i];
+          const int rc2 = pastix_amd_solve(D->plan, pbuf.data(), 1);
+          if (rc2) return rc2;
+          for (int64_t i = 0; i < n; i++) z[i] = pbuf[D->perm[i]];
+          return 0;
+        };
+        auto dot = [&](const double* u, const double* w) { double t = 0; for (int64_t i = 0; i < n; i++) t += u[i] * w[i]; return t; };
         int64_t iters = 0;
         double relerr = 0;
+        std::vector<double> r((size_t)n), z((size_t)n), w((size_t)n);
         for (int64_t c = 0; c < rhs; c++) {
           double* x = b + c * n;
           const double* f = D->rhs.data() + c * n;
-          double nb = 0;
-          for (int64_t i = 0; i < n; i++) nb += f[i] * f[i];
-          nb = std::sqrt(nb);
-          for (int64_t it = 0; it <= iparm[IPARM_ITERMAX]; it++) {
-            for (int64_t i = 0; i < n; i++) r[i] = f[i];
-            for (int64_t j = 0; j < n; j++)
-              for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
-                const int64_t i = row[q] - 1;
-                r[i] -= avals[q] * x[j];
-                if (sym && i != j) r[j] -= avals[q] * x[i];
+          double nb = std::sqrt(dot(f, f));
+          if (nb == 0) nb = 1;
+          auto residual = [&]() { ax(x, r.data()); for (int64_t i = 0; i < n; i++) r[i] = f[i] - r[i]; return std::sqrt(dot(r.data(), r.data())) / nb; };
+          int64_t it = 0;
+          relerr = residual();
+          if (mode == API_RAF_PIVOT) {
+            while (relerr >= eps && it < itermax) {
+              if ((rc = precond(r.data(), z.data()))) FAIL(rc);
+              for (int64_t i = 0; i < n; i++) x[i] += z[i];
+              it++;
+              relerr = residual();
+            }
+          } else if (mode == API_RAF_GRAD) {
+            std::vector<double> pdir((size_t)n);
+            if ((rc = precond(r.data(), z.data()))) FAIL(rc);
+            pdir = z;
+            double rz = dot(r.data(), z.data());
+            while (relerr >= eps && it < itermax) {
+              ax(pdir.data(), w.data());
+              const double alpha = rz / dot(pdir.data(), w.data());
+              for (int64_t i = 0; i < n; i++) { x[i] += alpha * pdir[i]; r[i] -= alpha * w[i]; }
+              it++;
+              relerr = std::sqrt(dot(r.data(), r.data())) / nb;
+              if (relerr < eps) break;
+              if ((rc = precond(r.data(), z.data()))) FAIL(rc);
+              const double rz2 = dot(r.data(), z.data());
+              const double beta = rz2 / rz;
+              rz = rz2;
+              for (int64_t i = 0; i < n; i++) pdir[i] = z[i] + beta * pdir[i];
+            }
+            relerr = residual();
+          } else {
+            // right-preconditioned GMRES(m): A M^-1 u = b, x = M^-1 u
+            const int m = (int)std::max<int64_t>(1, std::min<int64_t>(iparm[IPARM_GMRES_IM] > 0 ? iparm[IPARM_GMRES_IM] : 25, 200));
+            std::vector<std::vector<double>> V((size_t)m + 1, std::vector<double>((size_t)n));
+            std::vector<double> H((size_t)(m + 1) * m), cs((size_t)m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
+            while (relerr >= eps && it < itermax) {
+              const double beta = relerr * nb;
+              for (int64_t i = 0; i < n; i++) V[0][i] = r[i] / beta;
+              std::fill(g.begin(), g.end(), 0.0);
+              g[0] = beta;
+              int j = 0;
+              for (; j < m && it < itermax; j++) {
+                if ((rc = precond(V[j].data(), z.data()))) FAIL(rc);
+                ax(z.data(), w.data());
+                for (int i = 0; i <= j; i++) {                       // modified Gram-Schmidt
+                  const double h = dot(w.data(), V[i].data());
+                  H[(size_t)i * m + j] = h;
+                  for (int64_t q = 0; q < n; q++) w[q] -= h * V[i][q];
+                }
+                const double hn = std::sqrt(dot(w.data(), w.data()));
+                H[(size_t)(j + 1) * m + j] = hn;
+                if (hn > 0) for (int64_t q = 0; q < n; q++) V[j + 1][q] = w[q] / hn;
+                for (int i = 0; i < j; i++) {                        // previous Givens rotations on the new column
+                  const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+                  H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+                  H[(size_t)i * m + j] = t;
+                }
+                const double a0 = H[(size_t)j * m + j], a1 = H[(size_t)(j + 1) * m + j], rr = std::hypot(a0, a1);
+                cs[j] = rr > 0 ? a0 / rr : 1.0;
+                sn[j] = rr > 0 ? a1 / rr : 0.0;
+                H[(size_t)j * m + j] = rr;
+                H[(size_t)(j + 1) * m + j] = 0.0;
+                g[j + 1] = -sn[j] * g[j];
+                g[j] = cs[j] * g[j];
+                it++;
+                if (std::fabs(g[j + 1]) / nb < eps || hn == 0) { j++; break; }
               }
-            double nr = 0;
-            for (int64_t i = 0; i < n; i++) nr += r[i] * r[i];
-            relerr = nb > 0 ? std::sqrt(nr) / nb : std::sqrt(nr);
-            if (relerr < dparm[DPARM_EPSILON_REFINEMENT] || it == iparm[IPARM_ITERMAX]) break;
-            for (int64_t i = 0; i < n; i++) d[D->perm[i]] = r[i];
-            rc = pastix_amd_solve(D->plan, d.data(), 1);
-            if (rc) FAIL(rc);
-            for (int64_t i = 0; i < n; i++) x[i] += d[D->perm[i]];
-            iters++;
+              for (int i = j - 1; i >= 0; i--) {                     // back substitution H y = g
+                double t = g[i];
+                for (int q = i + 1; q < j; q++) t -= H[(size_t)i * m + q] * y[q];
+                y[i] = t / H[(size_t)i * m + i];
+              }
+              for (int64_t q = 0; q < n; q++) w[q] = 0.0;
+              for (int i = 0; i < j; i++) for (int64_t q = 0; q < n; q++) w[q] += y[i] * V[i][q];
+              if ((rc = precond(w.data(), z.data()))) FAIL(rc);
+              for (int64_t q = 0; q < n; q++) x[q] += z[q];
+              relerr = residual();
+            }
           }
+          iters = std::max(iters, it);
         }
         iparm[IPARM_NBITER] = iters;
         dparm[DPARM_RELATIVE_ERROR] = relerr;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         pa += (int64_t)KC * lda;
         pb += (int64_t)KC * lda;
       }
-#ifndef EXP_NO_DMA
+#ifndef EXP_NO_DMA   /* EXP_*: timing-only ablation switches of tools/bench_update (results are wrong with them) */
       if (has_next) {
         double* dA = sh[buf ^ 1][0] + wave * SLD;
         double* dB = sh[buf ^ 1][1] + wave * SLD;
@@ -561,140 +561,9 @@ __global__ __launch_bounds__(256) void k_diag_llt(double* __restrict__ L, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_diag_llt_lds : same factorization with the whole diagonal blok (w <= 128) resident in LDS: no global
-// round trip inside the 16-column block steps (the global version above spends ~170 us per 128-wide
-// blok on dependent L2 accesses; this one is the latency-critical kernel of every level).
-// ------------------------------------------------------------------------------------------------
-constexpr int DLD = 129;   // LDS leading dimension of the resident blok (odd: conflict-free columns)
-__global__ __launch_bounds__(256) void k_diag_llt_lds(double* __restrict__ L, const PanelTask* __restrict__ tasks,
-                                                      double* __restrict__ dinv_ws, double critere,
-                                                      long long* __restrict__ nbpivot, int* __restrict__ errflag) {
-  __shared__ double D[128 * DLD];      // D[c * DLD + r], lower triangle
-  __shared__ double Lo[16][17];
-  __shared__ double Ri[16];            // reciprocals of the tile's diagonal
-  const PanelTask tk = tasks[blockIdx.x];
-  double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
-  int npiv = 0;
-  {
-    // blok -> LDS: 8 columns per batch, all loads of a batch issued before their LDS stores (a load ->
-    // store pair per column would serialize 128 L2 round trips)
-    const int r = tid & 127, ch = tid >> 7;
-    for (int c0 = 0; c0 < w; c0 += 16) {
-      double v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int c = c0 + ch + 2 * q;
-        v[q] = A[min(r, w - 1) + (int64_t)min(c, w - 1) * ld];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const int c = c0 + ch + 2 * q;
-        if (c < w && r < w && r >= c) D[c * DLD + r] = v[q];
-      }
-    }
-  }
-  for (int kb = 0; kb < w; kb += 16) {
-    const int nb = min(16, w - kb), rem = w - kb - nb;
-    double* T = D + kb * DLD + kb;                       // tile element (i,c) at T[c * DLD + i]
-    for (int j = 0; j < nb; j++) {                       // PASTIX_potrf (compute_diag.c:124-153)
-      __syncthreads();
-      double d = T[j * DLD + j];
-      if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
-      if (!(d > 0.0) && tid == 0) atomicOr(errflag, 1);
-      double inv;
-      fast_sqrt_rsqrt(d, d, inv);
-      if (ti < nb && tc < nb) {
-        if (tc == j) {
-          if (ti == j) { Lo[j][j] = d; Ri[j] = inv; }
-          else if (ti > j) Lo[ti][j] = T[j * DLD + ti] * inv;
-        } else if (tc > j && ti >= tc) {
-          T[tc * DLD + ti] -= (T[j * DLD + ti] * inv) * (T[j * DLD + tc] * inv);
-        }
-      }
-    }
-    __syncthreads();
-    if (ti < nb && tc < nb && ti >= tc) T[tc * DLD + ti] = Lo[ti][tc];
-    if (tid < 16) {
-      // column c of inv(tile) by forward substitution, kept in registers (identity padding beyond nb)
-      const int c = tid;
-      double x[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int p = 0; p < 16; p++)
-          if (p < i) s -= ((i < nb && p < nb) ? Lo[i][p] : 0.0) * x[p];
-        x[i] = (i < nb && c < nb) ? ((i >= c) ? s * Ri[min(i, nb - 1)] : 0.0) : ((i == c) ? 1.0 : 0.0);
-      }
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
-#pragma unroll
-      for (int i = 0; i < 16; i++) dst[i + 16 * c] = x[i];
-    } else if (tid - 16 < rem) {
-      const int rr = kb + nb + tid - 16;                 // row of the blok
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = (c < nb) ? D[(kb + c) * DLD + rr] : 0.0;
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          double s = x[c];
-#pragma unroll
-          for (int p = 0; p < 16; p++)
-            if (p < c) s -= x[p] * Lo[c][p];
-          x[c] = s * Ri[c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < nb) D[(kb + c) * DLD + rr] = x[c];
-    }
-    __syncthreads();
-    if (rem > 0) {                                       // SYRK on the trailing part, in LDS
-      const int nt = (rem + 3) >> 2, r0 = kb + nb;
-      for (int id = tid; id < nt * nt; id += 256) {
-        const int tr = id % nt, tcc = id / nt;
-        if (tr < tcc) continue;
-        double c[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
-        for (int p = 0; p < nb; p++) {
-          const double* xp = D + (kb + p) * DLD + r0;
-          double xa[4], xb[4];
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            xa[a] = xp[min(4 * tr + a, rem - 1)];
-            xb[a] = xp[min(4 * tcc + a, rem - 1)];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            const int r = 4 * tr + a, cc = 4 * tcc + b;
-            if (r < rem && cc < rem && r >= cc) D[(r0 + cc) * DLD + r0 + r] -= c[a][b];
-          }
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const int r = tid & 127, ch = tid >> 7;
-    for (int c = ch; c < w; c += 2)
-      if (r < w && r >= c) A[r + (int64_t)c * ld] = D[c * DLD + r];
-  }
-  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_diag_llt_w : wave-synchronous version of k_diag_llt_lds (w <= 128).  Per 16-column block step:
+// k_diag_llt_w : the diagonal-blok factorization for w <= 128 with the blok resident in LDS (the global-memory
+// version above spends ~170 us per 128-wide blok on dependent L2 accesses; this is the latency-critical kernel
+// of every level).  Per 16-column block step:
 //   (A) wave 0 factors the 16x16 tile in registers, row i in lane i, columns broadcast with v_readlane
 //       (no barrier per column), and keeps the rows for (B');
 //   (B) waves 1-3: thread-per-row solve of the rows below against the tile (in LDS);
@@ -1100,11 +969,8 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag, int maxw) {
   if (n <= 0) return;
-  static const int diag_v = getenv("PASTIX_AMD_DIAG_KERNEL") ? atoi(getenv("PASTIX_AMD_DIAG_KERNEL")) : 2;
-  if (maxw <= 128 && diag_v == 2)
+  if (maxw <= 128)
     hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
-  else if (maxw <= 128)
-    hipLaunchKernelGGL(k_diag_llt_lds, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
   else
     hipLaunchKernelGGL(k_diag_llt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
 }

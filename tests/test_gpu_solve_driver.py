@@ -290,3 +290,30 @@ def test_pastix_ldlt_and_lu_through_the_entry_point(facto):
         assert iparm[px.IPARM["INERTIA"]] == n            # SPD: every D entry positive (sopalin3d.c:1144-1160)
     assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-12
     _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("mode", ["GMRES", "GRAD", "PIVOT"])
+def test_pastix_refinement_modes_recover_from_static_pivoting(mode):
+    """IPARM_REFINEMENT (api.h:353-365).  A huge DPARM_EPSILON_MAGN_CTRL makes the factorization clamp pivots
+    (static pivoting perturbs the factors), so the first solve is inaccurate and the refiner has real work."""
+    N = 8
+    n, cp, r, v = sy.laplacian_3d(N)
+    iparm, dparm = px.init_param()
+    assert iparm[px.IPARM["REFINEMENT"]] == px.API_RAF_GMRES and iparm[px.IPARM["GMRES_IM"]] == 25
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LLT
+    iparm[px.IPARM["REFINEMENT"]] = getattr(px, "API_RAF_" + mode)
+    dparm[px.DPARM["EPSILON_MAGN_CTRL"]] = -5.9          # critere = 5.9: some pivots of this matrix are clamped
+    pd = px.PastixData()
+    pd.set_grid(N, N, N)
+    b = np.random.default_rng(12).random(n)
+    rhs = b.copy()
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    pd = _run_tasks(pd, "ORDERING", "SOLVE", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["STATIC_PIVOTING"]] > 0
+    A = _sym_matvec(n, cp, r, v)
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) > 1e-6       # perturbed factors: poor first solve
+    pd = _run_tasks(pd, "REFINE", "REFINE", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-11
+    assert 0 < iparm[px.IPARM["NBITER"]] <= 250 and dparm[px.DPARM["RELATIVE_ERROR"]] < 1e-11
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
