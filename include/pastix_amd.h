@@ -71,7 +71,10 @@ typedef struct pastix_amd_options_s {
   int verbose;
   int external_arena;    /* 1: do not allocate the panel arena; the caller provides device memory with
                             pastix_amd_plan_set_arena (e.g. a torch tensor used with torch.distributed) */
-  int reserved[12];
+  int schur;             /* 1: IPARM_SCHUR semantics of compute_1d (sopalin_compute.c:767-772): the last cblk is not
+                            factorized; on return its panel holds the Schur complement (what pastix_getSchur reads).
+                            That cblk may be wider than 256 columns.  Solves are not available on such a plan. */
+  int reserved[11];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */

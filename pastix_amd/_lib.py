@@ -30,7 +30,7 @@ class Layout(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
-                ("external_arena", ctypes.c_int), ("reserved", ctypes.c_int * 12)]
+                ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("reserved", ctypes.c_int * 11)]
 
 
 class Stats(ctypes.Structure):

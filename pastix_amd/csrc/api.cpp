@@ -193,7 +193,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   };
   CHK(body());
 #undef CHK
-  for (int64_t k = 0; k < H.cblknbr; k++)
+  for (int64_t k = 0; k < H.cblknbr - (H.opts.schur ? 1 : 0); k++)     // (the Schur cblk is never factorized)
     p->maxw = std::max<int>(p->maxw, (int)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1));
   pastix_amd_stats_t& S = p->stats;
   S.fact_flops = H.fact_flops;
@@ -779,7 +779,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
 int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
-  if (p->distributed || p->cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (p->distributed || p->cplx || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);

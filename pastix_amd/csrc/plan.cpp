@@ -189,7 +189,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.poff[0] = 0;
   for (int64_t k = 0; k < nc; k++) {
     int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-    if (w > MAXW) return PASTIX_AMD_ERR_UNSUPPORTED;
+    if (w > MAXW && !(P.opts.schur && k == nc - 1)) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
     P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.tstride[k] * w : 0);
   }
@@ -223,13 +223,15 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
 
   // cblks by level
   P.lvl_cblk_ptr.assign(NL + 1, 0);
-  for (int64_t k = 0; k < nc; k++) if (P.role[k] == 1) P.lvl_cblk_ptr[P.level[k] + 1]++;
+  // Schur mode: the last cblk receives its contributions but is not factorized (sopalin_compute.c:767-772)
+  auto factored = [&](int64_t k) { return P.role[k] == 1 && !(P.opts.schur && k == nc - 1); };
+  for (int64_t k = 0; k < nc; k++) if (factored(k)) P.lvl_cblk_ptr[P.level[k] + 1]++;
   for (int l = 0; l < NL; l++) P.lvl_cblk_ptr[l + 1] += P.lvl_cblk_ptr[l];
   const int64_t nowned = P.lvl_cblk_ptr[NL];
   P.lvl_cblk.resize(nowned);
   {
     std::vector<int64_t> pos(P.lvl_cblk_ptr.begin(), P.lvl_cblk_ptr.end() - 1);
-    for (int64_t k = 0; k < nc; k++) if (P.role[k] == 1) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
+    for (int64_t k = 0; k < nc; k++) if (factored(k)) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
   }
 
   // ---- panel / trsm tasks per level ------------------------------------------------------------

@@ -21,7 +21,8 @@ def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
 
 
 class Plan:
-    def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0):
+    def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0,
+                 schur=False):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
         self.dtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float64
@@ -30,6 +31,7 @@ class Plan:
         opts.device = device
         opts.lookahead = lookahead
         opts.verbose = verbose
+        opts.schur = 1 if schur else 0
         check(_lib.lib().pastix_amd_plan_create(ctypes.byref(self.layout.c), factotype, floattype,
                                                 ctypes.byref(opts), ctypes.byref(self._h)),
               "pastix_amd_plan_create")

@@ -131,3 +131,38 @@ def test_all_pivots_clamped():
         L1, _ = p.download()
     assert st["nbpivot"] == nbo == n
     assert np.abs(L1 - Lo)[lower_mask(c4)].max() <= TOL
+
+
+@pytest.mark.parametrize("facto", [0, 1, 2])
+@pytest.mark.parametrize("widths", [[40, 30, 300], [128, 128, 64], [17, 500]])
+def test_schur_mode_leaves_the_schur_complement_in_the_last_cblk(widths, facto):
+    """IPARM_SCHUR at the sopalin boundary (compute_1d, sopalin_compute.c:767-772): the last cblk is updated but not
+    factorized, so its diagonal blok is S = A22 - A21 A11^-1 A12 (what pastix_getSchur returns); it may be wider
+    than 256 columns.  The other cblks are factorized as usual."""
+    c4, b4, n = dense_layout(widths)
+    A = spd(n, 21 + n)
+    if facto == 2:
+        A = A + np.triu(np.random.default_rng(7).standard_normal((n, n)), 1) * 0.1
+    L0 = panels_of(A, c4)
+    U0 = panels_of(A.T, c4) if facto == 2 else None
+    with Plan(c4, b4, facto, schur=True) as p:
+        p.upload(L0, U0)
+        st = p.factorize(1e-30)
+        L1, U1 = p.download()
+    assert st["nbpivot"] == 0
+    ns = widths[-1]
+    n1 = n - ns
+    S = A[n1:, n1:] - A[n1:, :n1] @ np.linalg.solve(A[:n1, :n1], A[:n1, n1:])
+    got = L1[-ns * ns:].reshape(ns, ns, order="F")
+    if facto == 2:
+        # LU: contributions to a diagonal blok from the U side are added transposed into coeftab
+        # (add_contrib_local, sopalin_compute.c:430-435,572-575), so the whole square of S sits in the L arena
+        assert np.abs(got - S).max() <= 1e-10 * np.abs(S).max()
+    else:
+        tri = np.tril_indices(ns)
+        assert np.abs(got - S)[tri].max() <= 1e-10 * np.abs(S).max()
+    # the factorized part equals an ordinary factorization of the same layout
+    Lo, Uo, _ = oracle_lib.sopalin(facto, c4, b4, L0, U0, 1e-30)
+    m = lower_mask(c4) if facto != 2 else np.ones(L1.size, bool)
+    m[-ns * ns:] = False
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
