@@ -17,6 +17,9 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
                    bool urgent);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
+void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
+                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* xr, double* xi);
+void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi);
 void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
                       int64_t ncols);
 void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
@@ -779,7 +782,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
 int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
-  if (p->distributed || p->cplx || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (p->distributed || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);
@@ -805,6 +808,36 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     if ((r = to_device(&p->dSolve, st))) return r;
     if ((r = to_device(&p->dBlok, bl))) return r;
     if ((r = to_device(&p->dChunk, ch))) return r;
+  }
+  if (p->cplx) {
+    // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device
+    double *dz = nullptr, *dxr = nullptr, *dxi = nullptr;
+    HIPCHK(hipMalloc((void**)&dz, (size_t)H.ncol * 2 * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dxr, (size_t)H.ncol * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dxi, (size_t)H.ncol * sizeof(double)));
+    double* xz = (double*)x_;
+    const bool scale = H.factotype == PASTIX_AMD_FACT_LDLT || H.factotype == PASTIX_AMD_FACT_LDLH;
+    for (int64_t j = 0; j < nrhs; j++) {
+      HIPCHK(hipMemcpyAsync(dz, xz + 2 * j * H.ncol, H.ncol * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+      launch_split(p->stream, dz, dxr, dxi, H.ncol);
+      for (int l = 0; l < H.nlevels; l++)
+        launch_zsolve_level(p->stream, true, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
+                            H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                            p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dxr, dxi);
+      if (scale) launch_zsolve_dscale(p->stream, p->arenas(), p->dSolve, H.lvl_cblk_ptr[H.nlevels], dxr, dxi);
+      for (int l = H.nlevels - 1; l >= 0; l--)
+        launch_zsolve_level(p->stream, false, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
+                            H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                            p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dxr, dxi);
+      launch_merge(p->stream, dz, dxr, dxi, H.ncol);
+      HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      HIPCHK(hipStreamSynchronize(p->stream));
+    }
+    HIPCHK(hipFree(dz));
+    HIPCHK(hipFree(dxr));
+    HIPCHK(hipFree(dxi));
+    HIPCHK(hipGetLastError());
+    return PASTIX_AMD_OK;
   }
   double* dx = nullptr;
   HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * sizeof(double)));

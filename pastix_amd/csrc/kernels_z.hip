@@ -514,6 +514,161 @@ __global__ __launch_bounds__(256) void k_trsm_zlu(const Arenas ar, const TrsmTas
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// complex triangular solves on the split planes (the data flow of up_down_smp, updo.c:114): same level schedule
+// and task tables as the real kernels of kernels.hip.  CONJ: the backward sweep uses L^H (Hermitian LDL^H,
+// updo.c:1328-1340,1437-1453) instead of L^T.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int z_panel_row_to_global(const DevBlok* __restrict__ bl, int fb, int lb, int p) {
+  int lo = fb, hi = lb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (bl[mid].coefind <= p) lo = mid; else hi = mid - 1;
+  }
+  return bl[lo].frow + (p - bl[lo].coefind);
+}
+
+__global__ __launch_bounds__(256) void k_zsolve_diag_fwd(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                         const SolveTask* __restrict__ tasks, double* __restrict__ xr,
+                                                         double* __restrict__ xi, int unit) {
+  __shared__ cz xs[MAXW];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* Ar = Lr + tk.off;
+  const double* Ai = Li + tk.off;
+  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
+  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[tk.fcol + c], xi[tk.fcol + c]};
+  __syncthreads();
+  for (int c = 0; c < w; c++) {
+    const int64_t dd = c + (int64_t)c * ld;
+    const cz xc = unit ? xs[c] : cmul(xs[c], cinv(cz{Ar[dd], Ai[dd]}));
+    __syncthreads();
+    if (tid == 0) xs[c] = xc;
+    for (int r = c + 1 + tid; r < w; r += 256) {
+      const int64_t o = r + (int64_t)c * ld;
+      xs[r] = csub(xs[r], cmul(cz{Ar[o], Ai[o]}, xc));
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < w; c += 256) { xr[tk.fcol + c] = xs[c].re; xi[tk.fcol + c] = xs[c].im; }
+}
+
+__global__ __launch_bounds__(256) void k_zsolve_off_fwd(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                        const SolveChunk* __restrict__ chunks,
+                                                        const DevBlok* __restrict__ bl, double* __restrict__ xr,
+                                                        double* __restrict__ xi) {
+  __shared__ cz xs[MAXW];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* Ar = Lr + ck.off;
+  const double* Ai = Li + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x;
+  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[ck.fcol + c], xi[ck.fcol + c]};
+  __syncthreads();
+  const int p = ck.row0 + tid;
+  if (tid < ck.nrows) {
+    cz sacc = cz{0.0, 0.0};
+    for (int c = 0; c < w; c++) {
+      const int64_t o = p + (int64_t)c * ld;
+      const cz m = cmul(cz{Ar[o], Ai[o]}, xs[c]);
+      sacc.re += m.re;
+      sacc.im += m.im;
+    }
+    const int gr = z_panel_row_to_global(bl, ck.fblok, ck.lblok, p);
+    unsafeAtomicAdd(&xr[gr], -sacc.re);
+    unsafeAtomicAdd(&xi[gr], -sacc.im);
+  }
+}
+
+template <bool CONJ>
+__global__ __launch_bounds__(256) void k_zsolve_off_bwd(const double* __restrict__ Br, const double* __restrict__ Bi,
+                                                        const SolveChunk* __restrict__ chunks,
+                                                        const DevBlok* __restrict__ bl, double* __restrict__ xr,
+                                                        double* __restrict__ xi) {
+  __shared__ double part[2][4][MAXW];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* Ar = Br + ck.off;
+  const double* Ai = Bi + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = ck.row0 + tid;
+  const bool valid = tid < ck.nrows;
+  const int gr = z_panel_row_to_global(bl, ck.fblok, ck.lblok, min(p, ld - 1));
+  const cz xrow = valid ? cz{xr[gr], xi[gr]} : cz{0.0, 0.0};
+  const int64_t po = min(p, ld - 1);
+  for (int c = 0; c < w; c++) {
+    const int64_t o = po + (int64_t)c * ld;
+    cz m = valid ? cmul(cj<CONJ>(cz{Ar[o], Ai[o]}), xrow) : cz{0.0, 0.0};
+    for (int o2 = 32; o2 > 0; o2 >>= 1) { m.re += __shfl_down(m.re, o2); m.im += __shfl_down(m.im, o2); }
+    if (lane == 0) { part[0][wave][c] = m.re; part[1][wave][c] = m.im; }
+  }
+  __syncthreads();
+  for (int c = tid; c < w; c += 256) {
+    unsafeAtomicAdd(&xr[ck.fcol + c], -(part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c]));
+    unsafeAtomicAdd(&xi[ck.fcol + c], -(part[1][0][c] + part[1][1][c] + part[1][2][c] + part[1][3][c]));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_zsolve_dscale(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                       const SolveTask* __restrict__ tasks, double* __restrict__ xr,
+                                                       double* __restrict__ xi) {
+  const SolveTask tk = tasks[blockIdx.x];
+  for (int c = threadIdx.x; c < tk.width; c += 256) {
+    const int64_t dd = tk.off + c + (int64_t)c * tk.stride;
+    const cz v = cmul(cz{xr[tk.fcol + c], xi[tk.fcol + c]}, cinv(cz{Lr[dd], Li[dd]}));
+    xr[tk.fcol + c] = v.re;
+    xi[tk.fcol + c] = v.im;
+  }
+}
+
+// mode 1: unit L^T or L^H (LDLt / LDLh); 2: U = upper triangle of the factored blok (LU)
+template <bool CONJ>
+__global__ __launch_bounds__(256) void k_zsolve_diag_bwd(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                         const SolveTask* __restrict__ tasks, double* __restrict__ xr,
+                                                         double* __restrict__ xi, int mode) {
+  __shared__ cz xs[MAXW];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* Ar = Lr + tk.off;
+  const double* Ai = Li + tk.off;
+  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
+  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[tk.fcol + c], xi[tk.fcol + c]};
+  __syncthreads();
+  for (int c = w - 1; c >= 0; c--) {
+    const int64_t dd = c + (int64_t)c * ld;
+    const cz xc = (mode == 1) ? xs[c] : cmul(xs[c], cinv(cz{Ar[dd], Ai[dd]}));
+    __syncthreads();
+    if (tid == 0) xs[c] = xc;
+    for (int r = tid; r < c; r += 256) {
+      const int64_t o = (mode == 2) ? r + (int64_t)c * ld : c + (int64_t)r * ld;
+      xs[r] = csub(xs[r], cmul(cj<CONJ>(cz{Ar[o], Ai[o]}), xc));
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < w; c += 256) { xr[tk.fcol + c] = xs[c].re; xi[tk.fcol + c] = xs[c].im; }
+}
+
+// fwd: unit L.  bwd: LDLt/LDLh gather through the L planes (transposed / conjugate-transposed), LU through the U planes.
+void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
+                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* xr, double* xi) {
+  const dim3 b(256);
+  if (fwd) {
+    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_fwd, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, 1);
+    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_fwd, dim3((unsigned)nchunk), b, 0, s, ar.p[0], ar.p[2], chunks, bl, xr, xi);
+    return;
+  }
+  const bool lu = factotype == PASTIX_AMD_FACT_LU, herm = factotype == PASTIX_AMD_FACT_LDLH;
+  const double* Br = lu ? ar.p[1] : ar.p[0];
+  const double* Bi = lu ? ar.p[3] : ar.p[2];
+  const int mode = lu ? 2 : 1;
+  if (herm) {
+    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_bwd<true>, dim3((unsigned)nchunk), b, 0, s, Br, Bi, chunks, bl, xr, xi);
+    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_bwd<true>, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
+  } else {
+    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_bwd<false>, dim3((unsigned)nchunk), b, 0, s, Br, Bi, chunks, bl, xr, xi);
+    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_bwd<false>, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
+  }
+}
+void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi) {
+  if (ntask > 0) hipLaunchKernelGGL(k_zsolve_dscale, dim3((unsigned)ntask), dim3(256), 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+}
+
 // interleaved complex <-> split planes
 __global__ void k_split(const double* __restrict__ z, double* __restrict__ re, double* __restrict__ im, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

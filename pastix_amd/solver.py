@@ -94,7 +94,9 @@ class Plan:
         return d
 
     def solve(self, x):
-        x = np.ascontiguousarray(x, dtype=np.float64)
+        """x (permuted numbering; n or n x nrhs) -> solution.  A contiguous 1-D array of the plan's dtype is solved in
+        place, like the reference's b; anything else is copied."""
+        x = np.ascontiguousarray(x, dtype=self.dtype)      # complex plans: interleaved complex128, like the reference
         nrhs = 1 if x.ndim == 1 else x.shape[1]
         xf = np.asfortranarray(x.reshape(len(x), nrhs))
         check(_lib.lib().pastix_amd_solve(self._h, _lib.ptr(xf), ctypes.c_int64(nrhs)), "pastix_amd_solve")

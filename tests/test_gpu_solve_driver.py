@@ -186,6 +186,11 @@ def test_config5_z_ldlt_elasticity_pattern(N):
         assert np.array_equal(Ld, L0)
         st = p.factorize(crit)
         L1, _ = p.download()
+        # end-to-end: complex triangular solves on the device, against the oracle's substitution
+        b = np.random.default_rng(2).random(n) + 1j * np.random.default_rng(3).random(n)
+        bp = np.empty(n, dtype=np.complex128)
+        bp[s["perm"]] = b
+        xd = p.solve(bp.copy())
     assert st["nbpivot"] == nbo == 0
     w = c4[:-1, 1] - c4[:-1, 0] + 1
     m = np.ones(len(L1), dtype=bool)
@@ -194,11 +199,9 @@ def test_config5_z_ldlt_elasticity_pattern(N):
         for c in range(int(w[k])):
             m[off[k] + c * c4[k, 3]: off[k] + c * c4[k, 3] + c] = False
     assert np.abs(L1 - Lo)[m].max() <= 1e-12 * np.abs(Lo[m]).max()
-    # end-to-end: solve with the oracle's substitution on the GPU factors
-    b = np.random.default_rng(2).random(n) + 0j
-    bp = np.empty(n, dtype=np.complex128)
-    bp[s["perm"]] = b
-    x = oracle_lib.solve(1, c4, b4, L1, None, bp)[s["perm"]]
+    xo = oracle_lib.solve(1, c4, b4, L1, None, bp)
+    assert np.abs(xd - xo).max() <= 1e-11 * np.abs(xo).max()
+    x = xd[s["perm"]]
     A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
     A = A + sp.tril(A, -1).T
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
@@ -317,3 +320,20 @@ def test_pastix_refinement_modes_recover_from_static_pivoting(mode):
     assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-11
     assert 0 < iparm[px.IPARM["NBITER"]] <= 250 and dparm[px.DPARM["RELATIVE_ERROR"]] < 1e-11
     _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("name", ["zrlap3d_8_ldlt", "zrlap3d_12_ldlt", "zrlap3d_8_ldlh", "zrlap3d_12_ldlh", "zrlap3d_8_lu",
+                                  "zrlap3d_12_lu", "zyoung4c_841_ldlt"])
+def test_z_solve_matches_reference(name, golden):
+    """Complex device solves (LDLt, LDLh, LU) on the device-resident factors vs the reference's own solution."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        p.factorize(g["critere"])
+        bp = np.empty(g["n"], dtype=np.complex128)
+        bp[g["perm"]] = g["b"]
+        x = p.solve(bp.copy())[g["perm"]]                       # (solve works in place, like the reference's b)
+        X2 = p.solve(np.stack([bp, 2j * bp], axis=1))           # two right-hand sides at once
+    assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
+    assert np.abs(X2[:, 1][g["perm"]] - 2j * g["x"]).max() <= 1e-10 * 2 * np.abs(g["x"]).max()
