@@ -193,7 +193,9 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
 int pastix_amd_factorize_level(pastix_amd_plan_t *plan, int level, int phase);
 int pastix_amd_factorize_end(pastix_amd_plan_t *plan, pastix_amd_stats_t *stats);
 
-/* triangular solves on the device-resident factors, x (permuted numbering, n x nrhs, ld n) in place */
+/* triangular solves on the device-resident factors (the data flow of up_down_smp, updo.c:114), x (permuted
+ * numbering, n x nrhs, ld n; `double`, or interleaved `double complex` for complex plans) in place.  Not available
+ * on distributed or Schur-mode plans (PASTIX_AMD_ERR_UNSUPPORTED). */
 int pastix_amd_solve(pastix_amd_plan_t *plan, void *x, pastix_amd_int_t nrhs);
 
 /* raw device pointers of the arenas (for callers that own device-side pipelines, e.g. RCCL fan-in) */
