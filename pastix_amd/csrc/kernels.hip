@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "plan.h"
 #include "devmath.h"
@@ -167,6 +168,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
   if (tk.nfull > 0) {
+    // two instantiations: tasks on a full 128 x 128 tile keep the branch-free loop
+    auto fast_loop = [&](auto fullt_c) {
+    constexpr bool FULLT = decltype(fullt_c)::value;
     // ---- leading full pieces, LDS-DMA version: every wave copies KC/NW k-lines of A and of B per chunk with
     // global_load_lds_dwordx4 (no staging registers, no ds_write), the MFMA operands are double-buffered in
     // registers so that the ds_reads of k-step s+1 are in flight under the MFMAs of k-step s, and the chunk
@@ -186,14 +190,25 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     int krem = (int)cur.k;                          // k-lines of the piece not yet issued
     bool negn = (cur.flags & 16) != 0, negc = negn;
     const double* zl = g_zero_line + 2 * lane;
+    // These pieces cover the whole VALID tile: tm x tn, smaller than 128 x 128 only for the last row tile of a panel
+    // and for target cblks narrower than 128 columns.  Lanes beyond tm / tn copy the zero line; with an odd tm
+    // (tn) the last lane brings one element of the next panel row along, which only reaches accumulator rows
+    // (columns) the epilogue never stores.  Bands beyond the valid tile are skipped on the MFMA pipe.
+    const bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
+    unsigned amt = 0, ant = 0;
+#pragma unroll
+    for (int s = 0; s < MI; s++) if (row0 + s * RS < (int)tk.tm) amt |= 1u << s;
+#pragma unroll
+    for (int s = 0; s < NI; s++) if (col0 + s * CS < (int)tk.tn) ant |= 1u << s;
+    const bool allb = FULLT || (amt == MALL && ant == 0xFu);
 #pragma unroll
     for (int q = 0; q < NL; q++) {
       const bool kv = wave + NW * q < krem;        // wave-uniform
-      PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, sh[0][0] + (wave + NW * q) * SLD);
-      PASTIX_AMD_GLDS(kv ? pb + (int64_t)q * NW * lda : zl, sh[0][1] + (wave + NW * q) * SLD);
+      PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, sh[0][0] + (wave + NW * q) * SLD);
+      PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, sh[0][1] + (wave + NW * q) * SLD);
     }
     krem -= KC;
-    touched = MALL | (0xFu << 4);
+    touched = amt | (ant << 4);
     const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
     const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
     double bm0[MI], an0[NI], bm1[MI], an1[NI];
@@ -234,10 +249,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
           PASTIX_AMD_GLDS(zl, dA + NW * q * SLD);
           PASTIX_AMD_GLDS(zl, dB + NW * q * SLD);
 #elif defined(EXP_DMA_HALF)
-          PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
 #else
-          PASTIX_AMD_GLDS(kv ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
-          PASTIX_AMD_GLDS(kv ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+          PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
 #endif
         }
         krem -= KC;
@@ -254,11 +269,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
 #pragma unroll
       for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
+      if (FULLT || allb) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            if ((amt >> mi) & (ant >> ni) & 1u)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      }
       if (negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
@@ -268,11 +292,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
 #pragma unroll
       for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
+      if (FULLT || allb) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            if ((amt >> mi) & (ant >> ni) & 1u)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+      }
       if (negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
@@ -282,11 +315,20 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
 #pragma unroll
       for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
+      if (FULLT || allb) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            if ((amt >> mi) & (ant >> ni) & 1u)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+      }
       if (negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
@@ -305,15 +347,27 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       }
       __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
       // ks3 from registers
+      if (FULLT || allb) {
 #pragma unroll
-      for (int mi = 0; mi < MI; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-        for (int ni = 0; ni < NI; ni++)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            if ((amt >> mi) & (ant >> ni) & 1u)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+      }
       if (!has_next) break;
       buf ^= 1;
     }
     __syncthreads();         // the general loop below restarts on buffer 0
+    };
+    if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{});
+    else fast_loop(std::false_type{});
   }
   if ((int)tk.nfull < tk.pn) {
   int pi = tk.p0 + (int)tk.nfull;

@@ -412,7 +412,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<int32_t> task_slot;
   std::vector<uint8_t> task_urgent;
   const bool hist_on = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
-  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0, hist_merged = 0;
+  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0, hist_merged = 0, hist_valid = 0;
   int64_t hist_groups = 0, hist_nonfull = 0;
   int64_t hist_c[3][3] = {{0}};
   P.slot_flops.assign(NL, 0.0);
@@ -470,10 +470,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tk.p0 = (int32_t)q;
     tk.pn = (int32_t)(e - q);
     tk.flags = carena | (raw[q].shared ? 4u : 0u);
-    {   // full pieces (whole 128x128 tile, any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
+    {   // pieces that cover the whole valid tile (any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
         // through its specialized loop; tk.nfull = how many
-      auto isfull = [](const Piece& pc) {
-        return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && pc.k > 0;
+      static const bool edge_fast = getenv("PASTIX_AMD_EDGE_FAST") ? atoi(getenv("PASTIX_AMD_EDGE_FAST")) != 0 : true;
+      auto isfull = [&](const Piece& pc) {   // covers the whole valid tile (tm x tn; 128 x 128 except at the edges)
+        return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0 &&
+               (edge_fast || (pc.m == TM && pc.n == TN));
       };
       // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
       part_tmp.clear();
@@ -520,6 +522,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           hist_f[cm][cn] += f;
           hist_c[cm][cn] += 1;
           if (!even) hist_odd += f;
+          if (it->dr == 0 && it->dc == 0 && (it->m == TM || it->m == tk.tm) && (it->n == TN || it->n == tk.tn)) hist_valid += f;
           // 16x16 sub-tiles the piece touches x chunks of 16: what the MFMA pipe executes for it
           const int rs = (it->dr + it->m + 15) / 16 - it->dr / 16, cs = (it->dc + it->n + 15) / 16 - it->dc / 16;
           hist_exec += 2.0 * 256.0 * rs * cs * ((it->k + 15) / 16 * 16);
@@ -580,7 +583,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     if (hist_on) {
       fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
-      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n   non-full pieces %lld in %lld (tile, source cblk) groups; merged-piece bound %.3e\n", hist_odd, hist_exec, hist_wave, hist_cyc, (long long)hist_nonfull, (long long)hist_groups, hist_merged);
+      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n   non-full pieces %lld in %lld (tile, source cblk) groups; merged-piece bound %.3e\n   covering the whole VALID tile (m = tm, n = tn): %.3e\n", hist_odd, hist_exec, hist_wave, hist_cyc, (long long)hist_nonfull, (long long)hist_groups, hist_merged, hist_valid);
     }
     phase("task grouping");
     P.slot_urgent_end.assign(NL, 0);
