@@ -18,7 +18,6 @@ There is no collective on the data path.  The orchestration is engine-agnostic (
 CPU tests drive the same code with a numpy engine over gloo).
 """
 import ctypes
-import heapq
 
 import numpy as np
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Calibration: what the vendor DGEMM (rocBLAS/hipBLASLt through torch.mm, fp64) reaches on this box, for the
 square case and for the rank-128 update shape C(MxM) -= A(Mx128) B(128xM) that k_update's pieces have."""
-import time
+
 import torch
 
 dev = torch.device("cuda", 0)
