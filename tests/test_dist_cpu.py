@@ -71,13 +71,14 @@ def _worker(rank, world, port, name, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["rlap3d_10_llt", "rlap3d_14_llt_bs24"])
-def test_two_rank_fanin_over_gloo(name, golden):
+@pytest.mark.parametrize("name,world", [("rlap3d_10_llt", 2), ("rlap3d_14_llt_bs24", 2), ("rlap3d_14_llt_bs24", 4)])
+def test_fanin_over_gloo(name, world, golden):
+    """world_size 2 and 4: per-rank plans, fan-in exchange in lockstep levels, pure senders running ahead."""
     g = golden(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
