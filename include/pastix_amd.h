@@ -193,6 +193,9 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
 int pastix_amd_factorize_level(pastix_amd_plan_t *plan, int level, int phase);
 int pastix_amd_factorize_end(pastix_amd_plan_t *plan, pastix_amd_stats_t *stats);
 
+/* one panel, device -> host (same layout as cblktab[cblk].coeftab / ucoeftab; U may be NULL): e.g. the Schur
+ * complement of a Schur-mode plan, which is what pastix_getSchur copies (pastix.c:6434-6470) */
+int pastix_amd_download_cblk(pastix_amd_plan_t *plan, pastix_amd_int_t cblk, void *L, void *U);
 /* triangular solves on the device-resident factors (the data flow of up_down_smp, updo.c:114), x (permuted
  * numbering, n x nrhs, ld n; `double`, or interleaved `double complex` for complex plans) in place.  Not available
  * on distributed or Schur-mode plans (PASTIX_AMD_ERR_UNSUPPORTED). */

@@ -20,7 +20,7 @@ enum {
   IPARM_MODIFY_PARAMETER = 0, IPARM_START_TASK = 1, IPARM_END_TASK = 2, IPARM_VERBOSE = 3, IPARM_DOF_NBR = 4,
   IPARM_ITERMAX = 5, IPARM_MATRIX_VERIFICATION = 6, IPARM_NBITER = 10, IPARM_AMALGAMATION_LEVEL = 13,
   IPARM_ORDERING = 14, IPARM_STATIC_PIVOTING = 20, IPARM_NNZEROS = 22, IPARM_BASEVAL = 24,
-  IPARM_MIN_BLOCKSIZE = 25, IPARM_MAX_BLOCKSIZE = 26, IPARM_FACTORIZATION = 30, IPARM_THREAD_NBR = 34,
+  IPARM_MIN_BLOCKSIZE = 25, IPARM_MAX_BLOCKSIZE = 26, IPARM_SCHUR = 27, IPARM_FACTORIZATION = 30, IPARM_THREAD_NBR = 34,
   IPARM_LEVEL_OF_FILL = 36, IPARM_RHS_MAKING = 38, IPARM_REFINEMENT = 39, IPARM_SYM = 40, IPARM_GMRES_IM = 44,
   IPARM_INERTIA = 54,
   IPARM_ESP_NBTASKS = 55, IPARM_FLOAT = 61, IPARM_ERROR_NUMBER = 63, IPARM_CUDA_NBR = 64
@@ -46,6 +46,13 @@ void pastix_amd_pastix(pastix_amd_data_t **pastix_data, int pastix_comm, pastix_
                        pastix_amd_int_t *colptr, pastix_amd_int_t *row, double *avals, pastix_amd_int_t *perm,
                        pastix_amd_int_t *invp, double *b, pastix_amd_int_t rhs, pastix_amd_int_t *iparm,
                        double *dparm);
+/* Schur mode (iparm[IPARM_SCHUR] = API_YES): pastix_setSchurUnknownList (pastix.c:6200-6215; list in the CSC's base,
+ * call it before the ordering task) isolates the unknowns at the end of the ordering as ONE cblk that is updated
+ * but not factorized; pastix_getSchur (pastix.c:6434-6470) copies that cblk's panel: nschur x nschur, column-major,
+ * in the order of the final permutation (lower triangle for LLt / LDLt, the whole square for LU).  The SOLVE and
+ * REFINE tasks are not available in Schur mode. */
+int pastix_amd_set_schur_unknown_list(pastix_amd_data_t **pastix_data, pastix_amd_int_t n, const pastix_amd_int_t *list);
+int pastix_amd_get_schur(pastix_amd_data_t *pastix_data, double *schur);
 /* extension: tell the ordering step that the matrix is an nx*ny*nz 7-point grid (geometric ND);
  * without it and without API_ORDER_PERSONAL the natural order is used (no Scotch/METIS here). */
 int pastix_amd_set_grid(pastix_amd_data_t **pastix_data, pastix_amd_int_t nx, pastix_amd_int_t ny,

@@ -18,7 +18,9 @@ typedef struct pastix_amd_symbolic_options_s {
   int max_blocksize;      /* IPARM_MAX_BLOCKSIZE role (pastix.c:372-373); default 128, capped at 256 */
   int amalgamation_pct;   /* IPARM_AMALGAMATION_LEVEL role: allowed extra fill in percent; default 5 */
   int max_merge_width;    /* do not create amalgamated nodes wider than this (0 = no limit) */
-  int reserved[13];
+  int schur_n;            /* IPARM_SCHUR: the last schur_n unknowns of the ordering (which must be mutually coupled in
+                             the pattern: a clique) stay ONE cblk, not split and not merged with anything else */
+  int reserved[12];
 } pastix_amd_symbolic_options_t;
 
 typedef struct pastix_amd_symbol_s pastix_amd_symbol_t;

@@ -70,12 +70,12 @@ EXPORTS = [
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
     "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena",
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
-    "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add",
+    "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add", "pastix_amd_download_cblk",
 ]
 # include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
 EXPORTS_HOST = [
     "pastix_amd_order_grid", "pastix_amd_symbolic", "pastix_amd_symbol_layout", "pastix_amd_symbol_perm",
-    "pastix_amd_symbol_info", "pastix_amd_symbol_destroy", "pastix_amd_pastix", "pastix_amd_set_grid",
+    "pastix_amd_symbol_info", "pastix_amd_symbol_destroy", "pastix_amd_pastix", "pastix_amd_set_grid", "pastix_amd_set_schur_unknown_list", "pastix_amd_get_schur",
     "pastix_amd_data_plan",
 ]
 

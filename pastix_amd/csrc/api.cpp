@@ -447,6 +447,23 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
   return PASTIX_AMD_OK;
 }
 
+int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, void* U) {
+  if (!p || !L || k < 0 || k >= p->host.cblknbr || p->host.role[k] != 1) return PASTIX_AMD_ERR_BADPARAMETER;
+  HIPCHK(hipSetDevice(p->device));
+  const Plan& H = p->host;
+  const int64_t off = H.poff[k], cnt = H.poff[k + 1] - H.poff[k];
+  HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->cplx) {
+    int r = z_transfer(p, false, L, p->dL, p->dLi, off, cnt);
+    if (r) return r;
+    if (U && p->dU && (r = z_transfer(p, false, U, p->dU, p->dUi, off, cnt))) return r;
+    return PASTIX_AMD_OK;
+  }
+  HIPCHK(hipMemcpy(L, p->dL + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  if (U && p->dU) HIPCHK(hipMemcpy(U, p->dU + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return PASTIX_AMD_OK;
+}
+
 // CoefMatrix_Init + Csc2solv_cblk (coefinit.c:283-296, csc_intern_solve.c:65-132): zero the panels,
 // then place every entry of the permuted (and, for symmetric input, mirrored) matrix whose row is
 // >= fcolnum of its column's cblk into its blok.  Destinations are computed on the host (binary

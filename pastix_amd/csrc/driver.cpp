@@ -30,6 +30,8 @@ struct pastix_amd_data_s {
   int64_t grid[3] = {0, 0, 0};
   double norm1 = 0;
   std::vector<double> rhs;           // right-hand side saved by the SOLVE step (sopar->b role)
+  std::vector<int64_t> schur_list;   // 0-based unknowns isolated at the end (pastix_setSchurUnknownList)
+  bool schur_on = false;             // the current analysis was made in Schur mode
   bool factorized = false;
 };
 
@@ -48,6 +50,7 @@ static void init_param(pastix_amd_int_t* iparm, double* dparm) {   // pastix_ini
   iparm[IPARM_BASEVAL] = 1;
   iparm[IPARM_MIN_BLOCKSIZE] = 60;
   iparm[IPARM_MAX_BLOCKSIZE] = 120;
+  iparm[IPARM_SCHUR] = API_NO;
   iparm[IPARM_FACTORIZATION] = PASTIX_AMD_FACT_LDLT;
   iparm[IPARM_THREAD_NBR] = 1;
   iparm[IPARM_CUDA_NBR] = 0;
@@ -75,6 +78,20 @@ int pastix_amd_set_grid(pastix_amd_data_t** pd, pastix_amd_int_t nx, pastix_amd_
 }
 
 pastix_amd_plan_t* pastix_amd_data_plan(pastix_amd_data_t* pd) { return pd ? pd->plan : nullptr; }
+
+int pastix_amd_set_schur_unknown_list(pastix_amd_data_t** pd, pastix_amd_int_t n, const pastix_amd_int_t* list) {
+  if (!pd || n <= 0 || !list) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (!*pd) { *pd = new (std::nothrow) pastix_amd_data_s(); if (!*pd) return PASTIX_AMD_ERR_ALLOC; }
+  (*pd)->schur_list.assign(list, list + n);          // converted to 0-based in the ordering task (CSC base)
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_get_schur(pastix_amd_data_t* pd, double* schur) {
+  if (!pd || !schur || !pd->plan || !pd->sym || !pd->schur_on || !pd->factorized) return PASTIX_AMD_ERR_BADPARAMETER;
+  pastix_amd_int_t info[8];
+  pastix_amd_symbol_info(pd->sym, info);
+  return pastix_amd_download_cblk(pd->plan, info[1] - 1, schur, nullptr);
+}
 
 void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_amd_int_t n,
                        pastix_amd_int_t* colptr, pastix_amd_int_t* row, double* avals, pastix_amd_int_t* perm,
@@ -117,6 +134,20 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         } else {
           for (int64_t i = 0; i < n; i++) D->perm[i] = i;   // no Scotch/METIS here: natural order
         }
+        D->schur_on = iparm[IPARM_SCHUR] == API_YES && !D->schur_list.empty();
+        if (D->schur_on) {
+          // isolate the listed unknowns at the end, keeping the relative order of everything (pastix.c:1404-1540)
+          const int64_t base = colptr[0], ns = (int64_t)D->schur_list.size();
+          std::vector<char> is_s((size_t)n, 0);
+          for (int64_t u : D->schur_list) {
+            if (u - base < 0 || u - base >= n || is_s[u - base]) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+            is_s[u - base] = 1;
+          }
+          std::vector<int64_t> inv((size_t)n);
+          for (int64_t i = 0; i < n; i++) inv[D->perm[i]] = i;
+          int64_t a = 0, bpos = n - ns;
+          for (int64_t p2 = 0; p2 < n; p2++) { const int64_t i = inv[p2]; D->perm[i] = is_s[i] ? bpos++ : a++; }
+        }
         break;
       }
       case API_TASK_SYMBFACT: {
@@ -125,7 +156,28 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         so.max_blocksize = (int)iparm[IPARM_MAX_BLOCKSIZE];
         so.amalgamation_pct = (int)iparm[IPARM_AMALGAMATION_LEVEL];
         if (D->sym) { pastix_amd_symbol_destroy(D->sym); D->sym = nullptr; }
-        rc = pastix_amd_symbolic(n, colptr, row, D->perm.data(), &so, &D->sym);
+        if (D->schur_on) {
+          // the Schur complement is dense: couple the isolated unknowns pairwise in the pattern handed to the
+          // symbolic step, which then keeps them as one unsplit cblk (schur_n)
+          const int64_t base = colptr[0], ns = (int64_t)D->schur_list.size();
+          std::vector<int64_t> sl(D->schur_list);
+          for (auto& u : sl) u -= base;
+          std::sort(sl.begin(), sl.end());
+          std::vector<char> is_s((size_t)n, 0);
+          for (int64_t u : sl) is_s[u] = 1;
+          std::vector<int64_t> cp2((size_t)n + 1), rw2;
+          rw2.reserve((size_t)(colptr[n] - base) + (size_t)ns * (size_t)(ns + 1) / 2);
+          for (int64_t j = 0; j < n; j++) {
+            cp2[j] = (int64_t)rw2.size() + 1;
+            for (int64_t q = colptr[j] - base; q < colptr[j + 1] - base; q++) rw2.push_back(row[q] - base + 1);
+            if (is_s[j]) for (int64_t u : sl) if (u > j) rw2.push_back(u + 1);
+          }
+          cp2[n] = (int64_t)rw2.size() + 1;
+          so.schur_n = (int)ns;
+          rc = pastix_amd_symbolic(n, cp2.data(), rw2.data(), D->perm.data(), &so, &D->sym);
+        } else {
+          rc = pastix_amd_symbolic(n, colptr, row, D->perm.data(), &so, &D->sym);
+        }
         if (rc) FAIL(rc);
         const pastix_amd_int_t *p, *ip;
         pastix_amd_symbol_perm(D->sym, &p, &ip);
@@ -144,6 +196,7 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         pastix_amd_layout_t lay;
         pastix_amd_symbol_layout(D->sym, &lay);
         pastix_amd_options_t o{};
+        o.schur = D->schur_on ? 1 : 0;
         if (D->plan) { pastix_amd_plan_destroy(D->plan); D->plan = nullptr; }
         rc = pastix_amd_plan_create(&lay, facto, PASTIX_AMD_REALDOUBLE, &o, &D->plan);
         if (rc) FAIL(rc);
@@ -178,6 +231,7 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
       }
       case API_TASK_SOLVE: {
         if (!D->factorized || !b) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        if (D->schur_on) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
         std::vector<double> x((size_t)n);
         D->rhs.assign(b, b + n * rhs);
         for (int64_t r = 0; r < rhs; r++) {
@@ -195,6 +249,7 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         // refinement (raff_pivot.c).  All three are preconditioned by the device solve with the factors and stop at
         // ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT or after IPARM_ITERMAX iterations; BICGSTAB requests run
         // GMRES.  The vectors and the SpMV stay on the host (the matrix is the caller's CSC).
+        if (D->schur_on) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
         if (!D->factorized || !b || !avals || (int64_t)D->rhs.size() != n * rhs) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
         const double eps = dparm[DPARM_EPSILON_REFINEMENT];
         const int64_t itermax = iparm[IPARM_ITERMAX];

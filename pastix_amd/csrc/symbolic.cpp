@@ -256,6 +256,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       for (idx j = 0; j < n; j++) if (parent[j] != -1) nchild[parent[j]]++;
       for (idx j = 0; j < n; j++) {
         bool merge = j > 0 && parent[j - 1] == j && cc[j - 1] == cc[j] + 1 && nchild[j] == 1;
+        if (o.schur_n > 0 && j == (idx)(n - o.schur_n)) merge = false;   // the Schur block starts its own supernode
         if (!merge) sfirst.push_back(j);
       }
     }
@@ -304,6 +305,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
         if (p == -1) continue;
         p = find(p);
         if (e.vc != ver[c] || e.vp != ver[p]) continue;
+        if (o.schur_n > 0 && (sfirst[c] >= n - o.schur_n) != (sfirst[p] >= n - o.schur_n)) continue;   // never across the Schur boundary
         if (e.cost > 0 && spent + e.cost > budget) break;      // cheapest remaining does not fit
         if (e.cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
         // merge c into p
@@ -392,10 +394,15 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
     for (idx a = 0; a < na; a++) {
       a_cblk0[a] = (idx)cfirst.size();
       idx w = afirst[a + 1] - afirst[a];
+      if (o.schur_n > 0 && afirst[a] >= (idx)(n - o.schur_n)) { cfirst.push_back(afirst[a]); continue; }   // the Schur cblk is not split
       for (idx c = afirst[a]; c < afirst[a + 1]; c += maxbs) cfirst.push_back(c);
       (void)w;
     }
     a_cblk0[na] = (idx)cfirst.size();
+    if (o.schur_n > 0 && (o.schur_n > n || cfirst.back() != (idx)(n - o.schur_n))) {   // the last unknowns were not a clique
+      delete S;
+      return PASTIX_AMD_ERR_BADPARAMETER;
+    }
     const idx ncb = (idx)cfirst.size();
     cfirst.push_back((idx)n);
     std::vector<idx> col2c((size_t)n);

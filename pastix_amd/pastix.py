@@ -10,7 +10,7 @@ IPARM_SIZE, DPARM_SIZE = 128, 64
 # api.h:124-197 / 219-234 / 253-260
 IPARM = dict(MODIFY_PARAMETER=0, START_TASK=1, END_TASK=2, VERBOSE=3, DOF_NBR=4, ITERMAX=5,
              MATRIX_VERIFICATION=6, NBITER=10, AMALGAMATION_LEVEL=13, ORDERING=14, STATIC_PIVOTING=20,
-             NNZEROS=22, BASEVAL=24, MIN_BLOCKSIZE=25, MAX_BLOCKSIZE=26, FACTORIZATION=30, THREAD_NBR=34,
+             NNZEROS=22, BASEVAL=24, MIN_BLOCKSIZE=25, MAX_BLOCKSIZE=26, SCHUR=27, FACTORIZATION=30, THREAD_NBR=34,
              LEVEL_OF_FILL=36, RHS_MAKING=38, REFINEMENT=39, SYM=40, GMRES_IM=44, INERTIA=54, FLOAT=61, ERROR_NUMBER=63,
              CUDA_NBR=64)
 DPARM = dict(EPSILON_REFINEMENT=5, RELATIVE_ERROR=6, EPSILON_MAGN_CTRL=10, FACT_TIME=20, FACT_FLOPS=22)
@@ -27,6 +27,18 @@ class PastixData:
 
     def __init__(self):
         self.h = ctypes.c_void_p()
+
+    def set_schur_unknown_list(self, unknowns):
+        """pastix_setSchurUnknownList: unknowns (CSC base) to isolate at the end; call before the ordering task."""
+        u = _lib.as_i64(unknowns)
+        _lib.check(_lib.lib().pastix_amd_set_schur_unknown_list(ctypes.byref(self.h), ctypes.c_int64(len(u)), _lib.ptr(u)),
+                   "pastix_amd_set_schur_unknown_list")
+
+    def get_schur(self, nschur):
+        """pastix_getSchur: the nschur x nschur Schur complement (column-major, order of the final permutation)."""
+        out = np.zeros(nschur * nschur, dtype=np.float64)
+        _lib.check(_lib.lib().pastix_amd_get_schur(self.h, _lib.ptr(out)), "pastix_amd_get_schur")
+        return out.reshape(nschur, nschur, order="F")
 
     def set_grid(self, nx, ny, nz):
         _lib.check(_lib.lib().pastix_amd_set_grid(ctypes.byref(self.h), ctypes.c_int64(nx), ctypes.c_int64(ny),

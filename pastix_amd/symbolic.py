@@ -10,7 +10,7 @@ from ._lib import Layout, check
 
 class SymOptions(ctypes.Structure):
     _fields_ = [("max_blocksize", ctypes.c_int), ("amalgamation_pct", ctypes.c_int),
-                ("max_merge_width", ctypes.c_int), ("reserved", ctypes.c_int * 13)]
+                ("max_merge_width", ctypes.c_int), ("schur_n", ctypes.c_int), ("reserved", ctypes.c_int * 12)]
 
 
 def order_grid(nx, ny, nz, leaf=8):
@@ -22,12 +22,13 @@ def order_grid(nx, ny, nz, leaf=8):
     return perm, invp
 
 
-def symbolic(n, colptr, rows, perm=None, max_blocksize=128, amalgamation_pct=5, max_merge_width=0):
+def symbolic(n, colptr, rows, perm=None, max_blocksize=128, amalgamation_pct=5, max_merge_width=0, schur_n=0):
     """Returns dict(perm, invp, cblk4, blok4, nnzl, nsuper_fund, nsuper_amalg)."""
     colptr, rows = _lib.as_i64(colptr), _lib.as_i64(rows)
     perm = _lib.as_i64(perm) if perm is not None else None
     o = SymOptions()
     o.max_blocksize, o.amalgamation_pct, o.max_merge_width = int(max_blocksize), int(amalgamation_pct), int(max_merge_width)
+    o.schur_n = int(schur_n)
     h = ctypes.c_void_p()
     L = _lib.lib()
     check(L.pastix_amd_symbolic(ctypes.c_int64(n), _lib.ptr(colptr), _lib.ptr(rows), _lib.ptr(perm),

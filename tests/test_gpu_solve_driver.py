@@ -337,3 +337,48 @@ def test_z_solve_matches_reference(name, golden):
         X2 = p.solve(np.stack([bp, 2j * bp], axis=1))           # two right-hand sides at once
     assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
     assert np.abs(X2[:, 1][g["perm"]] - 2j * g["x"]).max() <= 1e-10 * 2 * np.abs(g["x"]).max()
+
+
+@pytest.mark.parametrize("facto,ns", [("LLT", 40), ("LDLT", 36), ("LU", 300)])
+def test_pastix_schur_mode(facto, ns):
+    """IPARM_SCHUR through the entry point (the reference's schur.c example): pastix_setSchurUnknownList isolates
+    unknowns at the end, the factorization leaves their dense Schur complement in the last cblk, pastix_getSchur
+    returns it; checked against S = A22 - A21 A11^-1 A12 computed densely."""
+    import scipy.sparse as sp
+    N = 9
+    full = facto == "LU"
+    n, cp, r, v = sy.laplacian_3d(N, full=full)
+    if full:
+        v = v * (1.0 + 0.1 * np.random.default_rng(4).random(len(v)))
+    rng = np.random.default_rng(21)
+    schur = np.sort(rng.choice(n, size=ns, replace=False)) + 1          # 1-based like the CSC
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if full else px.API_SYM_YES
+    iparm[px.IPARM["SCHUR"]] = px.API_YES
+    pd = px.PastixData()
+    pd.set_grid(N, N, N)
+    pd.set_schur_unknown_list(schur)
+    b = np.zeros(n)
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    pd = _run_tasks(pd, "ORDERING", "NUMFACT", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert sorted((invp[n - ns:]).tolist()) == schur.tolist()             # the listed unknowns come last
+    S = pd.get_schur(ns)
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n)).toarray()
+    if not full:
+        A = A + np.tril(A, -1).T
+    order = invp - 1                                                      # new -> old
+    Ap = A[np.ix_(order, order)]
+    n1 = n - ns
+    Sref = Ap[n1:, n1:] - Ap[n1:, :n1] @ np.linalg.solve(Ap[:n1, :n1], Ap[:n1, n1:])
+    if full:
+        assert np.abs(S - Sref).max() <= 1e-10 * np.abs(Sref).max()
+    else:
+        tri = np.tril_indices(ns)
+        assert np.abs(S - Sref)[tri].max() <= 1e-10 * np.abs(Sref).max()
+    # solves are not part of Schur mode here
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["SOLVE"]
+    px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == -5
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)

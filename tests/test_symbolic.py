@@ -63,3 +63,30 @@ def test_bad_input_rejected():
     bad = np.zeros(n, dtype=np.int64)
     with pytest.raises(_lib.PastixAmdError):
         sy.symbolic(n, cp, r, bad)
+
+
+def test_schur_unknowns_stay_one_last_cblk():
+    """symbolic(schur_n): the last schur_n unknowns (coupled pairwise in the pattern) end up as ONE cblk at the end,
+    whatever its width, and no other column joins it."""
+    N = 9
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm0, _ = sy.order_grid(N, N, N)
+    for ns in (1, 7, 300):
+        schur = np.sort(np.random.default_rng(3).choice(n, size=ns, replace=False))
+        is_s = np.zeros(n, bool)
+        is_s[schur] = True
+        order = np.argsort(perm0)                                  # new -> old
+        perm = np.empty(n, dtype=np.int64)
+        perm[order[~is_s[order]]] = np.arange(n - ns)
+        perm[order[is_s[order]]] = np.arange(n - ns, n)
+        cols, cp2 = [], [1]
+        for j in range(n):
+            cols += list(r[cp[j] - 1:cp[j + 1] - 1])
+            if is_s[j]:
+                cols += [u + 1 for u in schur if u > j]
+            cp2.append(len(cols) + 1)
+        s = sy.symbolic(n, np.array(cp2), np.array(cols), perm, max_blocksize=64, schur_n=ns)
+        c4 = s["cblk4"]
+        assert c4[-2][0] == n - ns and c4[-2][1] == n - 1          # last real cblk = the Schur block, unsplit
+        assert sorted(np.argsort(s["perm"])[n - ns:].tolist()) == schur.tolist()
+        assert ((c4[:-2, 1] - c4[:-2, 0] + 1) <= 64).all()
