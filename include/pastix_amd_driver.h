@@ -42,9 +42,11 @@ enum { API_ORDER_SCOTCH = 0, API_ORDER_METIS = 1, API_ORDER_PERSONAL = 2, API_OR
 
 typedef struct pastix_amd_data_s pastix_amd_data_t;
 
+/* avals / b: PASTIX_FLOAT arrays -- `double` (iparm[IPARM_FLOAT] = API_REALDOUBLE, the D_pastix build) or interleaved
+ * `double complex` (API_COMPLEXDOUBLE, Z_pastix); single precision is not built. */
 void pastix_amd_pastix(pastix_amd_data_t **pastix_data, int pastix_comm, pastix_amd_int_t n,
-                       pastix_amd_int_t *colptr, pastix_amd_int_t *row, double *avals, pastix_amd_int_t *perm,
-                       pastix_amd_int_t *invp, double *b, pastix_amd_int_t rhs, pastix_amd_int_t *iparm,
+                       pastix_amd_int_t *colptr, pastix_amd_int_t *row, void *avals, pastix_amd_int_t *perm,
+                       pastix_amd_int_t *invp, void *b, pastix_amd_int_t rhs, pastix_amd_int_t *iparm,
                        double *dparm);
 /* Schur mode (iparm[IPARM_SCHUR] = API_YES): pastix_setSchurUnknownList (pastix.c:6200-6215; list in the CSC's base,
  * call it before the ordering task) isolates the unknowns at the end of the ordering as ONE cblk that is updated
@@ -52,7 +54,7 @@ void pastix_amd_pastix(pastix_amd_data_t **pastix_data, int pastix_comm, pastix_
  * in the order of the final permutation (lower triangle for LLt / LDLt, the whole square for LU).  The SOLVE and
  * REFINE tasks are not available in Schur mode. */
 int pastix_amd_set_schur_unknown_list(pastix_amd_data_t **pastix_data, pastix_amd_int_t n, const pastix_amd_int_t *list);
-int pastix_amd_get_schur(pastix_amd_data_t *pastix_data, double *schur);
+int pastix_amd_get_schur(pastix_amd_data_t *pastix_data, void *schur);
 /* extension: tell the ordering step that the matrix is an nx*ny*nz 7-point grid (geometric ND);
  * without it and without API_ORDER_PERSONAL the natural order is used (no Scotch/METIS here). */
 int pastix_amd_set_grid(pastix_amd_data_t **pastix_data, pastix_amd_int_t nx, pastix_amd_int_t ny,

@@ -12,10 +12,12 @@
 // preconditioned by the device solve; vectors and SpMV on the host.
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pastix_amd.h"
@@ -86,23 +88,30 @@ int pastix_amd_set_schur_unknown_list(pastix_amd_data_t** pd, pastix_amd_int_t n
   return PASTIX_AMD_OK;
 }
 
-int pastix_amd_get_schur(pastix_amd_data_t* pd, double* schur) {
+int pastix_amd_get_schur(pastix_amd_data_t* pd, void* schur) {
   if (!pd || !schur || !pd->plan || !pd->sym || !pd->schur_on || !pd->factorized) return PASTIX_AMD_ERR_BADPARAMETER;
   pastix_amd_int_t info[8];
   pastix_amd_symbol_info(pd->sym, info);
   return pastix_amd_download_cblk(pd->plan, info[1] - 1, schur, nullptr);
 }
 
-void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_amd_int_t n,
-                       pastix_amd_int_t* colptr, pastix_amd_int_t* row, double* avals, pastix_amd_int_t* perm,
-                       pastix_amd_int_t* invp, double* b, pastix_amd_int_t rhs, pastix_amd_int_t* iparm,
-                       double* dparm) {
-  (void)pastix_comm;
-  if (!iparm || !dparm) return;
-  if (iparm[IPARM_MODIFY_PARAMETER] == API_NO) {      // pastix.c:4755-4761: fill defaults and return
-    init_param(iparm, dparm);
-    return;
-  }
+}  // extern "C"
+
+namespace {
+inline double conj_(double x) { return x; }
+inline std::complex<double> conj_(const std::complex<double>& x) { return std::conj(x); }
+inline double real_(double x) { return x; }
+inline double real_(const std::complex<double>& x) { return x.real(); }
+
+// T = double (D_pastix) or std::complex<double> (Z_pastix): the reference compiles pastix.c once per precision
+// (redefine_functions.h:73-98); here one template serves both.
+template <typename T>
+void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd_int_t* colptr, pastix_amd_int_t* row,
+                 T* avals, pastix_amd_int_t* perm, pastix_amd_int_t* invp, T* b, pastix_amd_int_t rhs,
+                 pastix_amd_int_t* iparm, double* dparm) {
+  constexpr bool CPLX = !std::is_same<T, double>::value;
+  constexpr int floattype = CPLX ? PASTIX_AMD_COMPLEXDOUBLE : PASTIX_AMD_REALDOUBLE;
+  constexpr size_t TW = sizeof(T) / sizeof(double);
   iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_OK;
 #define FAIL(code) do { iparm[IPARM_ERROR_NUMBER] = (code); return; } while (0)
   if (!pastix_data || n <= 0) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
@@ -110,8 +119,9 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
   pastix_amd_data_s* D = *pastix_data;
   const int first = (int)iparm[IPARM_START_TASK], last = (int)iparm[IPARM_END_TASK];
   const int facto = (int)iparm[IPARM_FACTORIZATION];
-  const int sym = iparm[IPARM_SYM] == API_SYM_YES;
-  if (iparm[IPARM_FLOAT] != PASTIX_AMD_REALDOUBLE || iparm[IPARM_DOF_NBR] != 1) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
+  const int sym = iparm[IPARM_SYM] == API_SYM_YES || iparm[IPARM_SYM] == API_SYM_HER;
+  const bool herm = CPLX && (iparm[IPARM_SYM] == API_SYM_HER || facto == PASTIX_AMD_FACT_LDLH);   // mirrored entries conjugated
+  if (iparm[IPARM_DOF_NBR] != 1) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
   int rc;
 
   for (int task = first; task <= last; task++) {
@@ -198,9 +208,9 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         pastix_amd_options_t o{};
         o.schur = D->schur_on ? 1 : 0;
         if (D->plan) { pastix_amd_plan_destroy(D->plan); D->plan = nullptr; }
-        rc = pastix_amd_plan_create(&lay, facto, PASTIX_AMD_REALDOUBLE, &o, &D->plan);
+        rc = pastix_amd_plan_create(&lay, facto, floattype, &o, &D->plan);
         if (rc) FAIL(rc);
-        dparm[DPARM_FACT_FLOPS] = pastix_amd_fact_flops(&lay, facto, PASTIX_AMD_REALDOUBLE);
+        dparm[DPARM_FACT_FLOPS] = pastix_amd_fact_flops(&lay, facto, floattype);
         break;
       }
       case API_TASK_NUMFACT: {
@@ -210,8 +220,8 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         for (int64_t j = 0; j < n; j++)
           for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
             const int64_t i = row[q] - 1;
-            colsum[j] += std::fabs(avals[q]);
-            if (sym && i != j) colsum[i] += std::fabs(avals[q]);
+            colsum[j] += std::abs(avals[q]);
+            if (sym && i != j) colsum[i] += std::abs(avals[q]);
           }
         double nrm = 0;
         for (double v : colsum) nrm = std::max(nrm, v);
@@ -232,10 +242,11 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
       case API_TASK_SOLVE: {
         if (!D->factorized || !b) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
         if (D->schur_on) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
-        std::vector<double> x((size_t)n);
-        D->rhs.assign(b, b + n * rhs);
+        std::vector<T> x((size_t)n);
+        D->rhs.resize((size_t)(n * rhs) * TW);
+        std::memcpy(D->rhs.data(), b, (size_t)(n * rhs) * sizeof(T));
         for (int64_t r = 0; r < rhs; r++) {
-          double* br = b + r * n;
+          T* br = b + r * n;
           for (int64_t i = 0; i < n; i++) x[D->perm[i]] = br[i];
           rc = pastix_amd_solve(D->plan, x.data(), 1);
           if (rc) FAIL(rc);
@@ -250,39 +261,40 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
         // ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT or after IPARM_ITERMAX iterations; BICGSTAB requests run
         // GMRES.  The vectors and the SpMV stay on the host (the matrix is the caller's CSC).
         if (D->schur_on) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
-        if (!D->factorized || !b || !avals || (int64_t)D->rhs.size() != n * rhs) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+        if (!D->factorized || !b || !avals || D->rhs.size() != (size_t)(n * rhs) * TW) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
         const double eps = dparm[DPARM_EPSILON_REFINEMENT];
         const int64_t itermax = iparm[IPARM_ITERMAX];
         int mode = (int)iparm[IPARM_REFINEMENT];
         if (mode == API_RAF_BICGSTAB) mode = API_RAF_GMRES;
-        if (mode == API_RAF_GRAD && facto == PASTIX_AMD_FACT_LU) mode = API_RAF_GMRES;
-        auto ax = [&](const double* x, double* y) {           // y = A x  (symmetric input: lower triangle stored)
+        if (mode == API_RAF_GRAD && (facto == PASTIX_AMD_FACT_LU || (CPLX && !herm))) mode = API_RAF_GMRES;   // CG needs A = A^H
+        auto ax = [&](const T* x, T* y) {           // y = A x  (symmetric input: lower triangle stored)
           for (int64_t i = 0; i < n; i++) y[i] = 0.0;
           for (int64_t j = 0; j < n; j++)
             for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
               const int64_t i = row[q] - 1;
               y[i] += avals[q] * x[j];
-              if (sym && i != j) y[j] += avals[q] * x[i];
+              if (sym && i != j) y[j] += (herm ? conj_(avals[q]) : avals[q]) * x[i];
             }
         };
-        std::vector<double> pbuf((size_t)n);
-        auto precond = [&](const double* r, double* z) -> int {   // z = (factors)^-1 r
+        std::vector<T> pbuf((size_t)n);
+        auto precond = [&](const T* r, T* z) -> int {   // z = (factors)^-1 r
           for (int64_t i = 0; i < n; i++) pbuf[D->perm[i]] = r[i];
           const int rc2 = pastix_amd_solve(D->plan, pbuf.data(), 1);
           if (rc2) return rc2;
           for (int64_t i = 0; i < n; i++) z[i] = pbuf[D->perm[i]];
           return 0;
         };
-        auto dot = [&](const double* u, const double* w) { double t = 0; for (int64_t i = 0; i < n; i++) t += u[i] * w[i]; return t; };
+        auto dot = [&](const T* u, const T* w) { T t = 0; for (int64_t i = 0; i < n; i++) t += conj_(u[i]) * w[i]; return t; };   // <u, w> = u^H w
+        auto nrm = [&](const T* u) { return std::sqrt(real_(dot(u, u))); };
         int64_t iters = 0;
         double relerr = 0;
-        std::vector<double> r((size_t)n), z((size_t)n), w((size_t)n);
+        std::vector<T> r((size_t)n), z((size_t)n), w((size_t)n);
         for (int64_t c = 0; c < rhs; c++) {
-          double* x = b + c * n;
-          const double* f = D->rhs.data() + c * n;
-          double nb = std::sqrt(dot(f, f));
+          T* x = b + c * n;
+          const T* f = reinterpret_cast<const T*>(D->rhs.data()) + c * n;
+          double nb = nrm(f);
           if (nb == 0) nb = 1;
-          auto residual = [&]() { ax(x, r.data()); for (int64_t i = 0; i < n; i++) r[i] = f[i] - r[i]; return std::sqrt(dot(r.data(), r.data())) / nb; };
+          auto residual = [&]() { ax(x, r.data()); for (int64_t i = 0; i < n; i++) r[i] = f[i] - r[i]; return nrm(r.data()) / nb; };
           int64_t it = 0;
           relerr = residual();
           if (mode == API_RAF_PIVOT) {
@@ -293,20 +305,20 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
               relerr = residual();
             }
           } else if (mode == API_RAF_GRAD) {
-            std::vector<double> pdir((size_t)n);
+            std::vector<T> pdir((size_t)n);
             if ((rc = precond(r.data(), z.data()))) FAIL(rc);
             pdir = z;
-            double rz = dot(r.data(), z.data());
+            T rz = dot(r.data(), z.data());
             while (relerr >= eps && it < itermax) {
               ax(pdir.data(), w.data());
-              const double alpha = rz / dot(pdir.data(), w.data());
+              const T alpha = rz / dot(pdir.data(), w.data());
               for (int64_t i = 0; i < n; i++) { x[i] += alpha * pdir[i]; r[i] -= alpha * w[i]; }
               it++;
-              relerr = std::sqrt(dot(r.data(), r.data())) / nb;
+              relerr = nrm(r.data()) / nb;
               if (relerr < eps) break;
               if ((rc = precond(r.data(), z.data()))) FAIL(rc);
-              const double rz2 = dot(r.data(), z.data());
-              const double beta = rz2 / rz;
+              const T rz2 = dot(r.data(), z.data());
+              const T beta = rz2 / rz;
               rz = rz2;
               for (int64_t i = 0; i < n; i++) pdir[i] = z[i] + beta * pdir[i];
             }
@@ -314,42 +326,46 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
           } else {
             // right-preconditioned GMRES(m): A M^-1 u = b, x = M^-1 u
             const int m = (int)std::max<int64_t>(1, std::min<int64_t>(iparm[IPARM_GMRES_IM] > 0 ? iparm[IPARM_GMRES_IM] : 25, 200));
-            std::vector<std::vector<double>> V((size_t)m + 1, std::vector<double>((size_t)n));
-            std::vector<double> H((size_t)(m + 1) * m), cs((size_t)m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
+            std::vector<std::vector<T>> V((size_t)m + 1, std::vector<T>((size_t)n));
+            std::vector<T> H((size_t)(m + 1) * m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
+            std::vector<double> cs((size_t)m);
             while (relerr >= eps && it < itermax) {
               const double beta = relerr * nb;
               for (int64_t i = 0; i < n; i++) V[0][i] = r[i] / beta;
-              std::fill(g.begin(), g.end(), 0.0);
+              std::fill(g.begin(), g.end(), T(0.0));
               g[0] = beta;
               int j = 0;
               for (; j < m && it < itermax; j++) {
                 if ((rc = precond(V[j].data(), z.data()))) FAIL(rc);
                 ax(z.data(), w.data());
                 for (int i = 0; i <= j; i++) {                       // modified Gram-Schmidt
-                  const double h = dot(w.data(), V[i].data());
+                  const T h = dot(V[i].data(), w.data());
                   H[(size_t)i * m + j] = h;
                   for (int64_t q = 0; q < n; q++) w[q] -= h * V[i][q];
                 }
-                const double hn = std::sqrt(dot(w.data(), w.data()));
+                const double hn = nrm(w.data());
                 H[(size_t)(j + 1) * m + j] = hn;
                 if (hn > 0) for (int64_t q = 0; q < n; q++) V[j + 1][q] = w[q] / hn;
                 for (int i = 0; i < j; i++) {                        // previous Givens rotations on the new column
-                  const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
-                  H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+                  const T t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+                  H[(size_t)(i + 1) * m + j] = -conj_(sn[i]) * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
                   H[(size_t)i * m + j] = t;
                 }
-                const double a0 = H[(size_t)j * m + j], a1 = H[(size_t)(j + 1) * m + j], rr = std::hypot(a0, a1);
-                cs[j] = rr > 0 ? a0 / rr : 1.0;
-                sn[j] = rr > 0 ? a1 / rr : 0.0;
-                H[(size_t)j * m + j] = rr;
+                // rotation [c s; -conj(s) c] with real c that zeroes H(j+1,j) (which is real, = hn)
+                const T a0 = H[(size_t)j * m + j];
+                const double a1 = hn, rr = std::sqrt(std::norm(std::complex<double>(a0)) + a1 * a1);
+                const double a0abs = std::abs(a0);
+                cs[j] = rr > 0 ? a0abs / rr : 1.0;
+                sn[j] = rr > 0 ? (a0abs > 0 ? (a0 / a0abs) * (a1 / rr) : T(a1 / rr)) : T(0.0);
+                H[(size_t)j * m + j] = cs[j] * a0 + sn[j] * a1;
                 H[(size_t)(j + 1) * m + j] = 0.0;
-                g[j + 1] = -sn[j] * g[j];
+                g[j + 1] = -conj_(sn[j]) * g[j];
                 g[j] = cs[j] * g[j];
                 it++;
-                if (std::fabs(g[j + 1]) / nb < eps || hn == 0) { j++; break; }
+                if (std::abs(g[j + 1]) / nb < eps || hn == 0) { j++; break; }
               }
               for (int i = j - 1; i >= 0; i--) {                     // back substitution H y = g
-                double t = g[i];
+                T t = g[i];
                 for (int q = i + 1; q < j; q++) t -= H[(size_t)i * m + q] * y[q];
                 y[i] = t / H[(size_t)i * m + i];
               }
@@ -377,6 +393,28 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
     }
   }
 #undef FAIL
+}
+}  // namespace
+
+extern "C" {
+
+void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_amd_int_t n,
+                       pastix_amd_int_t* colptr, pastix_amd_int_t* row, void* avals, pastix_amd_int_t* perm,
+                       pastix_amd_int_t* invp, void* b, pastix_amd_int_t rhs, pastix_amd_int_t* iparm,
+                       double* dparm) {
+  (void)pastix_comm;
+  if (!iparm || !dparm) return;
+  if (iparm[IPARM_MODIFY_PARAMETER] == API_NO) {      // pastix.c:4755-4761: fill defaults and return
+    init_param(iparm, dparm);
+    return;
+  }
+  if (iparm[IPARM_FLOAT] == PASTIX_AMD_REALDOUBLE)
+    pastix_impl<double>(pastix_data, n, colptr, row, (double*)avals, perm, invp, (double*)b, rhs, iparm, dparm);
+  else if (iparm[IPARM_FLOAT] == PASTIX_AMD_COMPLEXDOUBLE)
+    pastix_impl<std::complex<double>>(pastix_data, n, colptr, row, (std::complex<double>*)avals, perm, invp,
+                                      (std::complex<double>*)b, rhs, iparm, dparm);
+  else
+    iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_ERR_UNSUPPORTED;      // single precision is not built
 }
 
 }  // extern "C"

@@ -20,6 +20,9 @@ API_SYM_YES, API_SYM_NO = 0, 1
 API_ORDER_SCOTCH, API_ORDER_PERSONAL = 0, 2
 API_FACT_LLT, API_FACT_LDLT, API_FACT_LU = 0, 1, 2
 API_RAF_GMRES, API_RAF_GRAD, API_RAF_PIVOT, API_RAF_BICGSTAB = 0, 1, 2, 3
+API_REALDOUBLE, API_COMPLEXDOUBLE = 1, 3          # api.h:522-525
+API_SYM_HER = 2
+API_FACT_LDLH = 3
 
 
 class PastixData:
@@ -34,9 +37,9 @@ class PastixData:
         _lib.check(_lib.lib().pastix_amd_set_schur_unknown_list(ctypes.byref(self.h), ctypes.c_int64(len(u)), _lib.ptr(u)),
                    "pastix_amd_set_schur_unknown_list")
 
-    def get_schur(self, nschur):
+    def get_schur(self, nschur, dtype=np.float64):
         """pastix_getSchur: the nschur x nschur Schur complement (column-major, order of the final permutation)."""
-        out = np.zeros(nschur * nschur, dtype=np.float64)
+        out = np.zeros(nschur * nschur, dtype=dtype)
         _lib.check(_lib.lib().pastix_amd_get_schur(self.h, _lib.ptr(out)), "pastix_amd_get_schur")
         return out.reshape(nschur, nschur, order="F")
 
@@ -55,7 +58,8 @@ def init_param():
 
 def pastix(pastix_data, n, colptr, rows, avals, perm, invp, b, nrhs, iparm, dparm):
     """void pastix(pastix_data_t**, MPI_Comm, n, colptr, row, avals, perm, invp, b, rhs, iparm, dparm)
-    (pastix.h:219-222).  Arrays are int64 / float64 numpy arrays, modified in place."""
+    (pastix.h:219-222).  Arrays are int64 / float64 numpy arrays (complex128 values and right-hand sides with
+    iparm[IPARM_FLOAT] = API_COMPLEXDOUBLE), modified in place."""
     pd = pastix_data if pastix_data is not None else PastixData()
     L = _lib.lib()
     L.pastix_amd_pastix.restype = None

@@ -382,3 +382,37 @@ def test_pastix_schur_mode(facto, ns):
     px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
     assert iparm[px.IPARM["ERROR_NUMBER"]] == -5
     _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("facto,herm", [("LDLT", False), ("LDLH", True), ("LU", False)])
+def test_z_pastix_entry_point(facto, herm):
+    """Z_pastix: complex double through the entry point -- BASELINE config 5 (complex-symmetric LDLt on the 3-dof
+    elasticity pattern), Hermitian LDLh and complex LU; solve + GMRES/CG refinement in complex arithmetic."""
+    import scipy.sparse as sp
+    N = 6
+    n, cp, r, v, _ = sy.elasticity_3d(N)                     # complex symmetric, lower triangle, diagonally dominant
+    rng = np.random.default_rng(17)
+    if herm:                                                  # Hermitian: real diagonal (already), lower triangle as given
+        pass
+    full = facto == "LU"
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    low = sp.tril(A, -1)
+    Afull = (A + (low.conj().T if herm else low.T)).tocsc()
+    if full:
+        Afull = Afull + sp.triu(Afull, 1).multiply(0.05)      # unsymmetric values on the symmetric pattern
+        Afull = Afull.tocsc()
+        Afull.sort_indices()
+        cp, r, v = Afull.indptr.astype(np.int64) + 1, Afull.indices.astype(np.int64) + 1, Afull.data.astype(np.complex128)
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FLOAT"]] = px.API_COMPLEXDOUBLE
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if full else (px.API_SYM_HER if herm else px.API_SYM_YES)
+    iparm[px.IPARM["REFINEMENT"]] = px.API_RAF_GRAD if herm else px.API_RAF_GMRES
+    b = (rng.random(n) + 1j * rng.random(n)).astype(np.complex128)
+    rhs = b.copy()
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    pd = _run_tasks(None, "ORDERING", "REFINE", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert np.linalg.norm(Afull @ b - rhs) / np.linalg.norm(rhs) < 1e-11
+    assert dparm[px.DPARM["RELATIVE_ERROR"]] < 1e-11 and iparm[px.IPARM["STATIC_PIVOTING"]] == 0
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
