@@ -25,7 +25,8 @@ typedef int64_t pastix_amd_int_t;
 
 /* IPARM_FACTORIZATION values (src/common/src/api.h:381-384) */
 enum { PASTIX_AMD_FACT_LLT = 0, PASTIX_AMD_FACT_LDLT = 1, PASTIX_AMD_FACT_LU = 2, PASTIX_AMD_FACT_LDLH = 3 };
-/* IPARM_FLOAT values (api.h:522-525): built: REALDOUBLE (LLt, LDLt, LU) and COMPLEXDOUBLE (symmetric LDLt) */
+/* IPARM_FLOAT values (api.h:522-525): built: REALDOUBLE (LLt, LDLt, LU) and COMPLEXDOUBLE (symmetric LDLt,
+ * Hermitian LDLh, LU) */
 enum { PASTIX_AMD_REALSINGLE = 0, PASTIX_AMD_REALDOUBLE = 1, PASTIX_AMD_COMPLEXSINGLE = 2, PASTIX_AMD_COMPLEXDOUBLE = 3 };
 
 enum {
