@@ -61,6 +61,8 @@ struct pastix_amd_plan_s {
   int nupdB_run = 0;
   bool own_stream = true, own_arena = true, distributed = false, overlapped = false;
   int overlap_mode = 0;
+  bool staged_overlap = false;        // two streams behind the level-stepped API (distributed plans)
+  int staged_lastB = -1;
   int nupd_run = 0;
   double crit_run = 0;
   double* dL = nullptr;      // L  (real part)
@@ -576,6 +578,13 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   p->nupd_run = 0;
   p->nupdB_run = 0;
   p->crit_run = critere;
+  // Level-stepped use (distributed plans): the same urgent / bulk split over two streams as pastix_amd_factorize's
+  // mode 1, one level at a time; PASTIX_AMD_DIST_OVERLAP=0 keeps one stream.  (pastix_amd_factorize sets
+  // `overlapped` itself after this call.)
+  static const char* dov = getenv("PASTIX_AMD_DIST_OVERLAP");
+  p->staged_overlap = p->distributed && p->stream2 && !(dov && atoi(dov) == 0);
+  p->staged_lastB = -1;
+  if (p->staged_overlap) { p->overlapped = true; p->overlap_mode = 1; }
   return PASTIX_AMD_OK;
 }
 
@@ -587,6 +596,35 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   const Plan& H = p->host;
   hipStream_t s = p->stream;
   const int64_t t0 = H.slot_task_ptr[l], t1 = H.slot_task_ptr[l + 1];
+  if (p->staged_overlap) {
+    hipStream_t s2 = p->stream2;
+    const int64_t tu = H.slot_urgent_end[l];
+    if (phase != 2) {
+      // A(l): targets of level l (among them every fan-in buffer of level l), on the caller's stream, which also
+      // carries the exchange and the panel kernels; B(l): the rest, beside them on the second stream
+      if (p->staged_lastB >= 0) { HIPCHK(hipStreamWaitEvent(s, p->evB[p->staged_lastB], 0)); p->staged_lastB = -1; }
+      if (tu > t0) {
+        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
+        launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, true);
+        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
+        p->nupd_run++;
+      }
+      if (t1 > tu) {
+        if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
+        else HIPCHK(hipStreamWaitEvent(s2, p->ev0, 0));
+        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
+        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
+        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
+        HIPCHK(hipEventRecord(p->evB[l], s2));
+        p->staged_lastB = l;
+        p->nupdB_run++;
+      }
+    }
+    if (phase == 1) return PASTIX_AMD_OK;
+    const int rc = launch_panels(p, l);
+    HIPCHK(hipEventRecord(p->evP[l], s));
+    return rc;
+  }
   if (t1 > t0 && phase != 2) {
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
     launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, t1 - t0, false);
@@ -630,6 +668,10 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   hipStream_t s = p->stream;
+  if (p->staged_overlap && p->nupdB_run > 0) {          // join the second stream
+    HIPCHK(hipEventRecord(p->evB[0], p->stream2));
+    HIPCHK(hipStreamWaitEvent(s, p->evB[0], 0));
+  }
   HIPCHK(hipEventRecord(p->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());

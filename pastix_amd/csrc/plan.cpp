@@ -419,10 +419,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
-  // (single-GPU plans: the two-stream driver of pastix_amd_factorize; it costs one more pass over the tile)
+  // (it costs one more pass over the tile)
   std::vector<Piece> part_tmp;
   const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
-                                                               : (owner == nullptr);
+                                                               : true;
   for (size_t q = 0; q < raw.size();) {
     size_t e = q;
     double work = 0;
