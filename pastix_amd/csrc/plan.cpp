@@ -158,14 +158,16 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
   }
   // cblks that receive contributions from more than one rank ("shared"): their contributions are
-  // scheduled left-looking with a window (see below) so that every rank works on the same target at
-  // the same level and the fan-in exchange never waits for a rank's bulk trailing update
+  // scheduled left-looking with a window (see below): a source older than `window` levels before the target
+  // contributes in the bulk launch `window` levels ahead of the target (second stream, off the critical
+  // path), the last `window` sources contribute as usual, and only the level just before the target is
+  // urgent -- so the fan-in exchange of a level never waits for a long left-looking update
   std::vector<uint8_t> shared(nc, 0);
   if (owner)
     for (int64_t k = 0; k < nc; k++)
       for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
         if (owner[k] != owner[P.blok[b].cblknum]) shared[P.blok[b].cblknum] = 1;
-  const int window = getenv("PASTIX_AMD_WINDOW") ? atoi(getenv("PASTIX_AMD_WINDOW")) : 0;
+  const int window = getenv("PASTIX_AMD_WINDOW") ? atoi(getenv("PASTIX_AMD_WINDOW")) : 4;
   // target-side layout: owned panels as given; shadow panels COMPACT -- only the bloks this rank contributes
   // into (fanin_touched), packed in blok order with their own leading dimension
   P.tstride.resize(nc);
