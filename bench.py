@@ -92,7 +92,14 @@ def main():
         if dist_test:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # RCCL's copy kernels go on a high-priority stream: they must get a CU slot between the bulk update
+            # workgroups of the second stream, like the panel kernels do
+            try:
+                pgo = dist.ProcessGroupNCCL.Options()
+                pgo.is_high_priority_stream = True
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=pgo)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from pastix_amd import Plan, fact_flops
     from pastix_amd import symbolic as sy
@@ -137,7 +144,12 @@ def main():
         b = rng.random(n)
         bp = np.empty(n)
         bp[s["perm"]] = b
+        t1 = time.time()
         x = plan.solve(bp)[s["perm"]]
+        solve_s = time.time() - t1          # host vector in -> host vector out (first call also builds the solve tables)
+        t1 = time.time()
+        plan.solve(bp.copy())
+        solve_s = min(solve_s, time.time() - t1)
         import scipy.sparse as sp
         A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
         Ax = A @ x if facto == 2 else A @ x + sp.tril(A, -1).T @ x
@@ -146,7 +158,7 @@ def main():
         res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_time_sum=uts, urgent_time_sum=urt, urgent_flops=st["urgent_flops"],
                    nurgent=st["nurgent_launches"], update_flops=ps["update_flops"],
                    update_bytes=ps["update_bytes"],
-                   nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
+                   nlaunch=st["nupdate_launches"], solve_s=solve_s, resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
                    blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
                    ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu")
         plan.close()
@@ -180,7 +192,7 @@ def main():
                        "fact_flops": res["flops"], "parallelism": res["parallelism"],
                        "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * a.gpus) * 100, 2),
                        "fact_time_s_per_step": round(res["fact_time"] / K, 4),
-                       "residual": res["resid"], "logdet_rel_err": res.get("logdet_rel_err"),
+                       "residual": res["resid"], "solve_s": round(res["solve_s"], 4) if "solve_s" in res else None, "logdet_rel_err": res.get("logdet_rel_err"),
                        "static_pivots": res["nbpivot"],
                        "analysis_s": {"symbolic": round(res["t_sym"], 2), "plan": round(res["t_plan"], 2),
                                       "fill_prepare": round(res["t_fill"], 2)}},

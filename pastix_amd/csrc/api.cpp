@@ -43,7 +43,9 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, double* x);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int maxw);
+void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
+                         const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
 }  // namespace pastix_amd
 
@@ -84,8 +86,8 @@ struct pastix_amd_plan_s {
   double* dFillValLi = nullptr;   // imaginary parts (complex)
   double* dFillValUi = nullptr;
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
-  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk* dChunk = nullptr;
-  std::vector<int64_t> lvl_chunk_ptr;
+  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
+  std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};
@@ -315,7 +317,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
-  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk);
+  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk); (void)hipFree(p->dChunkB); (void)hipFree(p->dRidx);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evT) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
@@ -845,21 +847,33 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);
-    std::vector<SolveChunk> ch;
+    std::vector<SolveChunk> ch, chB;
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
+    p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
+    std::vector<int64_t> roff((size_t)H.cblknbr + 1, 0);          // in level order, like st
+    for (int64_t q = 0; q < H.cblknbr; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
+    // panel rows per chunk.  Real: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly
+    // and one set of atomics per 256 rows); complex kernels: one row per thread
+    const int32_t CH = p->cplx ? 256 : 64;
+    const int32_t CHB = getenv("PASTIX_AMD_SOLVE_BCH") ? atoi(getenv("PASTIX_AMD_SOLVE_BCH")) : 256;
     for (int l = 0; l < H.nlevels; l++) {
       p->lvl_chunk_ptr[l] = (int64_t)ch.size();
+      p->lvl_chunkB_ptr[l] = (int64_t)chB.size();
       for (int64_t q = H.lvl_cblk_ptr[l]; q < H.lvl_cblk_ptr[l + 1]; q++) {
         const int32_t k = H.lvl_cblk[q];
         const int32_t w = (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1), sd = (int32_t)H.cblk[k].stride;
         st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
                           (int32_t)H.cblk[k + 1].bloknum};
-        for (int32_t r = w; r < sd; r += 256)
+        for (int32_t r = w; r < sd; r += CH)
           ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                  (int32_t)H.cblk[k + 1].bloknum, r, std::min(256, sd - r)});
+                                  (int32_t)H.cblk[k + 1].bloknum, r, std::min(CH, sd - r), roff[q]});
+        for (int32_t r = w; r < sd; r += CHB)
+          chB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                   (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q]});
       }
     }
     p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
+    p->lvl_chunkB_ptr[H.nlevels] = (int64_t)chB.size();
     std::vector<DevBlok> bl((size_t)H.bloknbr);
     for (int64_t b = 0; b < H.bloknbr; b++)
       bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
@@ -867,6 +881,15 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     if ((r = to_device(&p->dSolve, st))) return r;
     if ((r = to_device(&p->dBlok, bl))) return r;
     if ((r = to_device(&p->dChunk, ch))) return r;
+    if ((r = to_device(&p->dChunkB, chB))) return r;
+    if (!p->cplx) {
+      int64_t* droff = nullptr;
+      if ((r = to_device(&droff, roff))) return r;
+      HIPCHK(hipMalloc((void**)&p->dRidx, (size_t)std::max<int64_t>(roff[H.cblknbr], 1) * sizeof(int32_t)));
+      launch_solve_rowidx(p->stream, p->dSolve, H.cblknbr, droff, p->dBlok, p->dRidx);
+      HIPCHK(hipStreamSynchronize(p->stream));
+      HIPCHK(hipFree(droff));
+    }
   }
   if (p->cplx) {
     // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device
@@ -886,8 +909,8 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
       if (scale) launch_zsolve_dscale(p->stream, p->arenas(), p->dSolve, H.lvl_cblk_ptr[H.nlevels], dxr, dxi);
       for (int l = H.nlevels - 1; l >= 0; l--)
         launch_zsolve_level(p->stream, false, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
-                            H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                            p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dxr, dxi);
+                            H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
+                            p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, dxr, dxi);
       launch_merge(p->stream, dz, dxr, dxi, H.ncol);
       HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
@@ -906,12 +929,12 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     for (int l = 0; l < H.nlevels; l++)
       launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
+                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, p->maxw);
     if (H.factotype == PASTIX_AMD_FACT_LDLT) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx);
     for (int l = H.nlevels - 1; l >= 0; l--)
       launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dx);
+                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
+                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, p->maxw);
     HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
   }

@@ -914,6 +914,214 @@ __global__ __launch_bounds__(256) void k_solve_diag_fwd(const double* __restrict
   for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
 }
 
+// Triangular solve with the diagonal blok, one WAVE per cblk: lane i keeps x rows i, i+64, ... in registers, the
+// pivot value travels by readlane, and the blok streams through registers 16 columns ahead of the dependent
+// chain (the loads do not depend on x).  ~25 cycles per column instead of two workgroup barriers.
+//   MODE 0: forward, lower triangle (column c updates the rows below)
+//   MODE 1: backward with L^T (row c of L updates the rows above)      MODE 2: backward with the upper triangle
+// `unit`: unit diagonal.  The diagonal enters as a reciprocal (1 ulp from the division of the scalar kernels).
+template <int NS, int MODE>
+__global__ __launch_bounds__(64) void k_solve_diag_w(const double* __restrict__ L,
+                                                     const SolveTask* __restrict__ tasks,
+                                                     double* __restrict__ x, int unit) {
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width, lane = threadIdx.x;
+  double xr[NS], rinv[NS];
+  int64_t rcl[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int r = lane + 64 * j, rc = min(r, w - 1);
+    rcl[j] = rc;
+    xr[j] = r < w ? x[tk.fcol + rc] : 0.0;
+    rinv[j] = unit ? 1.0 : 1.0 / A[rc + rc * ld];
+  }
+  const int nb = (w + 15) >> 4;
+  auto col_of = [&](int cb, int i) { return MODE == 0 ? cb * 16 + i : w - 1 - (cb * 16 + i); };
+  auto load = [&](double (&a)[16][NS], int cb) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int64_t c = min(max(col_of(cb, i), 0), w - 1);
+#pragma unroll
+      for (int j = 0; j < NS; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
+    }
+  };
+  auto compute = [&](double (&a)[16][NS], int cb) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int c = col_of(cb, i);
+      if (c < 0 || c >= w) break;
+      const int slot = c >> 6, src = c & 63;
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < NS; j++)
+        if (j == slot) v = xr[j] * rinv[j];
+      const double xc = readlane_f64(v, src);
+#pragma unroll
+      for (int j = 0; j < NS; j++) {
+        const int r = lane + 64 * j;
+        const bool upd = MODE == 0 ? (r > c && r < w) : (r < c);
+        const double nx = upd ? __builtin_fma(-a[i][j], xc, xr[j]) : xr[j];
+        xr[j] = (r == c) ? xc : nx;
+      }
+    }
+  };
+  double a0[16][NS], a1[16][NS];
+  load(a0, 0);
+  for (int cb = 0; cb < nb; cb += 2) {
+    if (cb + 1 < nb) load(a1, cb + 1);
+    compute(a0, cb);
+    if (cb + 2 < nb) load(a0, cb + 2);
+    if (cb + 1 < nb) compute(a1, cb + 1);
+  }
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const int r = lane + 64 * j;
+    if (r < w) x[tk.fcol + r] = xr[j];
+  }
+}
+
+// The same solve for cblks of at most 128 columns on four waves: wave q keeps the 32 columns it will process in
+// registers (one memory round trip for the whole blok, all loads in flight at once), the waves take turns on the
+// chain and hand x over through LDS.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_solve_diag_q(const double* __restrict__ L,
+                                                      const SolveTask* __restrict__ tasks,
+                                                      double* __restrict__ x, int unit) {
+  __shared__ double xs[128];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t rcl[2];
+  double rinv[2], a[32][2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) rcl[j] = min(lane + 64 * j, w - 1);
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int g = 32 * wave + i;
+    const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
+  if (tid < w) xs[tid] = x[tk.fcol + tid];
+  __syncthreads();
+  for (int q = 0; q < 4; q++) {
+    if (wave == q && 32 * q < w) {
+      double xr[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) xr[j] = xs[rcl[j]];
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        const int g = 32 * q + i;
+        if (g >= w) break;
+        const int c = MODE == 0 ? g : w - 1 - g;
+        const int slot = c >> 6, src = c & 63;
+        const double v = slot ? xr[1] * rinv[1] : xr[0] * rinv[0];
+        const double xc = readlane_f64(v, src);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int r = lane + 64 * j;
+          const bool upd = MODE == 0 ? (r > c && r < w) : (r < c);
+          const double nx = upd ? __builtin_fma(-a[i][j], xc, xr[j]) : xr[j];
+          xr[j] = (r == c) ? xc : nx;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        if (lane + 64 * j < w) xs[lane + 64 * j] = xr[j];
+    }
+    __syncthreads();
+  }
+  if (tid < w) x[tk.fcol + tid] = xs[tid];
+}
+
+// panel row -> global row of every cblk, tabulated once (the solves' gather / scatter index)
+__global__ __launch_bounds__(256) void k_solve_rowidx(const SolveTask* __restrict__ tasks,
+                                                      const int64_t* __restrict__ roff,
+                                                      const DevBlok* __restrict__ bl, int32_t* __restrict__ ridx) {
+  const SolveTask tk = tasks[blockIdx.x];
+  int32_t* out = ridx + roff[blockIdx.x];
+  for (int b = tk.fblok + (threadIdx.x >> 5); b < tk.lblok; b += 8) {
+    const DevBlok bk = bl[b];
+    for (int i = threadIdx.x & 31; i <= bk.lrow - bk.frow; i += 32) out[bk.coefind + i] = bk.frow + i;
+  }
+}
+void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
+                         const DevBlok* bl, int32_t* ridx) {
+  if (ntask > 0) hipLaunchKernelGGL(k_solve_rowidx, dim3((unsigned)ntask), dim3(256), 0, s, tasks, roff, bl, ridx);
+}
+
+// forward, step 2 / backward, step 1 on chunks of 64 panel rows: lane = row, the four waves split the columns in
+// groups of 32 (32 independent coalesced loads per lane in flight, > 2 workgroups per CU on the tall top panels).
+__global__ __launch_bounds__(256) void k_solve_off_fwd64(const double* __restrict__ L,
+                                                         const SolveChunk* __restrict__ chunks,
+                                                         const int32_t* __restrict__ ridx, double* __restrict__ x) {
+  __shared__ double xs[MAXW];
+  __shared__ double part[4][64];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* A = L + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < w; c += 256) xs[c] = x[ck.fcol + c];
+  __syncthreads();
+  const int p = ck.row0 + lane;
+  const double* Ap = A + min(p, ld - 1);
+  double s = 0.0;
+  for (int c0 = wave * 32; c0 < w; c0 += 128) {
+    double a[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+    for (int i = 0; i < 32; i++) s = __builtin_fma(a[i], (c0 + i < w) ? xs[c0 + i] : 0.0, s);
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && lane < ck.nrows)
+    unsafeAtomicAdd(&x[ridx[ck.roff + p]], -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
+}
+
+__global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restrict__ L,
+                                                         const SolveChunk* __restrict__ chunks,
+                                                         const int32_t* __restrict__ ridx, double* __restrict__ x) {
+  const SolveChunk ck = chunks[blockIdx.x];
+  const double* A = L + ck.off;
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave * 32 >= w) return;
+  const int p = ck.row0 + lane;
+  for (int c0 = wave * 32; c0 < w; c0 += 128) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc[i] = 0.0;
+    for (int rb = 0; rb < ck.nrows; rb += 64) {          // the chunk's rows, 64 at a time
+      const int pp = min(p + rb, ld - 1);
+      const double xr = lane + rb < ck.nrows ? x[ridx[ck.roff + pp]] : 0.0;
+      const double* Ap = A + pp;
+      double a[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+      for (int i = 0; i < 32; i++) acc[i] = __builtin_fma(a[i], xr, acc[i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {          // transposed butterfly (see k_solve_off_bwd)
+      const int d = 32 >> k, half = 16 >> k;
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; i++) {
+        const double send = up ? acc[i] : acc[i + half];
+        const double keep = up ? acc[i + half] : acc[i];
+        acc[i] = keep + __shfl_xor(send, d);
+      }
+    }
+    acc[0] += __shfl_xor(acc[0], 1);
+    const int c = c0 + ((lane >> 1) & 31);
+    if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
+  }
+}
+
 // forward, step 2: x[row] -= L[row, :] . x_k for 256 panel rows per workgroup (one row per thread)
 __global__ __launch_bounds__(256) void k_solve_off_fwd(const double* __restrict__ L,
                                                        const SolveChunk* __restrict__ chunks,
@@ -933,6 +1141,9 @@ __global__ __launch_bounds__(256) void k_solve_off_fwd(const double* __restrict_
 }
 
 // backward, step 1: x_k[c] -= sum over 256 panel rows of L[row, c] * x[row]
+// One row per thread (coalesced column reads); the sum over the 64 rows of a wave for 32 columns at a time is a
+// transposed butterfly: at every step a lane hands half of its partial sums to its partner and keeps the other
+// half, so 32 columns cost 32 shuffles instead of 192; lanes 2c, 2c+1 end with column c.
 __global__ __launch_bounds__(256) void k_solve_off_bwd(const double* __restrict__ L,
                                                        const SolveChunk* __restrict__ chunks,
                                                        const DevBlok* __restrict__ bl, double* __restrict__ x) {
@@ -944,10 +1155,24 @@ __global__ __launch_bounds__(256) void k_solve_off_bwd(const double* __restrict_
   const bool valid = tid < ck.nrows;
   const double xr = valid ? x[panel_row_to_global(bl, ck.fblok, ck.lblok, min(p, ld - 1))] : 0.0;
   const double* Ap = A + min(p, ld - 1);
-  for (int c = 0; c < w; c++) {
-    double s = valid ? Ap[(int64_t)c * ld] * xr : 0.0;
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if (lane == 0) part[wave][c] = s;
+  for (int c0 = 0; c0 < w; c0 += 32) {
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld] * xr;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int d = 32 >> k, half = 16 >> k;
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; i++) {
+        const double send = up ? acc[i] : acc[i + half];
+        const double keep = up ? acc[i + half] : acc[i];
+        acc[i] = keep + __shfl_xor(send, d);
+      }
+    }
+    acc[0] += __shfl_xor(acc[0], 1);
+    const int c = c0 + ((lane >> 1) & 31);
+    if (!(lane & 1) && c < w) part[wave][c] = acc[0];
   }
   __syncthreads();
   for (int c = tid; c < w; c += 256)
@@ -1038,18 +1263,44 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
 }
 
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
+template <int MODE>
+static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
+                              int unit, int maxw) {
+  static const bool onewave = getenv("PASTIX_AMD_SOLVE_ONEWAVE") != nullptr;
+  if (maxw <= 128 && !onewave)
+    hipLaunchKernelGGL((k_solve_diag_q<MODE>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
+  else if (maxw <= 128)
+    hipLaunchKernelGGL((k_solve_diag_w<2, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x, unit);
+  else
+    hipLaunchKernelGGL((k_solve_diag_w<4, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x, unit);
+}
+// chunks: 64 panel rows each (SOLVE_CHUNK_ROWS)
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, double* x) {
+                        const DevBlok* bl, const int32_t* ridx, double* x, int maxw) {
+  static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;     // the first-generation kernels
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
   if (fwd) {
-    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
-    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
+    if (ntask > 0) {
+      if (scalar) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
+      else launch_solve_diag<0>(s, L, tasks, ntask, x, unit, maxw);
+    }
+    if (nchunk > 0) {
+      if (scalar) hipLaunchKernelGGL(k_solve_off_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
+      else hipLaunchKernelGGL(k_solve_off_fwd64, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, ridx, x);
+    }
   } else {
     const double* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
     const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
-    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, bl, x);
-    if (ntask > 0) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, mode);
+    if (nchunk > 0) {
+      if (scalar) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, bl, x);
+      else hipLaunchKernelGGL(k_solve_off_bwd64, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, ridx, x);
+    }
+    if (ntask > 0) {
+      if (scalar) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, mode);
+      else if (mode == 2) launch_solve_diag<2>(s, L, tasks, ntask, x, 0, maxw);
+      else launch_solve_diag<1>(s, L, tasks, ntask, x, mode == 1, maxw);
+    }
   }
 }
 

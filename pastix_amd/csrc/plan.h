@@ -69,6 +69,7 @@ struct SolveChunk {            // 256 off-diagonal panel rows of one cblk
   int64_t off;
   int32_t stride, width, fcol, fblok, lblok;
   int32_t row0, nrows;
+  int64_t roff;                // first entry of the cblk in the panel-row -> global-row table
 };
 
 
