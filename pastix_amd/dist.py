@@ -417,6 +417,21 @@ def bench_distributed(a, rank, world, local):
         tr.drain()                                  # pending fan-in sends, before the buffers are zeroed again
         return eng.end()
 
+    # open every point-to-point connection the factorization will use before anything is timed (RCCL sets a
+    # pair up on its first message), whatever --warmup is
+    peers = sorted({(int(q), int(owner[t])) for q, t in fanin_pairs(c4, b4, owner).tolist()})
+    dev = "cpu" if dist.get_backend() == "gloo" else eng.device
+    ops, keep = [], []
+    for src, dst in peers:
+        if src == rank:
+            keep.append(torch.zeros(1, dtype=torch.float64, device=dev))
+            ops.append(dist.P2POp(dist.isend, keep[-1], dst))
+        elif dst == rank:
+            keep.append(torch.zeros(1, dtype=torch.float64, device=dev))
+            ops.append(dist.P2POp(dist.irecv, keep[-1], src))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     for _ in range(a.warmup):
         step()
     dist.barrier()
