@@ -43,7 +43,7 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int maxw);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -921,22 +921,27 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     HIPCHK(hipGetLastError());
     return PASTIX_AMD_OK;
   }
+  // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes)
+  const int64_t NRB = std::min<int64_t>(nrhs, 4);
   double* dx = nullptr;
-  HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * NRB * sizeof(double)));
   double* x = (double*)x_;
-  for (int64_t j = 0; j < nrhs; j++) {
-    HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * sizeof(double), hipMemcpyHostToDevice, p->stream));
+  for (int64_t j = 0; j < nrhs;) {
+    const int nr = nrhs - j >= 4 ? 4 : nrhs - j >= 2 ? 2 : 1;
+    HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     for (int l = 0; l < H.nlevels; l++)
       launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, p->maxw);
-    if (H.factotype == PASTIX_AMD_FACT_LDLT) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx);
+                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw);
+    if (H.factotype == PASTIX_AMD_FACT_LDLT)
+      for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx + k * H.ncol);
     for (int l = H.nlevels - 1; l >= 0; l--)
       launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
-                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, p->maxw);
-    HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw);
+    HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    j += nr;
   }
   HIPCHK(hipFree(dx));
   HIPCHK(hipGetLastError());

@@ -985,8 +985,85 @@ __global__ __launch_bounds__(64) void k_solve_diag_w(const double* __restrict__ 
 // The same solve for cblks of at most 128 columns on four waves: wave q keeps the 32 columns it will process in
 // registers (one memory round trip for the whole blok, all loads in flight at once), the waves take turns on the
 // chain and hand x over through LDS.
-template <int MODE>
+template <int MODE, int NR>
 __global__ __launch_bounds__(256) void k_solve_diag_q(const double* __restrict__ L,
+                                                      const SolveTask* __restrict__ tasks,
+                                                      double* __restrict__ x, int64_t ldx, int unit) {
+  __shared__ double xs[NR][128];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* A = L + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t rcl[2];
+  double rinv[2], a[32][2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) rcl[j] = min(lane + 64 * j, w - 1);
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int g = 32 * wave + i;
+    const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
+  for (int i = tid; i < NR * 128; i += 256) {
+    const int q = i >> 7, r = i & 127;
+    if (r < w) xs[q][r] = x[q * ldx + tk.fcol + r];
+  }
+  __syncthreads();
+  // systolic: at step t wave q runs its 32 columns of the chain for right-hand side t - q.  One copy of the chain
+  // per wave (Q a compile-time constant: column numbers, slots and lane tests fold)
+  const bool rw[2] = {lane < w, lane + 64 < w};
+  auto chain = [&](auto Q, int k) {
+    constexpr int q = decltype(Q)::value;
+    // laundered lane id and width: without them the compiler hoists every step's lane masks and column numbers
+    // out of the t loop (they do not depend on t) and spills up to 1600 SGPRs
+    int lane = threadIdx.x, w = tk.width;
+    asm volatile("" : "+v"(lane), "+s"(w));
+    lane &= 63;
+    double xr[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) xr[j] = xs[k][rcl[j]];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int g = 32 * q + i;
+      if (g < w) {                                     // (no break: the 32 steps must stay unrolled)
+        const int c = MODE == 0 ? g : w - 1 - g;
+        const int slot = c >> 6, src = c & 63;
+        const double v = slot ? xr[1] * rinv[1] : xr[0] * rinv[0];
+        const double xc = readlane_f64(v, src);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int r = lane + 64 * j;
+          const bool upd = MODE == 0 ? (r > c && rw[j]) : (r < c);
+          const double nx = upd ? __builtin_fma(-a[i][j], xc, xr[j]) : xr[j];
+          xr[j] = (r == c) ? xc : nx;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+      if (rw[j]) xs[k][lane + 64 * j] = xr[j];
+  };
+  for (int t = 0; t < 3 + NR; t++) {
+    const int k = t - wave;
+    if (k >= 0 && k < NR && 32 * wave < w) {
+      if (wave == 0) chain(std::integral_constant<int, 0>{}, k);
+      else if (wave == 1) chain(std::integral_constant<int, 1>{}, k);
+      else if (wave == 2) chain(std::integral_constant<int, 2>{}, k);
+      else chain(std::integral_constant<int, 3>{}, k);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < NR * 128; i += 256) {
+    const int q = i >> 7, r = i & 127;
+    if (r < w) x[q * ldx + tk.fcol + r] = xs[q][r];
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_solve_diag_q1(const double* __restrict__ L,
                                                       const SolveTask* __restrict__ tasks,
                                                       double* __restrict__ x, int unit) {
   __shared__ double xs[128];
@@ -1055,70 +1132,109 @@ void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, c
   if (ntask > 0) hipLaunchKernelGGL(k_solve_rowidx, dim3((unsigned)ntask), dim3(256), 0, s, tasks, roff, bl, ridx);
 }
 
-// forward, step 2 / backward, step 1 on chunks of 64 panel rows: lane = row, the four waves split the columns in
-// groups of 32 (32 independent coalesced loads per lane in flight, > 2 workgroups per CU on the tall top panels).
+// forward, step 2 / backward, step 1 on chunks of panel rows, NR right-hand sides per pass over the panel (x is
+// n x NR, leading dimension ldx): lane = row, the four waves split the columns in groups (independent coalesced
+// loads in flight, > 2 workgroups per CU on the tall top panels).
+template <int NR>
 __global__ __launch_bounds__(256) void k_solve_off_fwd64(const double* __restrict__ L,
                                                          const SolveChunk* __restrict__ chunks,
-                                                         const int32_t* __restrict__ ridx, double* __restrict__ x) {
-  __shared__ double xs[MAXW];
-  __shared__ double part[4][64];
+                                                         const int32_t* __restrict__ ridx, double* __restrict__ x,
+                                                         int64_t ldx) {
+  __shared__ double xs[NR][MAXW];
+  __shared__ double part[4][NR][64];
   const SolveChunk ck = chunks[blockIdx.x];
   const double* A = L + ck.off;
   const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < w; c += 256) xs[c] = x[ck.fcol + c];
+  for (int i = tid; i < NR * MAXW; i += 256) {
+    const int q = i / MAXW, c = i - q * MAXW;
+    if (c < w) xs[q][c] = x[q * ldx + ck.fcol + c];
+  }
   __syncthreads();
   const int p = ck.row0 + lane;
   const double* Ap = A + min(p, ld - 1);
-  double s = 0.0;
+  double sacc[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) sacc[k] = 0.0;
   for (int c0 = wave * 32; c0 < w; c0 += 128) {
     double a[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
 #pragma unroll
-    for (int i = 0; i < 32; i++) s = __builtin_fma(a[i], (c0 + i < w) ? xs[c0 + i] : 0.0, s);
+    for (int i = 0; i < 32; i++) {
+      const double m = (c0 + i < w) ? a[i] : 0.0;
+#pragma unroll
+      for (int k = 0; k < NR; k++) sacc[k] = __builtin_fma(m, xs[k][min(c0 + i, MAXW - 1)], sacc[k]);
+    }
   }
-  part[wave][lane] = s;
+#pragma unroll
+  for (int k = 0; k < NR; k++) part[wave][k][lane] = sacc[k];
   __syncthreads();
-  if (wave == 0 && lane < ck.nrows)
-    unsafeAtomicAdd(&x[ridx[ck.roff + p]], -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]));
+  if (wave == 0 && lane < ck.nrows) {
+    const int64_t gr = ridx[ck.roff + p];
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+      unsafeAtomicAdd(&x[k * ldx + gr], -(part[0][k][lane] + part[1][k][lane] + part[2][k][lane] + part[3][k][lane]));
+  }
 }
 
+// backward: the sum over the 64 rows of a wave for G = 32/NR columns at a time is a *transposed butterfly*: at every
+// step a lane hands half of its partial sums to its partner and keeps the other half (G-1 shuffles for G columns
+// instead of 6G), then the 64/G lanes that hold the same column finish with plain steps.
+template <int NR>
 __global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restrict__ L,
                                                          const SolveChunk* __restrict__ chunks,
-                                                         const int32_t* __restrict__ ridx, double* __restrict__ x) {
+                                                         const int32_t* __restrict__ ridx, double* __restrict__ x,
+                                                         int64_t ldx) {
+  constexpr int G = 32 / NR;                 // columns per group
+  constexpr int LPC = 64 / G;                // lanes that end with the same column
   const SolveChunk ck = chunks[blockIdx.x];
   const double* A = L + ck.off;
   const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (wave * 32 >= w) return;
+  if (wave * G >= w) return;
   const int p = ck.row0 + lane;
-  for (int c0 = wave * 32; c0 < w; c0 += 128) {
-    double acc[32];
+  for (int c0 = wave * G; c0 < w; c0 += 4 * G) {
+    double acc[NR][G];
 #pragma unroll
-    for (int i = 0; i < 32; i++) acc[i] = 0.0;
+    for (int k = 0; k < NR; k++)
+#pragma unroll
+      for (int i = 0; i < G; i++) acc[k][i] = 0.0;
     for (int rb = 0; rb < ck.nrows; rb += 64) {          // the chunk's rows, 64 at a time
       const int pp = min(p + rb, ld - 1);
-      const double xr = lane + rb < ck.nrows ? x[ridx[ck.roff + pp]] : 0.0;
+      const bool rv = lane + rb < ck.nrows;
+      const int64_t gr = ridx[ck.roff + pp];
+      double xr[NR];
+#pragma unroll
+      for (int k = 0; k < NR; k++) xr[k] = rv ? x[k * ldx + gr] : 0.0;
       const double* Ap = A + pp;
-      double a[32];
+      double a[G];
 #pragma unroll
-      for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+      for (int i = 0; i < G; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
 #pragma unroll
-      for (int i = 0; i < 32; i++) acc[i] = __builtin_fma(a[i], xr, acc[i]);
+      for (int i = 0; i < G; i++)
+#pragma unroll
+        for (int k = 0; k < NR; k++) acc[k][i] = __builtin_fma(a[i], xr[k], acc[k][i]);
     }
 #pragma unroll
-    for (int k = 0; k < 5; k++) {          // transposed butterfly (see k_solve_off_bwd)
-      const int d = 32 >> k, half = 16 >> k;
-      const bool up = (lane & d) != 0;
+    for (int k = 0; k < NR; k++) {
 #pragma unroll
-      for (int i = 0; i < half; i++) {
-        const double send = up ? acc[i] : acc[i + half];
-        const double keep = up ? acc[i + half] : acc[i];
-        acc[i] = keep + __shfl_xor(send, d);
+      for (int n = G, d = 32; n > 1; n >>= 1, d >>= 1) {
+        const int half = n >> 1;
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+          const double send = up ? acc[k][i] : acc[k][i + half];
+          const double keep = up ? acc[k][i + half] : acc[k][i];
+          acc[k][i] = keep + __shfl_xor(send, d);
+        }
       }
+#pragma unroll
+      for (int d = LPC >> 1; d >= 1; d >>= 1) acc[k][0] += __shfl_xor(acc[k][0], d);
     }
-    acc[0] += __shfl_xor(acc[0], 1);
-    const int c = c0 + ((lane >> 1) & 31);
-    if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
+    const int c = c0 + ((lane / LPC) & (G - 1));
+    if ((lane & (LPC - 1)) == 0 && c < w) {
+#pragma unroll
+      for (int k = 0; k < NR; k++) unsafeAtomicAdd(&x[k * ldx + ck.fcol + c], -acc[k][0]);
+    }
   }
 }
 
@@ -1263,45 +1379,63 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
 }
 
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
-template <int MODE>
+template <int MODE, int NR>
 static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
-                              int unit, int maxw) {
+                              int64_t ldx, int unit, int maxw) {
   static const bool onewave = getenv("PASTIX_AMD_SOLVE_ONEWAVE") != nullptr;
-  if (maxw <= 128 && !onewave)
-    hipLaunchKernelGGL((k_solve_diag_q<MODE>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
-  else if (maxw <= 128)
-    hipLaunchKernelGGL((k_solve_diag_w<2, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x, unit);
-  else
-    hipLaunchKernelGGL((k_solve_diag_w<4, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x, unit);
+  if (maxw <= 128 && !onewave && NR == 1) {            // one right-hand side: the copy without the systolic loop
+    hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
+    return;
+  }
+  if (maxw <= 128 && !onewave) {
+    hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, ldx, unit);
+    return;
+  }
+  for (int k = 0; k < NR; k++) {            // cblks wider than 128: one right-hand side at a time
+    if (maxw <= 128)
+      hipLaunchKernelGGL((k_solve_diag_w<2, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x + k * ldx, unit);
+    else
+      hipLaunchKernelGGL((k_solve_diag_w<4, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x + k * ldx, unit);
+  }
 }
-// chunks: 64 panel rows each (SOLVE_CHUNK_ROWS)
-void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+// one level of the forward (fwd) or backward sweep for NR right-hand sides (x: n x NR, leading dimension ldx).
+// chunks: the 64-row list forward, the 256-row list backward.
+template <int NR>
+static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int maxw) {
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw) {
   static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;     // the first-generation kernels
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
+  const dim3 gt((unsigned)ntask), gc((unsigned)nchunk);
   if (fwd) {
     if (ntask > 0) {
-      if (scalar) hipLaunchKernelGGL(k_solve_diag_fwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
-      else launch_solve_diag<0>(s, L, tasks, ntask, x, unit, maxw);
+      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_fwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, unit);
+      else launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, maxw);
     }
     if (nchunk > 0) {
-      if (scalar) hipLaunchKernelGGL(k_solve_off_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, bl, x);
-      else hipLaunchKernelGGL(k_solve_off_fwd64, dim3((unsigned)nchunk), dim3(256), 0, s, L, chunks, ridx, x);
+      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_off_fwd, gc, dim3(256), 0, s, L, chunks, bl, x + k * ldx);
+      else hipLaunchKernelGGL(k_solve_off_fwd64<NR>, gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
     }
   } else {
     const double* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
     const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
     if (nchunk > 0) {
-      if (scalar) hipLaunchKernelGGL(k_solve_off_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, bl, x);
-      else hipLaunchKernelGGL(k_solve_off_bwd64, dim3((unsigned)nchunk), dim3(256), 0, s, B, chunks, ridx, x);
+      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_off_bwd, gc, dim3(256), 0, s, B, chunks, bl, x + k * ldx);
+      else hipLaunchKernelGGL(k_solve_off_bwd64<NR>, gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
     }
     if (ntask > 0) {
-      if (scalar) hipLaunchKernelGGL(k_solve_diag_bwd, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, mode);
-      else if (mode == 2) launch_solve_diag<2>(s, L, tasks, ntask, x, 0, maxw);
-      else launch_solve_diag<1>(s, L, tasks, ntask, x, mode == 1, maxw);
+      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_bwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, mode);
+      else if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, maxw);
+      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, maxw);
     }
   }
+}
+void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw) {
+  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
+  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
+  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {

@@ -40,6 +40,29 @@ def test_solve_ldlt_lu_matches_reference(name, golden):
     assert np.abs(x - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
 
 
+@pytest.mark.parametrize("name", ["rlap3d_12_llt", "rlap3d_12_ldlt", "rlap3d_12_lu"])
+@pytest.mark.parametrize("nrhs", [2, 4, 7])
+def test_multi_rhs_solve_equals_single_rhs_solves(name, nrhs, golden):
+    """Several right-hand sides share one pass over the panels (groups of 4, 2, 1): every column must equal the
+    single-vector solve, and column 0 the reference's solution."""
+    g = golden(name)
+    n = len(g["b"])
+    rng = np.random.default_rng(nrhs)
+    B = np.empty((n, nrhs))
+    B[:, 0] = g["b"]
+    B[:, 1:] = rng.standard_normal((n, nrhs - 1))
+    Bp = np.empty_like(B)
+    Bp[g["perm"]] = B
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.upload(g["L0"], g.get("U0"))
+        p.factorize(g["critere"])
+        X = p.solve(Bp.copy())
+        singles = np.stack([p.solve(Bp[:, j].copy()) for j in range(nrhs)], axis=1)
+    scale = np.abs(singles).max()
+    assert np.abs(X - singles).max() <= 1e-13 * scale
+    assert np.abs(X[g["perm"], 0] - g["x"]).max() <= 1e-10 * np.abs(g["x"]).max()
+
+
 def test_refill_is_idempotent_and_refactor_is_deterministic(golden):
     g = golden("rlap3d_10_llt")
     with Plan(g["cblk4"], g["blok4"], 0) as p:

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("-n", type=int, default=100)
 ap.add_argument("--facto", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--nrhs", type=int, default=1)
 a = ap.parse_args()
 N = a.n
 n, cp, r, v = sy.laplacian_3d(N)
@@ -28,17 +29,17 @@ st = p.factorize(1e-14)
 Al = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
 A = Al + sp.tril(Al, -1).T
 rng = np.random.default_rng(1)
-xs = rng.standard_normal(n)
+xs = rng.standard_normal((n, a.nrhs)) if a.nrhs > 1 else rng.standard_normal(n)
 b = A @ xs
 pm = np.asarray(s["perm"])
 nbytes = 8.0 * s["nnzl"] * (2 if a.facto != 2 else 2)        # both sweeps read the panels once
 for rep in range(a.reps):
-    bp = np.empty(n)
+    bp = np.empty(b.shape)
     bp[pm] = b
     t = time.time()
     xp = p.solve(bp)
     dt = time.time() - t
     x = xp[pm]
     res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
-    print("N=%d facto=%d solve %.1f ms  (%.0f GB/s over %.1f GB of panels)  residual %.2e" % (
-        N, a.facto, dt * 1e3, nbytes / dt * 1e-9, nbytes * 1e-9, res), flush=True)
+    print("N=%d facto=%d nrhs=%d solve %.1f ms = %.1f ms per rhs (%.0f GB/s over %.1f GB of panels)  residual %.2e" % (
+        N, a.facto, a.nrhs, dt * 1e3, dt * 1e3 / a.nrhs, nbytes / dt * 1e-9, nbytes * 1e-9, res), flush=True)
