@@ -158,7 +158,7 @@ def main():
         res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_time_sum=uts, urgent_time_sum=urt, urgent_flops=st["urgent_flops"],
                    nurgent=st["nurgent_launches"], update_flops=ps["update_flops"],
                    update_bytes=ps["update_bytes"],
-                   nlaunch=st["nupdate_launches"], solve_s=solve_s, resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
+                   nlaunch=st["nupdate_launches"], solve_s=solve_s, solve_dev_s=ps["solve_time"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
                    blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
                    ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu")
         plan.close()
@@ -209,6 +209,14 @@ def main():
                                              "share_of_update_flops": round(res.get("urgent_flops", 0.0) / max(res["update_flops"], 1.0), 4),
                                              "avg_launch_ms": round(res.get("urgent_time_sum", 0.0) / K / max(res.get("nurgent", 0), 1) * 1e3, 4)}},
         }
+        if res.get("solve_dev_s"):
+            # the next row of the path: forward + backward sweep, HBM-bound -- every panel entry is read
+            # once per sweep (LU: L forward, U backward)
+            sb = 2.0 * 8.0 * res["nnzl"]
+            out["solve"] = {"bound": "hbm", "achieved": round(sb / res["solve_dev_s"] * 1e-9, 1), "peak": 8000.0,
+                            "unit": "GB/s", "frac": round(sb / res["solve_dev_s"] / 8e12, 4),
+                            "device_s": round(res["solve_dev_s"], 4), "host_to_host_s": round(res["solve_s"], 4),
+                            "panel_bytes_per_solve": sb, "nrhs": 1}
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_grid, min(os.cpu_count() or 1, 64))
         print(json.dumps(out), flush=True)

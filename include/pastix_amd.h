@@ -99,7 +99,8 @@ typedef struct pastix_amd_stats_s {
                               k_update<.,1>; 0 with one stream) */
   double urgent_time_sum;  /* sum of their durations */
   pastix_amd_int_t nurgent_launches;
-  double reserved[2];
+  double solve_time;         /* s, device time of the last pastix_amd_solve call's sweeps (no host transfers) */
+  double reserved[1];
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;

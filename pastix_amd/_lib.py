@@ -42,7 +42,7 @@ class Stats(ctypes.Structure):
                 ("update_bytes", ctypes.c_double), ("full_flops", ctypes.c_double),
                 ("update_time_sum", ctypes.c_double), ("urgent_flops", ctypes.c_double),
                 ("urgent_time_sum", ctypes.c_double), ("nurgent_launches", ctypes.c_int64),
-                ("reserved", ctypes.c_double * 2)]
+                ("solve_time", ctypes.c_double), ("reserved", ctypes.c_double * 1)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -18,7 +18,8 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
-                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* xr, double* xi);
+                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, const int32_t* ridx, double* xr,
+                         double* xi, int maxw);
 void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi);
 void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
                       int64_t ncols);
@@ -852,9 +853,9 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
     std::vector<int64_t> roff((size_t)H.cblknbr + 1, 0);          // in level order, like st
     for (int64_t q = 0; q < H.cblknbr; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
-    // panel rows per chunk.  Real: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly
-    // and one set of atomics per 256 rows); complex kernels: one row per thread
-    const int32_t CH = p->cplx ? 256 : 64;
+    // panel rows per chunk: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly and
+    // one set of atomics per 256 rows)
+    const int32_t CH = 64;
     const int32_t CHB = getenv("PASTIX_AMD_SOLVE_BCH") ? atoi(getenv("PASTIX_AMD_SOLVE_BCH")) : 256;
     for (int l = 0; l < H.nlevels; l++) {
       p->lvl_chunk_ptr[l] = (int64_t)ch.size();
@@ -882,7 +883,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     if ((r = to_device(&p->dBlok, bl))) return r;
     if ((r = to_device(&p->dChunk, ch))) return r;
     if ((r = to_device(&p->dChunkB, chB))) return r;
-    if (!p->cplx) {
+    {
       int64_t* droff = nullptr;
       if ((r = to_device(&droff, roff))) return r;
       HIPCHK(hipMalloc((void**)&p->dRidx, (size_t)std::max<int64_t>(roff[H.cblknbr], 1) * sizeof(int32_t)));
@@ -905,12 +906,12 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
       for (int l = 0; l < H.nlevels; l++)
         launch_zsolve_level(p->stream, true, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
                             H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                            p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, dxr, dxi);
+                            p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dxr, dxi, p->maxw);
       if (scale) launch_zsolve_dscale(p->stream, p->arenas(), p->dSolve, H.lvl_cblk_ptr[H.nlevels], dxr, dxi);
       for (int l = H.nlevels - 1; l >= 0; l--)
         launch_zsolve_level(p->stream, false, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
                             H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
-                            p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, dxr, dxi);
+                            p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dxr, dxi, p->maxw);
       launch_merge(p->stream, dz, dxr, dxi, H.ncol);
       HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
@@ -926,9 +927,11 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   double* dx = nullptr;
   HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * NRB * sizeof(double)));
   double* x = (double*)x_;
+  p->stats.solve_time = 0.0;
   for (int64_t j = 0; j < nrhs;) {
     const int nr = nrhs - j >= 4 ? 4 : nrhs - j >= 2 ? 2 : 1;
     HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipEventRecord(p->ev0, p->stream));
     for (int l = 0; l < H.nlevels; l++)
       launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
@@ -939,8 +942,12 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
       launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
                          p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw);
+    HIPCHK(hipEventRecord(p->ev1, p->stream));
     HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    p->stats.solve_time += 1e-3 * ms;
     j += nr;
   }
   HIPCHK(hipFree(dx));

@@ -644,25 +644,223 @@ __global__ __launch_bounds__(256) void k_zsolve_diag_bwd(const double* __restric
   for (int c = tid; c < w; c += 256) { xr[tk.fcol + c] = xs[c].re; xi[tk.fcol + c] = xs[c].im; }
 }
 
+// ---- second generation (the complex counterparts of k_solve_diag_q1 / k_solve_off_fwd64 / k_solve_off_bwd64 of
+// kernels.hip; see there for the organisation) ----
+__device__ __forceinline__ double z_readlane(double v, int srclane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// MODE 0: forward, unit lower.  MODE 1: backward with unit L^T (CONJ: L^H).  MODE 2: backward with the upper
+// triangle (non-unit, LU).  cblks of at most 128 columns.
+template <int MODE, bool CONJ>
+__global__ __launch_bounds__(256) void k_zsolve_diag_q1(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                        const SolveTask* __restrict__ tasks,
+                                                        double* __restrict__ xre, double* __restrict__ xim) {
+  __shared__ double xs[2][128];
+  const SolveTask tk = tasks[blockIdx.x];
+  const double* Ar = Lr + tk.off;
+  const double* Ai = Li + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t rcl[2];
+  double ar[32][2], ai[32][2];
+  cz rinv[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) rcl[j] = min(lane + 64 * j, w - 1);
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const int g = 32 * wave + i;
+    const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int64_t o = MODE == 1 ? c + rcl[j] * ld : rcl[j] + c * ld;
+      ar[i][j] = Ar[o];
+      ai[i][j] = CONJ ? -Ai[o] : Ai[o];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int64_t dd = rcl[j] + rcl[j] * ld;
+    rinv[j] = MODE == 2 ? cinv(cz{Ar[dd], Ai[dd]}) : cz{1.0, 0.0};
+  }
+  if (tid < w) { xs[0][tid] = xre[tk.fcol + tid]; xs[1][tid] = xim[tk.fcol + tid]; }
+  __syncthreads();
+  for (int q = 0; q < 4; q++) {
+    if (wave == q && 32 * q < w) {
+      cz x[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) x[j] = cz{xs[0][rcl[j]], xs[1][rcl[j]]};
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        const int g = 32 * q + i;
+        if (g >= w) break;
+        const int c = MODE == 0 ? g : w - 1 - g;
+        const int slot = c >> 6, src = c & 63;
+        const cz v = slot ? cmul(x[1], rinv[1]) : cmul(x[0], rinv[0]);
+        const cz xc = cz{z_readlane(v.re, src), z_readlane(v.im, src)};
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int r = lane + 64 * j;
+          const bool upd = MODE == 0 ? (r > c && r < w) : (r < c);
+          const cz nx = upd ? csub(x[j], cmul(cz{ar[i][j], ai[i][j]}, xc)) : x[j];
+          x[j] = (r == c) ? xc : nx;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+        if (lane + 64 * j < w) { xs[0][lane + 64 * j] = x[j].re; xs[1][lane + 64 * j] = x[j].im; }
+    }
+    __syncthreads();
+  }
+  if (tid < w) { xre[tk.fcol + tid] = xs[0][tid]; xim[tk.fcol + tid] = xs[1][tid]; }
+}
+
+// 64 panel rows per workgroup, lane = row, the four waves split the columns in groups of 32
+__global__ __launch_bounds__(256) void k_zsolve_off_fwd64(const double* __restrict__ Lr, const double* __restrict__ Li,
+                                                          const SolveChunk* __restrict__ chunks,
+                                                          const int32_t* __restrict__ ridx, double* __restrict__ xre,
+                                                          double* __restrict__ xim) {
+  __shared__ double xs[2][MAXW];
+  __shared__ double part[2][4][64];
+  const SolveChunk ck = chunks[blockIdx.x];
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < w; c += 256) { xs[0][c] = xre[ck.fcol + c]; xs[1][c] = xim[ck.fcol + c]; }
+  __syncthreads();
+  const int p = ck.row0 + lane;
+  const double* Ar = Lr + ck.off + min(p, ld - 1);
+  const double* Ai = Li + ck.off + min(p, ld - 1);
+  double sr = 0.0, si = 0.0;
+  for (int c0 = wave * 32; c0 < w; c0 += 128) {
+    double a[32], b[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int64_t o = (int64_t)min(c0 + i, w - 1) * ld;
+      a[i] = Ar[o];
+      b[i] = Ai[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const bool v = c0 + i < w;
+      const double yr = v ? xs[0][min(c0 + i, MAXW - 1)] : 0.0, yi = v ? xs[1][min(c0 + i, MAXW - 1)] : 0.0;
+      sr = __builtin_fma(a[i], yr, __builtin_fma(-b[i], yi, sr));
+      si = __builtin_fma(a[i], yi, __builtin_fma(b[i], yr, si));
+    }
+  }
+  part[0][wave][lane] = sr;
+  part[1][wave][lane] = si;
+  __syncthreads();
+  if (wave == 0 && lane < ck.nrows) {
+    const int64_t gr = ridx[ck.roff + p];
+    unsafeAtomicAdd(&xre[gr], -(part[0][0][lane] + part[0][1][lane] + part[0][2][lane] + part[0][3][lane]));
+    unsafeAtomicAdd(&xim[gr], -(part[1][0][lane] + part[1][1][lane] + part[1][2][lane] + part[1][3][lane]));
+  }
+}
+
+// up to 256 rows per workgroup; per wave 16 columns at a time through the transposed butterfly (both planes)
+template <bool CONJ>
+__global__ __launch_bounds__(256) void k_zsolve_off_bwd64(const double* __restrict__ Br, const double* __restrict__ Bi,
+                                                          const SolveChunk* __restrict__ chunks,
+                                                          const int32_t* __restrict__ ridx, double* __restrict__ xre,
+                                                          double* __restrict__ xim) {
+  constexpr int G = 16, LPC = 64 / G;
+  const SolveChunk ck = chunks[blockIdx.x];
+  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave * G >= w) return;
+  const int p = ck.row0 + lane;
+  for (int c0 = wave * G; c0 < w; c0 += 4 * G) {
+    double accr[G], acci[G];
+#pragma unroll
+    for (int i = 0; i < G; i++) accr[i] = acci[i] = 0.0;
+    for (int rb = 0; rb < ck.nrows; rb += 64) {
+      const int pp = min(p + rb, ld - 1);
+      const bool rv = lane + rb < ck.nrows;
+      const int64_t gr = ridx[ck.roff + pp];
+      const double yr = rv ? xre[gr] : 0.0, yi = rv ? xim[gr] : 0.0;
+      const double* Ar = Br + ck.off + pp;
+      const double* Ai = Bi + ck.off + pp;
+      double a[G], b[G];
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        const int64_t o = (int64_t)min(c0 + i, w - 1) * ld;
+        a[i] = Ar[o];
+        b[i] = CONJ ? -Ai[o] : Ai[o];
+      }
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        accr[i] = __builtin_fma(a[i], yr, __builtin_fma(-b[i], yi, accr[i]));
+        acci[i] = __builtin_fma(a[i], yi, __builtin_fma(b[i], yr, acci[i]));
+      }
+    }
+#pragma unroll
+    for (int n = G, d = 32; n > 1; n >>= 1, d >>= 1) {
+      const int half = n >> 1;
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; i++) {
+        const double sr = up ? accr[i] : accr[i + half], kr = up ? accr[i + half] : accr[i];
+        const double si = up ? acci[i] : acci[i + half], ki = up ? acci[i + half] : acci[i];
+        accr[i] = kr + __shfl_xor(sr, d);
+        acci[i] = ki + __shfl_xor(si, d);
+      }
+    }
+#pragma unroll
+    for (int d = LPC >> 1; d >= 1; d >>= 1) {
+      accr[0] += __shfl_xor(accr[0], d);
+      acci[0] += __shfl_xor(acci[0], d);
+    }
+    const int c = c0 + ((lane / LPC) & (G - 1));
+    if ((lane & (LPC - 1)) == 0 && c < w) {
+      unsafeAtomicAdd(&xre[ck.fcol + c], -accr[0]);
+      unsafeAtomicAdd(&xim[ck.fcol + c], -acci[0]);
+    }
+  }
+}
+
 // fwd: unit L.  bwd: LDLt/LDLh gather through the L planes (transposed / conjugate-transposed), LU through the U planes.
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
-                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, double* xr, double* xi) {
-  const dim3 b(256);
+                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, const int32_t* ridx, double* xr,
+                         double* xi, int maxw) {
+  static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;      // the first-generation kernels
+  const dim3 b(256), gt((unsigned)ntask), gc((unsigned)nchunk);
+  const bool lu = factotype == PASTIX_AMD_FACT_LU, herm = factotype == PASTIX_AMD_FACT_LDLH;
+  const bool gen1 = scalar || maxw > 128;
   if (fwd) {
-    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_fwd, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, 1);
-    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_fwd, dim3((unsigned)nchunk), b, 0, s, ar.p[0], ar.p[2], chunks, bl, xr, xi);
+    if (ntask > 0) {
+      if (gen1) hipLaunchKernelGGL(k_zsolve_diag_fwd, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, 1);
+      else hipLaunchKernelGGL((k_zsolve_diag_q1<0, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    }
+    if (nchunk > 0) {
+      if (scalar) hipLaunchKernelGGL(k_zsolve_off_fwd, gc, b, 0, s, ar.p[0], ar.p[2], chunks, bl, xr, xi);
+      else hipLaunchKernelGGL(k_zsolve_off_fwd64, gc, b, 0, s, ar.p[0], ar.p[2], chunks, ridx, xr, xi);
+    }
     return;
   }
-  const bool lu = factotype == PASTIX_AMD_FACT_LU, herm = factotype == PASTIX_AMD_FACT_LDLH;
   const double* Br = lu ? ar.p[1] : ar.p[0];
   const double* Bi = lu ? ar.p[3] : ar.p[2];
   const int mode = lu ? 2 : 1;
-  if (herm) {
-    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_bwd<true>, dim3((unsigned)nchunk), b, 0, s, Br, Bi, chunks, bl, xr, xi);
-    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_bwd<true>, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
-  } else {
-    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_bwd<false>, dim3((unsigned)nchunk), b, 0, s, Br, Bi, chunks, bl, xr, xi);
-    if (ntask > 0) hipLaunchKernelGGL(k_zsolve_diag_bwd<false>, dim3((unsigned)ntask), b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
+  if (nchunk > 0) {
+    if (scalar) {
+      if (herm) hipLaunchKernelGGL(k_zsolve_off_bwd<true>, gc, b, 0, s, Br, Bi, chunks, bl, xr, xi);
+      else hipLaunchKernelGGL(k_zsolve_off_bwd<false>, gc, b, 0, s, Br, Bi, chunks, bl, xr, xi);
+    } else {
+      if (herm) hipLaunchKernelGGL(k_zsolve_off_bwd64<true>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
+      else hipLaunchKernelGGL(k_zsolve_off_bwd64<false>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
+    }
+  }
+  if (ntask > 0) {
+    if (gen1) {
+      if (herm) hipLaunchKernelGGL(k_zsolve_diag_bwd<true>, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
+      else hipLaunchKernelGGL(k_zsolve_diag_bwd<false>, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
+    } else if (lu) {
+      hipLaunchKernelGGL((k_zsolve_diag_q1<2, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    } else if (herm) {
+      hipLaunchKernelGGL((k_zsolve_diag_q1<1, true>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    } else {
+      hipLaunchKernelGGL((k_zsolve_diag_q1<1, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    }
   }
 }
 void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi) {
