@@ -598,7 +598,60 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       P.slot_next_end[sl] = q;
     }
     std::vector<Task> sorted(P.tasks.size());
-    if (order_mode == 0) {
+    if (order_mode == 2) {
+      // XCD-locality order of the bulk launch (everything after the urgent tasks of a slot).  Workgroup g of a launch
+      // runs on XCD g % 8, and an XCD keeps 64 of these workgroups resident: give every XCD 8x8 blocks of tasks that
+      // share their A operands along one axis and their B operands along the other (first piece's source rows),
+      // heavy tasks (by eighths of the heaviest) still first.
+      std::vector<int64_t> ra, rb, tmp;
+      for (int sl = 0; sl < NL; sl++) {
+        const int64_t b0 = P.slot_urgent_end[sl], n = P.slot_task_ptr[sl + 1] - b0;
+        if (n <= 0) continue;
+        ra.assign((size_t)n, 0);
+        rb.assign((size_t)n, 0);
+        tmp.resize((size_t)n);
+        double wmax = 0;
+        for (int64_t q = 0; q < n; q++) wmax = std::max(wmax, task_work[idx[b0 + q]]);
+        auto rank_by = [&](bool useA, std::vector<int64_t>& out) {
+          std::iota(tmp.begin(), tmp.end(), 0);
+          auto key = [&](int64_t q) {
+            const Piece& pc = P.pieces[P.tasks[idx[b0 + q]].p0];
+            return useA ? pc.a_off : pc.b_off;
+          };
+          std::sort(tmp.begin(), tmp.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+          int64_t r = -1, last = -1;
+          for (int64_t i = 0; i < n; i++) {
+            const int64_t k = key(tmp[i]);
+            if (i == 0 || k != last) { r++; last = k; }
+            out[tmp[i]] = r;
+          }
+        };
+        rank_by(true, ra);
+        rank_by(false, rb);
+        std::vector<int64_t> ord((size_t)n);
+        std::iota(ord.begin(), ord.end(), 0);
+        auto bucket = [&](int64_t q) { return std::min<int>(7, (int)(8.0 * task_work[idx[b0 + q]] / std::max(wmax, 1.0))); };
+        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
+          const int bx = bucket(x), by = bucket(y);
+          if (bx != by) return bx > by;
+          if ((ra[x] >> 3) != (ra[y] >> 3)) return (ra[x] >> 3) < (ra[y] >> 3);
+          if ((rb[x] >> 3) != (rb[y] >> 3)) return (rb[x] >> 3) < (rb[y] >> 3);
+          if (ra[x] != ra[y]) return ra[x] < ra[y];
+          if (rb[x] != rb[y]) return rb[x] < rb[y];
+          return x < y;
+        });
+        std::vector<int64_t> seq((size_t)n);
+        for (int64_t q = 0; q < n; q++) seq[q] = idx[b0 + ord[q]];
+        // chunk m (64 consecutive tasks of seq) -> XCD m % 8, resident slots (m / 8) * 64 ...
+        const int64_t nfull = (n / 512) * 512;
+        for (int64_t q = 0; q < nfull; q++) {
+          const int64_t m = q / 64, u = q % 64;
+          idx[b0 + ((m / 8) * 64 + u) * 8 + (m % 8)] = seq[q];
+        }
+        for (int64_t q = nfull; q < n; q++) idx[b0 + q] = seq[q];
+      }
+    }
+    if (order_mode == 0 || order_mode == 2) {
       for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
     } else {
       for (int s = 0; s < NL; s++) {
