@@ -54,6 +54,16 @@ using namespace pastix_amd;
 
 static constexpr size_t ARENA_PAD = 256;
 
+// see build_split below
+struct SplitMap {
+  bool active = false;
+  int64_t ocblknbr = 0;
+  std::vector<int64_t> first;                    // [ocblknbr+1] index of the first sub-cblk of an original cblk
+  std::vector<int64_t> owidth, ostride, ooff;    // original width, stride, offset in the packed original arena
+  std::vector<pastix_amd_cblk_t> cblk;           // the split layout
+  std::vector<pastix_amd_blok_t> blok;
+};
+
 struct pastix_amd_plan_s {
   Plan host;
   int device = 0;
@@ -82,6 +92,8 @@ struct pastix_amd_plan_s {
   long long* dNbpivot = nullptr;
   int* dErr = nullptr;
   int maxw = 0;
+  SplitMap split;                      // cblks wider than MAXW are factorized in column groups (build_split)
+  bool factored = false;               // panels hold factors (set by factorize, cleared by upload / fill)
   // cached coefficient fill (destinations + values) so that a re-fill is device-only
   int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
   double* dFillValLi = nullptr;   // imaginary parts (complex)
@@ -124,6 +136,83 @@ double pastix_amd_fact_flops(const pastix_amd_layout_t* layout, int factotype, i
   return fact_flops(layout, factotype, floattype);
 }
 
+// ------------------------------------------------------------------------------------------------
+// cblks wider than MAXW (the reference's blend leaves such supernodes unsplit in places, e.g. 334 columns on its own
+// orsirr.rua fixture): the engine factorizes an equivalent layout in which every such cblk is cut into column
+// groups of about SPLITW columns.  Sub-cblk j keeps the columns [c_j, c_j+1) and the panel rows from its own
+// diagonal blok down: the rest of the original diagonal blok becomes off-diagonal bloks facing the later
+// sub-cblks, and bloks facing a split cblk are cut at its column groups.  Mathematically the blocked algorithm
+// on the wide blok; only the host <-> device panel copies see the difference (split_io below).
+// ------------------------------------------------------------------------------------------------
+
+static constexpr int SPLITW = 128;
+
+static int build_split(const pastix_amd_layout_t* L, bool schur, SplitMap& M) {
+  const int64_t nc = L->cblknbr;
+  M.ocblknbr = nc;
+  M.first.assign((size_t)nc + 1, 0);
+  M.owidth.resize((size_t)nc);
+  M.ostride.resize((size_t)nc);
+  M.ooff.assign((size_t)nc + 1, 0);
+  bool any = false;
+  for (int64_t k = 0; k < nc; k++) {
+    const int64_t w = L->cblktab[k].lcolnum - L->cblktab[k].fcolnum + 1;
+    if (w <= 0 || L->cblktab[k].stride < w) return PASTIX_AMD_ERR_LAYOUT;
+    M.owidth[k] = w;
+    M.ostride[k] = L->cblktab[k].stride;
+    M.ooff[k + 1] = M.ooff[k] + w * M.ostride[k];
+    int64_t ns = 1;
+    if (w > MAXW && !(schur && k == nc - 1)) { ns = (w + SPLITW - 1) / SPLITW; any = true; }
+    M.first[k + 1] = M.first[k] + ns;
+  }
+  M.active = any;
+  if (!any) return 0;
+  // first column of sub j of cblk k: widths as even as possible
+  auto subcol = [&](int64_t k, int64_t j) {
+    const int64_t ns = M.first[k + 1] - M.first[k], w = M.owidth[k], base = w / ns, rem = w % ns;
+    return L->cblktab[k].fcolnum + j * base + std::min(j, rem);
+  };
+  M.cblk.clear();
+  M.blok.clear();
+  for (int64_t k = 0; k < nc; k++) {
+    const int64_t ns = M.first[k + 1] - M.first[k];
+    const int64_t fb = L->cblktab[k].bloknum, lb = L->cblktab[k + 1].bloknum;
+    if (lb <= fb) return PASTIX_AMD_ERR_LAYOUT;
+    for (int64_t j = 0; j < ns; j++) {
+      pastix_amd_cblk_t c;
+      c.fcolnum = subcol(k, j);
+      c.lcolnum = subcol(k, j + 1) - 1;
+      c.bloknum = (pastix_amd_int_t)M.blok.size();
+      int64_t coef = 0;
+      for (int64_t j2 = j; j2 < ns; j2++) {                       // own diagonal blok, then the later column groups
+        pastix_amd_blok_t b{subcol(k, j2), subcol(k, j2 + 1) - 1, M.first[k] + j2, coef};
+        coef += b.lrownum - b.frownum + 1;
+        M.blok.push_back(b);
+      }
+      for (int64_t q = fb + 1; q < lb; q++) {                     // the original off-diagonal bloks
+        const pastix_amd_blok_t& ob = L->bloktab[q];
+        const int64_t t = ob.cblknum;
+        if (t <= k || t >= nc) return PASTIX_AMD_ERR_LAYOUT;
+        const int64_t nt = M.first[t + 1] - M.first[t];
+        for (int64_t s2 = 0; s2 < nt; s2++) {
+          const int64_t lo = std::max<int64_t>(ob.frownum, subcol(t, s2));
+          const int64_t hi = std::min<int64_t>(ob.lrownum, subcol(t, s2 + 1) - 1);
+          if (lo > hi) continue;
+          pastix_amd_blok_t b{lo, hi, M.first[t] + s2, coef};
+          coef += hi - lo + 1;
+          M.blok.push_back(b);
+        }
+      }
+      c.stride = coef;
+      M.cblk.push_back(c);
+    }
+  }
+  pastix_amd_cblk_t last = L->cblktab[nc];
+  last.bloknum = (pastix_amd_int_t)M.blok.size();
+  M.cblk.push_back(last);
+  return 0;
+}
+
 static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, int floattype,
                               const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank,
                               pastix_amd_plan_t** out) {
@@ -132,12 +221,25 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   pastix_amd_plan_s* p = new (std::nothrow) pastix_amd_plan_s();
   if (!p) return PASTIX_AMD_ERR_ALLOC;
   int rc;
+  double oflops = 0;
   try {
-    rc = build_plan(layout, factotype, floattype, opts, owner, myrank, p->host);
+    if (!layout || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1) { delete p; return PASTIX_AMD_ERR_BADPARAMETER; }
+    rc = build_split(layout, opts && opts->schur, p->split);
+    pastix_amd_layout_t sl;
+    if (!rc && p->split.active) {
+      if (owner) rc = PASTIX_AMD_ERR_UNSUPPORTED;          // (the multi-GPU engine addresses panels by original cblk)
+      sl.cblknbr = (pastix_amd_int_t)p->split.cblk.size() - 1;
+      sl.bloknbr = (pastix_amd_int_t)p->split.blok.size();
+      sl.cblktab = p->split.cblk.data();
+      sl.bloktab = p->split.blok.data();
+      oflops = fact_flops(layout, factotype, floattype);
+    }
+    if (!rc) rc = build_plan(p->split.active ? &sl : layout, factotype, floattype, opts, owner, myrank, p->host);
   } catch (const std::bad_alloc&) {
     rc = PASTIX_AMD_ERR_ALLOC;
   }
   if (rc) { delete p; return rc; }
+  if (p->split.active) p->host.fact_flops = p->host.local_flops = oflops;   // DPARM_FACT_FLOPS is the caller's layout's
   Plan& H = p->host;
   p->device = H.opts.device;
   int ndev = 0;
@@ -273,6 +375,7 @@ int pastix_amd_fanin_touched(const pastix_amd_layout_t* layout, const int32_t* o
 
 int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const void* src, const int32_t* rows,
                               pastix_amd_int_t nrows) {
+  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !src || !rows || cblk < 0 || cblk >= p->host.cblknbr || nrows < 0) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (H.role[cblk] != 1 || p->cplx || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -284,6 +387,7 @@ int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const
 }
 
 int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU) {
+  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !dL || p->own_arena) return PASTIX_AMD_ERR_BADPARAMETER;
   p->dL = (double*)dL;
   p->dU = (double*)dU;
@@ -299,6 +403,7 @@ int pastix_amd_plan_set_stream(pastix_amd_plan_t* p, void* stream) {
 }
 
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t* p, pastix_amd_int_t* poff, int32_t* level, int8_t* role) {
+  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (poff) std::memcpy(poff, H.poff.data(), (size_t)(H.cblknbr + 1) * sizeof(int64_t));
@@ -365,10 +470,120 @@ static int z_transfer(pastix_amd_plan_t* p, bool to_device, void* host, double* 
   return 0;
 }
 
+// Host <-> device copies of ONE original cblk of a plan with split cblks (SplitMap).  hostL / hostU: the caller's
+// panels of that cblk in the reference's layout (ostride x owidth, column-major; complex: interleaved).
+// Sub-cblk j holds, for its columns, the panel rows from its own diagonal blok down: column c' of its panel is the
+// tail [off_j, ostride) of original column off_j + c'.  The blocks of the original diagonal blok ABOVE a column
+// group (rows of an earlier group) are not L entries: for LU they are U (kept transposed in the earlier group's U
+// panel) and are written back into coeftab's diagonal blok after a factorization, as the reference has them
+// (getrf works on coeftab's square blok, compute_diag.c:486-532); otherwise zeros.  ucoeftab's diagonal blok comes
+// back with the factor's U^T blocks below the groups' diagonals and zeros above -- the reference leaves its
+// initial fill there, nothing reads it.
+static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, void* hostU) {
+  const Plan& H = p->host;
+  const SplitMap& M = p->split;
+  const int es = p->cplx ? 2 : 1;
+  const int64_t s0 = M.first[k], ns = M.first[k + 1] - s0, os = M.ostride[k], ow = M.owidth[k];
+  auto xfer = [&](int arena, int64_t off, int64_t cnt, void* host) -> int {
+    double* re = arena ? p->dU : p->dL;
+    double* im = arena ? p->dUi : p->dLi;
+    if (p->cplx) return z_transfer(p, up, host, re, im, off, cnt);
+    if (up) HIPCHK(hipMemcpy(re + off, host, cnt * sizeof(double), hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(host, re + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  };
+  const bool haveU = p->dU && hostU;
+  if (ns == 1) {
+    int r = xfer(0, H.poff[s0], os * ow, hostL);
+    if (!r && haveU) r = xfer(1, H.poff[s0], os * ow, hostU);
+    return r;
+  }
+  const int64_t fcol = H.cblk[s0].fcolnum;
+  std::vector<std::vector<double>> tmp[2];
+  for (int a = 0; a < 2; a++) tmp[a].resize((size_t)ns);
+  for (int a = 0; a < (haveU ? 2 : 1); a++) {
+    double* host = (double*)(a ? hostU : hostL);
+    for (int64_t j = 0; j < ns; j++) {
+      const int64_t s = s0 + j, off = H.cblk[s].fcolnum - fcol, wj = H.cblk[s].lcolnum - H.cblk[s].fcolnum + 1;
+      const int64_t nr = H.cblk[s].stride;                      // == os - off
+      std::vector<double>& t = tmp[a][(size_t)j];
+      t.resize((size_t)(nr * wj * es));
+      if (up) {
+        for (int64_t c = 0; c < wj; c++)
+          memcpy(t.data() + c * nr * es, host + ((off + c) * os + off) * es, (size_t)(nr * es) * sizeof(double));
+        if (a == 1 && H.factotype == PASTIX_AMD_FACT_LU) {
+          // LU: the reference keeps the whole square A_kk in coeftab's diagonal blok and zeros in ucoeftab's
+          // (csc_intern_solve.c:65-132); the U^T blocks facing the later column groups are the transposes of
+          // coeftab's blocks right of this group's diagonal
+          const double* hl = (const double*)hostL;
+          for (int64_t c = 0; c < wj; c++)
+            for (int64_t pr = off + wj; pr < ow; pr++)             // original diagonal-blok row/col index of the later groups
+              for (int e = 0; e < es; e++)
+                t[(size_t)(((pr - off) + c * nr) * es + e)] = hl[(size_t)(((off + c) + pr * os) * es + e)];
+        }
+      }
+      int r = xfer(a, H.poff[s], nr * wj, t.data());
+      if (r) return r;
+      if (!up) {
+        for (int64_t c = 0; c < wj; c++)
+          memcpy(host + ((off + c) * os + off) * es, t.data() + c * nr * es, (size_t)(nr * es) * sizeof(double));
+      }
+    }
+  }
+  if (!up) {
+    // the blocks of the original diagonal blok above a column group: zeros, except for LU, where coeftab's square blok
+    // holds U there and ucoeftab's holds the transpose of L (both bloks are full squares in the reference, transposes
+    // of each other at fill time, csc_intern_solve.c:65-132)
+    const bool lu = H.factotype == PASTIX_AMD_FACT_LU && haveU;
+    if (lu && !p->factored)                       // before a factorization ucoeftab's diagonal blok is all zeros
+      for (int64_t c = 0; c < ow; c++) memset((double*)hostU + c * os * es, 0, (size_t)(ow * es) * sizeof(double));
+    for (int64_t j = 1; j < ns; j++) {
+      const int64_t offj = H.cblk[s0 + j].fcolnum - fcol, wj = H.cblk[s0 + j].lcolnum - H.cblk[s0 + j].fcolnum + 1;
+      for (int64_t c = 0; c < wj; c++) {
+        double* col[2] = {(double*)hostL + (offj + c) * os * es, haveU ? (double*)hostU + (offj + c) * os * es : nullptr};
+        for (int a = 0; a < (haveU ? 2 : 1); a++) {
+          memset(col[a], 0, (size_t)(offj * es) * sizeof(double));
+          if (!lu || (a == 1 && !p->factored)) continue;
+          for (int64_t i = 0; i < j; i++) {                      // rows of the earlier group i, from the OTHER arena's panel of i
+            const int64_t offi = H.cblk[s0 + i].fcolnum - fcol, wi = H.cblk[s0 + i].lcolnum - H.cblk[s0 + i].fcolnum + 1;
+            const int64_t ldi = H.cblk[s0 + i].stride;
+            const std::vector<double>& ot = tmp[1 - a][(size_t)i];
+            for (int64_t q = 0; q < wi; q++)
+              for (int e = 0; e < es; e++)
+                col[a][(offi + q) * es + e] = ot[(size_t)(((offj + c - offi) + q * ldi) * es + e)];
+          }
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+// all cblks of a plan with split cblks; tabs (per-cblk pointers) or packed arrays in the original layout
+static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab, void* packedL,
+                    void* packedU) {
+  const SplitMap& M = p->split;
+  const int es = p->cplx ? 2 : 1;
+  for (int64_t k = 0; k < M.ocblknbr; k++) {
+    void* hl = coeftab ? coeftab[k] : (void*)((double*)packedL + M.ooff[k] * es);
+    void* hu = coeftab ? (ucoeftab ? ucoeftab[k] : nullptr) : (packedU ? (void*)((double*)packedU + M.ooff[k] * es) : nullptr);
+    if (!hl) return PASTIX_AMD_ERR_BADPARAMETER;
+    int r = split_cblk_io(p, k, up, hl, hu);
+    if (r) return r;
+  }
+  return 0;
+}
+
 int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U) {
   if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   double t0 = now_s();
+  p->factored = false;
+  if (p->split.active) {
+    int r = split_io(p, true, nullptr, nullptr, (void*)L, (void*)U);
+    p->stats.h2d_time = now_s() - t0;
+    return r;
+  }
   if (p->cplx) {
     int r = z_transfer(p, true, (void*)L, p->dL, p->dLi, 0, p->host.coefnbr);
     if (r) return r;
@@ -388,6 +603,11 @@ int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
   HIPCHK(hipSetDevice(p->device));
   double t0 = now_s();
   HIPCHK(hipStreamSynchronize(p->stream));
+  if (p->split.active) {
+    int r = split_io(p, false, nullptr, nullptr, L, U);
+    p->stats.d2h_time = now_s() - t0;
+    return r;
+  }
   if (p->cplx) {
     int r = z_transfer(p, false, L, p->dL, p->dLi, 0, p->host.coefnbr);
     if (r) return r;
@@ -405,6 +625,12 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
   double t0 = now_s();
+  p->factored = false;
+  if (p->split.active) {
+    int r = split_io(p, true, coeftab, ucoeftab, nullptr, nullptr);
+    p->stats.h2d_time = now_s() - t0;
+    return r;
+  }
   for (int64_t k = 0; k < H.cblknbr; k++) {
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
     if (H.role[k] != 1) continue;
@@ -431,6 +657,12 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
   double t0 = now_s();
+  if (p->split.active) {
+    HIPCHK(hipStreamSynchronize(p->stream));
+    int r = split_io(p, false, coeftab, ucoeftab, nullptr, nullptr);
+    p->stats.d2h_time = now_s() - t0;
+    return r;
+  }
   for (int64_t k = 0; k < H.cblknbr; k++) {
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
     if (H.role[k] != 1) continue;
@@ -453,6 +685,7 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
 }
 
 int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, void* U) {
+  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !L || k < 0 || k >= p->host.cblknbr || p->host.role[k] != 1) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
@@ -558,6 +791,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
 int pastix_amd_refill(pastix_amd_plan_t* p) {
   if (!p || (!p->dFillIdxL && p->nFillL != 0) || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
+  p->factored = false;
   HIPCHK(hipSetDevice(p->device));
   HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
   if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
@@ -678,6 +912,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   HIPCHK(hipEventRecord(p->ev1, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
+  p->factored = true;
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   p->stats.fact_time = ms * 1e-3;

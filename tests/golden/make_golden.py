@@ -36,7 +36,42 @@ CASES = [
     ("zrlap3d_8_ldlh", "z", "rlap3d", "8", "ldlh", []),
     ("zrlap3d_12_ldlh", "z", "rlap3d", "12", "ldlh", []),
     ("zyoung4c_841_ldlt", "z", "mtx", "/root/reference/src/matrix/young4c.mtx", "ldlt", []),   # the reference's own fixture
+    # the reference's Harwell-Boeing fixture (oil reservoir, real unsymmetric values on a symmetric pattern): an
+    # irregular, non-grid structure under the identity ordering; converted to Matrix Market for the harness
+    ("orsirr_1030_lu", "d", "hb", "/root/reference/src/matrix/orsirr.rua", "lu", []),
 ]
+
+
+def hb_to_mtx(fn, out):
+    """Minimal Harwell-Boeing (assembled, real) reader -> MatrixMarket coordinate file (a data conversion)."""
+    import re
+    L = open(fn).read().split("\n")
+    ptrc, indc, valc = [int(x) for x in L[1].split()[1:4]]
+    typ = L[2][:3].upper()
+    nrow, ncol, nnz = [int(x) for x in L[2][3:].split()[:3]]
+    fm = re.findall(r"\(([^)]*)\)", L[3])
+    width = lambda f: int(re.search(r"[IiEeDdFf](\d+)", f).group(1))
+    pos = [4]
+
+    def take(nlines, f, count, conv):
+        w, vals = width(f), []
+        for ln in L[pos[0]:pos[0] + nlines]:
+            for i in range(0, len(ln.rstrip()), w):
+                t = ln[i:i + w].strip()
+                if t:
+                    vals.append(conv(t.replace("D", "E").replace("d", "e")))
+        pos[0] += nlines
+        return vals[:count]
+
+    ptr = take(ptrc, fm[0], ncol + 1, int)
+    ind = take(indc, fm[1], nnz, int)
+    val = take(valc, fm[2], nnz, float)
+    with open(out, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real %s\n" % ("symmetric" if typ[1] == "S" else "general"))
+        f.write("%d %d %d\n" % (nrow, ncol, nnz))
+        for j in range(ncol):
+            for q in range(ptr[j] - 1, ptr[j + 1] - 1):
+                f.write("%d %d %.17g\n" % (ind[q], j + 1, val[q]))
 
 
 def main():
@@ -47,6 +82,9 @@ def main():
             continue
         exe = os.path.join(ROOT, "oracle", "_ref", "ref_harness_" + prec)
         raw = "/tmp/%s.bin" % name
+        if kind == "hb":
+            hb_to_mtx(arg, "/tmp/%s.mtx" % name)
+            kind, arg = "mtx", "/tmp/%s.mtx" % name
         out = subprocess.run([exe, "dump", kind, arg, facto, "1", raw] + extra, env=env,
                              capture_output=True, text=True, check=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -92,11 +92,85 @@ def test_dense_blocks_match_oracle(widths, facto):
         assert np.abs(L1.reshape(n, n, order="F") - C)[np.tril_indices(n)].max() <= 1e-11 * np.abs(C).max()
 
 
-def test_wider_than_256_is_unsupported():
-    c4, b4, n = dense_layout([257])
-    with pytest.raises(PastixAmdError) as e:
-        Plan(c4, b4, 0)
-    assert e.value.code == -5
+@pytest.mark.parametrize("widths", [[257], [334, 20], [300, 177, 40], [40, 600, 30, 290]])
+@pytest.mark.parametrize("facto", [0, 1, 2])
+def test_cblks_wider_than_256_are_factorized_in_column_groups(widths, facto):
+    """The reference's blend can leave supernodes wider than the panel kernels' 256 columns (334 on its own
+    orsirr.rua fixture): the engine cuts them into column groups internally; panels go in and come out in the
+    caller's layout."""
+    c4, b4, n = dense_layout(widths)
+    A = spd(n, 31 + n)
+    if facto == 2:
+        A = A + np.triu(np.random.default_rng(9).standard_normal((n, n)), 1) * 0.1
+    L0 = panels_of(A, c4)
+    U0 = None
+    if facto == 2:                                  # the reference's fill: the square A_kk in coeftab, zeros in ucoeftab
+        U0 = panels_of(A.T, c4)
+        o = 0
+        for k in range(len(c4) - 1):
+            wk, sk = int(c4[k, 1] - c4[k, 0] + 1), int(c4[k, 3])
+            U0[o:o + wk * sk].reshape(wk, sk)[:, :wk] = 0.0
+            o += wk * sk
+    Lo, Uo, nbo = oracle_lib.sopalin(facto, c4, b4, L0, U0, 1e-30)
+    with Plan(c4, b4, facto) as p:
+        p.upload(L0, U0)
+        La, Ua = p.download()                       # round trip through the column groups before factorizing
+        st = p.factorize(1e-30)
+        L1, U1 = p.download()
+    lm = lower_mask(c4)
+    if facto == 2:
+        assert np.array_equal(La, L0) and np.array_equal(Ua, U0)
+    else:
+        assert np.array_equal(La[lm], L0[lm])
+    assert st["nbpivot"] == nbo == 0
+    m = lm if facto != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
+    if facto == 2:
+        assert np.abs(U1 - Uo).max() <= TOL * np.abs(Uo).max()      # incl. ucoeftab's diagonal blok = coeftab's transposed
+    # and the solve works on the column groups
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n)
+    b = A @ x
+    with Plan(c4, b4, facto) as p:
+        p.upload(L0, U0)
+        p.factorize(1e-30)
+        xs = p.solve(b.copy())
+    assert np.abs(xs - x).max() <= 1e-9 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("facto", [1, 3, 2])
+def test_complex_cblks_wider_than_256(facto):
+    """The column-group path on the split planes: z LDLt (complex symmetric), LDLh (Hermitian) and LU."""
+    from pastix_amd import COMPLEXDOUBLE
+    widths = [300, 20, 290]
+    c4, b4, n = dense_layout(widths)
+    rng = np.random.default_rng(17)
+    B = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    if facto == 3:
+        A = B @ B.conj().T + 4 * n * np.eye(n)             # Hermitian positive definite
+    else:
+        A = B @ B.T * 0.05 + 4 * n * np.eye(n)             # complex symmetric, diagonally dominant
+    if facto == 2:
+        A = A + np.triu(rng.standard_normal((n, n)), 1) * 0.1
+    L0 = panels_of(A, c4).astype(np.complex128)
+    U0 = None
+    if facto == 2:
+        U0 = panels_of(A.T, c4).astype(np.complex128)
+        o = 0
+        for k in range(len(c4) - 1):
+            wk, sk = int(c4[k, 1] - c4[k, 0] + 1), int(c4[k, 3])
+            U0[o:o + wk * sk].reshape(wk, sk)[:, :wk] = 0.0
+            o += wk * sk
+    Lo, Uo, nbo = oracle_lib.sopalin(facto, c4, b4, L0, U0, 1e-30)
+    with Plan(c4, b4, facto, floattype=COMPLEXDOUBLE) as p:
+        p.upload(L0, U0)
+        st = p.factorize(1e-30)
+        L1, U1 = p.download()
+    assert st["nbpivot"] == nbo == 0
+    m = lower_mask(c4) if facto != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
+    if facto == 2:
+        assert np.abs(U1 - Uo).max() <= TOL * np.abs(Uo).max()
 
 
 def test_bad_layout_is_rejected():
