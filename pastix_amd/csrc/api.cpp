@@ -44,7 +44,7 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -100,6 +100,7 @@ struct pastix_amd_plan_s {
   double* dFillValUi = nullptr;
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
+  std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1086,6 +1087,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     std::vector<SolveChunk> ch, chB;
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
+    p->lvl_maxw.assign((size_t)H.nlevels, 1);
     std::vector<int64_t> roff((size_t)H.cblknbr + 1, 0);          // in level order, like st
     for (int64_t q = 0; q < H.cblknbr; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
     // panel rows per chunk: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly and
@@ -1100,6 +1102,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
         const int32_t w = (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1), sd = (int32_t)H.cblk[k].stride;
         st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
                           (int32_t)H.cblk[k + 1].bloknum};
+        p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
         for (int32_t r = w; r < sd; r += CH)
           ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
                                   (int32_t)H.cblk[k + 1].bloknum, r, std::min(CH, sd - r), roff[q]});
@@ -1170,13 +1173,13 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     for (int l = 0; l < H.nlevels; l++)
       launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw);
+                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
     if (H.factotype == PASTIX_AMD_FACT_LDLT)
       for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx + k * H.ncol);
     for (int l = H.nlevels - 1; l >= 0; l--)
       launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
-                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw);
+                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
     HIPCHK(hipEventRecord(p->ev1, p->stream));
     HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));

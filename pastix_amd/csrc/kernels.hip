@@ -998,12 +998,32 @@ __global__ __launch_bounds__(256) void k_solve_diag_q(const double* __restrict__
   double rinv[2], a[32][2];
 #pragma unroll
   for (int j = 0; j < 2; j++) rcl[j] = min(lane + 64 * j, w - 1);
+  if constexpr (MODE == 1) {            // (see k_solve_diag_q1: column-wise reads turned through LDS)
+    extern __shared__ double S[];
+    const int ldl = w | 1;
 #pragma unroll
-  for (int i = 0; i < 32; i++) {
-    const int g = 32 * wave + i;
-    const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+    for (int i = 0; i < 32; i++) {
+      const int64_t c = min(wave + 4 * i, w - 1);
 #pragma unroll
-    for (int j = 0; j < 2; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
+      for (int j = 0; j < 2; j++) a[i][j] = A[rcl[j] + c * ld];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int c = wave + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int r = lane + 64 * j;
+        if (c < w && r >= c && r < w) S[r + c * ldl] = a[i][j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int g = 32 * wave + i;
+      const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) a[i][j] = A[rcl[j] + c * ld];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
@@ -1012,6 +1032,16 @@ __global__ __launch_bounds__(256) void k_solve_diag_q(const double* __restrict__
     if (r < w) xs[q][r] = x[q * ldx + tk.fcol + r];
   }
   __syncthreads();
+  if constexpr (MODE == 1) {
+    extern __shared__ double S[];
+    const int ldl = w | 1;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int c = min(max(w - 1 - (32 * wave + i), 0), w - 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) a[i][j] = S[c + (int)rcl[j] * ldl];
+    }
+  }
   // systolic: at step t wave q runs its 32 columns of the chain for right-hand side t - q.  One copy of the chain
   // per wave (Q a compile-time constant: column numbers, slots and lane tests fold)
   const bool rw[2] = {lane < w, lane + 64 < w};
@@ -1075,17 +1105,50 @@ __global__ __launch_bounds__(256) void k_solve_diag_q1(const double* __restrict_
   double rinv[2], a[32][2];
 #pragma unroll
   for (int j = 0; j < 2; j++) rcl[j] = min(lane + 64 * j, w - 1);
+  if constexpr (MODE == 1) {
+    // L^T: row c of L is needed with the lanes along the columns.  Read the blok column-wise (coalesced) and
+    // turn it through LDS (dynamic: lw x (lw|1) doubles for the widest cblk of the level; odd leading dimension)
+    // instead of 64 scattered 8-byte reads per instruction
+    extern __shared__ double S[];
+    const int ldl = w | 1;
 #pragma unroll
-  for (int i = 0; i < 32; i++) {
-    const int g = 32 * wave + i;
-    const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+    for (int i = 0; i < 32; i++) {
+      const int64_t c = min(wave + 4 * i, w - 1);
 #pragma unroll
-    for (int j = 0; j < 2; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
+      for (int j = 0; j < 2; j++) a[i][j] = A[rcl[j] + c * ld];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
+    if (tid < w) xs[tid] = x[tk.fcol + tid];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int c = wave + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int r = lane + 64 * j;
+        if (c < w && r >= c && r < w) S[r + c * ldl] = a[i][j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int c = min(max(w - 1 - (32 * wave + i), 0), w - 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) a[i][j] = S[c + (int)rcl[j] * ldl];     // (entries with r > c are never used)
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      const int g = 32 * wave + i;
+      const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) a[i][j] = A[rcl[j] + c * ld];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
+    if (tid < w) xs[tid] = x[tk.fcol + tid];
+    __syncthreads();
   }
-#pragma unroll
-  for (int j = 0; j < 2; j++) rinv[j] = unit ? 1.0 : 1.0 / A[rcl[j] + rcl[j] * ld];
-  if (tid < w) xs[tid] = x[tk.fcol + tid];
-  __syncthreads();
   for (int q = 0; q < 4; q++) {
     if (wave == q && 32 * q < w) {
       double xr[2];
@@ -1381,14 +1444,26 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
 template <int MODE, int NR>
 static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
-                              int64_t ldx, int unit, int maxw) {
+                              int64_t ldx, int unit, int maxw, int lvlw) {
   static const bool onewave = getenv("PASTIX_AMD_SOLVE_ONEWAVE") != nullptr;
+  // MODE 1 turns the blok through dynamic LDS sized for the widest cblk of the level
+  const size_t smem = MODE == 1 ? (size_t)lvlw * (lvlw | 1) * sizeof(double) : 0;
   if (maxw <= 128 && !onewave && NR == 1) {            // one right-hand side: the copy without the systolic loop
-    hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, unit);
+    static bool attr = false;
+    if (MODE == 1 && !attr) {
+      (void)hipFuncSetAttribute((const void*)k_solve_diag_q1<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, unit);
     return;
   }
   if (maxw <= 128 && !onewave) {
-    hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x, ldx, unit);
+    static bool attr = false;
+    if (MODE == 1 && !attr) {
+      (void)hipFuncSetAttribute((const void*)k_solve_diag_q<MODE, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
     return;
   }
   for (int k = 0; k < NR; k++) {            // cblks wider than 128: one right-hand side at a time
@@ -1403,14 +1478,14 @@ static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* t
 template <int NR>
 static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw) {
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw, int lvlw) {
   static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;     // the first-generation kernels
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
   const dim3 gt((unsigned)ntask), gc((unsigned)nchunk);
   if (fwd) {
     if (ntask > 0) {
       if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_fwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, unit);
-      else launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, maxw);
+      else launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, maxw, lvlw);
     }
     if (nchunk > 0) {
       if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_off_fwd, gc, dim3(256), 0, s, L, chunks, bl, x + k * ldx);
@@ -1425,17 +1500,17 @@ static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L,
     }
     if (ntask > 0) {
       if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_bwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, mode);
-      else if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, maxw);
-      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, maxw);
+      else if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, maxw, lvlw);
+      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, maxw, lvlw);
     }
   }
 }
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw) {
-  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
-  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
-  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw) {
+  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
+  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
+  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {
