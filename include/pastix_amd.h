@@ -130,6 +130,23 @@ int pastix_amd_z_he_sopalin(const pastix_amd_layout_t *layout, void *const *coef
 int pastix_amd_z_ge_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, void *const *ucoeftab,
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 
+/* single precision (S_ / C_ {po,sy,he,ge}_sopalin_thread, sopalin3d.h:381-467 under -DPREC_SIMPLE): coeftab[k] are
+ * `float` / interleaved `float complex` panels.  They are widened on the host, factorized by the fp64 engine and
+ * rounded back (dtype of the arithmetic stays f64; an fp32-MFMA path is not built).  The staged API takes the
+ * double types only. */
+int pastix_amd_s_po_sopalin(const pastix_amd_layout_t *layout, float *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_s_sy_sopalin(const pastix_amd_layout_t *layout, float *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_s_ge_sopalin(const pastix_amd_layout_t *layout, float *const *coeftab, float *const *ucoeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_c_sy_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_c_he_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, double critere,
+                            const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+int pastix_amd_c_ge_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, void *const *ucoeftab,
+                            double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+
 /* ---- staged API (analysis once, many factorizations; panels may stay on the device) -------- */
 int pastix_amd_plan_create(const pastix_amd_layout_t *layout, int factotype, int floattype,
                            const pastix_amd_options_t *opts, pastix_amd_plan_t **plan);

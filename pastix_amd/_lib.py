@@ -64,6 +64,8 @@ _lib = None
 EXPORTS = [
     "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
     "pastix_amd_z_he_sopalin", "pastix_amd_z_ge_sopalin",
+    "pastix_amd_s_po_sopalin", "pastix_amd_s_sy_sopalin", "pastix_amd_s_ge_sopalin",
+    "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",
     "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats",
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
     "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve",

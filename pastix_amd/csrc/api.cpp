@@ -1237,4 +1237,85 @@ int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* co
   return one_shot(PASTIX_AMD_FACT_LU, layout, coeftab, ucoeftab, critere, opts, stats);
 }
 
+
+// Single-precision drop-ins (S_ / C_ {po,sy,he,ge}_sopalin_thread): the caller's float panels are widened on the
+// host, factorized by the fp64 engine and rounded back -- results are at least as accurate as the reference's
+// single-precision run (parity tolerance 1e-4).  An fp32-MFMA path is not built.
+static int one_shot_single(int factotype, const pastix_amd_layout_t* layout, void* const* coeftab,
+                           void* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
+                           pastix_amd_stats_t* stats, bool cplx) {
+  if (!layout || !coeftab || !layout->cblktab) return PASTIX_AMD_ERR_BADPARAMETER;
+  const int64_t nc = layout->cblknbr;
+  const int es = cplx ? 2 : 1;
+  std::vector<std::vector<double>> L((size_t)nc), U;
+  std::vector<double*> lp((size_t)nc, nullptr), up;
+  const bool lu = factotype == PASTIX_AMD_FACT_LU;
+  if (lu) {
+    if (!ucoeftab) return PASTIX_AMD_ERR_BADPARAMETER;
+    U.resize((size_t)nc);
+    up.assign((size_t)nc, nullptr);
+  }
+  auto cnt = [&](int64_t k) {
+    return (int64_t)(layout->cblktab[k].lcolnum - layout->cblktab[k].fcolnum + 1) * layout->cblktab[k].stride * es;
+  };
+  try {
+    for (int64_t k = 0; k < nc; k++) {
+      if (!coeftab[k] || (lu && !ucoeftab[k])) return PASTIX_AMD_ERR_BADPARAMETER;
+      const int64_t n = cnt(k);
+      L[k].resize((size_t)n);
+      const float* src = (const float*)coeftab[k];
+      for (int64_t i = 0; i < n; i++) L[k][i] = (double)src[i];
+      lp[k] = L[k].data();
+      if (lu) {
+        U[k].resize((size_t)n);
+        const float* su = (const float*)ucoeftab[k];
+        for (int64_t i = 0; i < n; i++) U[k][i] = (double)su[i];
+        up[k] = U[k].data();
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  const int rc = one_shot(factotype, layout, lp.data(), lu ? up.data() : nullptr, critere, opts, stats,
+                          cplx ? PASTIX_AMD_COMPLEXDOUBLE : PASTIX_AMD_REALDOUBLE);
+  if (rc == 0 || rc == PASTIX_AMD_ERR_NUMERIC) {
+    for (int64_t k = 0; k < nc; k++) {
+      const int64_t n = cnt(k);
+      float* dst = (float*)coeftab[k];
+      for (int64_t i = 0; i < n; i++) dst[i] = (float)L[k][i];
+      if (lu) {
+        float* du = (float*)ucoeftab[k];
+        for (int64_t i = 0; i < n; i++) du[i] = (float)U[k][i];
+      }
+    }
+  }
+  return rc;
+}
+
+int pastix_amd_s_po_sopalin(const pastix_amd_layout_t* layout, float* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LLT, layout, (void* const*)coeftab, nullptr, critere, opts, stats, false);
+}
+int pastix_amd_s_sy_sopalin(const pastix_amd_layout_t* layout, float* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LDLT, layout, (void* const*)coeftab, nullptr, critere, opts, stats, false);
+}
+int pastix_amd_s_ge_sopalin(const pastix_amd_layout_t* layout, float* const* coeftab, float* const* ucoeftab,
+                            double critere, const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LU, layout, (void* const*)coeftab, (void* const*)ucoeftab, critere, opts, stats,
+                         false);
+}
+int pastix_amd_c_sy_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LDLT, layout, coeftab, nullptr, critere, opts, stats, true);
+}
+int pastix_amd_c_he_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, double critere,
+                            const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LDLH, layout, coeftab, nullptr, critere, opts, stats, true);
+}
+int pastix_amd_c_ge_sopalin(const pastix_amd_layout_t* layout, void* const* coeftab, void* const* ucoeftab,
+                            double critere, const pastix_amd_options_t* opts, pastix_amd_stats_t* stats) {
+  return one_shot_single(PASTIX_AMD_FACT_LU, layout, coeftab, ucoeftab, critere, opts, stats, true);
+}
+
 }  // extern "C"

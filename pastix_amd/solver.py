@@ -105,7 +105,8 @@ class Plan:
 
 def sopalin_tabs(factotype, cblk4, blok4, coeftab, ucoeftab=None, critere=0.0, lookahead=0):
     """One-shot drop-in call {po,sy,ge,he}_sopalin with the reference's per-cblk host buffers
-    (lists of 1-D float64 arrays -- D_ variants -- or complex128 arrays -- Z_ variants --, factorized in place)."""
+    (lists of 1-D float64 / complex128 / float32 / complex64 arrays -- the D_ / Z_ / S_ / C_ variants --, factorized in
+    place; the single-precision variants compute in f64)."""
     la = LayoutArrays(cblk4, blok4)
     n = la.cblknbr
     arr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in coeftab])
@@ -113,18 +114,31 @@ def sopalin_tabs(factotype, cblk4, blok4, coeftab, ucoeftab=None, critere=0.0, l
     opts.lookahead = lookahead
     s = Stats()
     L = _lib.lib()
-    if coeftab and coeftab[0].dtype == np.complex128:
+    dt = coeftab[0].dtype if coeftab else np.dtype(np.float64)
+    if dt in (np.complex128, np.complex64):
+        pre = "z" if dt == np.complex128 else "c"          # Z_ or C_ {sy,he,ge}_sopalin_thread
         cr = ctypes.c_double(critere)
         if factotype == FACT_LU:
             uarr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in ucoeftab])
-            rc = L.pastix_amd_z_ge_sopalin(ctypes.byref(la.c), arr, uarr, cr, ctypes.byref(opts), ctypes.byref(s))
+            rc = getattr(L, "pastix_amd_%s_ge_sopalin" % pre)(ctypes.byref(la.c), arr, uarr, cr, ctypes.byref(opts), ctypes.byref(s))
         elif factotype == FACT_LDLT:
-            rc = L.pastix_amd_z_sy_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+            rc = getattr(L, "pastix_amd_%s_sy_sopalin" % pre)(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
         elif factotype == 3:
-            rc = L.pastix_amd_z_he_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+            rc = getattr(L, "pastix_amd_%s_he_sopalin" % pre)(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
         else:
             rc = -5
-        check(rc, "pastix_amd_z_*_sopalin")
+        check(rc, "pastix_amd_%s_*_sopalin" % pre)
+        return s.as_dict()
+    if dt == np.float32:                                   # S_ {po,sy,ge}_sopalin_thread
+        cr = ctypes.c_double(critere)
+        if factotype == FACT_LLT:
+            rc = L.pastix_amd_s_po_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+        elif factotype == FACT_LDLT:
+            rc = L.pastix_amd_s_sy_sopalin(ctypes.byref(la.c), arr, cr, ctypes.byref(opts), ctypes.byref(s))
+        else:
+            uarr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in ucoeftab])
+            rc = L.pastix_amd_s_ge_sopalin(ctypes.byref(la.c), arr, uarr, cr, ctypes.byref(opts), ctypes.byref(s))
+        check(rc, "pastix_amd_s_*_sopalin")
         return s.as_dict()
     if factotype == FACT_LLT:
         rc = L.pastix_amd_d_po_sopalin(ctypes.byref(la.c), arr, ctypes.c_double(critere), ctypes.byref(opts), ctypes.byref(s))

@@ -200,3 +200,27 @@ def test_z_one_shot_tabs(name, golden):
     if utabs is not None:
         assert np.abs(np.concatenate(utabs) - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()
     assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", ["rlap3d_10_llt", "rlap3d_8_ldlt", "rlap3d_8_lu", "orsirr_1030_lu",
+                                  "zrlap3d_8_ldlt", "zrlap3d_8_ldlh", "zrlap3d_8_lu"])
+def test_single_precision_one_shot_tabs(name, golden):
+    """S_ / C_ {po,sy,he,ge}_sopalin_thread drop-ins: float panels in, float factors out (computed in f64).
+    Tolerance of the single-precision path: 1e-4 * max|L| against the reference's double factors
+    of the same (float-rounded) input."""
+    from pastix_amd.solver import sopalin_tabs
+    g = golden(name)
+    c4 = g["cblk4"]
+    cz = np.iscomplexobj(g["L0"])
+    st_ = np.complex64 if cz else np.float32
+    poff = np.concatenate([[0], np.cumsum(c4[:-1, 3] * (c4[:-1, 1] - c4[:-1, 0] + 1))])
+    tabs = [g["L0"][poff[k]:poff[k + 1]].astype(st_) for k in range(len(c4) - 1)]
+    utabs = [g["U0"][poff[k]:poff[k + 1]].astype(st_) for k in range(len(c4) - 1)] if g["facto"] == 2 else None
+    st = sopalin_tabs(g["facto"], c4, g["blok4"], tabs, utabs, critere=g["critere"])
+    assert tabs[0].dtype == st_
+    L1 = np.concatenate(tabs)
+    m = _lower_mask(c4) if g["facto"] != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - g["L1"])[m].max() <= 1e-4 * np.abs(g["L1"][m]).max()
+    if utabs is not None:
+        assert np.abs(np.concatenate(utabs) - g["U1"]).max() <= 1e-4 * np.abs(g["U1"]).max()
+    assert st["nbpivot"] == g["nbpivot"]
