@@ -120,8 +120,8 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-template <class T>
-static int to_device(T** d, const std::vector<T>& h) {
+template <class T, class A>
+static int to_device(T** d, const std::vector<T, A>& h) {
   size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
   HIPCHK(hipMalloc((void**)d, bytes));
   if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -318,7 +318,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.full_flops = H.full_flops;
   S.urgent_flops = H.urgent_flops;
   // the piece/task tables now live on the device; keep only what the host driver reads
-  std::vector<Piece>().swap(H.pieces);
+  decltype(H.pieces)().swap(H.pieces);
   std::vector<Task>().swap(H.tasks);
   *out = p;
   return PASTIX_AMD_OK;

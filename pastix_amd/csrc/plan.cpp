@@ -18,7 +18,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <numeric>
+#include <thread>
 
 namespace pastix_amd {
 
@@ -280,118 +283,142 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   const bool lu = factotype == PASTIX_AMD_FACT_LU;
   const bool ldlt = factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH;
   const bool herm = factotype == PASTIX_AMD_FACT_LDLH;
-  std::vector<RawPiece> raw;
-  raw.reserve((size_t)P.bloknbr * 8);
-  double uflops = 0, ubytes = 0;
+  // Source cblks are independent: piece generation runs on `nthr` host threads (PASTIX_AMD_PLAN_THREADS, default
+  // min(16, cores)), every thread into its own list; the lists are then bucketed by target tile and sorted in
+  // parallel.  The sort key is a total order, so the result does not depend on the number of threads.
+  const int nthr = [] {
+    const char* e = getenv("PASTIX_AMD_PLAN_THREADS");
+    int n = e ? atoi(e) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, std::min(n, 64));
+  }();
+  std::vector<std::vector<RawPiece>> traw((size_t)nthr);
+  std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
+  std::vector<int> terr((size_t)nthr, 0);
+  auto gen = [&](int tid) {
+    std::vector<RawPiece>& raw = traw[(size_t)tid];
+    raw.reserve((size_t)P.bloknbr * 8 / (size_t)nthr + 16);
+    double uflops = 0, ubytes = 0;
 
-  auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
-                  int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
-    // split the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t into tiles
-    const int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
-    const int64_t nct = (w_t + TN - 1) / TN;
-    const int64_t sk = P.cblk[k].stride;
-    const int64_t wk = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-    for (int64_t rt = trow / TM; rt * TM < trow + nrows; rt++) {
-      int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
-      for (int64_t ct = tcol / TN; ct * TN < tcol + ncols; ct++) {
-        int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
-        auto push = [&](uint16_t fl, uint8_t ca) {
-          RawPiece rp;
-          rp.tile = tile_base[t] + rt * nct + ct + (int64_t)ca * ntile;
-          // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
-          // targets: not before `window` levels ahead of the target's own level.
-          rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
-          rp.carena = ca;
-          rp.shared = shared[t];
-          rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
-          rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
-          rp.p.lda = (int32_t)sk;
-          rp.p.k = (uint16_t)wk;
-          rp.p.dr = (uint16_t)(r0 - rt * TM);
-          rp.p.m = (uint16_t)(r1 - r0);
-          rp.p.dc = (uint16_t)(c0 - ct * TN);
-          rp.p.n = (uint16_t)(c1 - c0);
-          rp.p.flags = fl;
-          raw.push_back(rp);
-          uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
-          ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
-        };
-        if (!cplx) {
-          push(flags, carena);
-        } else if (herm) {
-          // Hermitian product on split planes (SOPALIN_GEMM "N","C": the B operand, L D, is conjugated):
-          //   C_re -= A_re B_re^T + A_im B_im^T ;  C_im -= A_im B_re^T - A_re B_im^T
-          const int a = flags & 3, b = (flags >> 2) & 3;
-          push(AB(a, b), carena);
-          push(AB(a + 2, b + 2), carena);
-          push(AB(a + 2, b), (uint8_t)(carena + 2));
-          push((uint16_t)(AB(a, b + 2) | 16), (uint8_t)(carena + 2));
-        } else {
-          // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
-          //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T
-          const int a = flags & 3, b = (flags >> 2) & 3;
-          push(AB(a, b), carena);
-          push((uint16_t)(AB(a + 2, b + 2) | 16), carena);
-          push(AB(a, b + 2), (uint8_t)(carena + 2));
-          push(AB(a + 2, b), (uint8_t)(carena + 2));
-        }
-      }
-    }
-  };
-
-  for (int64_t k = 0; k < nc; k++) {
-    if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
-    const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
-    for (int64_t i = fb + 1; i < lb; i++) {
-      const int64_t t = P.blok[i].cblknum;
-      const int64_t tf = P.cblk[t].fcolnum;
-      const int64_t tfb = P.cblk[t].bloknum, tlb = P.cblk[t + 1].bloknum;
-      const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
-      const int64_t tcol = P.blok[i].frownum - tf;
-      int64_t b3 = tfb;
-      // runs of source bloks that land contiguously in the target panel
-      int64_t run_src = -1, run_dst = -1, run_len = 0;
-      bool run_diag = false;
-      auto flush = [&]() {
-        if (run_len <= 0) return;
-        if (!lu) {
-          // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? AB(0, 1) : AB(0, 0), 0);
-        } else if (!run_diag) {
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // L U^T -> L arena
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(1, 0), 1);   // U L^T -> U arena
-        } else {
-          // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
-          emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // lower/diag part
-        }
-        run_len = 0;
-      };
-      for (int64_t j = i; j < lb; j++) {
-        const int64_t fj = P.blok[j].frownum, lj = P.blok[j].lrownum, hj = lj - fj + 1;
-        while (b3 < tlb && !(fj >= P.blok[b3].frownum && lj <= P.blok[b3].lrownum)) b3++;
-        if (b3 >= tlb) return PASTIX_AMD_ERR_LAYOUT;   // containment (sopalin_compute.c:558-559)
-        if (P.tcoef[b3] < 0) return PASTIX_AMD_ERR_LAYOUT;   // (cannot happen: fanin_touched marks exactly these)
-        const int64_t dst = P.tcoef[b3] + (fj - P.blok[b3].frownum);
-        const bool diag = (b3 == tfb);
-        if (run_len > 0 && dst == run_dst + run_len && diag == run_diag && !(lu && diag)) {
-          run_len += hj;
-        } else {
-          flush();
-          run_src = P.blok[j].coefind; run_dst = dst; run_len = hj; run_diag = diag;
-        }
-        if (lu && diag) {
-          // flush per blok: the transposed U contribution needs (i,j) roles individually
-          flush();
-          if (j != i) {
-            // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
-            // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
-            emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, AB(0, 1), 0);
+    auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
+                    int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
+      // split the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t into tiles
+      const int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
+      const int64_t nct = (w_t + TN - 1) / TN;
+      const int64_t sk = P.cblk[k].stride;
+      const int64_t wk = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+      for (int64_t rt = trow / TM; rt * TM < trow + nrows; rt++) {
+        int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
+        for (int64_t ct = tcol / TN; ct * TN < tcol + ncols; ct++) {
+          int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
+          auto push = [&](uint16_t fl, uint8_t ca) {
+            RawPiece rp;
+            rp.tile = tile_base[t] + rt * nct + ct + (int64_t)ca * ntile;
+            // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
+            // targets: not before `window` levels ahead of the target's own level.
+            rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
+            rp.carena = ca;
+            rp.shared = shared[t];
+            rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
+            rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
+            rp.p.lda = (int32_t)sk;
+            rp.p.k = (uint16_t)wk;
+            rp.p.dr = (uint16_t)(r0 - rt * TM);
+            rp.p.m = (uint16_t)(r1 - r0);
+            rp.p.dc = (uint16_t)(c0 - ct * TN);
+            rp.p.n = (uint16_t)(c1 - c0);
+            rp.p.flags = fl;
+            raw.push_back(rp);
+            uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
+            ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
+          };
+          if (!cplx) {
+            push(flags, carena);
+          } else if (herm) {
+            // Hermitian product on split planes (SOPALIN_GEMM "N","C": the B operand, L D, is conjugated):
+            //   C_re -= A_re B_re^T + A_im B_im^T ;  C_im -= A_im B_re^T - A_re B_im^T
+            const int a = flags & 3, b = (flags >> 2) & 3;
+            push(AB(a, b), carena);
+            push(AB(a + 2, b + 2), carena);
+            push(AB(a + 2, b), (uint8_t)(carena + 2));
+            push((uint16_t)(AB(a, b + 2) | 16), (uint8_t)(carena + 2));
+          } else {
+            // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
+            //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T
+            const int a = flags & 3, b = (flags >> 2) & 3;
+            push(AB(a, b), carena);
+            push((uint16_t)(AB(a + 2, b + 2) | 16), carena);
+            push(AB(a, b + 2), (uint8_t)(carena + 2));
+            push(AB(a + 2, b), (uint8_t)(carena + 2));
           }
         }
       }
-      flush();
+    };
+
+    for (int64_t k = tid; k < nc; k += nthr) {
+      if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
+      const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
+      for (int64_t i = fb + 1; i < lb; i++) {
+        const int64_t t = P.blok[i].cblknum;
+        const int64_t tf = P.cblk[t].fcolnum;
+        const int64_t tfb = P.cblk[t].bloknum, tlb = P.cblk[t + 1].bloknum;
+        const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
+        const int64_t tcol = P.blok[i].frownum - tf;
+        int64_t b3 = tfb;
+        // runs of source bloks that land contiguously in the target panel
+        int64_t run_src = -1, run_dst = -1, run_len = 0;
+        bool run_diag = false;
+        auto flush = [&]() {
+          if (run_len <= 0) return;
+          if (!lu) {
+            // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
+            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? AB(0, 1) : AB(0, 0), 0);
+          } else if (!run_diag) {
+            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // L U^T -> L arena
+            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(1, 0), 1);   // U L^T -> U arena
+          } else {
+            // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
+            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // lower/diag part
+          }
+          run_len = 0;
+        };
+        for (int64_t j = i; j < lb; j++) {
+          const int64_t fj = P.blok[j].frownum, lj = P.blok[j].lrownum, hj = lj - fj + 1;
+          while (b3 < tlb && !(fj >= P.blok[b3].frownum && lj <= P.blok[b3].lrownum)) b3++;
+          if (b3 >= tlb) { terr[tid] = PASTIX_AMD_ERR_LAYOUT; return; }   // containment (sopalin_compute.c:558-559)
+          if (P.tcoef[b3] < 0) { terr[tid] = PASTIX_AMD_ERR_LAYOUT; return; }   // (cannot happen: fanin_touched marks exactly these)
+          const int64_t dst = P.tcoef[b3] + (fj - P.blok[b3].frownum);
+          const bool diag = (b3 == tfb);
+          if (run_len > 0 && dst == run_dst + run_len && diag == run_diag && !(lu && diag)) {
+            run_len += hj;
+          } else {
+            flush();
+            run_src = P.blok[j].coefind; run_dst = dst; run_len = hj; run_diag = diag;
+          }
+          if (lu && diag) {
+            // flush per blok: the transposed U contribution needs (i,j) roles individually
+            flush();
+            if (j != i) {
+              // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
+              // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
+              emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, AB(0, 1), 0);
+            }
+          }
+        }
+        flush();
+      }
     }
+    tuf[(size_t)tid] = uflops;
+    tub[(size_t)tid] = ubytes;
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; t++) th.emplace_back(gen, t);
+    gen(0);
+    for (auto& x : th) x.join();
   }
+  for (int t = 0; t < nthr; t++) if (terr[(size_t)t]) return terr[(size_t)t];
+  double uflops = 0, ubytes = 0;                       // (integer-valued doubles below 2^53: the sums are exact)
+  for (int t = 0; t < nthr; t++) { uflops += tuf[(size_t)t]; ubytes += tub[(size_t)t]; }
   P.update_flops = uflops;
 
   phase("piece generation");
@@ -400,14 +427,70 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // chunk_work multiply-adds; a chunk is launched in the slot right after its last source level, so
   // the tile is read-modified-written once per chunk instead of once per source (the reference does
   // it once per source blok pair under mutex_blok, sopalin_compute.c:563-580).
-  std::sort(raw.begin(), raw.end(), [](const RawPiece& a, const RawPiece& b) {
+  auto piece_less = [](const RawPiece& a, const RawPiece& b) {
     if (a.tile != b.tile) return a.tile < b.tile;
     if (a.lvl != b.lvl) return a.lvl < b.lvl;
     if (a.p.a_off != b.p.a_off) return a.p.a_off < b.p.a_off;   // deterministic accumulation order
-    return a.p.b_off < b.p.b_off;
-  });
+    if (a.p.b_off != b.p.b_off) return a.p.b_off < b.p.b_off;
+    if (a.p.flags != b.p.flags) return a.p.flags < b.p.flags;   // (complex: the planes of one product)
+    if (a.p.dr != b.p.dr) return a.p.dr < b.p.dr;
+    return a.p.dc < b.p.dc;
+  };
+  struct RawArr {                      // (uninitialised storage: a vector would zero ~10 GB on one thread first)
+    std::unique_ptr<RawPiece[]> p;
+    size_t n = 0;
+    size_t size() const { return n; }
+    RawPiece& operator[](size_t i) { return p[i]; }
+    const RawPiece& operator[](size_t i) const { return p[i]; }
+    RawPiece* begin() { return p.get(); }
+  } raw;
+  {
+    // counting sort into coarse tile bins (placement by thread order), then every bin sorted on its own
+    constexpr int64_t NB = 8192;
+    const int64_t tspan = std::max<int64_t>(ntile * 4, 1);
+    auto bin_of = [&](int64_t tile) { return (int64_t)((__int128)tile * NB / tspan); };
+    std::vector<std::vector<int64_t>> cnt((size_t)nthr, std::vector<int64_t>((size_t)NB + 1, 0));
+    auto par = [&](auto&& fn) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthr; t++) th.emplace_back(fn, t);
+      fn(0);
+      for (auto& x : th) x.join();
+    };
+    par([&](int t) { for (const RawPiece& r : traw[(size_t)t]) cnt[(size_t)t][(size_t)bin_of(r.tile)]++; });
+    std::vector<int64_t> binoff((size_t)NB + 1, 0);
+    for (int64_t b2 = 0; b2 < NB; b2++) {
+      int64_t c = 0;
+      for (int t = 0; t < nthr; t++) { const int64_t x = cnt[(size_t)t][(size_t)b2]; cnt[(size_t)t][(size_t)b2] = binoff[(size_t)b2] + c; c += x; }
+      binoff[(size_t)b2 + 1] = binoff[(size_t)b2] + c;
+    }
+    raw.n = (size_t)binoff[(size_t)NB];
+    raw.p.reset(new RawPiece[raw.n + 1]);
+    par([&](int t) {
+      std::vector<int64_t>& pos = cnt[(size_t)t];
+      for (const RawPiece& r : traw[(size_t)t]) raw[(size_t)pos[(size_t)bin_of(r.tile)]++] = r;
+      std::vector<RawPiece>().swap(traw[(size_t)t]);
+    });
+    std::atomic<int64_t> next{0};
+    par([&](int) {
+      for (;;) {
+        const int64_t b2 = next.fetch_add(1);
+        if (b2 >= NB) break;
+        std::sort(raw.begin() + binoff[(size_t)b2], raw.begin() + binoff[(size_t)b2 + 1], piece_less);
+      }
+    });
+  }
   phase("piece sort");
   P.pieces.resize(raw.size());
+  {
+    std::vector<std::thread> th;
+    const size_t n = raw.size(), per = (n + (size_t)nthr - 1) / (size_t)nthr;
+    auto cp = [&](int t) {
+      for (size_t i = (size_t)t * per; i < std::min(n, ((size_t)t + 1) * per); i++) P.pieces[i] = raw[i].p;
+    };
+    for (int t = 1; t < nthr; t++) th.emplace_back(cp, t);
+    cp(0);
+    for (auto& x : th) x.join();
+  }
   P.tasks.clear();
   P.slot_task_ptr.assign(NL + 1, 0);
   std::vector<double> task_work;
@@ -435,7 +518,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       tlev = P.level[tt];
     }
     while (e < raw.size() && raw[e].tile == raw[q].tile) {
-      P.pieces[e] = raw[e].p;
       work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
       e++;
       // close the chunk once enough work is gathered, but never split pieces of one source level

@@ -6,6 +6,8 @@
 // (sopalin_compute.c:938-945) becomes precomputed piece descriptors.
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "../../include/pastix_amd.h"
@@ -73,6 +75,19 @@ struct SolveChunk {            // 256 off-diagonal panel rows of one cblk
 };
 
 
+// std::allocator whose value-less construct() default-initialises (leaves trivially constructible T untouched)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+
 struct Plan {
   int factotype = 0, floattype = 1;
   pastix_amd_options_t opts{};
@@ -103,7 +118,7 @@ struct Plan {
                                          // level s itself (needed by this level's panel kernels); the rest of the
                                          // slot only feeds later levels and may overlap with the panel kernels
   std::vector<Task> tasks;
-  std::vector<Piece> pieces;
+  std::vector<Piece, NoInitAlloc<Piece>> pieces;   // (filled by parallel copies: no serial zero fill of ~10 GB first)
   double update_flops = 0;
   double full_flops = 0;                 // part of update_flops in full 128x128 pieces (specialized loop)
   double urgent_flops = 0;               // part of update_flops in the urgent tasks of their slots
