@@ -92,6 +92,8 @@ struct pastix_amd_plan_s {
   long long* dNbpivot = nullptr;
   int* dErr = nullptr;
   int maxw = 0;
+  double* dXws = nullptr;              // solve workspace (right-hand sides on the device), kept between calls
+  size_t nXws = 0;
   SplitMap split;                      // cblks wider than MAXW are factorized in column groups (build_split)
   bool factored = false;               // panels hold factors (set by factorize, cleared by upload / fill)
   // cached coefficient fill (destinations + values) so that a re-fill is device-only
@@ -424,7 +426,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
-  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk); (void)hipFree(p->dChunkB); (void)hipFree(p->dRidx);
+  (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk); (void)hipFree(p->dChunkB); (void)hipFree(p->dRidx); (void)hipFree(p->dXws);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evT) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
@@ -1132,10 +1134,14 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   }
   if (p->cplx) {
     // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device
-    double *dz = nullptr, *dxr = nullptr, *dxi = nullptr;
-    HIPCHK(hipMalloc((void**)&dz, (size_t)H.ncol * 2 * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&dxr, (size_t)H.ncol * sizeof(double)));
-    HIPCHK(hipMalloc((void**)&dxi, (size_t)H.ncol * sizeof(double)));
+    const size_t needz = (size_t)H.ncol * 4;
+    if (p->nXws < needz) {
+      (void)hipFree(p->dXws);
+      p->dXws = nullptr; p->nXws = 0;
+      HIPCHK(hipMalloc((void**)&p->dXws, needz * sizeof(double)));
+      p->nXws = needz;
+    }
+    double *dz = p->dXws, *dxr = p->dXws + 2 * (size_t)H.ncol, *dxi = p->dXws + 3 * (size_t)H.ncol;
     double* xz = (double*)x_;
     const bool scale = H.factotype == PASTIX_AMD_FACT_LDLT || H.factotype == PASTIX_AMD_FACT_LDLH;
     for (int64_t j = 0; j < nrhs; j++) {
@@ -1154,16 +1160,19 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
       HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
     }
-    HIPCHK(hipFree(dz));
-    HIPCHK(hipFree(dxr));
-    HIPCHK(hipFree(dxi));
     HIPCHK(hipGetLastError());
     return PASTIX_AMD_OK;
   }
   // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes)
   const int64_t NRB = std::min<int64_t>(nrhs, 4);
-  double* dx = nullptr;
-  HIPCHK(hipMalloc((void**)&dx, (size_t)H.ncol * NRB * sizeof(double)));
+  const size_t need = (size_t)H.ncol * (size_t)NRB;
+  if (p->nXws < need) {
+    (void)hipFree(p->dXws);
+    p->dXws = nullptr; p->nXws = 0;
+    HIPCHK(hipMalloc((void**)&p->dXws, need * sizeof(double)));
+    p->nXws = need;
+  }
+  double* dx = p->dXws;
   double* x = (double*)x_;
   p->stats.solve_time = 0.0;
   for (int64_t j = 0; j < nrhs;) {
@@ -1188,7 +1197,6 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     p->stats.solve_time += 1e-3 * ms;
     j += nr;
   }
-  HIPCHK(hipFree(dx));
   HIPCHK(hipGetLastError());
   return PASTIX_AMD_OK;
 }
