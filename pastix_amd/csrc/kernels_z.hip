@@ -879,11 +879,227 @@ __global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, c
   for (; i < n; i += stride) { z[2 * i] = re[i]; z[2 * i + 1] = im[i]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second generation of k_diag_zsy for cblks of at most 128 columns: the lower triangle of the diagonal blok lives
+// in REGISTERS for the whole kernel (2x2 complex blocks, nine per thread, loaded once with coalesced reads); every
+// 16-column step exchanges only the tile and the panel below it through LDS:
+//   S1  owners put the 16x16 diagonal tile (Ts) and the rows below it (Ws, raw) into LDS
+//   S2  wave 0 factors the tile in LDS without workgroup barriers (PASTIX_sytrf / hetrf, compute_diag.c:223-242,
+//       326-345), stores it
+//   S3  lanes 0-15 of wave 0 invert the unit-lower tile for the panel kernel (dinv_ws) while waves 1-3 solve the
+//       rows below (thread per row): Ws = L D, Xs = L, L stored
+//   S4  every thread updates the blocks it owns right of the step: C -= (L D) L^T (L^H) from Ws / Xs
+// No global read-modify-write and no reload per step (the first kernel does both): one memory round trip in,
+// results streamed out.
+// ------------------------------------------------------------------------------------------------
+template <bool HERM>
+__global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const PanelTask* __restrict__ tasks,
+                                                    double* __restrict__ dinv_ws, double critere,
+                                                    long long* __restrict__ nbpivot) {
+  constexpr int XR = 116, NBLK = 9;               // 64*65/2 = 2080 blocks of 2x2 <= 9 * 256
+  __shared__ cz Ts[16][17];
+  __shared__ cz Lo[16][17];
+  __shared__ cz Ti[16][17];
+  __shared__ cz Xs[16][XR];
+  __shared__ cz Ws[16][XR];
+  const PanelTask tk = tasks[blockIdx.x];
+  double* Ar = ar.p[0] + tk.off;
+  double* Ai = ar.p[2] + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb2 = (w + 1) >> 1, nblk = nb2 * (nb2 + 1) / 2;
+  // ---- block ownership: q = tid + 256 i -> (br, bc), packed lower by columns; load ----
+  int br[NBLK], bc[NBLK];
+  cz c[NBLK][2][2];
+#pragma unroll
+  for (int i = 0; i < NBLK; i++) {
+    const int q = tid + 256 * i;
+    int col = 0;
+    if (q < nblk) {
+      const double t = 2.0 * nb2 + 1.0;
+      col = (int)((t - sqrt(t * t - 8.0 * q)) * 0.5);
+      while (col > 0 && col * nb2 - col * (col - 1) / 2 > q) col--;
+      while ((col + 1) * nb2 - (col + 1) * col / 2 <= q) col++;
+    }
+    bc[i] = q < nblk ? col : -1;
+    br[i] = q < nblk ? col + (q - (col * nb2 - col * (col - 1) / 2)) : -1;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int r = 2 * br[i] + a, cc = 2 * bc[i] + b;
+        const bool v = q < nblk && r < w && cc < w && r >= cc;
+        const int64_t o = (int64_t)min(max(r, 0), w - 1) + (int64_t)min(max(cc, 0), w - 1) * ld;
+        const double re = Ar[o], im = Ai[o];
+        c[i][a][b] = v ? cz{re, im} : cz{0.0, 0.0};
+      }
+  }
+  int npiv = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    const int b0 = kb >> 1, b1 = (kb + 16) >> 1;          // 2x2-block range of the tile
+    // ---- S1 ----
+#pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+      if (bc[i] < b0 || bc[i] >= b1) continue;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int r = 2 * br[i] + a - kb, cc = 2 * bc[i] + b - kb;
+          if (r + kb >= w || cc >= nb || r < cc) continue;
+          if (r < nb) Ts[r][cc] = c[i][a][b];
+          else Ws[cc][r - nb] = c[i][a][b];
+        }
+    }
+    __syncthreads();
+    // ---- S2: tile factorization by wave 0 (four (ti, tc) pairs per lane, LDS is in order within a wave) ----
+    if (wave == 0) {
+      for (int j = 0; j < nb; j++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        cz d = Ts[j][j];
+        if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (lane == 0) npiv++; }   // ABS_FLOAT = cabs
+        const cz inv = cinv(d);
+        cz nv[4];
+        bool wr[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
+          wr[u] = false;
+          nv[u] = cz{0.0, 0.0};
+          if (ti < nb && tc < nb) {
+            if (tc == j) {
+              if (ti == j) Lo[j][j] = d;
+              else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
+            } else if (tc > j && ti >= tc) {
+              const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tc][j], inv);
+              if (!HERM) nv[u] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));      // GER with alpha = -d (x x^T)
+              else {                                                             // zher: alpha = -Re(d), x x^H
+                cz v = csub(Ts[ti][tc], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));
+                if (ti == tc) v.im = 0.0;
+                nv[u] = v;
+              }
+              wr[u] = true;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();                 // all reads of column j done before the updates land
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
+          if (wr[u]) Ts[ti][tc] = nv[u];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
+        if (ti < nb && tc < nb && ti >= tc) {
+          const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
+          Ar[o] = Lo[ti][tc].re;
+          Ai[o] = Lo[ti][tc].im;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- S3 ----
+    if (tid < 16) {
+      const int cix = tid;
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512;   // [256 re][256 im] per block
+      for (int i = 0; i < 16; i++) {
+        cz x;
+        if (i >= nb || cix >= nb) x = cz{(i == cix) ? 1.0 : 0.0, 0.0};
+        else if (i < cix) x = cz{0.0, 0.0};
+        else {
+          cz sacc = cz{(i == cix) ? 1.0 : 0.0, 0.0};
+          for (int pp = cix; pp < i; pp++) sacc = csub(sacc, cmul(Lo[i][pp], Ti[pp][cix]));
+          x = sacc;
+        }
+        Ti[i][cix] = x;
+      }
+      for (int i = 0; i < 16; i++) { dst[i + 16 * cix] = Ti[i][cix].re; dst[256 + i + 16 * cix] = Ti[i][cix].im; }
+    } else if (tid >= 64 && tid - 64 < rem) {
+      const int rr = tid - 64;
+      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
+      cz x[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) x[cc] = Ws[min(cc, nb - 1)][rr];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        if (cc < nb) {
+          cz sacc = x[cc];
+#pragma unroll
+          for (int pp = 0; pp < 16; pp++)
+            if (pp < cc) sacc = csub(sacc, cmul(x[pp], cj<HERM>(Lo[cc][pp])));
+          x[cc] = sacc;                                    // L*D  (TRSM "R","L","T"|"C","U")
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        if (cc < nb) {
+          const cz v = x[cc];
+          const cz sc = cmul(v, cinv(Lo[cc][cc]));
+          Ws[cc][rr] = v;
+          Xs[cc][rr] = sc;
+          Ar[o0 + (int64_t)cc * ld] = sc.re;
+          Ai[o0 + (int64_t)cc * ld] = sc.im;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- S4 ----
+    if (rem > 0) {
+#pragma unroll
+      for (int i = 0; i < NBLK; i++) {
+        if (bc[i] < b1) continue;                            // (also skips the unused slots, bc = -1)
+        const int r0 = 2 * br[i] - kb - nb, c0 = 2 * bc[i] - kb - nb;
+        cz acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[a][b] = cz{0.0, 0.0};
+        for (int pp = 0; pp < nb; pp++) {
+          cz xa[2], xb[2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            xa[a] = Ws[pp][min(r0 + a, XR - 1)];
+            xb[a] = Xs[pp][min(c0 + a, XR - 1)];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const cz m = cmul(xa[a], cj<HERM>(xb[b]));
+              acc[a][b].re += m.re;
+              acc[a][b].im += m.im;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            c[i][a][b].re -= acc[a][b].re;
+            c[i][a][b].im -= acc[a][b].im;
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+}
+
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv,
                      double critere, long long* nbpivot, int maxw) {
   if (n <= 0) return;
   const dim3 g((unsigned)n), b(256);
-  if (maxw <= 128) {
+  static const bool gen1 = getenv("PASTIX_AMD_ZDIAG_GEN1") != nullptr;
+  if (maxw <= 128 && !gen1) {
+    if (herm) hipLaunchKernelGGL((k_diag_zsy_r<true>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+    else hipLaunchKernelGGL((k_diag_zsy_r<false>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
+  } else if (maxw <= 128) {
     if (herm) hipLaunchKernelGGL((k_diag_zsy<true, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
     else hipLaunchKernelGGL((k_diag_zsy<false, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
   } else {
