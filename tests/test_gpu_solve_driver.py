@@ -439,3 +439,43 @@ def test_z_pastix_entry_point(facto, herm):
     assert np.linalg.norm(Afull @ b - rhs) / np.linalg.norm(rhs) < 1e-11
     assert dparm[px.DPARM["RELATIVE_ERROR"]] < 1e-11 and iparm[px.IPARM["STATIC_PIVOTING"]] == 0
     _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("facto", ["LLT", "LDLT", "LU"])
+def test_pastix_irregular_graph_personal_ordering(facto):
+    """A matrix that is not a grid: random sparse symmetric pattern (about 8 entries per row plus a few dense-ish
+    rows), reverse Cuthill-McKee ordering handed over as API_ORDER_PERSONAL.  Exercises the symbolic stand-in and
+    the plan on irregular supernodes (long skinny bloks, wide banded fronts)."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = 4000
+    rng = np.random.default_rng(77)
+    i = rng.integers(0, n, 4 * n)
+    j = np.clip(i + rng.integers(-60, 61, 4 * n), 0, n - 1)          # mostly local coupling ...
+    far = rng.integers(0, n, n // 20)
+    i = np.concatenate([i, far]); j = np.concatenate([j, rng.integers(0, n, n // 20)])   # ... and some long-range
+    P = sp.coo_matrix((rng.standard_normal(len(i)), (i, j)), shape=(n, n)).tocsr()
+    P = P + P.T
+    A = (P + sp.diags(np.abs(P).sum(axis=1).A1 + 1.0)).tocsc()       # symmetric, diagonally dominant -> SPD
+    if facto == "LU":
+        A = (A + sp.triu(P, 1).multiply(0.3)).tocsc()                # unsymmetric values, symmetric pattern
+    A.sort_indices()
+    rcm = reverse_cuthill_mckee(sp.csr_matrix(A), symmetric_mode=True).astype(np.int64)   # new -> old
+    invp = rcm + 1
+    perm = np.empty(n, dtype=np.int64)
+    perm[rcm] = np.arange(1, n + 1)
+    M = A if facto == "LU" else sp.tril(A).tocsc()
+    cp, r, v = M.indptr.astype(np.int64) + 1, M.indices.astype(np.int64) + 1, M.data.copy()
+    x0 = rng.standard_normal(n)
+    b = A @ x0
+    rhs = b.copy()
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if facto == "LU" else px.API_SYM_YES
+    iparm[px.IPARM["ORDERING"]] = px.API_ORDER_PERSONAL
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK["SOLVE"]
+    pd = px.pastix(None, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    assert np.linalg.norm(A @ b - rhs) / np.linalg.norm(rhs) < 1e-11
+    assert np.abs(b - x0).max() <= 1e-9 * np.abs(x0).max()
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
+    px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
