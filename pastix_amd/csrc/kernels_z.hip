@@ -884,8 +884,8 @@ __global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, c
 // in REGISTERS for the whole kernel (2x2 complex blocks, nine per thread, loaded once with coalesced reads); every
 // 16-column step exchanges only the tile and the panel below it through LDS:
 //   S1  owners put the 16x16 diagonal tile (Ts) and the rows below it (Ws, raw) into LDS
-//   S2  wave 0 factors the tile in LDS without workgroup barriers (PASTIX_sytrf / hetrf, compute_diag.c:223-242,
-//       326-345), stores it
+//   S2  the tile is factorized in LDS, one (row, column) pair per thread and one barrier per column (PASTIX_sytrf /
+//       hetrf, compute_diag.c:223-242, 326-345), and stored
 //   S3  lanes 0-15 of wave 0 invert the unit-lower tile for the panel kernel (dinv_ws) while waves 1-3 solve the
 //       rows below (thread per row): Ws = L D, Xs = L, L stored
 //   S4  every thread updates the blocks it owns right of the step: C -= (L D) L^T (L^H) from Ws / Xs
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
   double* Ar = ar.p[0] + tk.off;
   double* Ai = ar.p[2] + tk.off;
   const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int nb2 = (w + 1) >> 1, nblk = nb2 * (nb2 + 1) / 2;
   // ---- block ownership: q = tid + 256 i -> (br, bc), packed lower by columns; load ----
   int br[NBLK], bc[NBLK];
@@ -953,55 +953,33 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
         }
     }
     __syncthreads();
-    // ---- S2: tile factorization by wave 0 (four (ti, tc) pairs per lane, LDS is in order within a wave) ----
-    if (wave == 0) {
+    // ---- S2: tile factorization, one (ti, tj) pair per thread, one barrier per column (PASTIX_sytrf / hetrf) ----
+    {
+      const int ti = tid & 15, tj = tid >> 4;
       for (int j = 0; j < nb; j++) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
         cz d = Ts[j][j];
-        if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (lane == 0) npiv++; }   // ABS_FLOAT = cabs
+        if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // ABS_FLOAT = cabs
         const cz inv = cinv(d);
-        cz nv[4];
-        bool wr[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
-          wr[u] = false;
-          nv[u] = cz{0.0, 0.0};
-          if (ti < nb && tc < nb) {
-            if (tc == j) {
-              if (ti == j) Lo[j][j] = d;
-              else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
-            } else if (tc > j && ti >= tc) {
-              const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tc][j], inv);
-              if (!HERM) nv[u] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));      // GER with alpha = -d (x x^T)
-              else {                                                             // zher: alpha = -Re(d), x x^H
-                cz v = csub(Ts[ti][tc], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));
-                if (ti == tc) v.im = 0.0;
-                nv[u] = v;
-              }
-              wr[u] = true;
+        if (ti < nb && tj < nb) {
+          if (tj == j) {
+            if (ti == j) Lo[j][j] = d;
+            else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
+          } else if (tj > j && ti >= tj) {                        // (column j is not written in step j)
+            const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tj][j], inv);
+            if (!HERM) Ts[ti][tj] = csub(Ts[ti][tj], cmul(xi, cmul(d, xc)));     // GER with alpha = -d (x x^T)
+            else {                                                                 // zher: alpha = -Re(d), x x^H
+              cz v = csub(Ts[ti][tj], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));
+              if (ti == tj) v.im = 0.0;
+              Ts[ti][tj] = v;
             }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();                 // all reads of column j done before the updates land
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
-          if (wr[u]) Ts[ti][tc] = nv[u];
-        }
+        __syncthreads();
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int id = lane + 64 * u, ti = id & 15, tc = id >> 4;
-        if (ti < nb && tc < nb && ti >= tc) {
-          const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
-          Ar[o] = Lo[ti][tc].re;
-          Ai[o] = Lo[ti][tc].im;
-        }
+      if (ti < nb && tj < nb && ti >= tj) {
+        const int64_t o = (kb + ti) + (int64_t)(kb + tj) * ld;
+        Ar[o] = Lo[ti][tj].re;
+        Ai[o] = Lo[ti][tj].im;
       }
     }
     __syncthreads();
