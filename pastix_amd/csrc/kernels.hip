@@ -171,6 +171,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     // two instantiations: tasks on a full 128 x 128 tile keep the branch-free loop
     auto fast_loop = [&](auto fullt_c) {
     constexpr bool FULLT = decltype(fullt_c)::value;
+    // (wave-uniform copy: the k-line tests and the per-wave operand offsets go to the scalar unit.  Not row0 / col0:
+    // with scalar band masks the edge-tile variant branches per MFMA and the kernel spills)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ---- leading full pieces, LDS-DMA version: every wave copies KC/NW k-lines of A and of B per chunk with
     // global_load_lds_dwordx4 (no staging registers, no ds_write), the MFMA operands are double-buffered in
     // registers so that the ds_reads of k-step s+1 are in flight under the MFMAs of k-step s, and the chunk
