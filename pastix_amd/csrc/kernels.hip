@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
   if (tk.nfull > 0) {
     // two instantiations: tasks on a full 128 x 128 tile keep the branch-free loop
-    auto fast_loop = [&](auto fullt_c) {
+    auto fast_loop = [&](auto fullt_c, auto neg_c) {
     constexpr bool FULLT = decltype(fullt_c)::value;
+    constexpr bool NEG = decltype(neg_c)::value;   // the task has "+=" pieces (complex cross terms): sign flips compiled in
     // (wave-uniform copy: the k-line tests and the per-wave operand offsets go to the scalar unit.  Not row0 / col0:
     // with scalar band masks the edge-tile variant branches per MFMA and the kernel spills)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #endif
       const double* sA = sAw + buf * (2 * KC * SLD);
       const double* sB = sBw + buf * (2 * KC * SLD);
-      if (negc) {
+      if (NEG && negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
       }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
             if ((amt >> mi) & (ant >> ni) & 1u)
               acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
       }
-      if (negc) {
+      if (NEG && negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
       }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
             if ((amt >> mi) & (ant >> ni) & 1u)
               acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
       }
-      if (negc) {
+      if (NEG && negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
       }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
             if ((amt >> mi) & (ant >> ni) & 1u)
               acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
       }
-      if (negc) {
+      if (NEG && negc) {
 #pragma unroll
         for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
       }
@@ -369,8 +370,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     }
     __syncthreads();         // the general loop below restarts on buffer 0
     };
-    if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{});
-    else fast_loop(std::false_type{});
+    // four instantiations: full 128 x 128 tile or not (branch-free MFMA section), with or without sign flips (Task
+    // flag bit 3, set by the plan; real factorizations never have them: 16 vector instructions per chunk less)
+    if (tk.flags & 8u) {
+      if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{}, std::true_type{});
+      else fast_loop(std::false_type{}, std::true_type{});
+    } else {
+      if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{}, std::false_type{});
+      else fast_loop(std::false_type{}, std::false_type{});
+    }
   }
   if ((int)tk.nfull < tk.pn) {
   int pi = tk.p0 + (int)tk.nfull;

@@ -39,7 +39,8 @@ struct Task {
   int32_t ldc;
   uint16_t tm, tn;    // valid extent of the tile (<= TM, TN)
   int32_t p0, pn;     // piece range
-  uint32_t flags;     // bits 0-1: arena of C, bit 2: combine with atomics (tile shared by several tasks)
+  uint32_t flags;     // bits 0-1: arena of C, bit 2: combine with atomics (tile shared by several tasks),
+                      // bit 3: some of the leading full pieces are "+=" pieces (Piece flag 16)
   uint32_t nfull;     // the first nfull pieces are full 128x128 tiles with K % 16 == 0 (specialized loop)
 };
 static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
