@@ -255,8 +255,18 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #elif defined(EXP_DMA_HALF)
           PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
 #else
-          PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
-          PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+          if (FULLT) {                     // kv is wave-uniform: a scalar branch instead of 64-bit vector selects
+            if (kv) {
+              PASTIX_AMD_GLDS(pa + (int64_t)q * NW * lda, dA + NW * q * SLD);
+              PASTIX_AMD_GLDS(pb + (int64_t)q * NW * lda, dB + NW * q * SLD);
+            } else {
+              PASTIX_AMD_GLDS(zl, dA + NW * q * SLD);
+              PASTIX_AMD_GLDS(zl, dB + NW * q * SLD);
+            }
+          } else {
+            PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+            PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+          }
 #endif
         }
         krem -= KC;
