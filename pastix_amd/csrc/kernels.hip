@@ -188,12 +188,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     Piece cur = pieces[pi];
     Piece nextp = pieces[min(pi + 1, pend - 1)];
     int64_t lda = cur.lda;
-    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda + 2 * lane;
-    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda + 2 * lane;
+    // (wave-uniform pointers: the address arithmetic of the DMA stays on the scalar unit, the lane's 16 bytes are the
+    // vector offset of the load)
+    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+    const int lo2 = 2 * lane;
     int left = ((int)cur.k + KC - 1) / KC;
     int krem = (int)cur.k;                          // k-lines of the piece not yet issued
     bool negn = (cur.flags & 16) != 0, negc = negn;
-    const double* zl = g_zero_line + 2 * lane;
+    const double* zl = g_zero_line;
     // These pieces cover the whole VALID tile: tm x tn, smaller than 128 x 128 only for the last row tile of a panel
     // and for target cblks narrower than 128 columns.  Lanes beyond tm / tn copy the zero line; with an odd tm
     // (tn) the last lane brings one element of the next panel row along, which only reaches accumulator rows
@@ -208,8 +211,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #pragma unroll
     for (int q = 0; q < NL; q++) {
       const bool kv = wave + NW * q < krem;        // wave-uniform
-      PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, sh[0][0] + (wave + NW * q) * SLD);
-      PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, sh[0][1] + (wave + NW * q) * SLD);
+      PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, sh[0][0] + (wave + NW * q) * SLD);
+      PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * NW * lda : zl) + lo2, sh[0][1] + (wave + NW * q) * SLD);
     }
     krem -= KC;
     touched = amt | (ant << 4);
@@ -229,8 +232,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         if (++pi < pend) {
           cur = nextp;
           lda = cur.lda;
-          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda + 2 * lane;
-          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda + 2 * lane;
+          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
           left = ((int)cur.k + KC - 1) / KC;
           krem = (int)cur.k;
           negn = (cur.flags & 16) != 0;
@@ -250,22 +253,22 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
         for (int q = 0; q < NL; q++) {
           const bool kv = wave + NW * q < krem;
 #if defined(EXP_DMA_ZERO)
-          PASTIX_AMD_GLDS(zl, dA + NW * q * SLD);
-          PASTIX_AMD_GLDS(zl, dB + NW * q * SLD);
+          PASTIX_AMD_GLDS(zl + lo2, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS(zl + lo2, dB + NW * q * SLD);
 #elif defined(EXP_DMA_HALF)
-          PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
+          PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, dA + NW * q * SLD);
 #else
           if (FULLT) {                     // kv is wave-uniform: a scalar branch instead of 64-bit vector selects
             if (kv) {
-              PASTIX_AMD_GLDS(pa + (int64_t)q * NW * lda, dA + NW * q * SLD);
-              PASTIX_AMD_GLDS(pb + (int64_t)q * NW * lda, dB + NW * q * SLD);
+              PASTIX_AMD_GLDS(pa + (int64_t)q * NW * lda + lo2, dA + NW * q * SLD);
+              PASTIX_AMD_GLDS(pb + (int64_t)q * NW * lda + lo2, dB + NW * q * SLD);
             } else {
-              PASTIX_AMD_GLDS(zl, dA + NW * q * SLD);
-              PASTIX_AMD_GLDS(zl, dB + NW * q * SLD);
+              PASTIX_AMD_GLDS(zl + lo2, dA + NW * q * SLD);
+              PASTIX_AMD_GLDS(zl + lo2, dB + NW * q * SLD);
             }
           } else {
-            PASTIX_AMD_GLDS((kv && la) ? pa + (int64_t)q * NW * lda : zl, dA + NW * q * SLD);
-            PASTIX_AMD_GLDS((kv && lb) ? pb + (int64_t)q * NW * lda : zl, dB + NW * q * SLD);
+            PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, dA + NW * q * SLD);
+            PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * NW * lda : zl) + lo2, dB + NW * q * SLD);
           }
 #endif
         }
