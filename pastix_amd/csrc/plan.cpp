@@ -136,11 +136,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // chunk size: contributions into one tile are applied in groups whose accumulated inner
   // dimension reaches `chunk_k` (<=0: default 512; 1: every source on its own = right-looking;
   // huge: one group per tile = left-looking)
-  // Default: 512 (max 8 pieces per task) for small problems where parallelism is scarce, 2048 (16) for
-  // large ones where the tile read-modify-write and task prologue/epilogue matter more
-  // (measured at 200^3 on MI355X: 512 -> 7.81 s, 1024 -> 7.57 s, 2048 -> 7.53 s; at 100^3 512 is best).
-  const bool big = fact_flops(L, factotype, floattype) > 5e13;
-  if (P.opts.lookahead <= 0) P.opts.lookahead = big ? 2048 : 512;
+  // Default: 512 (max 8 pieces per task) for small problems where parallelism is scarce, 1024 from 1e12 flop,
+  // 2048 (16) for large ones where the tile read-modify-write and task prologue/epilogue matter more
+  // (MI355X: 200^3 512 -> 7.81 s, 1024 -> 7.57 s, 2048 -> 7.53 s; 100^3 512 -> 0.1580 s, 1024 -> 0.1553 s;
+  // 130^3 512 -> 0.6015 s, 1024 -> 0.5873 s; 60^3 512 -> 19.6 ms, 1024 -> 20.2 ms).
+  const double fl_total = fact_flops(L, factotype, floattype);
+  const bool big = fl_total > 5e13;
+  if (P.opts.lookahead <= 0) P.opts.lookahead = big ? 2048 : fl_total > 1e12 ? 1024 : 512;
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
   const int max_pieces = getenv("PASTIX_AMD_MAXPIECES") ? atoi(getenv("PASTIX_AMD_MAXPIECES")) : (big ? 16 : 8);
   const int64_t nc = L->cblknbr;
