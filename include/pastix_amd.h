@@ -68,7 +68,7 @@ typedef struct pastix_amd_options_s {
   int lookahead;         /* chunk size of the update schedule: contributions into one 128x128 target
                             tile are applied in groups whose accumulated inner dimension reaches this
                             value; 1 = every source separately (right-looking), huge = once per tile
-                            (left-looking); <=0 = default (512, or 2048 for factorizations above 5e13 flop) */
+                            (left-looking); <=0 = default (512, 1024 from 1e12 flop, 2048 above 5e13 flop) */
   int verbose;
   int external_arena;    /* 1: do not allocate the panel arena; the caller provides device memory with
                             pastix_amd_plan_set_arena (e.g. a torch tensor used with torch.distributed) */
