@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--blocksize", type=int, default=128)
     ap.add_argument("--chunk", type=int, default=0, help="update-schedule chunk (0 = engine default)")
     ap.add_argument("--facto", choices=["llt", "ldlt", "lu"], default="llt")
-    ap.add_argument("--cpu-sample-grid", type=int, default=70)
+    ap.add_argument("--cpu-sample-grid", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
