@@ -61,6 +61,53 @@ def cpu_baseline(sample_grid, threads):
             "sample": "oracle restatement (plain C, no BLAS), 3-D Laplacian %d^3 dLLt" % N}
 
 
+def engine_source_sha():
+    """Identity of the code the HBM-traffic counters were collected on: sha256 over the engine sources that shape
+    k_update and its schedule.  profiles/*/traffic_k_update.json records it (tools/profile_round.sh); a traffic
+    figure measured on other sources is stale and is reported as null."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "plan.cpp", "plan.h", "api.cpp"):
+        with open(os.path.join(ROOT, "pastix_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(grid, facto, blocksize):
+    """PMC-measured HBM bytes of the bulk k_update launches of one factorization of this workload, from the newest
+    profiles/rNN/traffic_k_update.json collected on exactly these engine sources; else None."""
+    import glob
+    sha = engine_source_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_k_update.json")), reverse=True):
+        try:
+            tj = json.load(open(f))
+            e = tj.get(str(grid))
+            if e and e.get("source_sha") == sha and facto == "llt" and blocksize == 128:
+                return e["bytes_per_factorization"], os.path.relpath(f, ROOT)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` (N>1) outside a launcher: start N ranks (one per GPU, RCCL) with torch.distributed.run
+    as a CHILD process -- before this process has made any GPU call -- and leave with its exit code."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()          # (does not initialise the GPU)
+    if ndev < a.gpus and os.environ.get("PASTIX_AMD_DIST_TEST") != "1":
+        raise SystemExit("bench.py: --gpus %d but this box has %d GPU(s); refusing to report a %d-GPU number "
+                         "(PASTIX_AMD_DIST_TEST=1 time-slices one GPU over gloo for validation only)"
+                         % (a.gpus, ndev, a.gpus))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.stderr.write("bench.py: launching %d ranks: %s\n" % (a.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,10 +121,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        # n_gpus in the JSON line is the number of ranks that ran; a mismatch would mislabel the measurement
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run "
+                         "--nproc-per-node %d, or run `python bench.py --gpus %d` and let it launch the ranks)"
+                         % (a.gpus, world, a.gpus, a.gpus))
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -86,6 +142,8 @@ def main():
     dist_test = os.environ.get("PASTIX_AMD_DIST_TEST") == "1"
     if dist_test:
         local = local % torch.cuda.device_count()
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) on this box: one rank per GPU" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -166,13 +224,11 @@ def main():
     if rank == 0:
         K = a.steps
         value = res["flops"] * K / res["wall"] * 1e-9
-        traffic = None
-        try:   # PMC-measured bytes per k_update launch for this workload (profiles/r01, see its _doc)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic_k_update.json")))
-            if a.gpus == 1 and a.facto == "llt" and a.blocksize == 128 and str(a.grid) in tj:
-                traffic = tj[str(a.grid)]["bytes_per_factorization"]
-        except Exception:  # noqa: BLE001
-            traffic = None
+        # HBM bytes of the bulk kernel from separate --pmc passes (tools/profile_round.sh); only a measurement taken
+        # on exactly these engine sources counts, anything else is stale -> null
+        traffic, traffic_src = (None, None)
+        if world == 1:
+            traffic, traffic_src = measured_traffic(a.grid, a.facto, a.blocksize)
         # Dominant kernel: k_update<8,0>, the bulk contribution launches.  achieved = its flops / the sum of its
         # launches' durations (HIP events around every launch, on the stream it is launched on) = what
         # rocprofv3 --kernel-trace --stats reports for that kernel.  The few urgent tasks of every level run as
@@ -183,14 +239,14 @@ def main():
         busy_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
         out = {
             "metric": "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": a.gpus, "steps": K, "warmup": a.warmup,
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": round(res["wall"] / K * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D 7-point Laplacian %d^3 (n=%d), double %s, geometric ND, max blocksize %d"
                                    % (a.grid, res["n"], a.facto, a.blocksize),
                        "cblknbr": res["cblk"], "bloknbr": res["blok"], "nnzL": res["nnzl"],
                        "fact_flops": res["flops"], "parallelism": res["parallelism"],
-                       "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * a.gpus) * 100, 2),
+                       "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * world) * 100, 2),
                        "fact_time_s_per_step": round(res["fact_time"] / K, 4),
                        "residual": res["resid"], "solve_s": round(res["solve_s"], 4) if "solve_s" in res else None, "logdet_rel_err": res.get("logdet_rel_err"),
                        "static_pivots": res["nbpivot"],
@@ -200,6 +256,7 @@ def main():
                          "peak": MFMA_F64_PEAK * 1e-12, "unit": "TFLOP/s",
                          "frac": round(upd_rate / MFMA_F64_PEAK, 4),
                          "traffic": None if traffic is None else traffic / max(res["nlaunch"], 1),
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) * (bulk_flops / max(res["update_flops"], 1.0)) / max(res["nlaunch"], 1),
                          "launches_per_step": res["nlaunch"],
                          "avg_launch_ms": round(ut_sum / K / max(res["nlaunch"], 1) * 1e3, 4),
@@ -217,7 +274,7 @@ def main():
                             "unit": "GB/s", "frac": round(sb / res["solve_dev_s"] / 8e12, 4),
                             "device_s": round(res["solve_dev_s"], 4), "host_to_host_s": round(res["solve_s"], 4),
                             "panel_bytes_per_solve": sb, "nrhs": 1}
-        if a.gpus == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_grid, min(os.cpu_count() or 1, 64))
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1083,6 +1083,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (p->distributed || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (!p->factored) return PASTIX_AMD_ERR_BADPARAMETER;       // panels hold no factors (refill / upload since)
   HIPCHK(hipSetDevice(p->device));
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)H.cblknbr);
@@ -1118,19 +1119,29 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     std::vector<DevBlok> bl((size_t)H.bloknbr);
     for (int64_t b = 0; b < H.bloknbr; b++)
       bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
-    int r;
-    if ((r = to_device(&p->dSolve, st))) return r;
-    if ((r = to_device(&p->dBlok, bl))) return r;
-    if ((r = to_device(&p->dChunk, ch))) return r;
-    if ((r = to_device(&p->dChunkB, chB))) return r;
-    {
-      int64_t* droff = nullptr;
+    // built into locals and published only when complete: a failed build leaves the plan without solve tables
+    SolveTask* dS = nullptr; DevBlok* dB = nullptr; SolveChunk *dC = nullptr, *dCB = nullptr; int32_t* dR = nullptr;
+    int64_t* droff = nullptr;
+    auto build = [&]() -> int {
+      int r;
+      if ((r = to_device(&dS, st))) return r;
+      if ((r = to_device(&dB, bl))) return r;
+      if ((r = to_device(&dC, ch))) return r;
+      if ((r = to_device(&dCB, chB))) return r;
       if ((r = to_device(&droff, roff))) return r;
-      HIPCHK(hipMalloc((void**)&p->dRidx, (size_t)std::max<int64_t>(roff[H.cblknbr], 1) * sizeof(int32_t)));
-      launch_solve_rowidx(p->stream, p->dSolve, H.cblknbr, droff, p->dBlok, p->dRidx);
+      HIPCHK(hipMalloc((void**)&dR, (size_t)std::max<int64_t>(roff[H.cblknbr], 1) * sizeof(int32_t)));
+      launch_solve_rowidx(p->stream, dS, H.cblknbr, droff, dB, dR);
       HIPCHK(hipStreamSynchronize(p->stream));
-      HIPCHK(hipFree(droff));
+      HIPCHK(hipGetLastError());
+      return 0;
+    };
+    const int rb = build();
+    (void)hipFree(droff);
+    if (rb) {
+      (void)hipFree(dS); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dCB); (void)hipFree(dR);
+      return rb;
     }
+    p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
   }
   if (p->cplx) {
     // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device

@@ -123,6 +123,22 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
   const bool herm = CPLX && (iparm[IPARM_SYM] == API_SYM_HER || facto == PASTIX_AMD_FACT_LDLH);   // mirrored entries conjugated
   if (iparm[IPARM_DOF_NBR] != 1) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
   int rc;
+  // IPARM_BASEVAL = colptr[0] (pastix.c:1671-1678): the steps below index a 1-based CSC; a 0-based one is rebased
+  // into a private copy (perm / invp / the Schur list stay in the caller's base, kass.c:143-156)
+  const int64_t base0 = colptr ? colptr[0] : 1;
+  std::vector<pastix_amd_int_t> cp1, rw1;
+  if (colptr && row && base0 != 1) {
+    if (base0 != 0) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
+    try {
+      cp1.assign(colptr, colptr + n + 1);
+      rw1.assign(row, row + (colptr[n] - base0));
+    } catch (const std::bad_alloc&) { FAIL(PASTIX_AMD_ERR_ALLOC); }
+    for (auto& v : cp1) v += 1 - base0;
+    for (auto& v : rw1) v += 1 - base0;
+    colptr = cp1.data();
+    row = rw1.data();
+  }
+  if (colptr) iparm[IPARM_BASEVAL] = base0;
 
   for (int task = first; task <= last; task++) {
     switch (task) {
@@ -136,7 +152,7 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         D->invp.assign((size_t)n, 0);
         if (iparm[IPARM_ORDERING] == API_ORDER_PERSONAL) {
           if (!perm) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
-          const int64_t base = colptr[0];            // "same base as the CSC" (kass.c:143-156)
+          const int64_t base = base0;                // "same base as the CSC" (kass.c:143-156)
           for (int64_t i = 0; i < n; i++) D->perm[i] = perm[i] - base;
         } else if (D->grid[0] * D->grid[1] * D->grid[2] == n) {
           rc = pastix_amd_order_grid(D->grid[0], D->grid[1], D->grid[2], 8, D->perm.data(), D->invp.data());
@@ -147,7 +163,7 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         D->schur_on = iparm[IPARM_SCHUR] == API_YES && !D->schur_list.empty();
         if (D->schur_on) {
           // isolate the listed unknowns at the end, keeping the relative order of everything (pastix.c:1404-1540)
-          const int64_t base = colptr[0], ns = (int64_t)D->schur_list.size();
+          const int64_t base = base0, ns = (int64_t)D->schur_list.size();
           std::vector<char> is_s((size_t)n, 0);
           for (int64_t u : D->schur_list) {
             if (u - base < 0 || u - base >= n || is_s[u - base]) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
@@ -169,9 +185,10 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         if (D->schur_on) {
           // the Schur complement is dense: couple the isolated unknowns pairwise in the pattern handed to the
           // symbolic step, which then keeps them as one unsplit cblk (schur_n)
-          const int64_t base = colptr[0], ns = (int64_t)D->schur_list.size();
+          const int64_t ns = (int64_t)D->schur_list.size();
           std::vector<int64_t> sl(D->schur_list);
-          for (auto& u : sl) u -= base;
+          for (auto& u : sl) u -= base0;
+          const int64_t base = 1;                    // (colptr / row are 1-based here, see above)
           std::sort(sl.begin(), sl.end());
           std::vector<char> is_s((size_t)n, 0);
           for (int64_t u : sl) is_s[u] = 1;
@@ -193,7 +210,7 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         pastix_amd_symbol_perm(D->sym, &p, &ip);
         D->perm.assign(p, p + n);
         D->invp.assign(ip, ip + n);
-        const int64_t base = colptr[0];
+        const int64_t base = base0;
         if (perm) for (int64_t i = 0; i < n; i++) perm[i] = D->perm[i] + base;    // pastix.c:1734
         if (invp) for (int64_t i = 0; i < n; i++) invp[i] = D->invp[i] + base;
         pastix_amd_int_t info[8];
@@ -230,7 +247,7 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         const double critere = eps < 0 ? -eps : nrm * std::sqrt(eps);
         rc = pastix_amd_fill_csc(D->plan, sym, n, colptr, row, avals, D->perm.data());
         if (rc) FAIL(rc);
-        pastix_amd_stats_t st;
+        pastix_amd_stats_t st{};
         rc = pastix_amd_factorize(D->plan, critere, &st);
         dparm[DPARM_FACT_TIME] = st.fact_time;           // sopalin3d.c:1125-1132
         iparm[IPARM_STATIC_PIVOTING] = st.nbpivot;        // pastix.c:3853

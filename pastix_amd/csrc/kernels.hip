@@ -20,8 +20,12 @@
 // segments for the read-modify-write of the tile).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "plan.h"
 #include "devmath.h"
@@ -1465,6 +1469,24 @@ void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n,
     hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device
+// ordinal).  A failure is reported and the launch skipped (the error surfaces through hipGetLastError in the caller).
+static bool dyn_lds_attr_once(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return true;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    fprintf(stderr, "pastix_amd: hipFuncSetAttribute(dynamic LDS %d B) failed on device %d: %s\n", bytes, dev, hipGetErrorString(e));
+    return false;
+  }
+  done.insert({fn, dev});
+  return true;
+}
+
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
 template <int MODE, int NR>
 static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
@@ -1473,20 +1495,12 @@ static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* t
   // MODE 1 turns the blok through dynamic LDS sized for the widest cblk of the level
   const size_t smem = MODE == 1 ? (size_t)lvlw * (lvlw | 1) * sizeof(double) : 0;
   if (maxw <= 128 && !onewave && NR == 1) {            // one right-hand side: the copy without the systolic loop
-    static bool attr = false;
-    if (MODE == 1 && !attr) {
-      (void)hipFuncSetAttribute((const void*)k_solve_diag_q1<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
-      attr = true;
-    }
+    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE>, 128 * 129 * 8)) return;
     hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, unit);
     return;
   }
   if (maxw <= 128 && !onewave) {
-    static bool attr = false;
-    if (MODE == 1 && !attr) {
-      (void)hipFuncSetAttribute((const void*)k_solve_diag_q<MODE, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 129 * 8);
-      attr = true;
-    }
+    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
     hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
     return;
   }

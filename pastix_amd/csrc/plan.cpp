@@ -296,7 +296,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<std::vector<RawPiece>> traw((size_t)nthr);
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
-  auto gen = [&](int tid) {
+  auto gen_body = [&](int tid) {
     std::vector<RawPiece>& raw = traw[(size_t)tid];
     raw.reserve((size_t)P.bloknbr * 8 / (size_t)nthr + 16);
     double uflops = 0, ubytes = 0;
@@ -412,6 +412,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     tuf[(size_t)tid] = uflops;
     tub[(size_t)tid] = ubytes;
   };
+  // (an exception must not leave a worker thread: std::terminate would take the host process down)
+  auto gen = [&](int tid) {
+    try { gen_body(tid); } catch (const std::bad_alloc&) { terr[(size_t)tid] = PASTIX_AMD_ERR_ALLOC; }
+  };
   {
     std::vector<std::thread> th;
     for (int t = 1; t < nthr; t++) th.emplace_back(gen, t);
@@ -453,9 +457,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     auto bin_of = [&](int64_t tile) { return (int64_t)((__int128)tile * NB / tspan); };
     std::vector<std::vector<int64_t>> cnt((size_t)nthr, std::vector<int64_t>((size_t)NB + 1, 0));
     auto par = [&](auto&& fn) {
+      auto guarded = [&](int t) {
+        try { fn(t); } catch (const std::bad_alloc&) { terr[(size_t)t] = PASTIX_AMD_ERR_ALLOC; }
+      };
       std::vector<std::thread> th;
-      for (int t = 1; t < nthr; t++) th.emplace_back(fn, t);
-      fn(0);
+      for (int t = 1; t < nthr; t++) th.emplace_back(guarded, t);
+      guarded(0);
       for (auto& x : th) x.join();
     };
     par([&](int t) { for (const RawPiece& r : traw[(size_t)t]) cnt[(size_t)t][(size_t)bin_of(r.tile)]++; });
@@ -481,6 +488,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       }
     });
   }
+  for (int t = 0; t < nthr; t++) if (terr[(size_t)t]) return terr[(size_t)t];
   phase("piece sort");
   P.pieces.resize(raw.size());
   {
@@ -741,13 +749,18 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     if (order_mode == 0 || order_mode == 2) {
       for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
     } else {
+      // the urgent tasks [slot_task_ptr, slot_urgent_end) and the bulk of a slot are launched separately by the
+      // two-stream driver (api.cpp): interleave each range on its own so that the split points stay valid
       for (int s = 0; s < NL; s++) {
-        const int64_t b0 = P.slot_task_ptr[s], n = P.slot_task_ptr[s + 1] - b0;
-        const int64_t q8 = n / 8, r8 = n % 8;        // XCD x gets q8 + (x < r8) tasks
-        int64_t pos = 0;
-        for (int64_t x = 0; x < 8; x++) {
-          const int64_t cnt = q8 + (x < r8 ? 1 : 0);
-          for (int64_t j = 0; j < cnt; j++) sorted[b0 + j * 8 + x] = P.tasks[idx[b0 + pos++]];
+        const int64_t cuts[3] = {P.slot_task_ptr[s], P.slot_urgent_end[s], P.slot_task_ptr[s + 1]};
+        for (int part = 0; part < 2; part++) {
+          const int64_t b0 = cuts[part], n = cuts[part + 1] - b0;
+          const int64_t q8 = n / 8, r8 = n % 8;        // XCD x gets q8 + (x < r8) tasks
+          int64_t pos = 0;
+          for (int64_t x = 0; x < 8; x++) {
+            const int64_t cnt = q8 + (x < r8 ? 1 : 0);
+            for (int64_t j = 0; j < cnt; j++) sorted[b0 + j * 8 + x] = P.tasks[idx[b0 + pos++]];
+          }
         }
       }
     }

@@ -44,3 +44,22 @@ def test_bad_layout_rejected(golden):
     assert rc == -6 and not h
     rc = _lib.lib().pastix_amd_plan_create(None, 0, 1, None, ctypes.byref(h))
     assert rc == -1
+
+
+def test_bench_refuses_to_mislabel_the_gpu_count():
+    """bench.py --gpus N: N ranks run or it exits non-zero BEFORE printing a line -- never `n_gpus` != ranks that ran."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # (a) launcher's world size disagrees with --gpus
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+    # (b) no launcher and fewer GPUs than ranks (this container has none): refuses instead of running one rank
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
