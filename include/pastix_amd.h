@@ -200,11 +200,12 @@ int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t 
  * when a contribution starts or ends on an odd row. */
 int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);
 /* host-only schedule statistics of one rank (no device needed): per launch slot the update flops, the
- * largest task (multiply-adds), the task count, and per level the panel (diag+trsm) flops */
+ * largest task (multiply-adds), the task count, per level the panel (diag+trsm) flops, and the part of the slot's
+ * flops whose targets are of the slot's own level (the urgent tasks the level's panel kernels wait for) */
 int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
                             const int32_t *owner, int32_t myrank, pastix_amd_int_t maxlevels, double *slot_flops,
                             double *slot_maxwork, pastix_amd_int_t *slot_tasks, double *level_panel_flops,
-                            pastix_amd_int_t *nlevels);
+                            pastix_amd_int_t *nlevels, double *slot_urgent_flops /* may be NULL */);
 int pastix_amd_plan_set_stream(pastix_amd_plan_t *plan, void *hip_stream);     /* run on the caller's stream */
 int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
 /* phase 0: contributions of slot `level` then the owned cblks of `level`; 1: contributions only;

@@ -343,7 +343,7 @@ int pastix_amd_plan_create_dist(const pastix_amd_layout_t* layout, int factotype
 int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, const pastix_amd_options_t* opts,
                             const int32_t* owner, int32_t myrank, pastix_amd_int_t maxlevels, double* slot_flops,
                             double* slot_maxwork, pastix_amd_int_t* slot_tasks, double* level_panel_flops,
-                            pastix_amd_int_t* nlevels) {
+                            pastix_amd_int_t* nlevels, double* slot_urgent_flops) {
   if (!layout || !nlevels) return PASTIX_AMD_ERR_BADPARAMETER;
   Plan P;
   int rc;
@@ -356,6 +356,7 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
   *nlevels = P.nlevels;
   for (int l = 0; l < P.nlevels && l < maxlevels; l++) {
     if (slot_flops) slot_flops[l] = P.slot_flops[l];
+    if (slot_urgent_flops) slot_urgent_flops[l] = P.slot_urgent_flops[l];
     if (slot_maxwork) slot_maxwork[l] = P.slot_maxwork[l];
     if (slot_tasks) slot_tasks[l] = P.slot_task_ptr[l + 1] - P.slot_task_ptr[l];
     if (level_panel_flops) {

@@ -511,6 +511,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   int64_t hist_groups = 0, hist_nonfull = 0;
   int64_t hist_c[3][3] = {{0}};
   P.slot_flops.assign(NL, 0.0);
+  P.slot_urgent_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
@@ -649,7 +650,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     task_work.push_back(work + 4096.0 * double(e - q));
     task_slot.push_back(slot);
     task_urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
-    if (P.level[t] == slot) P.urgent_flops += 2.0 * work;
+    if (P.level[t] == slot) { P.urgent_flops += 2.0 * work; P.slot_urgent_flops[slot] += 2.0 * work; }
     P.slot_task_ptr[slot + 1]++;
     ubytes += 16.0 * double(tk.tm) * double(tk.tn);
     P.slot_flops[slot] += 2.0 * work;

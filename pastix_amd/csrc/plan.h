@@ -126,6 +126,7 @@ struct Plan {
   double update_bytes = 0;               // algorithmic bytes of the update kernel: operands read once per
                                          // piece (8k(m+n)) + one read-modify-write of the tile per task (16 tm tn)
   std::vector<double> slot_flops;        // [nlevels] update flops per slot
+  std::vector<double> slot_urgent_flops; // [nlevels] part of slot_flops in the urgent tasks (targets of level == slot)
   std::vector<int64_t> slot_pieces;      // [nlevels]
   std::vector<int32_t> slot_maxpn;       // [nlevels] longest piece list of a task in the slot
   std::vector<double> slot_maxwork;      // [nlevels] largest task (multiply-adds)

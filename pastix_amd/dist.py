@@ -199,7 +199,7 @@ def fanin_rows(cblk4, blok4, mask, src, t):
 
 
 def plan_profile(cblk4, blok4, owner, rank, chunk=0, maxlevels=100000):
-    """Host-only schedule statistics of one rank: (slot_flops, slot_maxwork, slot_tasks, panel_flops)."""
+    """Host-only schedule statistics of one rank: (slot_flops, slot_maxwork, slot_tasks, panel_flops, slot_urgent_flops)."""
     la = LayoutArrays(cblk4, blok4)
     opts = Options()
     opts.lookahead = chunk
@@ -207,13 +207,15 @@ def plan_profile(cblk4, blok4, owner, rank, chunk=0, maxlevels=100000):
     sm = np.zeros(maxlevels)
     stn = np.zeros(maxlevels, dtype=np.int64)
     pf = np.zeros(maxlevels)
+    uf = np.zeros(maxlevels)
     nl = ctypes.c_int64(0)
     own = np.ascontiguousarray(owner, dtype=np.int32) if owner is not None else None
     check(_lib.lib().pastix_amd_plan_profile(ctypes.byref(la.c), 0, ctypes.byref(opts), _lib.ptr(own),
                                              ctypes.c_int32(rank), ctypes.c_int64(maxlevels), _lib.ptr(sf), _lib.ptr(sm),
-                                             _lib.ptr(stn), _lib.ptr(pf), ctypes.byref(nl)), "pastix_amd_plan_profile")
+                                             _lib.ptr(stn), _lib.ptr(pf), ctypes.byref(nl), _lib.ptr(uf)),
+          "pastix_amd_plan_profile")
     n = nl.value
-    return sf[:n], sm[:n], stn[:n], pf[:n]
+    return sf[:n], sm[:n], stn[:n], pf[:n], uf[:n]
 
 
 class Exchange:

@@ -39,6 +39,12 @@ CASES = [
     # the reference's Harwell-Boeing fixture (oil reservoir, real unsymmetric values on a symmetric pattern): an
     # irregular, non-grid structure under the identity ordering; converted to Matrix Market for the harness
     ("orsirr_1030_lu", "d", "hb", "/root/reference/src/matrix/orsirr.rua", "lu", []),
+    # IPARM_MIN/MAX_BLOCKSIZE 64/128 at 20^3: blend cuts the 609-column root into 4 cblks of 152/153 columns
+    # (splitOnProcs, splitpart.c:431-475: nseq = width / max, pieces of width / nseq), so target panels have whole
+    # 128x128 tiles -- the update kernel's branch-free full-tile loop and multi-piece tasks against the reference itself
+    ("rlap3d_20_llt_bs128", "d", "rlap3d", "20", "llt", ["64", "128"]),
+    ("rlap3d_20_lu_bs128", "d", "rlap3d", "20", "lu", ["64", "128"]),
+    ("zrlap3d_20_ldlt_bs128", "z", "rlap3d", "20", "ldlt", ["64", "128"]),
 ]
 
 

@@ -224,3 +224,46 @@ def test_single_precision_one_shot_tabs(name, golden):
     if utabs is not None:
         assert np.abs(np.concatenate(utabs) - g["U1"]).max() <= 1e-4 * np.abs(g["U1"]).max()
     assert st["nbpivot"] == g["nbpivot"]
+
+
+FAST = ["rlap3d_20_llt_bs128", "rlap3d_20_lu_bs128", "zrlap3d_20_ldlt_bs128"]
+
+
+@pytest.mark.parametrize("lookahead", [1024, 2048])
+@pytest.mark.parametrize("name", FAST)
+def test_fast_path_matches_reference_golden(name, lookahead, golden):
+    """Layouts blend made with IPARM_MAX_BLOCKSIZE 128 (152-column cblks): whole 128x128 target tiles, i.e. the update
+    kernel's branch-free full-tile DMA loop, tasks with several full pieces and the chunk sizes of the large
+    configurations (1024 / 2048) -- compared with the reference's own factors, not with the oracle."""
+    from pastix_amd import COMPLEXDOUBLE, REALDOUBLE
+    g = golden(name)
+    cz = np.iscomplexobj(g["L0"])
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE if cz else REALDOUBLE,
+              lookahead=lookahead) as p:
+        ps = p.stats()
+        assert ps["full_flops"] > 0.15 * ps["update_flops"]         # whole-tile pieces exist (25 % of the update at 20^3)
+        p.upload(g["L0"], g["U0"] if g["facto"] == 2 else None)
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+    m = _lower_mask(g["cblk4"]) if g["facto"] == 1 else np.ones(L1.size, bool)
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    if g["facto"] == 2:
+        assert np.abs(U1 - g["U1"]).max() <= TOL * max(scale, np.abs(g["U1"]).max())
+    assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("order", ["1", "2"])
+@pytest.mark.parametrize("name", ["rlap3d_20_llt_bs128", "rlap3d_12_lu"])
+def test_task_orders_keep_the_urgent_split(name, order, golden, monkeypatch):
+    """PASTIX_AMD_TASK_ORDER=1/2 (XCD-locality orders inside a launch) with the default two-stream driver: the tasks a
+    level's panels wait for must still be the ones launched in front of them."""
+    monkeypatch.setenv("PASTIX_AMD_TASK_ORDER", order)
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.upload(g["L0"], g["U0"] if g["facto"] == 2 else None)
+        p.factorize(g["critere"])
+        L1, U1 = p.download()
+    assert np.abs(L1 - g["L1"]).max() <= TOL * np.abs(g["L1"]).max()
+    if g["facto"] == 2:
+        assert np.abs(U1 - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()

@@ -1,49 +1,114 @@
 #!/usr/bin/env python3
 """Host-only estimate of multi-GPU scaling from the per-rank schedules (no GPU needed).
-Model: a launch of F flops with T tasks whose largest task has W multiply-adds takes
-max(F / R_chip, (2W) / R_wg) + t0, ranks advance in lockstep per level; a level with fan-in traffic adds
-t_msg + (largest per-rank bytes sent or received in that level) / BW_rank."""
-import os, sys, time
+
+Two models of the same plans (pastix_amd_plan_profile per rank + the fan-in messages of dist.py):
+
+  lockstep : round 1's schedule -- all ranks walk the levels together, a level with fan-in traffic adds
+             t_msg + (largest per-rank bytes of the level) / BW_rank.
+  async    : the dependency-driven schedule of the native engine (pastix_amd_factorize_dist): every rank runs its own
+             two streams; per level l on rank q
+                 A(l) = urgent contributions   starts after P(l-1) and B(l-1)              (panel stream)
+                 sends of level-l fan-in blocks leave right after A(l) (one channel per peer: rendezvous with the
+                 owner, which posts the receive after its own A(l); a message costs t_msg + bytes / BW_link)
+                 P(l) = diag + panel solve      starts after A(l) and the arrival (+ add) of every block for level l
+                 B(l) = bulk contributions      starts after P(l-1) and B(l-1)               (second stream)
+             nothing else couples the ranks.
+A launch of F flops whose largest task has W multiply-adds takes max(F / R_chip, 2 W / R_wg) + t0.
+"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-from pastix_amd import symbolic as sy, dist as pd
+import numpy as np  # noqa: E402
+
+from pastix_amd import dist as pd  # noqa: E402
+from pastix_amd import symbolic as sy  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+RANKS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
 R_chip, R_wg, t0 = 60e12, 60e12 / 400, 30e-6
-t_msg, BW_rank = 80e-6, 150e9      # per-level exchange latency; per-rank aggregate xGMI rate assumed (of 7 x 153 GB/s peak)
-n, cp, r, v = sy.laplacian_3d(N); perm, _ = sy.order_grid(N, N, N); s = sy.symbolic(n, cp, r, perm)
+R_panel = R_chip / 4                       # diag + panel-solve kernels
+t_msg = 40e-6                              # per message: launch + rendezvous of a send/recv pair
+BW_link = 120e9                            # one xGMI link, achieved (153 GB/s peak)
+BW_rank = 150e9                            # lockstep model only: per-rank aggregate assumed in round 1
+t_lock = 80e-6                             # lockstep model only: per-level exchange latency
+HBM = 4e12                                 # owner-side add of a received block (read block + RMW panel)
+
+n, cp, r, v = sy.laplacian_3d(N)
+perm, _ = sy.order_grid(N, N, N)
+s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
 c4, b4 = s["cblk4"], s["blok4"]
-base = None
-for P in (1, 2, 4, 8):
+level = pd.levels_of(c4, b4)
+w = (c4[:-1, 1] - c4[:-1, 0] + 1)
+cb = np.repeat(np.arange(len(c4) - 1), np.diff(c4[:, 2]))
+h = b4[:, 1] - b4[:, 0] + 1
+
+
+def launch(F, W):
+    return max(F / R_chip, 2 * W / R_wg) + t0 if F > 0 else 0.0
+
+
+base = {}
+for P in RANKS:
     owner = pd.partition(c4, b4, P)
     per = [pd.plan_profile(c4, b4, owner if P > 1 else None, q) for q in range(P)]
     nl = len(per[0][0])
-    tot = 0.0
+    # messages: (level, sender, owner, bytes)
+    msgs = [[] for _ in range(nl)]
     comm = np.zeros((nl, P, 2))
     if P > 1:
-        level = pd.levels_of(c4, b4)
         mask = pd.fanin_touched(c4, b4, owner)
-        w = (c4[:-1, 1] - c4[:-1, 0] + 1)
-        cb = np.repeat(np.arange(len(c4) - 1), np.diff(c4[:, 2]))
-        h = b4[:, 1] - b4[:, 0] + 1
         for q in range(P):
             byt = 8.0 * h * w[cb] * ((mask >> np.uint64(q)) & np.uint64(1))
-            np.add.at(comm[:, q, 0], level[cb], byt)                       # sent by q at the target's level
-            np.add.at(comm[:, :, 1], (level[cb], owner[cb]), byt)          # received by the owner
-    tcomm = 0.0
+            per_t = np.bincount(cb, weights=byt, minlength=len(w))
+            for t in np.nonzero(per_t)[0]:
+                msgs[level[t]].append((q, int(owner[t]), per_t[t]))
+            np.add.at(comm[:, q, 0], level[cb], byt)
+            np.add.at(comm[:, :, 1], (level[cb], owner[cb]), byt)
+    # ---- lockstep ----
+    tot = tcomm = 0.0
     for l in range(nl):
-        tl = 0.0
         if comm[l].max() > 0:
-            tc = t_msg + comm[l].max() / BW_rank
+            tc = t_lock + comm[l].max() / BW_rank
             tot += tc
             tcomm += tc
-        for sf, sm, stn, pf in per:
-            t = 0.0
-            if stn[l] > 0: t += max(sf[l] / R_chip, 2 * sm[l] / R_wg) + t0
-            if pf[l] > 0: t += pf[l] / (R_chip / 4) + 2 * t0
+        tl = 0.0
+        for sf, sm, stn, pf, uf in per:
+            t = launch(sf[l], sm[l]) if stn[l] > 0 else 0.0
+            if pf[l] > 0:
+                t += pf[l] / R_panel + 2 * t0
             tl = max(tl, t)
         tot += tl
-    if base is None: base = tot
-    print("P=%d levels=%d est time %.4f s (fan-in %.4f s, %.2f GB sent by the busiest rank) speedup %.2f  rank flops share max %.3f" % (
-        P, nl, tot, tcomm, comm[:, :, 0].sum(axis=0).max() * 1e-9, base / tot,
-        max(p[0].sum() for p in per) / sum(p[0].sum() for p in per)), flush=True)
+    # ---- async ----
+    TP = np.zeros(P)      # panel stream: end of P(l-1)
+    TB = np.zeros(P)      # bulk stream: end of B(l-1)
+    wait_msg = np.zeros(P)
+    for l in range(nl):
+        TA = np.zeros(P)
+        for q, (sf, sm, stn, pf, uf) in enumerate(per):
+            a = launch(uf[l], min(sm[l], uf[l] / 2)) if uf[l] > 0 else 0.0
+            TA[q] = max(TP[q], TB[q]) + a if uf[l] > 0 else TP[q]
+        arrive = TA.copy()
+        link_busy = {}
+        for (src, dst, byt) in sorted(msgs[l], key=lambda m: TA[m[0]]):
+            start = max(TA[src], TA[dst], link_busy.get((src, dst), 0.0))
+            end = start + t_msg + byt / BW_link
+            link_busy[(src, dst)] = end
+            arrive[dst] = max(arrive[dst], end + byt * 3 / HBM)
+        for q, (sf, sm, stn, pf, uf) in enumerate(per):
+            b = launch(sf[l] - uf[l], sm[l]) if sf[l] - uf[l] > 0 else 0.0
+            startB = max(TP[q], TB[q])
+            wait_msg[q] += max(0.0, arrive[q] - TA[q]) if pf[l] > 0 else 0.0
+            if pf[l] > 0:
+                TP[q] = max(TA[q], arrive[q]) + pf[l] / R_panel + 2 * t0
+            else:
+                TP[q] = max(TA[q], arrive[q])
+            TB[q] = startB + b if b > 0 else TB[q]
+    tasync = float(max(TP.max(), TB.max()))
+    if P == RANKS[0]:
+        base = {"lock": tot, "async": tasync}
+    print("P=%d levels=%d  lockstep %.4f s (fan-in %.4f s) speedup %.2f | async %.4f s speedup %.2f "
+          "(panel stream waiting for fan-in blocks: max %.4f s) | busiest rank sends %.2f GB, flops share max %.3f"
+          % (P, nl, tot, tcomm, base["lock"] / tot, tasync, base["async"] / tasync, wait_msg.max(),
+             comm[:, :, 0].sum(axis=0).max() * 1e-9, max(p[0].sum() for p in per) / sum(p[0].sum() for p in per)),
+          flush=True)
