@@ -206,6 +206,41 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, co
                             const int32_t *owner, int32_t myrank, pastix_amd_int_t maxlevels, double *slot_flops,
                             double *slot_maxwork, pastix_amd_int_t *slot_tasks, double *level_panel_flops,
                             pastix_amd_int_t *nlevels, double *slot_urgent_flops /* may be NULL */);
+/* ---- multi-GPU driver: asynchronous fan-in over RCCL point-to-point (csrc/dist.cpp) ------------------------------
+ * One process per GPU.  Every rank: plan_create_dist (own arena), fill_csc, then ONCE pastix_amd_dist_attach_rccl,
+ * then pastix_amd_factorize_dist as often as needed (pastix_amd_refill in between).  The reference's counterpart is the
+ * fan-in protocol of sopalin_compute.c:600-733 (accumulate, send when the last local contribution has landed) and
+ * sopalin_sendrecv.c:182-485,1219-1556,2393-2775 (receives posted ahead, the owner adds).  Here a rank's whole
+ * factorization is enqueued on HIP streams -- one channel (2-rank RCCL communicator + stream) per peer -- and the host
+ * never waits for a peer; no collective on the data path. */
+#define PASTIX_AMD_DIST_ID_BYTES 128
+typedef struct pastix_amd_dist_info_s {
+  int32_t world, rank, npeers, nplanes;   /* nplanes: arenas per fan-in block (1 LLt/LDLt, 2 LU or complex, 4 complex LU) */
+  pastix_amd_int_t nsend, nrecv;          /* fan-in blocks per factorization */
+  double bytes_sent, bytes_recv;          /* per factorization */
+  double staging_bytes;                   /* receive staging area */
+  double fanin_buffer_bytes;              /* this rank's fan-in buffers (compact shadow panels), one plane */
+  char transport[16];                     /* "rccl" | "loopback" */
+} pastix_amd_dist_info_t;
+/* an RCCL unique id (ncclGetUniqueId); the job needs one per communicating pair, made on any rank and shipped to both
+ * members out of band (bench.py: torch.distributed) */
+int pastix_amd_dist_unique_id(void *id128);
+/* ids: world*world entries of PASTIX_AMD_DIST_ID_BYTES, entry [a*world + b] for a < b (others unused).  Collective. */
+int pastix_amd_dist_attach_rccl(pastix_amd_plan_t *plan, int32_t world, const void *ids);
+/* the rank plans of ONE process wired to each other (device-to-device copies): single-GPU emulation of a job, used by
+ * the tests to run the same driver where RCCL cannot (one GPU) */
+int pastix_amd_dist_attach_local(pastix_amd_plan_t *const *plans, int32_t world);
+int pastix_amd_dist_info(const pastix_amd_plan_t *plan, pastix_amd_dist_info_t *info);
+int pastix_amd_factorize_dist(pastix_amd_plan_t *plan, double critere, pastix_amd_stats_t *stats);
+/* drives the plans of pastix_amd_dist_attach_local with one host thread per rank; stats / rcs: [world] or NULL */
+int pastix_amd_factorize_dist_local(pastix_amd_plan_t *const *plans, int32_t world, double critere,
+                                    pastix_amd_stats_t *stats, int32_t *rcs);
+/* host only: the fan-in blocks of one rank in the order both ends of every channel issue them, 6 integers each:
+ * {level, peer, cblk, dir (0 send, 1 receive), nrows, width}.  out may be NULL (count only). */
+int pastix_amd_dist_schedule(const pastix_amd_layout_t *layout, int factotype, int floattype, const int32_t *owner,
+                             int32_t myrank, int32_t world, pastix_amd_int_t cap, pastix_amd_int_t *out,
+                             pastix_amd_int_t *nmsg, int32_t *nplanes);
+
 int pastix_amd_plan_set_stream(pastix_amd_plan_t *plan, void *hip_stream);     /* run on the caller's stream */
 int pastix_amd_factorize_begin(pastix_amd_plan_t *plan, double critere);
 /* phase 0: contributions of slot `level` then the owned cblks of `level`; 1: contributions only;

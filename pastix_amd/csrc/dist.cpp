@@ -1,0 +1,553 @@
+// dist.cpp -- multi-GPU numerical factorization: one rank per GPU, elimination-tree subtrees mapped one per GPU,
+// asynchronous fan-in of aggregated contributions over RCCL point-to-point.
+//
+// Reference model.  With several MPI processes PaStiX accumulates the contributions a process makes to a remote
+// cblk in a FanInTarget buffer (add_contrib_target, src/sopalin/src/sopalin_compute.c:600-733: SUBTRACTED into a
+// zero-initialised block), sends the block the moment its last local contribution has landed (:708-729, the
+// communication thread of sopalin_sendrecv.c:2393-2775 with receives posted ahead :1219-1556) and the owner ADDS it
+// into the panel before the cblk is factorized (recv_handle_fanin, sopalin_sendrecv.c:182-485, the add :384-404).
+//
+// Here the whole factorization of a rank is ENQUEUED without the host ever waiting for a peer:
+//   * panel stream (high priority): per level l   A(l) urgent contributions -> adds of the received blocks of level l
+//     -> P(l) diagonal factor + panel solve;   second stream: B(l), the bulk contributions (api.cpp, two-stream split);
+//   * one channel per peer = one 2-rank RCCL communicator + one HIP stream.  The fan-in blocks a rank holds for the
+//     cblks of level l are complete when A(l) is (every older contribution ran in an earlier bulk launch, which A(l)
+//     waits for), so the channel waits for the event recorded behind A(l) and sends; the owner's channel receives into
+//     a staging area and the panel stream waits for that channel's event before it adds.  A rank that only sends never
+//     waits; a rank that receives waits on the device, for exactly the blocks its next panel needs.
+//   * Both ends of a channel issue their operations in the same order -- by (level of the target cblk, peer, cblk) --
+//     and all operations of one (level, peer) form one ncclGroup, so the rendezvous cannot deadlock: everything an
+//     operation waits for was enqueued earlier, on every rank, by induction over the levels.
+// No collective is involved on the data path.  The schedule (which blocks, in which order, which rows) is host logic,
+// exported as pastix_amd_dist_schedule so that the CPU tests replay it over gloo.
+//
+// Transports: RCCL (librccl resolved at run time: dlopen, no link dependency, the copy PyTorch loaded is reused when
+// there is one) and an in-process loopback (several rank plans sharing one GPU, host threads, device-to-device copies)
+// used by the single-GPU tests to run the very same driver.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include "engine.h"
+
+namespace {
+
+// arenas (planes) that receive contributions: L; + U for LU; + the imaginary planes for complex
+int planes_of(int factotype, bool cplx, int out[4]) {
+  int n = 0;
+  out[n++] = 0;
+  if (factotype == PASTIX_AMD_FACT_LU) out[n++] = 1;
+  if (cplx) {
+    out[n++] = 2;
+    if (factotype == PASTIX_AMD_FACT_LU) out[n++] = 3;
+  }
+  return n;
+}
+
+struct DistMsg {
+  int32_t level, peer, cblk, dir;   // dir 0: this rank sends its fan-in block of `cblk` to `peer` (= owner); 1: receives
+  int64_t nrows, width;             // the block is nrows x width per plane, column-major, ld = nrows
+  int64_t off;                      // send: arena offset of the compact fan-in panel; recv: offset in the staging area
+                                    // of plane 0 of this message (plane q follows at + q * nrows * width)
+  int64_t rows_off;                 // recv: first entry of the block's row map (panel row of every block row)
+};
+
+struct DistSchedule {
+  int world = 1, myrank = 0, nplanes = 1;
+  int planes[4] = {0, 0, 0, 0};
+  std::vector<DistMsg> msgs;        // sorted by (level, peer, cblk)
+  std::vector<int32_t> rows;
+  int64_t stage_elems = 0;
+  std::vector<int> peers;           // ascending
+  std::vector<std::pair<int, int>> pairs;   // every communicating pair (a < b) of the whole job, lexicographic
+};
+
+// Deterministic from (layout, owner): every rank derives its own list and, implicitly, the matching one of its peers.
+int build_schedule(const Plan& P, int world, DistSchedule& S) {
+  if (P.owner.empty() || world < 1 || world > 64) return PASTIX_AMD_ERR_BADPARAMETER;
+  const int64_t nc = P.cblknbr;
+  const int me = P.myrank;
+  S.world = world;
+  S.myrank = me;
+  S.nplanes = planes_of(P.factotype, P.floattype == PASTIX_AMD_COMPLEXDOUBLE, S.planes);
+  S.msgs.clear();
+  S.rows.clear();
+  S.stage_elems = 0;
+  std::vector<uint64_t> pairbits((size_t)world, 0);          // pairbits[a] bit b: a sends to b
+  for (int64_t t = 0; t < nc; t++) {
+    const int ot = P.owner[t];
+    if (ot < 0 || ot >= world) return PASTIX_AMD_ERR_BADPARAMETER;
+    uint64_t senders = 0;
+    for (int64_t b = P.cblk[t].bloknum; b < P.cblk[t + 1].bloknum; b++) senders |= P.fanin_mask[b];
+    senders &= ~(1ull << ot);
+    for (int r = 0; r < world; r++)
+      if ((senders >> r) & 1ull) pairbits[(size_t)r] |= 1ull << ot;
+    const int64_t w = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
+    if (ot == me) {
+      for (int r = 0; r < world; r++) {
+        if (!((senders >> r) & 1ull)) continue;
+        DistMsg m{P.level[t], r, (int32_t)t, 1, 0, w, 0, (int64_t)S.rows.size()};
+        for (int64_t b = P.cblk[t].bloknum; b < P.cblk[t + 1].bloknum; b++) {
+          if (!((P.fanin_mask[b] >> r) & 1ull)) continue;
+          const int64_t h = P.blok[b].lrownum - P.blok[b].frownum + 1;
+          for (int64_t i = 0; i < h; i++) S.rows.push_back((int32_t)(P.blok[b].coefind + i));
+          m.nrows += h;
+        }
+        S.msgs.push_back(m);
+      }
+    } else if ((senders >> me) & 1ull) {
+      if (P.role[t] != 2) return PASTIX_AMD_ERR_LAYOUT;
+      S.msgs.push_back(DistMsg{P.level[t], ot, (int32_t)t, 0, P.tstride[t], w, P.poff[t], 0});
+    }
+  }
+  std::sort(S.msgs.begin(), S.msgs.end(), [](const DistMsg& a, const DistMsg& b) {
+    if (a.level != b.level) return a.level < b.level;
+    if (a.peer != b.peer) return a.peer < b.peer;
+    return a.cblk < b.cblk;
+  });
+  for (DistMsg& m : S.msgs)
+    if (m.dir == 1) { m.off = S.stage_elems; S.stage_elems += m.nrows * m.width * S.nplanes; }
+  uint64_t mine = 0;
+  S.pairs.clear();
+  for (int a = 0; a < world; a++)
+    for (int b = a + 1; b < world; b++)
+      if (((pairbits[(size_t)a] >> b) & 1ull) || ((pairbits[(size_t)b] >> a) & 1ull)) {
+        S.pairs.emplace_back(a, b);
+        if (a == me) mine |= 1ull << b;
+        if (b == me) mine |= 1ull << a;
+      }
+  S.peers.clear();
+  for (int r = 0; r < world; r++)
+    if ((mine >> r) & 1ull) S.peers.push_back(r);
+  return PASTIX_AMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transports
+// ------------------------------------------------------------------------------------------------
+struct Transport {
+  virtual ~Transport() {}
+  virtual int group_begin(int peer) = 0;
+  virtual int send(int peer, const double* buf, int64_t count, hipStream_t s) = 0;
+  virtual int recv(int peer, double* buf, int64_t count, hipStream_t s) = 0;
+  virtual int group_end(int peer) = 0;
+  virtual const char* name() const = 0;
+};
+
+// --- RCCL, resolved at run time ---
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // a copy that is already in the process (PyTorch's) first, then the ROCm installation's
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+      if (api.h) break;
+    }
+    for (const char* n : names) {
+      if (api.h) break;
+      api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!api.h) return;
+#define SYM(f) api.f = (decltype(api.f))dlsym(api.h, "nccl" #f)
+    SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart); SYM(GroupEnd);
+    SYM(GetErrorString);
+#undef SYM
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart ||
+        !api.GroupEnd) {
+      dlclose(api.h);
+      api.h = nullptr;
+    }
+  });
+  return api.h ? &api : nullptr;
+}
+
+#define NCCLCHK(x)                                                                                     \
+  do {                                                                                                 \
+    ncclResult_t r_ = (x);                                                                             \
+    if (r_ != ncclSuccess) {                                                                           \
+      fprintf(stderr, "pastix_amd: RCCL error '%s' at %s:%d\n",                                        \
+              rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "?", __FILE__, __LINE__); \
+      return PASTIX_AMD_ERR_DEVICE;                                                                    \
+    }                                                                                                  \
+  } while (0)
+
+struct RcclTransport : Transport {
+  int me = 0;
+  std::map<int, ncclComm_t> comm;     // per peer: a 2-rank communicator (rank 0 = the lower job rank)
+  ~RcclTransport() override {
+    if (RcclApi* a = rccl())
+      for (auto& c : comm) if (c.second) (void)a->CommDestroy(c.second);
+  }
+  int group_begin(int) override { NCCLCHK(rccl()->GroupStart()); return 0; }
+  int group_end(int) override { NCCLCHK(rccl()->GroupEnd()); return 0; }
+  int send(int peer, const double* buf, int64_t count, hipStream_t s) override {
+    NCCLCHK(rccl()->Send(buf, (size_t)count, ncclDouble, me < peer ? 1 : 0, comm[peer], s));
+    return 0;
+  }
+  int recv(int peer, double* buf, int64_t count, hipStream_t s) override {
+    NCCLCHK(rccl()->Recv(buf, (size_t)count, ncclDouble, me < peer ? 1 : 0, comm[peer], s));
+    return 0;
+  }
+  const char* name() const override { return "rccl"; }
+};
+
+// --- loopback: rank plans of one process share a GPU; a send publishes (event, pointer), the matching receive -- the
+// k-th receive from a peer matches that peer's k-th send, as on an in-order channel -- waits for the event on its own
+// stream and copies device to device.  Test infrastructure for the driver on single-GPU boxes. ---
+struct LocalHub {
+  std::mutex mu;
+  std::condition_variable cv;
+  struct Posted { hipEvent_t ev; const double* ptr; int64_t count; };
+  std::map<std::pair<int, int>, std::deque<Posted>> q;     // (src, dst) -> posted sends
+  std::vector<hipEvent_t> pool;                            // all events ever made (destroyed with the hub)
+  bool failed = false;
+  ~LocalHub() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+
+struct LocalTransport : Transport {
+  std::shared_ptr<LocalHub> hub;
+  int me = 0;
+  int group_begin(int) override { return 0; }
+  int group_end(int) override { return 0; }
+  int send(int peer, const double* buf, int64_t count, hipStream_t s) override {
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, s));
+    {
+      std::lock_guard<std::mutex> g(hub->mu);
+      hub->pool.push_back(ev);
+      hub->q[{me, peer}].push_back(LocalHub::Posted{ev, buf, count});
+    }
+    hub->cv.notify_all();
+    return 0;
+  }
+  int recv(int peer, double* buf, int64_t count, hipStream_t s) override {
+    LocalHub::Posted p;
+    {
+      std::unique_lock<std::mutex> g(hub->mu);
+      auto& dq = hub->q[{peer, me}];
+      hub->cv.wait(g, [&] { return !dq.empty() || hub->failed; });
+      if (hub->failed) return PASTIX_AMD_ERR_DEVICE;
+      p = dq.front();
+      dq.pop_front();
+    }
+    if (p.count != count) return PASTIX_AMD_ERR_LAYOUT;       // the two ends disagree on the schedule
+    HIPCHK(hipStreamWaitEvent(s, p.ev, 0));
+    HIPCHK(hipMemcpyAsync(buf, p.ptr, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  const char* name() const override { return "loopback"; }
+};
+
+}  // namespace
+
+// state a distributed plan carries once a transport is attached
+struct pastix_amd_dist_s {
+  DistSchedule S;
+  std::unique_ptr<Transport> T;
+  std::map<int, hipStream_t> chan;          // per peer
+  double* dStage = nullptr;
+  int32_t* dRows = nullptr;
+  std::vector<hipEvent_t> events;           // pool reused by every factorization (grown on demand)
+  size_t nev_used = 0;
+  double bytes_sent = 0, bytes_recv = 0;
+  int64_t nsend = 0, nrecv = 0;
+};
+
+static void dist_free(pastix_amd_dist_s* D) {
+  if (!D) return;
+  for (auto& c : D->chan) if (c.second) { (void)hipStreamSynchronize(c.second); (void)hipStreamDestroy(c.second); }
+  D->T.reset();
+  (void)hipFree(D->dStage);
+  (void)hipFree(D->dRows);
+  for (hipEvent_t e : D->events) (void)hipEventDestroy(e);
+  delete D;
+}
+
+static int dist_attach_common(pastix_amd_plan_t* p, int world, std::unique_ptr<Transport> T, DistSchedule&& S) {
+  std::unique_ptr<pastix_amd_dist_s, void (*)(pastix_amd_dist_s*)> D(new (std::nothrow) pastix_amd_dist_s(), dist_free);
+  if (!D) return PASTIX_AMD_ERR_ALLOC;
+  (void)world;
+  D->S = std::move(S);
+  D->T = std::move(T);
+  HIPCHK(hipSetDevice(p->device));
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  for (int peer : D->S.peers) {
+    hipStream_t s = nullptr;
+    HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));   // like the panel stream: between the bulk workgroups
+    D->chan[peer] = s;
+  }
+  HIPCHK(hipMalloc((void**)&D->dStage, (size_t)std::max<int64_t>(D->S.stage_elems, 1) * sizeof(double)));
+  int r;
+  if ((r = to_device(&D->dRows, D->S.rows))) return r;
+  for (const DistMsg& m : D->S.msgs) {
+    const double b = 8.0 * (double)m.nrows * (double)m.width * D->S.nplanes;
+    if (m.dir == 0) { D->bytes_sent += b; D->nsend++; } else { D->bytes_recv += b; D->nrecv++; }
+  }
+  if (p->dist) p->dist_free(p->dist);
+  p->dist = D.release();
+  p->dist_free = dist_free;
+  return PASTIX_AMD_OK;
+}
+
+extern "C" {
+
+// Host only: the fan-in messages of one rank, in the order both ends of every channel issue them.
+// out[i*6 .. i*6+5] = {level, peer, cblk, dir (0 send / 1 recv), nrows, width}; returns the count through *nmsg
+// (out may be NULL to size it; at most `cap` messages are written).  *nplanes = arenas per message.
+int pastix_amd_dist_schedule(const pastix_amd_layout_t* layout, int factotype, int floattype, const int32_t* owner,
+                             int32_t myrank, int32_t world, pastix_amd_int_t cap, pastix_amd_int_t* out,
+                             pastix_amd_int_t* nmsg, int32_t* nplanes) {
+  if (!layout || !owner || !nmsg || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1)
+    return PASTIX_AMD_ERR_BADPARAMETER;
+  try {
+    Plan P;
+    P.factotype = factotype;
+    P.floattype = floattype;
+    P.cblknbr = layout->cblknbr;
+    P.bloknbr = layout->bloknbr;
+    P.cblk.assign(layout->cblktab, layout->cblktab + layout->cblknbr + 1);
+    P.blok.assign(layout->bloktab, layout->bloktab + layout->bloknbr);
+    int rc = owner_view(layout, owner, myrank, P);
+    if (rc) return rc;
+    DistSchedule S;
+    if ((rc = build_schedule(P, world, S))) return rc;
+    *nmsg = (pastix_amd_int_t)S.msgs.size();
+    if (nplanes) *nplanes = S.nplanes;
+    if (out)
+      for (size_t i = 0; i < S.msgs.size() && (pastix_amd_int_t)i < cap; i++) {
+        const DistMsg& m = S.msgs[i];
+        pastix_amd_int_t* o = out + 6 * i;
+        o[0] = m.level; o[1] = m.peer; o[2] = m.cblk; o[3] = m.dir; o[4] = m.nrows; o[5] = m.width;
+      }
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_dist_unique_id(void* id128) {
+  if (!id128) return PASTIX_AMD_ERR_BADPARAMETER;
+  RcclApi* a = rccl();
+  if (!a) { fprintf(stderr, "pastix_amd: librccl not found\n"); return PASTIX_AMD_ERR_DEVICE; }
+  static_assert(sizeof(ncclUniqueId) == PASTIX_AMD_DIST_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  NCCLCHK(a->GetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return PASTIX_AMD_OK;
+}
+
+// ids: world x world x 128 bytes; entry [a * world + b], a < b, made by pastix_amd_dist_unique_id on ANY one rank and
+// distributed out of band (bench.py: all_gather over torch.distributed).  Collective over the job: every rank calls it,
+// pairs are initialised in lexicographic order on both of their members.
+int pastix_amd_dist_attach_rccl(pastix_amd_plan_t* p, int32_t world, const void* ids) {
+  if (!p || !ids || !p->distributed || world < 2) return PASTIX_AMD_ERR_BADPARAMETER;
+  RcclApi* a = rccl();
+  if (!a) { fprintf(stderr, "pastix_amd: librccl not found\n"); return PASTIX_AMD_ERR_DEVICE; }
+  DistSchedule S;
+  int rc = build_schedule(p->host, world, S);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(p->device));
+  std::unique_ptr<RcclTransport> T(new (std::nothrow) RcclTransport());
+  if (!T) return PASTIX_AMD_ERR_ALLOC;
+  T->me = S.myrank;
+  for (auto& pr : S.pairs) {
+    if (pr.first != S.myrank && pr.second != S.myrank) continue;
+    const int peer = pr.first == S.myrank ? pr.second : pr.first;
+    ncclUniqueId id;
+    std::memcpy(&id, (const char*)ids + ((size_t)pr.first * world + pr.second) * PASTIX_AMD_DIST_ID_BYTES, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCLCHK(a->CommInitRank(&c, 2, id, S.myrank == pr.first ? 0 : 1));
+    T->comm[peer] = c;
+  }
+  return dist_attach_common(p, world, std::move(T), std::move(S));
+}
+
+// Test / single-box emulation: `world` rank plans of ONE process (typically sharing one GPU) are wired to each other.
+int pastix_amd_dist_attach_local(pastix_amd_plan_t* const* plans, int32_t world) {
+  if (!plans || world < 2) return PASTIX_AMD_ERR_BADPARAMETER;
+  std::shared_ptr<LocalHub> hub;
+  try { hub = std::make_shared<LocalHub>(); } catch (const std::bad_alloc&) { return PASTIX_AMD_ERR_ALLOC; }
+  for (int r = 0; r < world; r++) {
+    pastix_amd_plan_t* p = plans[r];
+    if (!p || !p->distributed || p->host.myrank != r) return PASTIX_AMD_ERR_BADPARAMETER;
+    DistSchedule S;
+    int rc = build_schedule(p->host, world, S);
+    if (rc) return rc;
+    std::unique_ptr<LocalTransport> T(new (std::nothrow) LocalTransport());
+    if (!T) return PASTIX_AMD_ERR_ALLOC;
+    T->hub = hub;
+    T->me = r;
+    if ((rc = dist_attach_common(p, world, std::move(T), std::move(S)))) return rc;
+  }
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_dist_info(const pastix_amd_plan_t* p, pastix_amd_dist_info_t* info) {
+  if (!p || !info || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
+  const pastix_amd_dist_s* D = p->dist;
+  std::memset(info, 0, sizeof(*info));
+  info->world = D->S.world;
+  info->rank = D->S.myrank;
+  info->npeers = (int32_t)D->S.peers.size();
+  info->nplanes = D->S.nplanes;
+  info->nsend = D->nsend;
+  info->nrecv = D->nrecv;
+  info->bytes_sent = D->bytes_sent;
+  info->bytes_recv = D->bytes_recv;
+  info->staging_bytes = 8.0 * (double)D->S.stage_elems;
+  double fb = 0;
+  const Plan& H = p->host;
+  for (int64_t k = 0; k < H.cblknbr; k++) if (H.role[k] == 2) fb += 8.0 * (double)(H.poff[k + 1] - H.poff[k]);
+  info->fanin_buffer_bytes = fb;
+  std::strncpy(info->transport, D->T->name(), sizeof(info->transport) - 1);
+  return PASTIX_AMD_OK;
+}
+
+// The numerical factorization of this rank's share (the device replacement of sopalin_smp + the communication thread,
+// sopalin3d.c:790-1025, sopalin_sendrecv.c:2393-2775).  Everything is enqueued; the host waits only at the end.
+int pastix_amd_factorize_dist(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
+  if (!p || !p->distributed || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
+  pastix_amd_dist_s* D = p->dist;
+  const DistSchedule& S = D->S;
+  const Plan& H = p->host;
+  int rc = pastix_amd_factorize_begin(p, critere);
+  if (rc) return rc;
+  hipStream_t s1 = p->stream;
+  D->nev_used = 0;
+  auto new_event = [&](hipEvent_t* out) -> int {
+    if (D->nev_used == D->events.size()) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      D->events.push_back(e);
+    }
+    *out = D->events[D->nev_used++];
+    return 0;
+  };
+  double* const arena[4] = {p->dL, p->dU, p->dLi, p->dUi};
+  size_t mi = 0;
+  const size_t nm = S.msgs.size();
+  for (int l = 0; l < H.nlevels; l++) {
+    if ((rc = pastix_amd_factorize_level(p, l, 1))) return rc;            // A(l) on the panel stream, B(l) beside it
+    const size_t m0 = mi;
+    while (mi < nm && S.msgs[mi].level == l) mi++;
+    if (mi > m0) {
+      bool any_send = false;
+      for (size_t i = m0; i < mi; i++) any_send |= S.msgs[i].dir == 0;
+      hipEvent_t evA = nullptr;
+      if (any_send) {
+        if ((rc = new_event(&evA))) return rc;
+        HIPCHK(hipEventRecord(evA, s1));                                    // this rank's blocks for level l are complete
+      }
+      for (size_t g0 = m0; g0 < mi;) {                                      // one group per peer
+        size_t g1 = g0;
+        const int peer = S.msgs[g0].peer;
+        bool gs = false, gr = false;
+        while (g1 < mi && S.msgs[g1].peer == peer) { (S.msgs[g1].dir == 0 ? gs : gr) = true; g1++; }
+        hipStream_t cs = D->chan[peer];
+        if (gs) HIPCHK(hipStreamWaitEvent(cs, evA, 0));
+        if ((rc = D->T->group_begin(peer))) return rc;
+        for (size_t i = g0; i < g1; i++) {
+          const DistMsg& m = S.msgs[i];
+          const int64_t cnt = m.nrows * m.width;
+          for (int q = 0; q < S.nplanes; q++) {
+            if (m.dir == 0) rc = D->T->send(peer, arena[S.planes[q]] + m.off, cnt, cs);
+            else rc = D->T->recv(peer, D->dStage + m.off + q * cnt, cnt, cs);
+            if (rc) { (void)D->T->group_end(peer); return rc; }
+          }
+        }
+        if ((rc = D->T->group_end(peer))) return rc;
+        if (gr) {
+          hipEvent_t evC;
+          if ((rc = new_event(&evC))) return rc;
+          HIPCHK(hipEventRecord(evC, cs));
+          HIPCHK(hipStreamWaitEvent(s1, evC, 0));                           // the panel stream needs these blocks now
+        }
+        g0 = g1;
+      }
+      // recv_handle_fanin (sopalin_sendrecv.c:384-404): the owner ADDS the aggregated blocks, in a fixed order
+      for (size_t i = m0; i < mi; i++) {
+        const DistMsg& m = S.msgs[i];
+        if (m.dir != 1) continue;
+        const int64_t cnt = m.nrows * m.width;
+        for (int q = 0; q < S.nplanes; q++)
+          launch_fanin_add(s1, arena[S.planes[q]] + H.poff[m.cblk], H.cblk[m.cblk].stride, D->dStage + m.off + q * cnt,
+                           D->dRows + m.rows_off, m.nrows, m.width);
+      }
+    }
+    if ((rc = pastix_amd_factorize_level(p, l, 2))) return rc;            // P(l)
+  }
+  // the channels join the panel stream: every send has left before the caller may zero the fan-in buffers again
+  for (auto& c : D->chan) {
+    hipEvent_t e;
+    if ((rc = new_event(&e))) return rc;
+    HIPCHK(hipEventRecord(e, c.second));
+    HIPCHK(hipStreamWaitEvent(s1, e, 0));
+  }
+  return pastix_amd_factorize_end(p, stats);
+}
+
+// Single-process emulation of a whole job: the rank plans (attached with pastix_amd_dist_attach_local) are driven by
+// one host thread each, exactly as separate processes would drive them.  rcs[r] / stats[r] per rank (may be NULL).
+int pastix_amd_factorize_dist_local(pastix_amd_plan_t* const* plans, int32_t world, double critere,
+                                    pastix_amd_stats_t* stats, int32_t* rcs) {
+  if (!plans || world < 2) return PASTIX_AMD_ERR_BADPARAMETER;
+  for (int r = 0; r < world; r++)
+    if (!plans[r] || !plans[r]->dist) return PASTIX_AMD_ERR_BADPARAMETER;
+  std::vector<int> rc((size_t)world, 0);
+  std::vector<std::thread> th;
+  auto run = [&](int r) {
+    try {
+      rc[(size_t)r] = pastix_amd_factorize_dist(plans[r], critere, stats ? stats + r : nullptr);
+    } catch (...) {
+      rc[(size_t)r] = PASTIX_AMD_ERR_ALLOC;
+    }
+    if (rc[(size_t)r] && rc[(size_t)r] != PASTIX_AMD_ERR_NUMERIC) {
+      // release peers blocked in a loopback receive
+      if (auto* lt = dynamic_cast<LocalTransport*>(plans[r]->dist->T.get())) {
+        { std::lock_guard<std::mutex> g(lt->hub->mu); lt->hub->failed = true; }
+        lt->hub->cv.notify_all();
+      }
+    }
+  };
+  try {
+    for (int r = 1; r < world; r++) th.emplace_back(run, r);
+  } catch (...) {
+    for (auto& t : th) t.join();
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  run(0);
+  for (auto& t : th) t.join();
+  int first = 0;
+  for (int r = 0; r < world; r++) {
+    if (rcs) rcs[r] = rc[(size_t)r];
+    if (!first && rc[(size_t)r]) first = rc[(size_t)r];
+  }
+  return first;
+}
+
+}  // extern "C"

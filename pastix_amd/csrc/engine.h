@@ -1,0 +1,135 @@
+// engine.h -- internal: the plan object behind pastix_amd_plan_t and the kernel launchers (kernels*.hip) shared by the
+// translation units of the engine (api.cpp: life cycle, transfers, single-GPU driver, solves; dist.cpp: the
+// multi-GPU fan-in driver).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+#include "plan.h"
+
+namespace pastix_amd {
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
+                   bool urgent);
+void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int maxw);
+void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
+                         const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, const int32_t* ridx, double* xr,
+                         double* xi, int maxw);
+void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi);
+void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src, const int32_t* rows, int64_t nrows,
+                      int64_t ncols);
+void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int maxw);
+void launch_trsm_zlu(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
+void launch_trsm_zsy(hipStream_t s, bool herm, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv,
+                     int maxw);
+void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n);
+void launch_merge(hipStream_t s, double* z, const double* re, const double* im, int64_t n);
+void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                     long long* nbpivot, int* errflag, int maxw);
+void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
+void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
+void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                      long long* nbpivot);
+void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
+                    double critere, long long* nbpivot);
+void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                      int maxw);
+void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
+                    int maxw);
+void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
+void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
+                         const DevBlok* bl, int32_t* ridx);
+void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
+}  // namespace pastix_amd
+
+using namespace pastix_amd;
+
+static constexpr size_t ARENA_PAD = 256;
+
+// see build_split below
+struct SplitMap {
+  bool active = false;
+  int64_t ocblknbr = 0;
+  std::vector<int64_t> first;                    // [ocblknbr+1] index of the first sub-cblk of an original cblk
+  std::vector<int64_t> owidth, ostride, ooff;    // original width, stride, offset in the packed original arena
+  std::vector<pastix_amd_cblk_t> cblk;           // the split layout
+  std::vector<pastix_amd_blok_t> blok;
+};
+
+struct pastix_amd_dist_s;            // dist.cpp: fan-in schedule, channels, transport
+
+struct pastix_amd_plan_s {
+  Plan host;
+  pastix_amd_dist_s* dist = nullptr;
+  void (*dist_free)(pastix_amd_dist_s*) = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;      // second stream: non-urgent contributions overlap the panel kernels
+  std::vector<hipEvent_t> evP, evB;   // per level: panels done (stream), bulk contributions done (stream2)
+  std::vector<hipEvent_t> evT;        // timing pairs of the bulk launches
+  int nupdB_run = 0;
+  bool own_stream = true, own_arena = true, distributed = false, overlapped = false;
+  int overlap_mode = 0;
+  bool staged_overlap = false;        // two streams behind the level-stepped API (distributed plans)
+  int staged_lastB = -1;
+  int nupd_run = 0;
+  double crit_run = 0;
+  double* dL = nullptr;      // L  (real part)
+  double* dU = nullptr;      // U / L*D (real part)
+  double* dLi = nullptr;     // imaginary planes (complex double only)
+  double* dUi = nullptr;
+  bool cplx = false;
+  Arenas arenas() const { return Arenas{{dL, dU, dLi, dUi}}; }
+  double* dDinv = nullptr;
+  Task* dTasks = nullptr;
+  Piece* dPieces = nullptr;
+  PanelTask* dPanel = nullptr;
+  TrsmTask* dTrsm = nullptr;
+  long long* dNbpivot = nullptr;
+  int* dErr = nullptr;
+  int maxw = 0;
+  double* dXws = nullptr;              // solve workspace (right-hand sides on the device), kept between calls
+  size_t nXws = 0;
+  SplitMap split;                      // cblks wider than MAXW are factorized in column groups (build_split)
+  bool factored = false;               // panels hold factors (set by factorize, cleared by upload / fill)
+  // cached coefficient fill (destinations + values) so that a re-fill is device-only
+  int64_t* dFillIdxL = nullptr; double* dFillValL = nullptr; int64_t nFillL = 0;
+  double* dFillValLi = nullptr;   // imaginary parts (complex)
+  double* dFillValUi = nullptr;
+  int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
+  SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
+  std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
+  std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
+  std::vector<hipEvent_t> ev;      // event pairs around update launches
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  pastix_amd_stats_t stats{};
+};
+
+#define HIPCHK(x)                                                                        \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "pastix_amd: HIP error '%s' at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? PASTIX_AMD_ERR_ALLOC : PASTIX_AMD_ERR_DEVICE;   \
+    }                                                                                    \
+  } while (0)
+
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T, class A>
+static inline int to_device(T** d, const std::vector<T, A>& h) {
+  size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  HIPCHK(hipMalloc((void**)d, bytes));
+  if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+

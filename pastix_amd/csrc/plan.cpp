@@ -117,6 +117,64 @@ int fanin_touched(const pastix_amd_layout_t* L, const int32_t* owner, uint64_t* 
   return PASTIX_AMD_OK;
 }
 
+// Ownership view of a layout for one rank (multi-GPU fan-in): owned cblks are factorized here; a remote
+// cblk that receives contributions from an owned source gets a zero-initialised shadow panel in which the (negated)
+// local contributions are accumulated (add_contrib_target, sopalin_compute.c:600-733).  Shadow panels are COMPACT:
+// only the bloks this rank contributes into (fanin_touched), packed in blok order with their own leading dimension.
+// Fills role, tstride, tcoef, poff, fanin_mask, owner, myrank and the dependency levels from P.cblk / P.blok / P.opts.
+int owner_view(const pastix_amd_layout_t* L, const int32_t* owner, int32_t myrank, Plan& P) {
+  const int64_t nc = P.cblknbr;
+  int rc;
+  P.myrank = owner ? myrank : 0;
+  P.owner.clear();
+  if (owner) P.owner.assign(owner, owner + nc);
+  P.role.assign(nc, owner ? 0 : 1);
+  if (owner) {
+    for (int64_t k = 0; k < nc; k++) if (owner[k] == myrank) P.role[k] = 1;
+    for (int64_t k = 0; k < nc; k++) {
+      if (P.role[k] != 1) continue;
+      for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
+        if (P.role[P.blok[b].cblknum] == 0) P.role[P.blok[b].cblknum] = 2;
+    }
+  }
+  P.tstride.resize(nc);
+  P.tcoef.resize(P.bloknbr);
+  for (int64_t k = 0; k < nc; k++) P.tstride[k] = P.cblk[k].stride;
+  for (int64_t b = 0; b < P.bloknbr; b++) P.tcoef[b] = P.blok[b].coefind;
+  P.fanin_mask.clear();
+  if (owner) {
+    P.fanin_mask.assign((size_t)P.bloknbr, 0);
+    if ((rc = fanin_touched(L, owner, P.fanin_mask.data()))) return rc;
+    const std::vector<uint64_t>& mask = P.fanin_mask;
+    for (int64_t t = 0; t < nc; t++) {
+      if (P.role[t] != 2) continue;
+      int64_t off = 0;
+      for (int64_t b = P.cblk[t].bloknum; b < P.cblk[t + 1].bloknum; b++) {
+        if ((mask[b] >> myrank) & 1ull) { P.tcoef[b] = off; off += P.blok[b].lrownum - P.blok[b].frownum + 1; }
+        else P.tcoef[b] = -1;
+      }
+      P.tstride[t] = off;
+    }
+  }
+  P.poff.resize(nc + 1);
+  P.poff[0] = 0;
+  for (int64_t k = 0; k < nc; k++) {
+    int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+    if (w > MAXW && !(P.opts.schur && k == nc - 1)) return PASTIX_AMD_ERR_UNSUPPORTED;
+    if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
+    P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.tstride[k] * w : 0);
+  }
+  // dependency levels: cblk t can be factorized once every source cblk with a blok facing it has been
+  P.level.assign(nc, 0);
+  for (int64_t k = 0; k < nc; k++)
+    for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++) {
+      int64_t t = P.blok[b].cblknum;
+      P.level[t] = std::max(P.level[t], P.level[k] + 1);
+    }
+  P.nlevels = 1 + *std::max_element(P.level.begin(), P.level.end());
+  return PASTIX_AMD_OK;
+}
+
 int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& P) {
   int rc = check_layout(L);
@@ -150,18 +208,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.bloknbr = L->bloknbr;
   P.cblk.assign(L->cblktab, L->cblktab + nc + 1);
   P.blok.assign(L->bloktab, L->bloktab + L->bloknbr);
-  // ownership (multi-GPU fan-in): owned cblks are factorized here; a remote cblk that
-  // receives contributions from an owned source gets a zero-initialised shadow panel in which the
-  // (negated) local contributions are accumulated (add_contrib_target, sopalin_compute.c:600-733)
-  P.role.assign(nc, owner ? 0 : 1);
-  if (owner) {
-    for (int64_t k = 0; k < nc; k++) if (owner[k] == myrank) P.role[k] = 1;
-    for (int64_t k = 0; k < nc; k++) {
-      if (P.role[k] != 1) continue;
-      for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
-        if (P.role[P.blok[b].cblknum] == 0) P.role[P.blok[b].cblknum] = 2;
-    }
-  }
+  if ((rc = owner_view(L, owner, myrank, P))) return rc;
   // cblks that receive contributions from more than one rank ("shared"): their contributions are
   // scheduled left-looking with a window (see below): a source older than `window` levels before the target
   // contributes in the bulk launch `window` levels ahead of the target (second stream, off the critical
@@ -173,33 +220,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++)
         if (owner[k] != owner[P.blok[b].cblknum]) shared[P.blok[b].cblknum] = 1;
   const int window = getenv("PASTIX_AMD_WINDOW") ? atoi(getenv("PASTIX_AMD_WINDOW")) : 4;
-  // target-side layout: owned panels as given; shadow panels COMPACT -- only the bloks this rank contributes
-  // into (fanin_touched), packed in blok order with their own leading dimension
-  P.tstride.resize(nc);
-  P.tcoef.resize(P.bloknbr);
-  for (int64_t k = 0; k < nc; k++) P.tstride[k] = P.cblk[k].stride;
-  for (int64_t b = 0; b < P.bloknbr; b++) P.tcoef[b] = P.blok[b].coefind;
-  if (owner) {
-    std::vector<uint64_t> mask((size_t)P.bloknbr);
-    if ((rc = fanin_touched(L, owner, mask.data()))) return rc;
-    for (int64_t t = 0; t < nc; t++) {
-      if (P.role[t] != 2) continue;
-      int64_t off = 0;
-      for (int64_t b = P.cblk[t].bloknum; b < P.cblk[t + 1].bloknum; b++) {
-        if ((mask[b] >> myrank) & 1ull) { P.tcoef[b] = off; off += P.blok[b].lrownum - P.blok[b].frownum + 1; }
-        else P.tcoef[b] = -1;
-      }
-      P.tstride[t] = off;
-    }
-  }
-  P.poff.resize(nc + 1);
-  P.poff[0] = 0;
-  for (int64_t k = 0; k < nc; k++) {
-    int64_t w = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-    if (w > MAXW && !(P.opts.schur && k == nc - 1)) return PASTIX_AMD_ERR_UNSUPPORTED;
-    if (P.cblk[k].stride > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
-    P.poff[k + 1] = P.poff[k] + (P.role[k] ? P.tstride[k] * w : 0);
-  }
   P.coefnbr = P.poff[nc];
   P.ncol = P.cblk[nc - 1].lcolnum + 1;
   P.fact_flops = fact_flops(L, factotype, floattype);
@@ -218,15 +238,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tph = tnow();
   auto phase = [&](const char* name) { if (ptime) { double t = tnow(); fprintf(stderr, "[plan] %-28s %.2f s\n", name, t - tph); tph = t; } };
-  // ---- dependency levels -----------------------------------------------------------------
-  P.level.assign(nc, 0);
-  for (int64_t k = 0; k < nc; k++)
-    for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++) {
-      int64_t t = P.blok[b].cblknum;
-      P.level[t] = std::max(P.level[t], P.level[k] + 1);
-    }
-  P.nlevels = 1 + *std::max_element(P.level.begin(), P.level.end());
-  const int NL = P.nlevels;
+  const int NL = P.nlevels;             // (dependency levels: owner_view)
 
   // cblks by level
   P.lvl_cblk_ptr.assign(NL + 1, 0);

@@ -98,6 +98,9 @@ struct Plan {
   std::vector<int64_t> poff;             // panel offsets [cblknbr+1] (absent cblks have size 0)
   std::vector<int8_t> role;              // per cblk: 1 owned (factorized here), 2 shadow (fan-in
                                          // accumulator for a remote cblk), 0 absent
+  std::vector<int32_t> owner;            // [cblknbr] rank that factorizes the cblk (empty on one GPU)
+  int32_t myrank = 0;
+  std::vector<uint64_t> fanin_mask;      // [bloknbr] fanin_touched (empty on one GPU)
   double local_flops = 0;                // fact_flops restricted to owned cblks
   std::vector<int32_t> level;            // dependency level of each cblk
   int32_t nlevels = 0;
@@ -141,6 +144,7 @@ struct Plan {
 int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
+int owner_view(const pastix_amd_layout_t* layout, const int32_t* owner, int32_t myrank, Plan& plan);
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
 int fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask);
 

@@ -3,19 +3,19 @@ contributions over point-to-point messages.
 
 Reference model: proportional mapping + fan-in of PaStiX (`FanInTarget`, src/blend/src/ftgt.h:67-113;
 `add_contrib_target`, src/sopalin/src/sopalin_compute.c:600-733: local contributions are SUBTRACTED into a
-zero-initialised buffer; `recv_handle_fanin`, src/sopalin/src/sopalin_sendrecv.c:384-389: the owner ADDS
-the received block).  Here every rank holds one plan over the same layout
-(`pastix_amd_plan_create_dist`): its owned panels plus "shadow" panels for the remote cblks it
-contributes to.  All ranks walk the dependency levels in lockstep:
+zero-initialised buffer and the buffer is sent when its last local contribution has landed;
+`recv_handle_fanin`, src/sopalin/src/sopalin_sendrecv.c:384-389: the owner ADDS the received block).
 
-    for l in levels:
-        update(l)                      # contributions scheduled into slot l (into owned or shadow panels)
-        exchange shadows of the cblks of level l  (one message per (sender, cblk), RCCL send/recv)
-        owner adds the received blocks
-        panels(l)                      # diagonal factor + panel solve of the owned cblks of level l
+The product path is the native driver (`pastix_amd_factorize_dist`, csrc/dist.cpp; `DistPlan` below): every rank
+holds one plan over the same layout -- its owned panels plus compact fan-in buffers for the remote cblks it contributes
+to -- and enqueues its whole factorization on HIP streams, one RCCL channel per peer; the host never waits for a peer
+and there is no collective on the data path.  This module adds what sits around it: the partition (proportional
+mapping), the bootstrap of the RCCL channels over torch.distributed, bench.py's N>1 leg, and a Python mirror of the
+driver's message schedule (`factorize_scheduled`) that the CPU tests run over gloo with a numpy engine.
 
-There is no collective on the data path.  The orchestration is engine-agnostic (GPU engine below; the
-CPU tests drive the same code with a numpy engine over gloo).
+`factorize_levels` / `GpuEngine` / `TorchTransport` are round 1's lockstep protocol over torch.distributed; it is
+kept as the validation path for boxes with fewer GPUs than ranks (PASTIX_AMD_DIST_TEST=1: ranks time-slice one GPU,
+messages staged through gloo), where RCCL cannot run.
 """
 import ctypes
 
@@ -385,56 +385,293 @@ class GpuEngine:
               "pastix_amd_plan_fanin_add")
 
 
+# ------------------------------------------------------------------------------------------------
+# native asynchronous driver (csrc/dist.cpp)
+# ------------------------------------------------------------------------------------------------
+class DistInfo(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("npeers", ctypes.c_int32),
+                ("nplanes", ctypes.c_int32), ("nsend", ctypes.c_int64), ("nrecv", ctypes.c_int64),
+                ("bytes_sent", ctypes.c_double), ("bytes_recv", ctypes.c_double), ("staging_bytes", ctypes.c_double),
+                ("fanin_buffer_bytes", ctypes.c_double), ("transport", ctypes.c_char * 16)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["transport"] = d["transport"].decode()
+        return d
+
+
+ID_BYTES = 128
+
+
+def schedule(cblk4, blok4, owner, rank, world, factotype=0, floattype=1):
+    """Fan-in blocks of one rank in channel order (pastix_amd_dist_schedule, host only): int64 array [nmsg, 6] =
+    (level, peer, cblk, dir 0 send / 1 receive, nrows, width) and the number of arenas per block."""
+    la = LayoutArrays(cblk4, blok4)
+    own = np.ascontiguousarray(owner, dtype=np.int32)
+    n = ctypes.c_int64(0)
+    npl = ctypes.c_int32(0)
+    f = _lib.lib().pastix_amd_dist_schedule
+    check(f(ctypes.byref(la.c), factotype, floattype, _lib.ptr(own), ctypes.c_int32(rank), ctypes.c_int32(world),
+            ctypes.c_int64(0), None, ctypes.byref(n), ctypes.byref(npl)), "pastix_amd_dist_schedule")
+    out = np.zeros((max(n.value, 1), 6), dtype=np.int64)
+    check(f(ctypes.byref(la.c), factotype, floattype, _lib.ptr(own), ctypes.c_int32(rank), ctypes.c_int32(world),
+            ctypes.c_int64(n.value), _lib.ptr(out), ctypes.byref(n), ctypes.byref(npl)), "pastix_amd_dist_schedule")
+    return out[:n.value], npl.value
+
+
+def factorize_scheduled(engine, msgs, nlevels, rows_of, isend, irecv):
+    """Python mirror of pastix_amd_factorize_dist's message flow, for the CPU tests: same schedule, same order per
+    channel, sends leave right after the level's contributions, a rank waits only for the blocks its next panels need.
+    engine: update(l), panels(l), pack(cblk, rows) -> 1-D tensor, add_rows(cblk, rows, buf); rows_of(src, cblk) ->
+    panel rows of the block rank `src` sends for `cblk`; isend(t, peer) / irecv(t, peer) -> work handles."""
+    import torch
+    pending, mi = [], 0
+    for l in range(nlevels):
+        engine.update(l)
+        recvs = []
+        while mi < len(msgs) and msgs[mi][0] == l:
+            _lvl, peer, t, dr, nrows, width = (int(x) for x in msgs[mi])
+            if dr == 0:
+                buf = engine.pack(t, rows_of(engine.rank, t))
+                assert buf.numel() == nrows * width
+                pending.append((isend(buf, peer), buf))
+            else:
+                buf = torch.empty(nrows * width, dtype=torch.float64)
+                recvs.append((irecv(buf, peer), t, peer, buf))
+            mi += 1
+        for w, t, peer, buf in recvs:
+            w.wait()
+            engine.add_rows(t, rows_of(peer, t), buf)
+        engine.panels(l)
+    for w, _b in pending:
+        w.wait()
+
+
+class DistPlan:
+    """One rank's plan for the native multi-GPU driver (own arena on the device)."""
+
+    def __init__(self, cblk4, blok4, owner, rank, device_index, factotype=0, floattype=1, chunk=0):
+        self.layout = LayoutArrays(cblk4, blok4)
+        self.rank, self.factotype, self.floattype = rank, factotype, floattype
+        self.dtype = np.complex128 if floattype == 3 else np.float64
+        opts = Options()
+        opts.device = device_index
+        opts.lookahead = chunk
+        self._h = ctypes.c_void_p()
+        self.owner = np.ascontiguousarray(owner, dtype=np.int32)
+        check(_lib.lib().pastix_amd_plan_create_dist(ctypes.byref(self.layout.c), factotype, floattype,
+                                                     ctypes.byref(opts), _lib.ptr(self.owner), ctypes.c_int32(rank),
+                                                     ctypes.byref(self._h)), "pastix_amd_plan_create_dist")
+        nc = self.layout.cblknbr
+        self.poff = np.zeros(nc + 1, dtype=np.int64)
+        self.level = np.zeros(nc, dtype=np.int32)
+        self.role = np.zeros(nc, dtype=np.int8)
+        check(_lib.lib().pastix_amd_plan_layout_info(self._h, _lib.ptr(self.poff), _lib.ptr(self.level),
+                                                     _lib.ptr(self.role)), "pastix_amd_plan_layout_info")
+
+    def close(self):
+        if self._h:
+            _lib.lib().pastix_amd_plan_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def stats(self):
+        s = Stats()
+        check(_lib.lib().pastix_amd_plan_stats(self._h, ctypes.byref(s)), "pastix_amd_plan_stats")
+        return s.as_dict()
+
+    def info(self):
+        d = DistInfo()
+        check(_lib.lib().pastix_amd_dist_info(self._h, ctypes.byref(d)), "pastix_amd_dist_info")
+        return d.as_dict()
+
+    def fill_csc(self, sym, n, colptr, rows, vals, perm):
+        colptr, rows, perm = _lib.as_i64(colptr), _lib.as_i64(rows), _lib.as_i64(perm)
+        vals = np.ascontiguousarray(vals, dtype=self.dtype)
+        check(_lib.lib().pastix_amd_fill_csc(self._h, int(sym), ctypes.c_int64(n), _lib.ptr(colptr), _lib.ptr(rows),
+                                             _lib.ptr(vals), _lib.ptr(perm)), "pastix_amd_fill_csc")
+
+    def refill(self):
+        check(_lib.lib().pastix_amd_refill(self._h), "pastix_amd_refill")
+
+    def _tabs(self, arrs):
+        n = self.layout.cblknbr
+        return (ctypes.c_void_p * n)(*[a.ctypes.data if a is not None else None for a in arrs])
+
+    def upload_owned(self, L_full, U_full=None):
+        """Owned panels from packed full-layout arrays (the goldens' L0 / U0)."""
+        off = self.layout.panel_offsets()
+        own = self.role == 1
+        self._keepL = [np.ascontiguousarray(L_full[off[k]:off[k + 1]], dtype=self.dtype) if own[k] else None
+                       for k in range(self.layout.cblknbr)]
+        self._keepU = None
+        if U_full is not None:
+            self._keepU = [np.ascontiguousarray(U_full[off[k]:off[k + 1]], dtype=self.dtype) if own[k] else None
+                           for k in range(self.layout.cblknbr)]
+        # (fan-in buffers start from zeros: a refill without cached values clears the arenas first)
+        check(_lib.lib().pastix_amd_upload_tabs(self._h, self._tabs(self._keepL),
+                                                self._tabs(self._keepU) if self._keepU else None),
+              "pastix_amd_upload_tabs")
+
+    def download_owned(self):
+        """{cblk: (L panel, U panel or None)} of the owned cblks, in the reference's per-cblk layout."""
+        off = self.layout.panel_offsets()
+        out = {}
+        lu = self.factotype == 2
+        for k in np.nonzero(self.role == 1)[0]:
+            L = np.empty(int(off[k + 1] - off[k]), dtype=self.dtype)
+            U = np.empty_like(L) if lu else None
+            check(_lib.lib().pastix_amd_download_cblk(self._h, ctypes.c_int64(int(k)), _lib.ptr(L), _lib.ptr(U)),
+                  "pastix_amd_download_cblk")
+            out[int(k)] = (L, U)
+        return out
+
+    def attach_rccl(self, world, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint8)
+        assert ids.size == world * world * ID_BYTES
+        check(_lib.lib().pastix_amd_dist_attach_rccl(self._h, ctypes.c_int32(world), _lib.ptr(ids)),
+              "pastix_amd_dist_attach_rccl")
+
+    def factorize(self, critere):
+        s = Stats()
+        check(_lib.lib().pastix_amd_factorize_dist(self._h, ctypes.c_double(critere), ctypes.byref(s)),
+              "pastix_amd_factorize_dist")
+        return s.as_dict()
+
+    def diag_logsum(self):
+        """sum of log of the diagonal entries of the owned factor panels (LLt: log det A = 2 x the job-wide sum)."""
+        c4 = self.layout.cblk4
+        tot = 0.0
+        for k, (L, _u) in self.download_owned().items():
+            w, sd = int(c4[k, 1] - c4[k, 0] + 1), int(c4[k, 3])
+            tot += float(np.log(L[np.arange(w) * (sd + 1)]).sum())
+        return tot
+
+
+def attach_local(plans):
+    """Wire the rank plans of this process to each other (single-GPU emulation of a job)."""
+    n = len(plans)
+    arr = (ctypes.c_void_p * n)(*[p._h for p in plans])
+    check(_lib.lib().pastix_amd_dist_attach_local(arr, ctypes.c_int32(n)), "pastix_amd_dist_attach_local")
+
+
+def factorize_local(plans, critere):
+    n = len(plans)
+    arr = (ctypes.c_void_p * n)(*[p._h for p in plans])
+    st = (Stats * n)()
+    rcs = (ctypes.c_int32 * n)()
+    check(_lib.lib().pastix_amd_factorize_dist_local(arr, ctypes.c_int32(n), ctypes.c_double(critere), st, rcs),
+          "pastix_amd_factorize_dist_local")
+    return [s.as_dict() for s in st]
+
+
+def exchange_unique_ids(cblk4, blok4, owner, rank, world):
+    """One RCCL unique id per communicating pair: made by the pair's lower rank, gathered over torch.distributed
+    (the bootstrap; works over nccl and gloo).  Returns the [world, world, 128] uint8 table attach_rccl takes."""
+    import torch
+    import torch.distributed as dist
+    pairs = {(min(int(r), int(owner[t])), max(int(r), int(owner[t]))) for r, t in fanin_pairs(cblk4, blok4, owner).tolist()}
+    mine = np.zeros((world, ID_BYTES), dtype=np.uint8)
+    for a, b in sorted(pairs):
+        if a == rank:
+            buf = np.zeros(ID_BYTES, dtype=np.uint8)
+            check(_lib.lib().pastix_amd_dist_unique_id(_lib.ptr(buf)), "pastix_amd_dist_unique_id")
+            mine[b] = buf
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(mine).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy() for o in out]).reshape(world, world, ID_BYTES)
+
+
+def _bcast_layout(rank, make):
+    """The analysis (ordering + symbolic) runs on rank 0 only; the layout travels as int64 tensors."""
+    import torch
+    import torch.distributed as dist
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    if rank == 0:
+        s = make()
+        arrs = [np.ascontiguousarray(s["cblk4"], dtype=np.int64), np.ascontiguousarray(s["blok4"], dtype=np.int64),
+                np.ascontiguousarray(s["perm"], dtype=np.int64)]
+        meta = torch.tensor([arrs[0].shape[0], arrs[1].shape[0], arrs[2].shape[0], int(s["nnzl"])], dtype=torch.int64, device=dev)
+    else:
+        arrs = None
+        meta = torch.zeros(4, dtype=torch.int64, device=dev)
+    dist.broadcast(meta, 0)
+    m = [int(x) for x in meta.cpu()]
+    shapes = [(m[0], 4), (m[1], 4), (m[2],)]
+    out = []
+    for i, sh in enumerate(shapes):
+        t = torch.from_numpy(arrs[i]).to(dev) if rank == 0 else torch.empty(sh, dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        out.append(t.cpu().numpy())
+    return {"cblk4": out[0], "blok4": out[1], "perm": out[2], "nnzl": m[3]}
+
+
 def bench_distributed(a, rank, world, local):
-    """bench.py's N>1 leg: every rank analyses the same matrix, owns a share of the elimination tree."""
+    """bench.py's N>1 leg: rank 0 analyses the matrix, every rank plans and factorizes its share of the elimination
+    tree; fan-in over RCCL point-to-point through the native driver.  With PASTIX_AMD_DIST_TEST=1 (ranks time-slicing
+    fewer GPUs, gloo) the lockstep torch.distributed protocol runs instead, for validation only."""
     import time
     import torch
     import torch.distributed as dist
     from . import fact_flops
     from . import symbolic as sy
     N = a.grid
+    facto = {"llt": 0, "ldlt": 1, "lu": 2}[a.facto]
+    native = dist.get_backend() != "gloo"
+    if not native and facto != 0:
+        raise SystemExit("the gloo validation path is d LLt only")
     t0 = time.time()
-    n, cp, r, v = sy.laplacian_3d(N)
-    perm, _ = sy.order_grid(N, N, N)
-    s = sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
+    n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
+
+    def analyse():
+        perm, _ = sy.order_grid(N, N, N)
+        return sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
+
+    s = _bcast_layout(rank, analyse)
     c4, b4 = s["cblk4"], s["blok4"]
-    flops = fact_flops(c4, b4, 0)
+    flops = fact_flops(c4, b4, facto)
     owner = partition(c4, b4, world)
-    level = levels_of(c4, b4)
-    exch = Exchange(c4, b4, owner, level, rank)
     t_sym = time.time() - t0
     t0 = time.time()
-    eng = GpuEngine(c4, b4, owner, rank, local, chunk=a.chunk)
-    t_plan = time.time() - t0
-    tr = TorchTransport(eng.device)
     crit = 6.0 * 2 * np.sqrt(1e-31)
-    t0 = time.time()
-    eng.fill_csc(1, n, cp, r, v, s["perm"])
-    t_fill = time.time() - t0
+    if native:
+        eng = DistPlan(c4, b4, owner, rank, local, factotype=facto, chunk=a.chunk)
+        t_plan = time.time() - t0
+        eng.attach_rccl(world, exchange_unique_ids(c4, b4, owner, rank, world))
+        t0 = time.time()
+        eng.fill_csc(0 if facto == 2 else 1, n, cp, r, v, s["perm"])
+        t_fill = time.time() - t0
 
-    def step():
-        eng.refill()
-        eng.begin(crit)
-        factorize_levels(eng, exch, tr)
-        tr.drain()                                  # pending fan-in sends, before the buffers are zeroed again
-        return eng.end()
+        def step():
+            eng.refill()
+            return eng.factorize(crit)
+    else:
+        level = levels_of(c4, b4)
+        exch = Exchange(c4, b4, owner, level, rank)
+        eng = GpuEngine(c4, b4, owner, rank, local, chunk=a.chunk)
+        t_plan = time.time() - t0
+        tr = TorchTransport(eng.device)
+        t0 = time.time()
+        eng.fill_csc(1, n, cp, r, v, s["perm"])
+        t_fill = time.time() - t0
 
-    # open every point-to-point connection the factorization will use before anything is timed (RCCL sets a
-    # pair up on its first message), whatever --warmup is
-    peers = sorted({(int(q), int(owner[t])) for q, t in fanin_pairs(c4, b4, owner).tolist()})
-    dev = "cpu" if dist.get_backend() == "gloo" else eng.device
-    ops, keep = [], []
-    for src, dst in peers:
-        if src == rank:
-            keep.append(torch.zeros(1, dtype=torch.float64, device=dev))
-            ops.append(dist.P2POp(dist.isend, keep[-1], dst))
-        elif dst == rank:
-            keep.append(torch.zeros(1, dtype=torch.float64, device=dev))
-            ops.append(dist.P2POp(dist.irecv, keep[-1], src))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    for _ in range(a.warmup):
+        def step():
+            eng.refill()
+            eng.begin(crit)
+            factorize_levels(eng, exch, tr)
+            tr.drain()                                  # pending fan-in sends, before the buffers are zeroed again
+            return eng.end()
+
+    # one untimed factorization whatever --warmup is: RCCL sets a channel up on its first message
+    step()
+    for _ in range(max(a.warmup - 1, 0)):
         step()
     dist.barrier()
     torch.cuda.synchronize()
@@ -449,35 +686,43 @@ def bench_distributed(a, rank, world, local):
     dist.barrier()
     wall = time.time() - t0
     ps = eng.stats()
-    # size-independent check of the distributed factors (no solve across ranks here): log det A = 2 sum log L_kk
-    # over the owned cblks of all ranks, against the analytic spectrum of the 7-point Dirichlet Laplacian
-    # (eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)))
-    wid = (c4[:-1, 1] - c4[:-1, 0] + 1).astype(np.int64)
-    own = np.nonzero(eng.role == 1)[0]
-    rep = np.repeat(own, wid[own])
-    col = np.arange(len(rep), dtype=np.int64) - np.repeat(np.cumsum(wid[own]) - wid[own], wid[own])
-    didx = eng.poff[rep] + col * (c4[rep, 3] + 1)
-    dvals = eng.arena[torch.from_numpy(didx).to(eng.device)]
-    ld_local = float(2.0 * torch.log(dvals).sum().item()) if len(didx) else 0.0
+    # size-independent check of the distributed factors: log det A = 2 sum log L_kk (LLt; LDLt: sum log d_k; LU: the
+    # diagonal of L carries the pivots) over the owned cblks of all ranks, against the analytic spectrum of the 7-point
+    # Dirichlet Laplacian (eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)))
+    if native:
+        ld_local = eng.diag_logsum() * (2.0 if facto == 0 else 1.0)
+        info = eng.info()
+        fanin_gb, arena_gb = info["fanin_buffer_bytes"] * 1e-9, 8e-9 * float(eng.poff[-1])
+        nsend, transport = info["nsend"], info["transport"]
+    else:
+        wid = (c4[:-1, 1] - c4[:-1, 0] + 1).astype(np.int64)
+        own = np.nonzero(eng.role == 1)[0]
+        rep = np.repeat(own, wid[own])
+        col = np.arange(len(rep), dtype=np.int64) - np.repeat(np.cumsum(wid[own]) - wid[own], wid[own])
+        didx = eng.poff[rep] + col * (c4[rep, 3] + 1)
+        dvals = eng.arena[torch.from_numpy(didx).to(eng.device)]
+        ld_local = float(2.0 * torch.log(dvals).sum().item()) if len(didx) else 0.0
+        nsend, transport = sum(len(x) for x in exch.sends), "torch.distributed/gloo lockstep (validation)"
+        arena_gb = 8e-9 * float(eng.poff[-1])
+        fanin_gb = 8e-9 * float(sum(int(eng.poff[k + 1] - eng.poff[k]) for k in np.nonzero(eng.role == 2)[0]))
     cs = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
     ld_exact = float(np.log(6.0 - cs[:, None, None] - cs[None, :, None] - cs[None, None, :]).sum())
-    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"], ld_local], dtype=torch.float64,
-                      device="cpu" if dist.get_backend() == "gloo" else eng.device)
+    tw = torch.tensor([wall, ut, ps["update_flops"], ps["local_flops"], ld_local, st["update_time_sum"]], dtype=torch.float64,
+                      device="cpu" if dist.get_backend() == "gloo" else torch.device("cuda", local))
     mx = tw.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     sm = tw.clone()
     dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    nsend = sum(len(x) for x in exch.sends)
     ld_err = abs(float(sm[4]) - ld_exact) / abs(ld_exact)
     if not ld_err < 1e-9:
         raise RuntimeError("distributed factorization failed its log-det check: %.15g vs %.15g" % (float(sm[4]), ld_exact))
     res = dict(wall=float(mx[0]), flops=flops, logdet_rel_err=ld_err, fact_time=ft, update_time=float(sm[1]) / world,
+               update_time_sum=float(sm[5]) / world, urgent_flops=0.0,
                update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
                n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
                t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
-               parallelism="subtree-per-gpu fan-in x%d (rank0 owns %.1f%% of flops, %d fan-in sends/rank0, "
-                           "rank0 arena %.1f GB of which fan-in buffers %.1f GB)"
-                           % (world, 100.0 * ps["local_flops"] / flops, nsend, 8e-9 * float(eng.poff[-1]),
-                              8e-9 * float(sum(int(eng.poff[k + 1] - eng.poff[k]) for k in np.nonzero(eng.role == 2)[0]))))
+               parallelism="%d ranks, one per GPU: elimination-tree subtrees + asynchronous fan-in, transport %s "
+                           "(rank 0: %.1f%% of the flops, %d fan-in blocks sent, arena %.1f GB of which fan-in buffers %.1f GB)"
+                           % (world, transport, 100.0 * ps["local_flops"] / flops, nsend, arena_gb, fanin_gb))
     eng.close()
     return res

@@ -37,6 +37,15 @@ class NumpyEngine:
     def add(self, k, buf, src):
         self.panels_[k].add_(buf)
 
+    # compact blocks of the native driver's schedule (pastix_amd.dist.factorize_scheduled)
+    def pack(self, k, rows):
+        """rows x width block of this rank's fan-in buffer for cblk k, column-major like the device's compact panels"""
+        return torch.from_numpy(np.ascontiguousarray(self._mat(k)[rows, :].T).ravel().copy())
+
+    def add_rows(self, k, rows, buf):
+        w = int(self.w[k])
+        self._mat(k)[rows, :] += buf.numpy().reshape(w, len(rows)).T
+
     def update(self, l):
         """contributions of every owned source of level l-1 (right-looking)"""
         c4, b4 = self.c4, self.b4

@@ -114,3 +114,90 @@ def test_fanin_touched_regions(golden):
         for r, t in sorted(pairs)[:50]:
             rows = pd.fanin_rows(c4, b4, mask, r, t)
             assert len(rows) > 0 and len(np.unique(rows)) == len(rows) and rows.max() < c4[t, 3]
+
+
+def _worker_sched(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fixture_io
+    from np_engine import NumpyEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = fixture_io.load_npz(os.path.join(HERE, "golden", name + ".npz"))
+    c4, b4 = g["cblk4"], g["blok4"]
+    owner = pd.partition(c4, b4, world)
+    level = pd.levels_of(c4, b4)
+    eng = NumpyEngine(c4, b4, owner, level, rank, g["L0"])
+    msgs, npl = pd.schedule(c4, b4, owner, rank, world)
+    mask = pd.fanin_touched(c4, b4, owner)
+    pd.factorize_scheduled(eng, msgs, int(level.max()) + 1, lambda src, t: pd.fanin_rows(c4, b4, mask, src, t),
+                           lambda buf, peer: dist.isend(buf, peer), lambda buf, peer: dist.irecv(buf, peer))
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    err = 0.0
+    for k in np.nonzero(owner == rank)[0]:
+        ref = g["L1"][off[k]:off[k + 1]].reshape(int(w[k]), -1).T
+        got = eng.panel(k).numpy().reshape(int(w[k]), -1).T
+        wk = int(w[k])
+        m = np.ones_like(ref, dtype=bool)
+        m[:wk, :wk] = np.tril(np.ones((wk, wk), dtype=bool))
+        err = max(err, float(np.abs(got - ref)[m].max()))
+    q.put((rank, err, int((msgs[:, 3] == 0).sum()), npl))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("rlap3d_10_llt", 2), ("rlap3d_14_llt_bs24", 2), ("rlap3d_14_llt_bs24", 4),
+                                        ("rlap3d_14_llt_bs24", 3)])
+def test_native_schedule_over_gloo(name, world, golden):
+    """The message schedule of the native driver (pastix_amd_dist_schedule: which compact blocks, in which order per
+    channel) replayed by world_size 2/3/4 gloo processes with the numpy engine: factors equal the reference's."""
+    g = golden(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker_sched, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scale = np.abs(g["L1"]).max()
+    for rank, err, nsend, npl in res:
+        assert err <= 1e-11 * scale and npl == 1
+    assert sum(r[2] for r in res) > 0
+
+
+@pytest.mark.parametrize("facto,floattype,npl", [(0, 1, 1), (1, 1, 1), (2, 1, 2), (1, 3, 2), (3, 3, 2), (2, 3, 4)])
+def test_native_schedule_is_consistent_between_ranks(facto, floattype, npl, golden):
+    """Every send has exactly one matching receive (same level, cblk, extent) on the owner, both ends list the blocks
+    of a channel in the same order, and the arenas per block follow the factorization (LU: L and U; complex: + the
+    imaginary planes)."""
+    g = golden("rlap3d_14_llt_bs24")
+    c4, b4 = g["cblk4"], g["blok4"]
+    for world in (2, 3, 5, 8):
+        owner = pd.partition(c4, b4, world)
+        sch = []
+        for r in range(world):
+            m, n = pd.schedule(c4, b4, owner, r, world, facto, floattype)
+            assert n == npl
+            sch.append(m)
+        level = pd.levels_of(c4, b4)
+        nsend = 0
+        for a in range(world):
+            assert (np.diff(sch[a][:, 0]) >= 0).all()                      # by level
+            for b in range(world):
+                if a == b:
+                    continue
+                ab = sch[a][sch[a][:, 1] == b]                             # channel (a, b) seen from a
+                ba = sch[b][sch[b][:, 1] == a]                             # ... and from b
+                assert len(ab) == len(ba)
+                assert np.array_equal(ab[:, [0, 2, 4, 5]], ba[:, [0, 2, 4, 5]])   # same blocks, same order
+                assert np.array_equal(ab[:, 3], 1 - ba[:, 3])              # a send here is a receive there
+                nsend += int((ab[:, 3] == 0).sum())
+                for lvl, _p, t, d, nr, wd in ab.tolist():
+                    assert lvl == level[t] and owner[t] == (b if d == 0 else a)
+        assert nsend == len(pd.fanin_pairs(c4, b4, owner))

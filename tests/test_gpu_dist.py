@@ -1,0 +1,184 @@
+"""Multi-GPU driver (csrc/dist.cpp, pastix_amd_factorize_dist) on the GPU.
+
+* single-GPU boxes: the rank plans of one process share the GPU, wired by the loopback transport and driven by one
+  host thread per rank -- the same driver, schedule, channels, events and add kernels as over RCCL, against the
+  reference's own factors for d LLt / LDLt / LU and z LDLt / LDLh / LU;
+* boxes with >= 2 GPUs: world = 2 processes over the nccl backend (RCCL), one GPU each, same check.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import HERE, ROOT
+from pastix_amd import dist as pd
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+TOL = 1e-12
+
+
+def _lower_mask_cblk(w, s):
+    m = np.ones((w, s), dtype=bool)           # [col][row]
+    for c in range(w):
+        m[c, :c] = False
+    return m.ravel()
+
+
+def _check_owned(g, plan, owner, rank):
+    c4 = g["cblk4"]
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    scale = max(np.abs(g["L1"]).max(), np.abs(g["U1"]).max() if g["facto"] == 2 else 0.0)
+    got = plan.download_owned()
+    assert sorted(got) == sorted(np.nonzero(owner == rank)[0].tolist())
+    for k, (L, U) in got.items():
+        ref = g["L1"][off[k]:off[k + 1]]
+        m = _lower_mask_cblk(int(w[k]), int(c4[k, 3])) if g["facto"] in (1, 3) else np.ones(ref.size, bool)
+        assert np.abs(L - ref)[m].max() <= TOL * scale, k
+        if g["facto"] == 2:
+            assert np.abs(U - g["U1"][off[k]:off[k + 1]]).max() <= TOL * scale, k
+
+
+CASES = [("rlap3d_14_llt_bs24", 2), ("rlap3d_14_llt_bs24", 4), ("rlap3d_14_llt_bs24", 3), ("rlap3d_20_llt_bs128", 4),
+         ("rlap3d_12_ldlt", 2), ("rlap3d_12_lu", 2), ("rlap3d_12_lu", 4), ("rlap3d_20_lu_bs128", 2),
+         ("zrlap3d_12_ldlt", 2), ("zrlap3d_12_ldlh", 3), ("zrlap3d_12_lu", 2), ("zrlap3d_8_lu", 4)]
+
+
+@pytest.mark.parametrize("name,world", CASES)
+def test_native_driver_loopback_matches_reference(name, world, golden):
+    g = golden(name)
+    c4, b4 = g["cblk4"], g["blok4"]
+    cz = np.iscomplexobj(g["L0"])
+    owner = pd.partition(c4, b4, world)
+    plans = [pd.DistPlan(c4, b4, owner, r, 0, factotype=g["facto"], floattype=3 if cz else 1) for r in range(world)]
+    try:
+        pd.attach_local(plans)
+        infos = [p.info() for p in plans]
+        assert all(i["transport"] == "loopback" and i["world"] == world for i in infos)
+        assert sum(i["nsend"] for i in infos) == sum(i["nrecv"] for i in infos) > 0
+        assert abs(sum(i["bytes_sent"] for i in infos) - sum(i["bytes_recv"] for i in infos)) < 1
+        for rep in range(2):                       # the second pass checks that nothing of the first one lingers
+            for p in plans:
+                if rep == 0:
+                    p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+                else:
+                    p.refill()
+            sts = pd.factorize_local(plans, g["critere"])
+            assert sum(s["nbpivot"] for s in sts) == g["nbpivot"]
+            for r, p in enumerate(plans):
+                _check_owned(g, p, owner, r)
+    finally:
+        for p in plans:
+            p.close()
+
+
+def test_native_driver_loopback_is_repeatable(golden):
+    """The owner adds the received blocks in a fixed order; what remains timing dependent is the order of the fp64
+    atomics with which the split-K tasks of a shared target tile combine (plan.cpp): repeated runs agree to rounding."""
+    g = golden("rlap3d_14_llt_bs24")
+    c4, b4 = g["cblk4"], g["blok4"]
+    world = 4
+    owner = pd.partition(c4, b4, world)
+    plans = [pd.DistPlan(c4, b4, owner, r, 0) for r in range(world)]
+    try:
+        pd.attach_local(plans)
+        runs = []
+        for rep in range(3):
+            for p in plans:
+                p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"]) if rep == 0 else p.refill()
+            pd.factorize_local(plans, g["critere"])
+            runs.append([p.download_owned() for p in plans])
+        scale = np.abs(g["L1"]).max()
+        for other in runs[1:]:
+            for a, b in zip(runs[0], other):
+                for k in a:
+                    assert np.abs(a[k][0] - b[k][0]).max() <= 1e-14 * scale
+    finally:
+        for p in plans:
+            p.close()
+
+
+def test_native_driver_on_own_layout_at_scale():
+    """36^3 on the repo's own layout (128-wide cblks), 4 emulated ranks: log det A from the distributed factors against
+    the analytic spectrum of the Dirichlet Laplacian (size-independent check, as bench.py --gpus N uses it)."""
+    from pastix_amd import symbolic as sy
+    N, world = 36, 4
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    c4, b4 = s["cblk4"], s["blok4"]
+    owner = pd.partition(c4, b4, world)
+    plans = [pd.DistPlan(c4, b4, owner, q, 0) for q in range(world)]
+    try:
+        pd.attach_local(plans)
+        for p in plans:
+            p.fill_csc(1, n, cp, r, v, s["perm"])
+        pd.factorize_local(plans, 1e-14)
+        ld = 2.0 * sum(p.diag_logsum() for p in plans)
+        cs = 2.0 * np.cos(np.arange(1, N + 1) * np.pi / (N + 1))
+        exact = float(np.log(6.0 - cs[:, None, None] - cs[None, :, None] - cs[None, None, :]).sum())
+        assert abs(ld - exact) <= 1e-11 * abs(exact)
+    finally:
+        for p in plans:
+            p.close()
+
+
+# ---- RCCL, world = 2 (needs two GPUs) -----------------------------------------------------------------
+def _rccl_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import fixture_io
+    from pastix_amd import dist as pdd
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    g = fixture_io.load_npz(os.path.join(HERE, "golden", name + ".npz"))
+    c4, b4 = g["cblk4"], g["blok4"]
+    cz = np.iscomplexobj(g["L0"])
+    owner = pdd.partition(c4, b4, world)
+    ok, msg = True, ""
+    try:
+        with pdd.DistPlan(c4, b4, owner, rank, rank, factotype=g["facto"], floattype=3 if cz else 1) as p:
+            p.attach_rccl(world, pdd.exchange_unique_ids(c4, b4, owner, rank, world))
+            assert p.info()["transport"] == "rccl"
+            p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+            for rep in range(2):
+                if rep:
+                    p.refill()
+                st = p.factorize(g["critere"])
+                _check_owned(g, p, owner, rank)
+            nb = torch.tensor([st["nbpivot"]], device="cuda")
+            dist.all_reduce(nb)
+            assert int(nb.item()) == g["nbpivot"]
+    except Exception as e:  # noqa: BLE001
+        ok, msg = False, repr(e)
+    q.put((rank, ok, msg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["rlap3d_14_llt_bs24", "rlap3d_20_llt_bs128", "rlap3d_12_lu", "zrlap3d_12_ldlt"])
+def test_native_driver_over_rccl_world2(name):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, msg in res:
+        assert ok, (rank, msg)
