@@ -131,6 +131,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run "
                          "--nproc-per-node %d, or run `python bench.py --gpus %d` and let it launch the ranks)"
                          % (a.gpus, world, a.gpus, a.gpus))
+    if world > 1:
+        # every rank drives 2 compute streams + one channel stream per peer: give each its own hardware queue (the HIP
+        # runtime multiplexes streams over 4 by default; a channel waiting for its peer must not stall a compute stream)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))

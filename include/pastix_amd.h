@@ -225,6 +225,8 @@ typedef struct pastix_amd_dist_info_s {
 /* an RCCL unique id (ncclGetUniqueId); the job needs one per communicating pair, made on any rank and shipped to both
  * members out of band (bench.py: torch.distributed) */
 int pastix_amd_dist_unique_id(void *id128);
+/* self-test of the RCCL binding on one device: a 1-rank communicator sends `count` doubles to itself in a group */
+int pastix_amd_dist_selftest_rccl(int device, pastix_amd_int_t count);
 /* ids: world*world entries of PASTIX_AMD_DIST_ID_BYTES, entry [a*world + b] for a < b (others unused).  Collective. */
 int pastix_amd_dist_attach_rccl(pastix_amd_plan_t *plan, int32_t world, const void *ids);
 /* the rank plans of ONE process wired to each other (device-to-device copies): single-GPU emulation of a job, used by

@@ -27,7 +27,7 @@ MKL=${MKL_LIBDIR:-/opt/conda/lib}
 OB=$(ls /usr/local/lib/python3*/dist-packages/scipy.libs/libscipy_openblas*.so 2>/dev/null | head -1)
 if [ "$BLAS" = openblas ]; then
   [ -n "$OB" ] || { echo "no scipy OpenBLAS in this image"; exit 0; }
-  for f in scal axpy copy gemm trsv trsm syrk syr ger gemv swap dot nrm2; do
+  for f in scal axpy copy gemm trsv trsm syrk syr ger geru gerc her herk gemv swap dot nrm2; do
     RENAMES="$RENAMES -Dd${f}_=scipy_d${f}_ -Dz${f}_=scipy_z${f}_"
   done
 fi
@@ -80,3 +80,24 @@ else
   gcc -o "$OUT/ref_harness_$PREC" "$OBJ"/*.o -L"$MKL" -Wl,-rpath,"$MKL" -lmkl_rt -lpthread -lm -lrt
 fi
 echo "built $OUT/ref_harness_$PREC$SUF"
+
+# ---- the reference as the CALLER of the MI355X engine (oracle/ref_amd_sopalin3d.c + integration/sopalin_amd_stub.h):
+# same objects, except that the four sopalin3d variants are rebuilt from the wrapper TU, which includes the reference's
+# sopalin3d.c from where it lies and redirects its sopalin_launch_thread() calls to the stub.
+LIBAMD="$HERE/../pastix_amd/lib"
+# (OpenBLAS build only: the MKL of this image sits beside an older libstdc++ that libpastix_amd.so / the HIP runtime
+# cannot run with)
+if [ -e "$LIBAMD/libpastix_amd.so" ] && [ "$BLAS" = openblas ]; then
+  AOBJ="$OBJ/amd"
+  mkdir -p "$AOBJ"
+  INCAMD="-I$HERE/../include"
+  $CC $INCAMD -DCHOL_SOPALIN -DAMD_HOOK=pastix_amd_launch_po -c "$HERE/ref_amd_sopalin3d.c" -o "$AOBJ/sopalin3d_po.o" &
+  $CC $INCAMD -DCHOL_SOPALIN -DSOPALIN_LU -DAMD_HOOK=pastix_amd_launch_ge -c "$HERE/ref_amd_sopalin3d.c" -o "$AOBJ/sopalin3d_ge.o" &
+  $CC $INCAMD -DAMD_HOOK=pastix_amd_launch_sy -c "$HERE/ref_amd_sopalin3d.c" -o "$AOBJ/sopalin3d_sy.o" &
+  $CC $INCAMD -DHERMITIAN -DAMD_HOOK=pastix_amd_launch_he -c "$HERE/ref_amd_sopalin3d.c" -o "$AOBJ/sopalin3d_he.o" &
+  wait
+  REST=$(ls "$OBJ"/*.o | grep -v -E "/sopalin3d_(po|ge|sy|he)\.o$")
+  RP="-Wl,-rpath,\$ORIGIN/../../pastix_amd/lib -Wl,-rpath,/opt/rocm/lib"
+  gcc -o "$OUT/ref_harness_$PREC${SUF}_amd" $REST "$AOBJ"/*.o "$OB" -Wl,-rpath,"$(dirname "$OB")" -L"$LIBAMD" -lpastix_amd $RP -lpthread -lm -lrt
+  echo "built $OUT/ref_harness_$PREC${SUF}_amd (reference pastix() -> blend -> MI355X engine -> reference updo)"
+fi

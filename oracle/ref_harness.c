@@ -15,7 +15,7 @@
  *   time:  same pipeline without dumping; prints one JSON line with DPARM_FACT_FLOPS /
  *          DPARM_FACT_TIME (bench.py's cpu_baseline kind="reference").
  *
- * usage: ref_harness {dump|time} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]
+ * usage: ref_harness {dump|time|amd} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]
  *        (rlap3d = 3-D 7-point pattern with deterministic pseudo-random values:
  *         SPD for llt/ldlt, unsymmetric diagonally dominant for lu)
  */
@@ -253,6 +253,10 @@ static void wints(FILE *f, const PASTIX_INT *p, long cnt, long add)
   for (i = 0; i < cnt; i++) w64(f, (int64_t)p[i] + add);
 }
 
+/* set by oracle/ref_amd_sopalin3d.c (the *_amd build): factorizations handed to the MI355X engine */
+int pastix_amd_hook_calls = 0;
+int pastix_amd_hook_last_rc = 0;
+
 int main(int argc, char **argv)
 {
   pastix_data_t *pd = NULL;
@@ -269,10 +273,12 @@ int main(int argc, char **argv)
   int minbs = -1, maxbs = -1;
 
   if (argc < 7) {
-    fprintf(stderr, "usage: %s {dump|time} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]\n", argv[0]);
+    fprintf(stderr, "usage: %s {dump|time|amd} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]\n", argv[0]);
     return 2;
   }
   dump = !strcmp(argv[1], "dump");
+  /* mode "amd" (the *_amd build): like "time", with the numerical factorization on the MI355X engine */
+  if (!strcmp(argv[1], "amd")) setenv("PASTIX_AMD_ENGINE", "1", 1);
   kind = argv[2];
   facto = !strcmp(argv[4], "llt") ? API_FACT_LLT : !strcmp(argv[4], "ldlt") ? API_FACT_LDLT
         : !strcmp(argv[4], "lu") ? API_FACT_LU : API_FACT_LDLH;
@@ -471,9 +477,10 @@ int main(int argc, char **argv)
     }
     OUT("{\"kind\": \"%s\", \"arg\": \"%s\", \"facto\": \"%s\", \"n\": %ld, \"threads\": %d, "
         "\"cblknbr\": %ld, \"bloknbr\": %ld, \"nnzl\": %ld, \"flops\": %.6e, \"time\": %.6f, "
-        "\"gflops\": %.3f, \"static_pivots\": %ld, \"residual\": %.3e}\n",
+        "\"gflops\": %.3f, \"static_pivots\": %ld, \"residual\": %.3e, \"gpu_engine_calls\": %d, "
+        "\"gpu_engine_rc\": %d, \"inertia\": %ld}\n",
         kind, argv[3], argv[4], n, nthr, (long)sm->cblknbr, (long)sm->bloknbr, nnzl, flops, t,
-        flops / t * 1e-9, npiv, resid);
+        flops / t * 1e-9, npiv, resid, pastix_amd_hook_calls, pastix_amd_hook_last_rc, (long)iparm[IPARM_INERTIA]);
   }
   iparm[IPARM_START_TASK] = API_TASK_CLEAN;
   iparm[IPARM_END_TASK] = API_TASK_CLEAN;

@@ -361,6 +361,44 @@ int pastix_amd_dist_unique_id(void* id128) {
   return PASTIX_AMD_OK;
 }
 
+// One rank, one communicator, a grouped send-to-self through the very entry points (run-time resolved librccl, ncclDouble,
+// group calls, a non-default stream) the fan-in channels use: the part of the RCCL path a single-GPU box can execute.
+int pastix_amd_dist_selftest_rccl(int device, pastix_amd_int_t count) {
+  if (count < 1) return PASTIX_AMD_ERR_BADPARAMETER;
+  RcclApi* a = rccl();
+  if (!a) { fprintf(stderr, "pastix_amd: librccl not found\n"); return PASTIX_AMD_ERR_DEVICE; }
+  HIPCHK(hipSetDevice(device));
+  ncclUniqueId id;
+  NCCLCHK(a->GetUniqueId(&id));
+  ncclComm_t c = nullptr;
+  NCCLCHK(a->CommInitRank(&c, 1, id, 0));
+  int rc = PASTIX_AMD_OK;
+  double *src = nullptr, *dst = nullptr;
+  hipStream_t s = nullptr;
+  std::vector<double> h((size_t)count), back((size_t)count, 0.0);
+  for (int64_t i = 0; i < count; i++) h[(size_t)i] = 0.5 * (double)i - 3.0;
+  auto body = [&]() -> int {
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void**)&src, (size_t)count * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dst, (size_t)count * sizeof(double)));
+    HIPCHK(hipMemcpy(src, h.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dst, 0, (size_t)count * sizeof(double)));
+    NCCLCHK(a->GroupStart());
+    NCCLCHK(a->Send(src, (size_t)count, ncclDouble, 0, c, s));
+    NCCLCHK(a->Recv(dst, (size_t)count, ncclDouble, 0, c, s));
+    NCCLCHK(a->GroupEnd());
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(back.data(), dst, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return std::memcmp(back.data(), h.data(), (size_t)count * sizeof(double)) ? PASTIX_AMD_ERR_NUMERIC : PASTIX_AMD_OK;
+  };
+  rc = body();
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  if (s) (void)hipStreamDestroy(s);
+  (void)a->CommDestroy(c);
+  return rc;
+}
+
 // ids: world x world x 128 bytes; entry [a * world + b], a < b, made by pastix_amd_dist_unique_id on ANY one rank and
 // distributed out of band (bench.py: all_gather over torch.distributed).  Collective over the job: every rank calls it,
 // pairs are initialised in lexicographic order on both of their members.

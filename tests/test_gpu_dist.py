@@ -125,6 +125,14 @@ def test_native_driver_on_own_layout_at_scale():
             p.close()
 
 
+def test_rccl_binding_selftest():
+    """librccl resolved at run time, ncclDouble, grouped send + receive on a non-default stream: a 1-rank communicator
+    sending to itself -- the part of the RCCL path one GPU can execute."""
+    import ctypes
+    from pastix_amd import _lib
+    assert _lib.lib().pastix_amd_dist_selftest_rccl(0, ctypes.c_int64(100003)) == 0
+
+
 # ---- RCCL, world = 2 (needs two GPUs) -----------------------------------------------------------------
 def _rccl_worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

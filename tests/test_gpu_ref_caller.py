@@ -1,0 +1,86 @@
+"""The reference as the CALLER of the MI355X engine (north_star: "the host-side C driver and the symbolic pipeline stay
+as-is and hand the SolverMatrix across a thin C-ABI").
+
+oracle/_ref/ref_harness_{d,z}_ob_amd (built by oracle/build_ref.sh in the development container, travels with gpurun)
+is the REAL PaStiX 5.2.2.16 -- pastix(), kass, blend, CoefMatrix_Init, updo -- in which the numerical factorization call
+of sopalin_thread() (src/sopalin/src/sopalin3d.c:1411) is bound to integration/sopalin_amd_stub.h -> libpastix_amd.so.
+Mode `amd` runs the factorization on the GPU, mode `time` of the same binary on the reference's CPU engine; both then
+solve with the reference's own updo and report ||Ax-b||/||b||, IPARM_STATIC_PIVOTING, IPARM_INERTIA.
+Skipped where oracle/_ref was not built (a clean clone without /root/reference)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _run(prec, mode, kind, arg, facto, extra=()):
+    exe = os.path.join(REF, "ref_harness_%s_ob_amd" % prec)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_harness_%s_ob_amd not built (needs /root/reference at build time)" % prec)
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1")
+    env.pop("PASTIX_AMD_ENGINE", None)
+    out = subprocess.run([exe, mode, kind, str(arg), facto, "1", "/dev/null"] + [str(x) for x in extra], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _write_mtx(g, path):
+    """Matrix Market file of a golden fixture's CSC (data the reference's own fixture files hold)."""
+    cp, rows, vals = g["colptr"], g["rows"], g["vals"]
+    n = int(g["n"])
+    cz = np.iscomplexobj(vals)
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n" % ("complex" if cz else "real",
+                                                                 "symmetric" if g["sym"] else "general"))
+        f.write("%d %d %d\n" % (n, n, len(rows)))
+        for j in range(n):
+            for q in range(cp[j] - 1, cp[j + 1] - 1):
+                if cz:
+                    f.write("%d %d %.17g %.17g\n" % (rows[q], j + 1, vals[q].real, vals[q].imag))
+                else:
+                    f.write("%d %d %.17g\n" % (rows[q], j + 1, vals[q]))
+
+
+@pytest.mark.parametrize("prec,kind,arg,facto,extra", [
+    ("d", "rlap3d", 20, "llt", ()),                # north_star's case: 20^3 through pastix() -> blend -> GPU -> updo
+    ("d", "rlap3d", 20, "llt", (64, 128)),         # blend with MAX_BLOCKSIZE 128: whole 128x128 tiles
+    ("d", "lap1d", 1000, "llt", ()),               # BASELINE config 1's generator
+    ("d", "rlap3d", 16, "ldlt", ()),
+    ("d", "rlap3d", 16, "lu", ()),
+    ("z", "rlap3d", 12, "ldlt", ()),
+    ("z", "rlap3d", 12, "ldlh", ()),
+    ("z", "rlap3d", 10, "lu", ()),
+])
+def test_reference_pastix_drives_the_gpu_engine(prec, kind, arg, facto, extra):
+    gpu = _run(prec, "amd", kind, arg, facto, extra)
+    cpu = _run(prec, "time", kind, arg, facto, extra)
+    assert gpu["gpu_engine_calls"] == 1 and gpu["gpu_engine_rc"] == 0      # the factorization ran on the MI355X engine
+    assert cpu["gpu_engine_calls"] == 0
+    assert gpu["residual"] <= 1e-10                                         # reference updo on the GPU's factors
+    assert gpu["static_pivots"] == cpu["static_pivots"]                     # IPARM_STATIC_PIVOTING
+    assert gpu["inertia"] == cpu["inertia"]                                 # IPARM_INERTIA (real LDLt: n, else -1)
+    assert gpu["flops"] == cpu["flops"] and gpu["nnzl"] == cpu["nnzl"]
+
+
+@pytest.mark.parametrize("prec,name,facto", [("z", "zyoung4c_841_ldlt", "ldlt"), ("d", "orsirr_1030_lu", "lu")])
+def test_reference_fixture_matrices_through_the_gpu_engine(prec, name, facto, golden, tmp_path):
+    """The reference's own matrix files (young4c.mtx: complex symmetric 841^2; orsirr.rua: real unsymmetric 1030^2 with
+    a 334-column supernode), re-written from the committed fixtures."""
+    g = golden(name)
+    path = str(tmp_path / (name + ".mtx"))
+    _write_mtx(g, path)
+    gpu = _run(prec, "amd", "mtx", path, facto)
+    cpu = _run(prec, "time", "mtx", path, facto)
+    assert gpu["gpu_engine_calls"] == 1 and gpu["gpu_engine_rc"] == 0
+    assert gpu["residual"] <= max(1e-10, 10 * cpu["residual"])
+    assert gpu["static_pivots"] == cpu["static_pivots"] == g["nbpivot"]
+    assert gpu["cblknbr"] == len(g["cblk4"]) - 1                            # the layout blend made is the fixture's
