@@ -8,8 +8,9 @@
  *
  * API_CALL(sopalin_amd)(sopalin_data) replaces the call
  *     sopalin_launch_thread(..., API_CALL(sopalin_smp), sopalin_data, ...)        (sopalin3d.c:1411-1416)
- * of sopalin_thread(): same inputs (panels allocated and filled by CoefMatrix_Allocate / CoefMatrix_Init,
- * coefinit.c:104-465; critere computed by init_struct_sopalin, sopalin3d.c:586-606), same outputs (factors in place in
+ * of sopalin_thread(): same inputs (critere computed by init_struct_sopalin, sopalin3d.c:586-606; the panels are
+ * allocated and filled by the reference's threads inside that call -- sopalin_init_smp, sopalin_init.c:1196-1211 -- and
+ * the stub keeps exactly that part), same outputs (factors in place in
  * coeftab / ucoeftab for updo.c; sopar->diagchange -> IPARM_STATIC_PIVOTING; DPARM_FACT_TIME; IPARM_INERTIA,
  * sopalin3d.c:1119-1160).  Returns 0, or a PASTIX_AMD_ERR_* code on which the caller falls back to the CPU engine.
  */
@@ -19,6 +20,26 @@
 #include <stdlib.h>
 
 #include "pastix_amd.h"
+
+/* The host part of sopalin_smp that must still run, once per computing thread: sopalin_init_smp allocates and fills the
+ * thread's panels (CoefMatrix_Allocate + CoefMatrix_Init, sopalin_init.c:1196-1211 -- with their barriers across the
+ * SOLV_THRDNBR threads and NUMA-local first touch, exactly as for the CPU engine) and sopalin_clean_smp releases the
+ * thread's work buffers (sopalin3d.c:712 and :1082 bracket the task loop the GPU replaces). */
+static void *API_CALL(sopalin_amd_init_smp)(void *arg)
+{
+  sopthread_data_t *argument     = (sopthread_data_t *)arg;
+  Sopalin_Data_t   *sopalin_data = (Sopalin_Data_t *)(argument->data);
+  SolverMatrix     *datacode     = sopalin_data->datacode;
+  PASTIX_INT        me           = argument->me;
+  int               init         = INIT_COMPUTE;
+
+  if (THREAD_FUNNELED_OFF) init = init | INIT_SEND;
+  if (THREAD_COMM_OFF)     init = init | INIT_RECV;
+  sopalin_init_smp(sopalin_data, me, 1, init);
+  SYNCHRO_THREAD;
+  sopalin_clean_smp(sopalin_data, me);
+  return NULL;
+}
 
 static int API_CALL(sopalin_amd)(Sopalin_Data_t *sopalin_data)
 {
@@ -35,6 +56,11 @@ static int API_CALL(sopalin_amd)(Sopalin_Data_t *sopalin_data)
 
   if (SOLV_PROCNBR != 1)                       /* MPI runs keep the CPU engine (the multi-GPU driver is bound apart) */
     return PASTIX_AMD_ERR_UNSUPPORTED;
+  /* panels: allocated and filled by the reference's own threads, as sopalin_smp starts (see above) */
+  sopalin_launch_thread(sopalin_data, SOLV_PROCNUM, SOLV_PROCNBR, datacode->btree,
+                        sopar->iparm[IPARM_VERBOSE],
+                        SOLV_THRDNBR, API_CALL(sopalin_amd_init_smp), sopalin_data,
+                        0, NULL, NULL, 0, NULL, NULL);
   cb   = (pastix_amd_cblk_t *)malloc((SYMB_CBLKNBR + 1) * sizeof(*cb));
   bl   = (pastix_amd_blok_t *)malloc((SYMB_BLOKNBR > 0 ? SYMB_BLOKNBR : 1) * sizeof(*bl));
   ctab = (void **)malloc(SYMB_CBLKNBR * sizeof(void *));

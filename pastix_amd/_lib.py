@@ -104,6 +104,22 @@ def _share_hip_runtime_with_torch():
         pass
 
 
+def share_rccl_with_torch():
+    """Same for RCCL: the multi-GPU driver resolves librccl at run time (csrc/dist.cpp) and takes a copy that is already
+    in the process.  PyTorch's wheel bundles its own librccl.so next to the HIP runtime loaded above; the ROCm
+    installation's copy beside that runtime corrupts the heap at exit.  Call before the first RCCL use."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -43,72 +43,6 @@ constexpr int SLD = 144;      // LDS line length in doubles: 128 rows + 16 pad -
 
 // NW waves per workgroup share one 128x128 target tile: NW=4 -> 2x2 waves of 64x64 (16 MFMA tiles per
 // wave), NW=8 -> 4x2 waves of 32x64 (8 MFMA tiles per wave, 4 waves per SIMD at 2 workgroups per CU).
-template <int NW>
-struct Stage {
-  static constexpr int NLD = KC * 128 / (64 * NW);   // loads per thread per operand per chunk
-  double a[NLD];
-  double b[NLD];
-};
-
-template <int NW>
-__device__ __forceinline__ void stage_load(Stage<NW>& st, const double* __restrict__ Ab,
-                                           const double* __restrict__ Bb, const Piece& pc, int kc, int tid,
-                                           bool full) {
-  // Raw loads only; masking happens in stage_store, after the MFMA section, so that nothing here
-  // depends on the loaded values (no s_waitcnt in front of the MFMAs).  Partial pieces read from
-  // clamped (always valid) addresses.
-  constexpr int KS = 64 * NW / 128;                  // k lines covered by one pass of the workgroup
-  const int row = tid & 127, k0 = tid >> 7;
-  if (full) {
-    const double* pa = Ab + row + (int64_t)(kc + k0) * pc.lda;
-    const double* pb = Bb + row + (int64_t)(kc + k0) * pc.lda;
-    const int64_t step = (int64_t)KS * pc.lda;
-#pragma unroll
-    for (int q = 0; q < Stage<NW>::NLD; q++) {
-      st.a[q] = pa[q * step];
-      st.b[q] = pb[q * step];
-    }
-  } else {
-    const int rac = min(max(row - (int)pc.dr, 0), (int)pc.m - 1);
-    const int rbc = min(max(row - (int)pc.dc, 0), (int)pc.n - 1);
-    const int klast = (int)pc.k - 1;
-#pragma unroll
-    for (int q = 0; q < Stage<NW>::NLD; q++) {
-      const int kkc = min(kc + k0 + KS * q, klast);
-      st.a[q] = Ab[rac + (int64_t)kkc * pc.lda];
-      st.b[q] = Bb[rbc + (int64_t)kkc * pc.lda];
-    }
-  }
-}
-
-template <int NW>
-__device__ __forceinline__ void stage_store(const Stage<NW>& st, double* sA, double* sB, const Piece& pc, int kc,
-                                            int tid, bool full) {
-  constexpr int KS = 64 * NW / 128;
-  const int row = tid & 127, k0 = tid >> 7;
-  const double sgn = (pc.flags & 16) ? -1.0 : 1.0;   // "+=" pieces (complex cross terms): negate B
-  if (full) {
-#pragma unroll
-    for (int q = 0; q < Stage<NW>::NLD; q++) {
-      sA[(k0 + KS * q) * SLD + row] = st.a[q];
-      sB[(k0 + KS * q) * SLD + row] = sgn * st.b[q];
-    }
-  } else {
-    const int ra = row - (int)pc.dr, rb = row - (int)pc.dc;
-    const bool va = ra >= 0 && ra < (int)pc.m, vb = rb >= 0 && rb < (int)pc.n;
-    const int klast = (int)pc.k - 1;
-#pragma unroll
-    for (int q = 0; q < Stage<NW>::NLD; q++) {
-      const bool kv = kc + k0 + KS * q <= klast;
-      sA[(k0 + KS * q) * SLD + row] = (va && kv) ? st.a[q] : 0.0;
-      sB[(k0 + KS * q) * SLD + row] = (vb && kv) ? sgn * st.b[q] : 0.0;
-    }
-  }
-}
-
-__device__ __forceinline__ bool piece_full(const Piece& pc) {
-  return pc.dr == 0 && pc.dc == 0 && pc.m == TM && pc.n == TN && (pc.k & (KC - 1)) == 0;
-}
 
 // Epilogue variant for tiles that several workgroups update in the same launch (split piece lists of
 // the multi-GPU fan-in schedule): accumulate with f64 atomics instead of an exclusive read-modify-write.
@@ -171,10 +105,18 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     for (int ni = 0; ni < NI; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
 
   unsigned touched = 0;                         // union of active (mi | ni<<4) masks
-  if (tk.nfull > 0) {
-    // two instantiations: tasks on a full 128 x 128 tile keep the branch-free loop
-    auto fast_loop = [&](auto fullt_c, auto neg_c) {
-    constexpr bool FULLT = decltype(fullt_c)::value;
+  {
+    // One software-pipelined LDS-DMA loop for every kind of piece, three instantiations (MODE):
+    //   0  whole-tile pieces of a full 128 x 128 tile: branch-free;
+    //   1  whole-tile pieces of a smaller valid tile (last row tile of a panel, target cblks narrower than 128
+    //      columns): lane and band masks fixed per task;
+    //   2  partial pieces (any rectangle [dr, dr+m) x [dc, dc+n) of the tile): lane masks, band masks and the operand
+    //      shift are recomputed per piece (every K / 16 chunks), the stray element a 16-byte DMA lane drags in at an
+    //      odd piece boundary is zeroed in LDS before anything reads it.
+    auto fast_loop = [&](auto mode_c, auto neg_c, const int pbeg, const int pend) {
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool FULLT = MODE == 0;
+    constexpr bool PART = MODE == 2;
     constexpr bool NEG = decltype(neg_c)::value;   // the task has "+=" pieces (complex cross terms): sign flips compiled in
     // (wave-uniform copy: the k-line tests and the per-wave operand offsets go to the scalar unit.  Not row0 / col0:
     // with scalar band masks the edge-tile variant branches per MFMA and the kernel spills)
@@ -187,15 +129,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     // read (i+1, ks0) | MFMA ks3.  RAW: own vmcnt(0), then the barrier, then the read.  WAR: buffer i is
     // re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired.
     constexpr int NL = KC / NW;                    // k-lines per wave per operand per chunk
-    int pi = tk.p0;
-    const int pend = tk.p0 + (int)tk.nfull;
+    int pi = pbeg;
     Piece cur = pieces[pi];
     Piece nextp = pieces[min(pi + 1, pend - 1)];
     int64_t lda = cur.lda;
     // (wave-uniform pointers: the address arithmetic of the DMA stays on the scalar unit, the lane's 16 bytes are the
-    // vector offset of the load)
-    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+    // vector offset of the load).  Partial pieces: tile row r holds source row r - dr, so the pointers are shifted by
+    // -dr / -dc; lanes wholly outside the piece copy the zero line instead and never use them.
+    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
+    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
     const int lo2 = 2 * lane;
     int left = ((int)cur.k + KC - 1) / KC;
     int krem = (int)cur.k;                          // k-lines of the piece not yet issued
@@ -205,13 +147,42 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     // and for target cblks narrower than 128 columns.  Lanes beyond tm / tn copy the zero line; with an odd tm
     // (tn) the last lane brings one element of the next panel row along, which only reaches accumulator rows
     // (columns) the epilogue never stores.  Bands beyond the valid tile are skipped on the MFMA pipe.
-    const bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
-    unsigned amt = 0, ant = 0;
+    bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
+    unsigned amt = 0, ant = 0;                     // bands of the chunk in the MFMA section
+    unsigned amn = 0, ann = 0;                     // ... of the chunk being copied (PART: they change with the piece)
+    int fixn = -1;                                 // PART: LDS element (relative to the A image of a buffer) this lane zeroes
+    // per-piece set-up of a partial piece: lanes 2l, 2l+1 of a k-line intersect the piece; 16-row / 16-col bands it
+    // touches; stray elements: a lane that straddles an odd boundary brings the source row next to the piece along
+    // (lanes 0-15 / 16-31 / 32-47 / 48-63 look after the rows dr-1, dr+m of A and dc-1, dc+n of B, one k-line each)
+    auto piece_setup = [&](const Piece& pc) {
+      const int dr = pc.dr, re = (int)pc.dr + (int)pc.m, dc = pc.dc, ce = (int)pc.dc + (int)pc.n;
+      la = lo2 + 1 >= dr && lo2 < re;
+      lb = lo2 + 1 >= dc && lo2 < ce;
+      amn = 0;
+      ann = 0;
 #pragma unroll
-    for (int s = 0; s < MI; s++) if (row0 + s * RS < (int)tk.tm) amt |= 1u << s;
+      for (int s = 0; s < MI; s++) if (row0 + s * RS < re && row0 + s * RS + 16 > dr) amn |= 1u << s;
 #pragma unroll
-    for (int s = 0; s < NI; s++) if (col0 + s * CS < (int)tk.tn) ant |= 1u << s;
-    const bool allb = FULLT || (amt == MALL && ant == 0xFu);
+      for (int s = 0; s < NI; s++) if (col0 + s * CS < ce && col0 + s * CS + 16 > dc) ann |= 1u << s;
+      const int j = lane >> 4;
+      const int e = j == 0 ? dr - 1 : j == 1 ? re : j == 2 ? dc - 1 : ce;      // the row next to the boundary
+      const bool odd = (j == 0 || j == 2) ? (e & 1) == 0 && e >= 0 : (e & 1) != 0 && e < 128;   // shares a lane with a piece row
+      fixn = odd ? (j >= 2 ? KC * SLD : 0) + (lane & 15) * SLD + e : -1;
+      touched |= amn | (ann << 4);
+    };
+    if (PART) {
+      piece_setup(cur);
+    } else {
+#pragma unroll
+      for (int s = 0; s < MI; s++) if (row0 + s * RS < (int)tk.tm) amn |= 1u << s;
+#pragma unroll
+      for (int s = 0; s < NI; s++) if (col0 + s * CS < (int)tk.tn) ann |= 1u << s;
+      touched |= amn | (ann << 4);
+    }
+    amt = amn;
+    ant = ann;
+    int fixc = fixn;
+    bool allb = FULLT || (amt == MALL && ant == 0xFu);
 #pragma unroll
     for (int q = 0; q < NL; q++) {
       const bool kv = wave + NW * q < krem;        // wave-uniform
@@ -219,11 +190,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
       PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * NW * lda : zl) + lo2, sh[0][1] + (wave + NW * q) * SLD);
     }
     krem -= KC;
-    touched = amt | (ant << 4);
     const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
     const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
     double bm0[MI], an0[NI], bm1[MI], an1[NI];
     __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
+    if (PART && fixc >= 0) sh[0][0][fixc] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
 #pragma unroll
     for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
 #pragma unroll
@@ -232,16 +203,18 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     while (true) {
       bool has_next = true;
       negc = negn;
+      if (PART) { amt = amn; ant = ann; fixc = fixn; allb = amt == MALL && ant == 0xFu; }
       if (--left == 0) {
         if (++pi < pend) {
           cur = nextp;
           lda = cur.lda;
-          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
+          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
           left = ((int)cur.k + KC - 1) / KC;
           krem = (int)cur.k;
           negn = (cur.flags & 16) != 0;
           nextp = pieces[min(pi + 1, pend - 1)];
+          if (PART) piece_setup(cur);
         } else {
           has_next = false;
         }
@@ -357,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #ifndef EXP_NO_BARRIER
       __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
 #endif
+      if (PART && has_next && fixn >= 0) sh[buf ^ 1][0][fixn] = 0.0;
       {
         // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
         const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
@@ -387,103 +361,24 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     }
     __syncthreads();         // the general loop below restarts on buffer 0
     };
-    // four instantiations: full 128 x 128 tile or not (branch-free MFMA section), with or without sign flips (Task
-    // flag bit 3, set by the plan; real factorizations never have them: 16 vector instructions per chunk less)
-    if (tk.flags & 8u) {
-      if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{}, std::true_type{});
-      else fast_loop(std::false_type{}, std::true_type{});
+    // instantiations: MODE x sign flips (Task flag bit 3, set by the plan; real factorizations never have them: 16
+    // vector instructions per chunk less).  The plan puts the whole-tile pieces of a task first (Task::nfull).
+    // Exactly one instance runs per task: tasks made of whole-tile pieces only (the bulk of the flops) take MODE 0 / 1,
+    // a task with any partial piece runs all its pieces through MODE 2 (a whole-tile piece is its special case).
+    const int plast = tk.p0 + tk.pn;
+    const bool neg = (tk.flags & 8u) != 0;
+    if ((int)tk.nfull == tk.pn) {
+      if (tk.tm == TM && tk.tn == TN) {
+        if (neg) fast_loop(std::integral_constant<int, 0>{}, std::true_type{}, tk.p0, plast);
+        else fast_loop(std::integral_constant<int, 0>{}, std::false_type{}, tk.p0, plast);
+      } else {
+        if (neg) fast_loop(std::integral_constant<int, 1>{}, std::true_type{}, tk.p0, plast);
+        else fast_loop(std::integral_constant<int, 1>{}, std::false_type{}, tk.p0, plast);
+      }
     } else {
-      if (tk.tm == TM && tk.tn == TN) fast_loop(std::true_type{}, std::false_type{});
-      else fast_loop(std::false_type{}, std::false_type{});
+      if (neg) fast_loop(std::integral_constant<int, 2>{}, std::true_type{}, tk.p0, plast);
+      else fast_loop(std::integral_constant<int, 2>{}, std::false_type{}, tk.p0, plast);
     }
-  }
-  if ((int)tk.nfull < tk.pn) {
-  int pi = tk.p0 + (int)tk.nfull;
-  const int pend = tk.p0 + tk.pn;
-  Piece cur = pieces[pi];
-  Piece nextp = pieces[min(pi + 1, pend - 1)];  // descriptor prefetched one piece ahead
-  int kc = 0, buf = 0;
-  Stage<NW> st;
-  {
-    const double* Ab = ar.p[cur.flags & 3] + cur.a_off;
-    const double* Bb = ar.p[(cur.flags >> 2) & 3] + cur.b_off;
-    const bool full = piece_full(cur);
-    stage_load<NW>(st, Ab, Bb, cur, 0, tid, full);
-    stage_store<NW>(st, sh[0][0], sh[0][1], cur, 0, tid, full);
-  }
-  __syncthreads();
-  while (true) {
-    int npi = pi, nkc = kc + KC;
-    const bool adv = nkc >= (int)cur.k;
-    if (adv) { npi = pi + 1; nkc = 0; }
-    const Piece nxt = adv ? nextp : cur;
-    const bool has_next = npi < pend;
-    const bool nfull = piece_full(nxt);
-    if (has_next) {
-      const double* Ab = ar.p[nxt.flags & 3] + nxt.a_off;
-      const double* Bb = ar.p[(nxt.flags >> 2) & 3] + nxt.b_off;
-      stage_load<NW>(st, Ab, Bb, nxt, nkc, tid, nfull);
-    }
-    if (adv) nextp = pieces[min(npi + 1, pend - 1)];
-    // ---- MFMA on the staged chunk ----
-    {
-      unsigned am = 0, an = 0;                  // wave-uniform sub-tile activity
-#pragma unroll
-      for (int s = 0; s < MI; s++) {
-        const int r0 = row0 + s * RS;
-        if (r0 < (int)cur.dr + (int)cur.m && r0 + 16 > (int)cur.dr) am |= 1u << s;
-      }
-#pragma unroll
-      for (int s = 0; s < NI; s++) {
-        const int c0 = col0 + s * CS;
-        if (c0 < (int)cur.dc + (int)cur.n && c0 + 16 > (int)cur.dc) an |= 1u << s;
-      }
-      if (am && an) {
-        touched |= am | (an << 4);
-        const double* sA = sh[buf][0] + row0 + l15;
-        const double* sB = sh[buf][1] + col0 + l15;
-        const int ksteps = (min(KC, (int)cur.k - kc) + 3) >> 2;
-        if (am == MALL && an == 0xFu) {
-          for (int ks = 0; ks < ksteps; ks++) {
-            const int kk = (ks * 4 + g) * SLD;
-            double bm[MI], an_[NI];
-#pragma unroll
-            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * RS];    // rows -> MFMA B operand
-#pragma unroll
-            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * CS];   // cols -> MFMA A operand
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-              for (int ni = 0; ni < NI; ni++)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
-          }
-        } else {
-          for (int ks = 0; ks < ksteps; ks++) {
-            const int kk = (ks * 4 + g) * SLD;
-            double bm[MI], an_[NI];
-#pragma unroll
-            for (int s = 0; s < MI; s++) bm[s] = sA[kk + s * RS];
-#pragma unroll
-            for (int s = 0; s < NI; s++) an_[s] = sB[kk + s * CS];
-#pragma unroll
-            for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-              for (int ni = 0; ni < NI; ni++)
-                if ((am >> mi) & (an >> ni) & 1u)
-                  acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an_[ni], bm[mi], acc[mi][ni], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (has_next) stage_store<NW>(st, sh[buf ^ 1][0], sh[buf ^ 1][1], nxt, nkc, tid, nfull);
-    __syncthreads();
-    if (!has_next) break;
-    cur = nxt;
-    pi = npi;
-    kc = nkc;
-    buf ^= 1;
-  }
-
   }
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column).  Loads of one

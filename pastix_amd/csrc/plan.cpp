@@ -594,10 +594,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       std::copy(part_tmp.begin(), part_tmp.end(), P.pieces.begin() + wpos);
       auto mid = P.pieces.begin() + wpos;
       tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
-      for (auto it = P.pieces.begin() + q; it != mid; ++it) {
-        P.full_flops += 2.0 * it->m * (double)it->n * it->k;
-        if (it->flags & 16) tk.flags |= 8u;            // the DMA loop needs its sign-flipping variant
-      }
+      for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
+      for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it)
+        if (it->flags & 16) tk.flags |= 8u;            // the update kernel needs its sign-flipping variant
+
       if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
         {   // how many non-full pieces share (tile, source cblk): candidates for multi-segment merged pieces
           int64_t lastk = -1;

@@ -532,6 +532,7 @@ class DistPlan:
         return out
 
     def attach_rccl(self, world, ids):
+        _lib.share_rccl_with_torch()
         ids = np.ascontiguousarray(ids, dtype=np.uint8)
         assert ids.size == world * world * ID_BYTES
         check(_lib.lib().pastix_amd_dist_attach_rccl(self._h, ctypes.c_int32(world), _lib.ptr(ids)),
@@ -576,6 +577,7 @@ def exchange_unique_ids(cblk4, blok4, owner, rank, world):
     import torch
     import torch.distributed as dist
     pairs = {(min(int(r), int(owner[t])), max(int(r), int(owner[t]))) for r, t in fanin_pairs(cblk4, blok4, owner).tolist()}
+    _lib.share_rccl_with_torch()
     mine = np.zeros((world, ID_BYTES), dtype=np.uint8)
     for a, b in sorted(pairs):
         if a == rank:

@@ -130,6 +130,7 @@ def test_rccl_binding_selftest():
     sending to itself -- the part of the RCCL path one GPU can execute."""
     import ctypes
     from pastix_amd import _lib
+    _lib.share_rccl_with_torch()
     assert _lib.lib().pastix_amd_dist_selftest_rccl(0, ctypes.c_int64(100003)) == 0
 
 

@@ -11,7 +11,7 @@ int main(int argc, char** argv) {
   int pool = argc > 4 ? atoi(argv[4]) : 64;        // number of distinct source panels
   const int pm = getenv("PM") ? atoi(getenv("PM")) : 128, pn = getenv("PN") ? atoi(getenv("PN")) : 128;   // piece extents
   const int pdr = getenv("PDR") ? atoi(getenv("PDR")) : 0, pdc = getenv("PDC") ? atoi(getenv("PDC")) : 0;
-  int rows = 4096;                                 // rows per source panel
+  int rows = getenv("ROWS") ? atoi(getenv("ROWS")) : 4096;   // rows per source panel (= lda of the pieces)
   int64_t src_elems = (int64_t)pool * rows * K;
   int64_t c_elems = (int64_t)ntask * 128 * 128;
   double *d; CK(hipMalloc(&d, (src_elems + c_elems) * 8));
