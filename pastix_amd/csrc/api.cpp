@@ -201,6 +201,31 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.update_bytes = H.update_bytes;
   S.full_flops = H.full_flops;
   S.urgent_flops = H.urgent_flops;
+  // developer aid (tools/replay_slot.hip): PASTIX_AMD_DUMP_SLOT=<slot>[:file] writes the bulk tasks of one launch slot
+  // with their pieces, to replay that launch alone under different task orders / kernel variants
+  if (const char* ds = getenv("PASTIX_AMD_DUMP_SLOT")) {
+    const int sl = atoi(ds);
+    const char* fn = strchr(ds, ':') ? strchr(ds, ':') + 1 : "/tmp/pastix_amd_slot.bin";
+    if (sl >= 0 && sl < H.nlevels) {
+      const int64_t t0 = H.slot_urgent_end[sl], t1 = H.slot_task_ptr[sl + 1];
+      std::vector<Task> tk(H.tasks.begin() + t0, H.tasks.begin() + t1);
+      std::vector<Piece> pc;
+      for (Task& t : tk) {
+        const int32_t np0 = (int32_t)pc.size();
+        pc.insert(pc.end(), H.pieces.begin() + t.p0, H.pieces.begin() + t.p0 + t.pn);
+        t.p0 = np0;
+      }
+      if (FILE* f = fopen(fn, "wb")) {
+        const int64_t hdr[4] = {H.coefnbr, (int64_t)tk.size(), (int64_t)pc.size(), sl};
+        fwrite(hdr, sizeof(hdr), 1, f);
+        fwrite(tk.data(), sizeof(Task), tk.size(), f);
+        fwrite(pc.data(), sizeof(Piece), pc.size(), f);
+        fclose(f);
+        fprintf(stderr, "pastix_amd: slot %d dumped to %s (%zu tasks, %zu pieces, %.3e flops)\n", sl, fn, tk.size(), pc.size(),
+                H.slot_flops[sl]);
+      }
+    }
+  }
   // the piece/task tables now live on the device; keep only what the host driver reads
   decltype(H.pieces)().swap(H.pieces);
   std::vector<Task>().swap(H.tasks);

@@ -759,7 +759,74 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         for (int64_t q = nfull; q < n; q++) idx[b0 + q] = seq[q];
       }
     }
-    if (order_mode == 0 || order_mode == 2) {
+    if (order_mode == 3) {
+      // 2-D blocks over (A rows, B rows) of the tasks' first pieces, as tools/replay_slot.hip order 1 (measured on dumped
+      // launches of 160^3: +1 ... +4 % against heaviest-first in tile order, random order -10 %): inside a work class
+      // (quarters of the heaviest task, heavy first) runs of 512 tasks form 16 x 32 blocks -- the tasks a full chip runs
+      // together read 16 + 32 operand row blocks per source instead of ~256 + 2 -- and every block is dealt so that
+      // workgroup g (-> XCD g % 8, each with its own L2) belongs to one 8 x 8 sub-block.
+      std::vector<int64_t> ra, rb, tmp, ord, seq;
+      std::vector<std::vector<int64_t>> Lx(8);
+      for (int sl = 0; sl < NL; sl++) {
+        const int64_t b0 = P.slot_urgent_end[sl], n = P.slot_task_ptr[sl + 1] - b0;
+        if (n < 1024) continue;                    // (a launch that does not fill the chip twice keeps heaviest-first)
+        ra.assign((size_t)n, 0);
+        rb.assign((size_t)n, 0);
+        tmp.resize((size_t)n);
+        double wmax = 0;
+        for (int64_t q = 0; q < n; q++) wmax = std::max(wmax, task_work[idx[b0 + q]]);
+        auto rank_by = [&](bool useA, std::vector<int64_t>& out) {
+          std::iota(tmp.begin(), tmp.end(), 0);
+          auto key = [&](int64_t q) {
+            const Piece& pc = P.pieces[P.tasks[idx[b0 + q]].p0];
+            return useA ? pc.a_off : pc.b_off;
+          };
+          std::sort(tmp.begin(), tmp.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
+          int64_t r = -1, last = -1;
+          for (int64_t i = 0; i < n; i++) {
+            const int64_t k = key(tmp[i]);
+            if (i == 0 || k != last) { r++; last = k; }
+            out[tmp[i]] = r;
+          }
+        };
+        rank_by(true, ra);
+        rank_by(false, rb);
+        ord.resize((size_t)n);
+        std::iota(ord.begin(), ord.end(), 0);
+        auto bucket = [&](int64_t q) { return std::min<int>(3, (int)(4.0 * task_work[idx[b0 + q]] / std::max(wmax, 1.0))); };
+        auto sub = [&](int64_t q) { return (int)(((ra[q] / 8) % 2) * 4 + (rb[q] / 8) % 4); };
+        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
+          const int bx = bucket(x), by = bucket(y);
+          if (bx != by) return bx > by;
+          if (rb[x] / 32 != rb[y] / 32) return rb[x] / 32 < rb[y] / 32;
+          if (ra[x] / 16 != ra[y] / 16) return ra[x] / 16 < ra[y] / 16;
+          const int sx = sub(x), sy = sub(y);
+          if (sx != sy) return sx < sy;
+          if (ra[x] != ra[y]) return ra[x] < ra[y];
+          if (rb[x] != rb[y]) return rb[x] < rb[y];
+          return x < y;
+        });
+        seq.clear();
+        for (int64_t i = 0; i < n;) {
+          int64_t j = i;
+          for (auto& l : Lx) l.clear();
+          while (j < n && bucket(ord[j]) == bucket(ord[i]) && rb[ord[j]] / 32 == rb[ord[i]] / 32 &&
+                 ra[ord[j]] / 16 == ra[ord[i]] / 16) {
+            Lx[(size_t)sub(ord[j])].push_back(ord[j]);
+            j++;
+          }
+          for (size_t v = 0;; v++) {
+            bool any = false;
+            for (int x = 0; x < 8; x++)
+              if (v < Lx[(size_t)x].size()) { seq.push_back(idx[b0 + Lx[(size_t)x][v]]); any = true; }
+            if (!any) break;
+          }
+          i = j;
+        }
+        for (int64_t q = 0; q < n; q++) idx[b0 + q] = seq[(size_t)q];
+      }
+    }
+    if (order_mode == 0 || order_mode == 2 || order_mode == 3) {
       for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
     } else {
       // the urgent tasks [slot_task_ptr, slot_urgent_end) and the bulk of a slot are launched separately by the

@@ -25,6 +25,27 @@ int main(int argc, char** argv) {
     tasks[t] = Task{src_elems + (int64_t)t * 128 * 128, 128, 128, 128, t * P, P, 0, (unsigned)((getenv("NOFAST") || pm != 128 || pn != 128) ? 0 : P)};
     for (int p = 0; p < P; p++) {
       int s = (t * 7 + p * 13) % pool; int ra = ((t * 31 + p) % (rows / 128)) * 128, rb = ((t * 17 + 3 * p) % (rows / 128)) * 128;
+      // STRUCT: the access pattern of a top-of-tree launch: task (rt, ct) of the trailing matrix reads A(rt, source p) and
+      // B(ct, source p) from P source panels of `rows` rows.  1: tasks in (ct, rt) order (heaviest-first order of the
+      // plan = creation order); 2: 2-D blocks -- every run of 512 tasks is a 16 x 32 block of (rt, ct), and workgroup g
+      // goes to XCD g % 8, which gets an 8 x 8 sub-block
+      static const int st = getenv("STRUCT") ? atoi(getenv("STRUCT")) : 0;
+      if (st) {
+        const int R = rows / 128;
+        int rt, ct;
+        if (st == 1) { ct = t / R; rt = t % R; }
+        else {
+          const int blk = t / 512, u = t % 512;        // block of 512 tasks; u -> XCD u % 8, slot u / 8
+          const int x = u % 8, v = u / 8;              // XCD x holds the 8 x 8 sub-block (x / 4, x % 4) of the 16 x 32 block
+          const int br = blk % (R / 16), bc = blk / (R / 16);
+          rt = br * 16 + (x / 4) * 8 + v / 8;
+          ct = bc * 32 + (x % 4) * 8 + v % 8;
+        }
+        s = p % pool; ra = (rt % R) * 128; rb = (ct % R) * 128;
+      }
+      static const int offa = getenv("OFFA") ? atoi(getenv("OFFA")) : 0, offb = getenv("OFFB") ? atoi(getenv("OFFB")) : 0;
+      if (ra + 128 + offa <= rows) ra += offa;          // operand rows not aligned to 16 B / to the 128-B cache line
+      if (rb + 128 + offb <= rows) rb += offb;
       pieces[(size_t)t * P + p] = Piece{(int64_t)s * rows * K + ra, (int64_t)s * rows * K + rb, rows, (uint16_t)K, (uint16_t)pdr, (uint16_t)pm, (uint16_t)pdc, (uint16_t)pn, 0};
     }
   }
