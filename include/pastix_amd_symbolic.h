@@ -20,7 +20,14 @@ typedef struct pastix_amd_symbolic_options_s {
   int max_merge_width;    /* do not create amalgamated nodes wider than this (0 = no limit) */
   int schur_n;            /* IPARM_SCHUR: the last schur_n unknowns of the ordering (which must be mutually coupled in
                              the pattern: a clique) stay ONE cblk, not split and not merged with anything else */
-  int reserved[12];
+  int blend_split;        /* 0: cut wide supernodes into cblks of max_blocksize columns (last one narrower): full
+                             128-column tiles for the device kernels.  1: blend's own rule (splitOnProcs,
+                             src/blend/src/splitpart.c:387-516): equal pieces of width / (width / max) columns, and
+                             supernodes that would give fewer than 4 pieces stay whole */
+  int min_blocksize;      /* IPARM_MIN_BLOCKSIZE role (pastix.c:372): lower bound of the piece width with several
+                             candidate processors; default max_blocksize / 2 */
+  int candidate_procs;    /* candidate processors of a supernode in blend's rule (1 = sequential / one GPU) */
+  int reserved[9];
 } pastix_amd_symbolic_options_t;
 
 typedef struct pastix_amd_symbol_s pastix_amd_symbol_t;
@@ -30,6 +37,14 @@ typedef struct pastix_amd_symbol_s pastix_amd_symbol_t;
  * invp: new->old, both 0-based, length nx*ny*nz. */
 int pastix_amd_order_grid(pastix_amd_int_t nx, pastix_amd_int_t ny, pastix_amd_int_t nz, int leaf,
                           pastix_amd_int_t *perm, pastix_amd_int_t *invp);
+
+/* Nested dissection of a general symmetric-pattern graph (the fallback where neither Scotch / METIS nor a grid hint is
+ * available; the reference calls Scotch here, pastix.c:1540-1680): recursive bisection by level structures -- breadth
+ * first search from a pseudo-peripheral vertex, the middle level is the separator (George's automatic nested
+ * dissection) -- separators numbered last, parts of at most `leaf` vertices numbered in reverse Cuthill-McKee order.
+ * CSC 1-based, lower triangle or full pattern.  perm: old->new, invp: new->old, 0-based. */
+int pastix_amd_order_graph(pastix_amd_int_t n, const pastix_amd_int_t *colptr, const pastix_amd_int_t *rows, int leaf,
+                           pastix_amd_int_t *perm, pastix_amd_int_t *invp);
 
 /* Symbolic factorization of the pattern (CSC 1-based; lower triangle or full, symmetric pattern)
  * under the ordering perm (0-based old->new; NULL = natural).  The ordering is refined

@@ -78,7 +78,7 @@ EXPORTS = [
 ]
 # include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
 EXPORTS_HOST = [
-    "pastix_amd_order_grid", "pastix_amd_symbolic", "pastix_amd_symbol_layout", "pastix_amd_symbol_perm",
+    "pastix_amd_order_grid", "pastix_amd_order_graph", "pastix_amd_symbolic", "pastix_amd_symbol_layout", "pastix_amd_symbol_perm",
     "pastix_amd_symbol_info", "pastix_amd_symbol_destroy", "pastix_amd_pastix", "pastix_amd_set_grid", "pastix_amd_set_schur_unknown_list", "pastix_amd_get_schur",
     "pastix_amd_data_plan",
 ]

@@ -158,7 +158,9 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
           rc = pastix_amd_order_grid(D->grid[0], D->grid[1], D->grid[2], 8, D->perm.data(), D->invp.data());
           if (rc) FAIL(rc);
         } else {
-          for (int64_t i = 0; i < n; i++) D->perm[i] = i;   // no Scotch/METIS here: natural order
+          // no Scotch / METIS on this box: nested dissection of the graph by level structures (symbolic.cpp)
+          rc = pastix_amd_order_graph(n, colptr, row, 64, D->perm.data(), D->invp.data());
+          if (rc) FAIL(rc);
         }
         D->schur_on = iparm[IPARM_SCHUR] == API_YES && !D->schur_list.empty();
         if (D->schur_on) {
@@ -180,6 +182,8 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         if (!colptr || !row || D->perm.empty()) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
         pastix_amd_symbolic_options_t so{};
         so.max_blocksize = (int)iparm[IPARM_MAX_BLOCKSIZE];
+        so.min_blocksize = (int)iparm[IPARM_MIN_BLOCKSIZE];
+        so.blend_split = 1;                          // IPARM_MIN/MAX_BLOCKSIZE mean what they mean to blend (splitpart.c)
         so.amalgamation_pct = (int)iparm[IPARM_AMALGAMATION_LEVEL];
         if (D->sym) { pastix_amd_symbol_destroy(D->sym); D->sym = nullptr; }
         if (D->schur_on) {

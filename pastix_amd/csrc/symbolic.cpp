@@ -100,6 +100,131 @@ int pastix_amd_order_grid(pastix_amd_int_t nx, pastix_amd_int_t ny, pastix_amd_i
   return PASTIX_AMD_OK;
 }
 
+// George's automatic nested dissection on a general graph (see the header): an explicit work list instead of recursion;
+// `parts` holds vertex lists, numbering is assigned from the END of the order backwards so that every separator comes
+// after both of its parts.
+int pastix_amd_order_graph(pastix_amd_int_t n, const pastix_amd_int_t* colptr, const pastix_amd_int_t* rows, int leaf,
+                           pastix_amd_int_t* perm, pastix_amd_int_t* invp) {
+  if (n <= 0 || !colptr || !rows || !perm || !invp || n > 0x7ffffff0LL) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (leaf <= 0) leaf = 64;
+  try {
+    // symmetric adjacency, 0-based, no diagonal
+    std::vector<int64_t> xadj((size_t)n + 1, 0);
+    const int64_t nnz = colptr[n] - 1;
+    for (int64_t j = 0; j < n; j++)
+      for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+        const int64_t i = rows[q] - 1;
+        if (i < 0 || i >= n) return PASTIX_AMD_ERR_BADPARAMETER;
+        if (i != j) { xadj[i + 1]++; xadj[j + 1]++; }
+      }
+    (void)nnz;
+    for (int64_t j = 0; j < n; j++) xadj[j + 1] += xadj[j];
+    std::vector<idx> adj((size_t)xadj[n]);
+    {
+      std::vector<int64_t> pos(xadj.begin(), xadj.end() - 1);
+      for (int64_t j = 0; j < n; j++)
+        for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
+          const int64_t i = rows[q] - 1;
+          if (i != j) { adj[pos[i]++] = (idx)j; adj[pos[j]++] = (idx)i; }
+        }
+    }
+    std::vector<int32_t> part((size_t)n, 0);       // id of the part a vertex currently belongs to (-1: numbered)
+    std::vector<idx> lvl((size_t)n, -1), queue;
+    std::vector<std::vector<idx>> parts;
+    parts.emplace_back((size_t)n);
+    std::iota(parts[0].begin(), parts[0].end(), 0);
+    std::vector<size_t> work{0};
+    int64_t next = n;                              // numbers are handed out downwards
+    std::vector<int64_t> ip((size_t)n, -1);
+    auto bfs = [&](idx root, int32_t pid) {        // level structure of root's component inside part pid -> queue, lvl
+      queue.clear();
+      queue.push_back(root);
+      lvl[root] = 0;
+      for (size_t h = 0; h < queue.size(); h++) {
+        const idx v = queue[h];
+        for (int64_t q = xadj[v]; q < xadj[v + 1]; q++) {
+          const idx u = adj[q];
+          if (part[u] == pid && lvl[u] < 0) { lvl[u] = lvl[v] + 1; queue.push_back(u); }
+        }
+      }
+    };
+    while (!work.empty()) {
+      const size_t wi = work.back();
+      work.pop_back();
+      std::vector<idx> verts;
+      verts.swap(parts[wi]);
+      const int32_t pid = (int32_t)wi;
+      if (verts.empty()) continue;
+      // one connected component at a time
+      idx root = verts[0];
+      bfs(root, pid);
+      if (queue.size() < verts.size()) {           // disconnected: split off this component, requeue both
+        std::vector<idx> comp(queue), rest;
+        for (idx v : comp) lvl[v] = -1;
+        const int32_t cid = (int32_t)parts.size();
+        for (idx v : comp) part[v] = cid;
+        for (idx v : verts) if (part[v] == pid) rest.push_back(v);
+        parts.push_back(std::move(comp));
+        parts[wi] = std::move(rest);
+        work.push_back(wi);
+        work.push_back((size_t)cid);
+        continue;
+      }
+      if ((int64_t)verts.size() <= leaf) {
+        // leaf: reverse Cuthill-McKee = the BFS order from a pseudo-peripheral vertex, reversed; numbers go downwards,
+        // so handing them out in BFS order gives exactly the reversed order
+        for (idx v : queue) lvl[v] = -1;
+        idx far = queue.back();
+        bfs(far, pid);
+        for (idx v : queue) { ip[--next] = v; part[v] = -1; lvl[v] = -1; }
+        continue;
+      }
+      // pseudo-peripheral vertex: repeat BFS from the farthest vertex while the eccentricity grows
+      idx ecc = lvl[queue.back()];
+      for (int it = 0; it < 4; it++) {
+        const idx far = queue.back();
+        for (idx v : queue) lvl[v] = -1;
+        bfs(far, pid);
+        const idx e2 = lvl[queue.back()];
+        if (e2 <= ecc) break;
+        ecc = e2;
+      }
+      const idx depth = lvl[queue.back()];
+      if (depth < 2) {                             // (nearly) a clique: no separator to find
+        for (idx v : queue) { ip[--next] = v; part[v] = -1; lvl[v] = -1; }
+        continue;
+      }
+      // separator = the level that halves the vertex count (by cumulative level sizes)
+      std::vector<int64_t> cnt((size_t)depth + 1, 0);
+      for (idx v : queue) cnt[(size_t)lvl[v]]++;
+      int64_t acc = 0;
+      idx mid = 1;
+      for (idx l = 0; l <= depth; l++) {
+        acc += cnt[(size_t)l];
+        if (2 * acc >= (int64_t)queue.size()) { mid = l; break; }
+      }
+      mid = std::max<idx>(1, std::min<idx>(mid, depth - 1));
+      const int32_t aid = (int32_t)parts.size(), bid = aid + 1;
+      std::vector<idx> A, B;
+      for (idx v : queue) {
+        if (lvl[v] == mid) { ip[--next] = v; part[v] = -1; }      // separator: numbered now (after both halves)
+        else if (lvl[v] < mid) { A.push_back(v); part[v] = aid; }
+        else { B.push_back(v); part[v] = bid; }
+        lvl[v] = -1;
+      }
+      parts.push_back(std::move(A));
+      parts.push_back(std::move(B));
+      work.push_back((size_t)aid);
+      work.push_back((size_t)bid);
+    }
+    if (next != 0) return PASTIX_AMD_ERR_BADPARAMETER;
+    for (int64_t k = 0; k < n; k++) { invp[k] = ip[(size_t)k]; perm[ip[(size_t)k]] = k; }
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  return PASTIX_AMD_OK;
+}
+
 void pastix_amd_symbol_destroy(pastix_amd_symbol_t* s) { delete s; }
 
 int pastix_amd_symbol_layout(const pastix_amd_symbol_t* s, pastix_amd_layout_t* out) {
@@ -134,7 +259,10 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
   pastix_amd_symbolic_options_t o{};
   if (opts_in) o = *opts_in;
   if (o.max_blocksize <= 0) o.max_blocksize = 128;
-  if (o.max_blocksize > 256) o.max_blocksize = 256;
+  if (o.max_blocksize > 256 && !o.blend_split) o.max_blocksize = 256;   // (blend's rule may leave wider cblks: the
+                                                                        // engine factorizes those as column groups)
+  if (o.min_blocksize <= 0) o.min_blocksize = std::max(1, o.max_blocksize / 2);
+  if (o.candidate_procs <= 0) o.candidate_procs = 1;
   if (o.amalgamation_pct < 0) o.amalgamation_pct = 0;
   const double ratio = (o.amalgamation_pct == 0 && !opts_in) ? 0.05 : o.amalgamation_pct * 0.01;
   pastix_amd_symbol_t* S = new (std::nothrow) pastix_amd_symbol_t();
@@ -395,8 +523,28 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       a_cblk0[a] = (idx)cfirst.size();
       idx w = afirst[a + 1] - afirst[a];
       if (o.schur_n > 0 && afirst[a] >= (idx)(n - o.schur_n)) { cfirst.push_back(afirst[a]); continue; }   // the Schur cblk is not split
-      for (idx c = afirst[a]; c < afirst[a + 1]; c += maxbs) cfirst.push_back(c);
-      (void)w;
+      if (!o.blend_split) {
+        for (idx c = afirst[a]; c < afirst[a + 1]; c += maxbs) cfirst.push_back(c);
+        continue;
+      }
+      // blend's splitOnProcs (src/blend/src/splitpart.c:387-516, DOF_CONSTANT build, dof 1).  One candidate processor:
+      // a cblk no wider than IPARM_MAX_BLOCKSIZE stays; else nseq = width / max pieces of width / nseq columns, the
+      // last one taking the remainder.  Several candidates (abs = 4, the reference's default): the piece width is
+      // width / (abs * procs) clamped to [IPARM_MIN_BLOCKSIZE, IPARM_MAX_BLOCKSIZE].  In both cases "no parallelism
+      // available above 4 splitted cblk": fewer than 4 pieces -> the cblk is left whole (:479-481).
+      idx nseq;
+      if (o.candidate_procs == 1) {
+        if (w <= maxbs) { cfirst.push_back(afirst[a]); continue; }
+        nseq = w / maxbs;
+      } else {
+        idx pas = w / (4 * (idx)o.candidate_procs);
+        pas = std::max<idx>(pas, (idx)o.min_blocksize);
+        pas = std::min<idx>(pas, maxbs);
+        nseq = w / pas;
+      }
+      if (nseq < 4) { cfirst.push_back(afirst[a]); continue; }
+      const idx pas = w / nseq;
+      for (idx q = 0; q < nseq; q++) cfirst.push_back(afirst[a] + pas * q);
     }
     a_cblk0[na] = (idx)cfirst.size();
     if (o.schur_n > 0 && (o.schur_n > n || cfirst.back() != (idx)(n - o.schur_n))) {   // the last unknowns were not a clique

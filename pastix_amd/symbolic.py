@@ -10,7 +10,8 @@ from ._lib import Layout, check
 
 class SymOptions(ctypes.Structure):
     _fields_ = [("max_blocksize", ctypes.c_int), ("amalgamation_pct", ctypes.c_int),
-                ("max_merge_width", ctypes.c_int), ("schur_n", ctypes.c_int), ("reserved", ctypes.c_int * 12)]
+                ("max_merge_width", ctypes.c_int), ("schur_n", ctypes.c_int), ("blend_split", ctypes.c_int),
+                ("min_blocksize", ctypes.c_int), ("candidate_procs", ctypes.c_int), ("reserved", ctypes.c_int * 9)]
 
 
 def order_grid(nx, ny, nz, leaf=8):
@@ -22,13 +23,25 @@ def order_grid(nx, ny, nz, leaf=8):
     return perm, invp
 
 
-def symbolic(n, colptr, rows, perm=None, max_blocksize=128, amalgamation_pct=5, max_merge_width=0, schur_n=0):
+def order_graph(n, colptr, rows, leaf=64):
+    """Nested dissection of a general graph (pastix_amd_order_graph): the fallback ordering of the pastix() driver."""
+    colptr, rows = _lib.as_i64(colptr), _lib.as_i64(rows)
+    perm = np.empty(n, dtype=np.int64)
+    invp = np.empty(n, dtype=np.int64)
+    check(_lib.lib().pastix_amd_order_graph(ctypes.c_int64(n), _lib.ptr(colptr), _lib.ptr(rows), int(leaf),
+                                            _lib.ptr(perm), _lib.ptr(invp)), "pastix_amd_order_graph")
+    return perm, invp
+
+
+def symbolic(n, colptr, rows, perm=None, max_blocksize=128, amalgamation_pct=5, max_merge_width=0, schur_n=0,
+             blend_split=False, min_blocksize=0, candidate_procs=1):
     """Returns dict(perm, invp, cblk4, blok4, nnzl, nsuper_fund, nsuper_amalg)."""
     colptr, rows = _lib.as_i64(colptr), _lib.as_i64(rows)
     perm = _lib.as_i64(perm) if perm is not None else None
     o = SymOptions()
     o.max_blocksize, o.amalgamation_pct, o.max_merge_width = int(max_blocksize), int(amalgamation_pct), int(max_merge_width)
     o.schur_n = int(schur_n)
+    o.blend_split, o.min_blocksize, o.candidate_procs = int(bool(blend_split)), int(min_blocksize), int(candidate_procs)
     h = ctypes.c_void_p()
     L = _lib.lib()
     check(L.pastix_amd_symbolic(ctypes.c_int64(n), _lib.ptr(colptr), _lib.ptr(rows), _lib.ptr(perm),

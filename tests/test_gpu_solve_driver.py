@@ -479,3 +479,37 @@ def test_pastix_irregular_graph_personal_ordering(facto):
     assert np.abs(b - x0).max() <= 1e-9 * np.abs(x0).max()
     iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
     px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("base", [1, 0])
+@pytest.mark.parametrize("name,facto", [("orsirr_1030_lu", "LU"), ("rlap3d_12_llt", "LLT")])
+def test_pastix_default_ordering_on_a_general_graph(name, facto, base, golden):
+    """No API_ORDER_PERSONAL and no grid hint: the driver orders the graph itself (nested dissection by level
+    structures, pastix_amd_order_graph -- the reference calls Scotch here), cuts the supernodes with blend's rule under
+    IPARM_MIN/MAX_BLOCKSIZE, factorizes and solves.  orsirr.rua is the reference's own irregular fixture.  base 0: the
+    same through a 0-based CSC (IPARM_BASEVAL = colptr[0])."""
+    g = golden(name)
+    n = int(g["n"])
+    cp, r, v = g["colptr"].astype(np.int64), g["rows"].astype(np.int64), g["vals"].copy()
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    Afull = A if facto == "LU" else A + sp.tril(A, -1).T
+    x0 = np.random.default_rng(4).standard_normal(n)
+    b = Afull @ x0
+    rhs = b.copy()
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if facto == "LU" else px.API_SYM_YES
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK["REFINE"]
+    cpb, rb = cp - (1 - base), r - (1 - base)
+    pd = px.pastix(None, n, cpb, rb, v, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    assert iparm[px.IPARM["BASEVAL"]] == base
+    assert np.array_equal(np.sort(perm), np.arange(n) + base) and np.array_equal(invp[perm - base] - base, np.arange(n))
+    assert np.linalg.norm(Afull @ b - rhs) / np.linalg.norm(rhs) < 1e-10
+    # the ordering is a fill-reducing one: far fewer factor entries than under the natural order
+    nat = sy.symbolic(n, cp, r, None)["nnzl"]
+    assert iparm[px.IPARM["NNZEROS"]] < (0.8 if name.startswith("orsirr") else 0.5) * nat
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
+    px.pastix(pd, n, cpb, rb, v, perm, invp, b, 1, iparm, dparm)
