@@ -527,149 +527,214 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
-  // (it costs one more pass over the tile)
-  std::vector<Piece> part_tmp;
   const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
                                                                : true;
-  for (size_t q = 0; q < raw.size();) {
-    size_t e = q;
-    double work = 0;
-    int tlev;
-    {
-      const int64_t tile0 = raw[q].tile - (int64_t)raw[q].carena * ntile;
-      const int64_t tt = std::upper_bound(tile_base.begin(), tile_base.end(), tile0) - tile_base.begin() - 1;
-      tlev = P.level[tt];
-    }
-    while (e < raw.size() && raw[e].tile == raw[q].tile) {
-      work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
-      e++;
-      // close the chunk once enough work is gathered, but never split pieces of one source level
-      // (many small pieces are flushed early by count: each costs a latency-bound pass, and keeping
-      // them for the tile's last chunk would put them on the critical path of the dependency chain)
-      if (raw[q].shared) {
-        // shared tile: every slot gets its own tasks; a long list is cut into several tasks that run
-        // concurrently and combine with f64 atomics (split-K), so that the few tiles of one target
-        // cblk still fill the chip
-        if (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl ||
-            work >= chunk_work || (int)(e - q) >= max_pieces) break;
-        continue;
+  // The tiles are independent: the sorted piece list is cut at tile boundaries into one range per host thread, every
+  // thread groups its tiles into its own lists, which are concatenated in range order (= the serial result).
+  struct GOut {
+    std::vector<Task> tasks;
+    std::vector<double> work;
+    std::vector<int32_t> slot;
+    std::vector<uint8_t> urgent;
+    std::vector<double> slot_flops, slot_urgent_flops, slot_maxwork;
+    std::vector<int64_t> slot_pieces, slot_cnt;
+    std::vector<int32_t> slot_maxpn;
+    std::vector<Piece> part_tmp;
+    double urgent_flops = 0, full_flops = 0, ubytes = 0;
+  };
+  const int gthr = hist_on ? 1 : nthr;             // (the shape histogram keeps one set of counters)
+  std::vector<GOut> gout((size_t)gthr);
+  std::vector<size_t> gcut((size_t)gthr + 1, raw.size());
+  gcut[0] = 0;
+  for (int t = 1; t < gthr; t++) {
+    size_t c = raw.size() * (size_t)t / (size_t)gthr;
+    while (c < raw.size() && c > 0 && raw[c].tile == raw[c - 1].tile) c++;
+    gcut[(size_t)t] = std::max(c, gcut[(size_t)t - 1]);
+  }
+  auto group = [&](int gt) {
+    GOut& O = gout[(size_t)gt];
+    const size_t qb = gcut[(size_t)gt], qe = gcut[(size_t)gt + 1];
+    O.slot_flops.assign(NL, 0.0);
+    O.slot_urgent_flops.assign(NL, 0.0);
+    O.slot_maxwork.assign(NL, 0.0);
+    O.slot_pieces.assign(NL, 0);
+    O.slot_cnt.assign(NL, 0);
+    O.slot_maxpn.assign(NL, 0);
+      for (size_t q = qb; q < qe;) {
+      size_t e = q;
+      double work = 0;
+      int tlev;
+      {
+        const int64_t tile0 = raw[q].tile - (int64_t)raw[q].carena * ntile;
+        const int64_t tt = std::upper_bound(tile_base.begin(), tile_base.end(), tile0) - tile_base.begin() - 1;
+        tlev = P.level[tt];
       }
-      if ((work >= chunk_work || (int)(e - q) >= max_pieces) &&
-          (e == raw.size() || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
-      // contributions from the level right below the target's are the only ones that cannot be computed
-      // before that level's panel kernels: keep them in tasks of their own (the urgent set of their slot) and
-      // flush everything older one slot earlier, where it overlaps with the panel kernels (api.cpp, two streams)
-      if (urgent_split && e < raw.size() && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
-          raw[e - 1].lvl < tlev - 1) break;
-    }
-    int slot = raw[e - 1].lvl + 1;
-    int64_t tile = raw[q].tile;
-    uint8_t carena = raw[q].carena;
-    tile -= (int64_t)carena * ntile;
-    int64_t t = std::upper_bound(tile_base.begin(), tile_base.end(), tile) - tile_base.begin() - 1;
-    int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1, nct = (w_t + TN - 1) / TN;
-    int64_t rt = (tile - tile_base[t]) / nct, ct = (tile - tile_base[t]) % nct;
-    Task tk{};
-    tk.c_off = P.poff[t] + rt * TM + ct * TN * P.tstride[t];
-    tk.ldc = (int32_t)P.tstride[t];
-    tk.tm = (uint16_t)std::min<int64_t>(TM, P.tstride[t] - rt * TM);
-    tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
-    tk.p0 = (int32_t)q;
-    tk.pn = (int32_t)(e - q);
-    tk.flags = carena | (raw[q].shared ? 4u : 0u);
-    {   // pieces that cover the whole valid tile (any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
-        // through its specialized loop; tk.nfull = how many
-      static const bool edge_fast = getenv("PASTIX_AMD_EDGE_FAST") ? atoi(getenv("PASTIX_AMD_EDGE_FAST")) != 0 : true;
-      auto isfull = [&](const Piece& pc) {   // covers the whole valid tile (tm x tn; 128 x 128 except at the edges)
-        return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0 &&
-               (edge_fast || (pc.m == TM && pc.n == TN));
-      };
-      // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
-      part_tmp.clear();
-      size_t wpos = q;
-      for (size_t z = q; z < e; z++) {
-        if (isfull(P.pieces[z])) P.pieces[wpos++] = P.pieces[z];
-        else part_tmp.push_back(P.pieces[z]);
+      while (e < qe && raw[e].tile == raw[q].tile) {
+        work += double(raw[e].p.m) * raw[e].p.n * raw[e].p.k;
+        e++;
+        // close the chunk once enough work is gathered, but never split pieces of one source level
+        // (many small pieces are flushed early by count: each costs a latency-bound pass, and keeping
+        // them for the tile's last chunk would put them on the critical path of the dependency chain)
+        if (raw[q].shared) {
+          // shared tile: every slot gets its own tasks; a long list is cut into several tasks that run
+          // concurrently and combine with f64 atomics (split-K), so that the few tiles of one target
+          // cblk still fill the chip
+          if (e == qe || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl ||
+              work >= chunk_work || (int)(e - q) >= max_pieces) break;
+          continue;
+        }
+        if ((work >= chunk_work || (int)(e - q) >= max_pieces) &&
+            (e == qe || raw[e].tile != raw[q].tile || raw[e].lvl != raw[e - 1].lvl)) break;
+        // contributions from the level right below the target's are the only ones that cannot be computed
+        // before that level's panel kernels: keep them in tasks of their own (the urgent set of their slot) and
+        // flush everything older one slot earlier, where it overlaps with the panel kernels (api.cpp, two streams)
+        if (urgent_split && e < qe && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
+            raw[e - 1].lvl < tlev - 1) break;
       }
-      std::copy(part_tmp.begin(), part_tmp.end(), P.pieces.begin() + wpos);
-      auto mid = P.pieces.begin() + wpos;
-      tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
-      for (auto it = P.pieces.begin() + q; it != mid; ++it) P.full_flops += 2.0 * it->m * (double)it->n * it->k;
-      for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it)
-        if (it->flags & 16) tk.flags |= 8u;            // the update kernel needs its sign-flipping variant
+      int slot = raw[e - 1].lvl + 1;
+      int64_t tile = raw[q].tile;
+      uint8_t carena = raw[q].carena;
+      tile -= (int64_t)carena * ntile;
+      int64_t t = std::upper_bound(tile_base.begin(), tile_base.end(), tile) - tile_base.begin() - 1;
+      int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1, nct = (w_t + TN - 1) / TN;
+      int64_t rt = (tile - tile_base[t]) / nct, ct = (tile - tile_base[t]) % nct;
+      Task tk{};
+      tk.c_off = P.poff[t] + rt * TM + ct * TN * P.tstride[t];
+      tk.ldc = (int32_t)P.tstride[t];
+      tk.tm = (uint16_t)std::min<int64_t>(TM, P.tstride[t] - rt * TM);
+      tk.tn = (uint16_t)std::min<int64_t>(TN, w_t - ct * TN);
+      tk.p0 = (int32_t)q;
+      tk.pn = (int32_t)(e - q);
+      tk.flags = carena | (raw[q].shared ? 4u : 0u);
+      {   // pieces that cover the whole valid tile (any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
+          // through its specialized loop; tk.nfull = how many
+        static const bool edge_fast = getenv("PASTIX_AMD_EDGE_FAST") ? atoi(getenv("PASTIX_AMD_EDGE_FAST")) != 0 : true;
+        auto isfull = [&](const Piece& pc) {   // covers the whole valid tile (tm x tn; 128 x 128 except at the edges)
+          return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0 &&
+                 (edge_fast || (pc.m == TM && pc.n == TN));
+        };
+        // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
+        O.part_tmp.clear();
+        size_t wpos = q;
+        for (size_t z = q; z < e; z++) {
+          if (isfull(P.pieces[z])) P.pieces[wpos++] = P.pieces[z];
+          else O.part_tmp.push_back(P.pieces[z]);
+        }
+        std::copy(O.part_tmp.begin(), O.part_tmp.end(), P.pieces.begin() + wpos);
+        auto mid = P.pieces.begin() + wpos;
+        tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
+        for (auto it = P.pieces.begin() + q; it != mid; ++it) O.full_flops += 2.0 * it->m * (double)it->n * it->k;
+        for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it)
+          if (it->flags & 16) tk.flags |= 8u;            // the update kernel needs its sign-flipping variant
 
-      if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
-        {   // how many non-full pieces share (tile, source cblk): candidates for multi-segment merged pieces
-          int64_t lastk = -1;
-          int rs_lo = 999, rs_hi = -1, cs_lo = 999, cs_hi = -1, kk = 0;
-          auto flushg = [&]() {
-            if (lastk < 0) return;
-            hist_groups++;
-            // merged piece: bounding sub-tile box, busiest-wave model with cyclic ownership
+        if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
+          {   // how many non-full pieces share (tile, source cblk): candidates for multi-segment merged pieces
+            int64_t lastk = -1;
+            int rs_lo = 999, rs_hi = -1, cs_lo = 999, cs_hi = -1, kk = 0;
+            auto flushg = [&]() {
+              if (lastk < 0) return;
+              hist_groups++;
+              // merged piece: bounding sub-tile box, busiest-wave model with cyclic ownership
+              int mx = 0;
+              for (int wr = 0; wr < 4; wr++)
+                for (int wc = 0; wc < 2; wc++) {
+                  int r = 0, c = 0;
+                  for (int t = 0; t < 2; t++) { int b = wr + 4 * t; if (b >= rs_lo && b <= rs_hi) r++; }
+                  for (int t = 0; t < 4; t++) { int b = wc + 2 * t; if (b >= cs_lo && b <= cs_hi) c++; }
+                  mx = std::max(mx, r * c);
+                }
+              hist_merged += 2.0 * 256.0 * mx * 8 * ((kk + 15) / 16 * 16);
+            };
+            for (auto it = mid; it != P.pieces.begin() + e; ++it) {
+              const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), it->a_off) - P.poff.begin() - 1;
+              if (k != lastk) { flushg(); lastk = k; rs_lo = cs_lo = 999; rs_hi = cs_hi = -1; kk = it->k; }
+              rs_lo = std::min(rs_lo, it->dr / 16); rs_hi = std::max(rs_hi, (it->dr + it->m - 1) / 16);
+              cs_lo = std::min(cs_lo, it->dc / 16); cs_hi = std::max(cs_hi, (it->dc + it->n - 1) / 16);
+              hist_nonfull++;
+            }
+            flushg();
+          }
+          for (auto it = mid; it != P.pieces.begin() + e; ++it) {
+            const double f = 2.0 * it->m * (double)it->n * it->k;
+            const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
+            const int cm = it->m >= 96 ? 2 : it->m >= 32 ? 1 : 0, cn = it->n >= 96 ? 2 : it->n >= 32 ? 1 : 0;
+            hist_f[cm][cn] += f;
+            hist_c[cm][cn] += 1;
+            if (!even) hist_odd += f;
+            if (it->dr == 0 && it->dc == 0 && (it->m == TM || it->m == tk.tm) && (it->n == TN || it->n == tk.tn)) hist_valid += f;
+            // 16x16 sub-tiles the piece touches x chunks of 16: what the MFMA pipe executes for it
+            const int rs = (it->dr + it->m + 15) / 16 - it->dr / 16, cs = (it->dc + it->n + 15) / 16 - it->dc / 16;
+            hist_exec += 2.0 * 256.0 * rs * cs * ((it->k + 15) / 16 * 16);
+            // time-like: the busiest wave (32x64 wave tiles) x 8 waves
             int mx = 0;
             for (int wr = 0; wr < 4; wr++)
               for (int wc = 0; wc < 2; wc++) {
                 int r = 0, c = 0;
-                for (int t = 0; t < 2; t++) { int b = wr + 4 * t; if (b >= rs_lo && b <= rs_hi) r++; }
-                for (int t = 0; t < 4; t++) { int b = wc + 2 * t; if (b >= cs_lo && b <= cs_hi) c++; }
+                for (int t = 0; t < 2; t++) { int lo = wr * 32 + t * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
+                for (int t = 0; t < 4; t++) { int lo = wc * 64 + t * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
                 mx = std::max(mx, r * c);
               }
-            hist_merged += 2.0 * 256.0 * mx * 8 * ((kk + 15) / 16 * 16);
-          };
-          for (auto it = mid; it != P.pieces.begin() + e; ++it) {
-            const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), it->a_off) - P.poff.begin() - 1;
-            if (k != lastk) { flushg(); lastk = k; rs_lo = cs_lo = 999; rs_hi = cs_hi = -1; kk = it->k; }
-            rs_lo = std::min(rs_lo, it->dr / 16); rs_hi = std::max(rs_hi, (it->dr + it->m - 1) / 16);
-            cs_lo = std::min(cs_lo, it->dc / 16); cs_hi = std::max(cs_hi, (it->dc + it->n - 1) / 16);
-            hist_nonfull++;
+            hist_wave += 2.0 * 256.0 * mx * 8 * ((it->k + 15) / 16 * 16);
+            int mxc = 0;   // cyclic sub-tile ownership: wave (wr,wc) owns row sub-tiles wr, wr+4 and col sub-tiles wc, wc+2, wc+4, wc+6
+            for (int wr = 0; wr < 4; wr++)
+              for (int wc = 0; wc < 2; wc++) {
+                int r = 0, c = 0;
+                for (int t = 0; t < 2; t++) { int lo = (wr + 4 * t) * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
+                for (int t = 0; t < 4; t++) { int lo = (wc + 2 * t) * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
+                mxc = std::max(mxc, r * c);
+              }
+            hist_cyc += 2.0 * 256.0 * mxc * 8 * ((it->k + 15) / 16 * 16);
           }
-          flushg();
-        }
-        for (auto it = mid; it != P.pieces.begin() + e; ++it) {
-          const double f = 2.0 * it->m * (double)it->n * it->k;
-          const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
-          const int cm = it->m >= 96 ? 2 : it->m >= 32 ? 1 : 0, cn = it->n >= 96 ? 2 : it->n >= 32 ? 1 : 0;
-          hist_f[cm][cn] += f;
-          hist_c[cm][cn] += 1;
-          if (!even) hist_odd += f;
-          if (it->dr == 0 && it->dc == 0 && (it->m == TM || it->m == tk.tm) && (it->n == TN || it->n == tk.tn)) hist_valid += f;
-          // 16x16 sub-tiles the piece touches x chunks of 16: what the MFMA pipe executes for it
-          const int rs = (it->dr + it->m + 15) / 16 - it->dr / 16, cs = (it->dc + it->n + 15) / 16 - it->dc / 16;
-          hist_exec += 2.0 * 256.0 * rs * cs * ((it->k + 15) / 16 * 16);
-          // time-like: the busiest wave (32x64 wave tiles) x 8 waves
-          int mx = 0;
-          for (int wr = 0; wr < 4; wr++)
-            for (int wc = 0; wc < 2; wc++) {
-              int r = 0, c = 0;
-              for (int t = 0; t < 2; t++) { int lo = wr * 32 + t * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
-              for (int t = 0; t < 4; t++) { int lo = wc * 64 + t * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
-              mx = std::max(mx, r * c);
-            }
-          hist_wave += 2.0 * 256.0 * mx * 8 * ((it->k + 15) / 16 * 16);
-          int mxc = 0;   // cyclic sub-tile ownership: wave (wr,wc) owns row sub-tiles wr, wr+4 and col sub-tiles wc, wc+2, wc+4, wc+6
-          for (int wr = 0; wr < 4; wr++)
-            for (int wc = 0; wc < 2; wc++) {
-              int r = 0, c = 0;
-              for (int t = 0; t < 2; t++) { int lo = (wr + 4 * t) * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
-              for (int t = 0; t < 4; t++) { int lo = (wc + 2 * t) * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
-              mxc = std::max(mxc, r * c);
-            }
-          hist_cyc += 2.0 * 256.0 * mxc * 8 * ((it->k + 15) / 16 * 16);
         }
       }
+      O.tasks.push_back(tk);
+      O.work.push_back(work + 4096.0 * double(e - q));
+      O.slot.push_back(slot);
+      O.urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
+      if (P.level[t] == slot) { O.urgent_flops += 2.0 * work; O.slot_urgent_flops[slot] += 2.0 * work; }
+      O.slot_cnt[slot]++;
+      O.ubytes += 16.0 * double(tk.tm) * double(tk.tn);
+      O.slot_flops[slot] += 2.0 * work;
+      O.slot_pieces[slot] += (int64_t)(e - q);
+      O.slot_maxpn[slot] = std::max<int32_t>(O.slot_maxpn[slot], (int32_t)(e - q));
+      O.slot_maxwork[slot] = std::max(O.slot_maxwork[slot], work);
+      q = e;
     }
-    P.tasks.push_back(tk);
-    task_work.push_back(work + 4096.0 * double(e - q));
-    task_slot.push_back(slot);
-    task_urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
-    if (P.level[t] == slot) { P.urgent_flops += 2.0 * work; P.slot_urgent_flops[slot] += 2.0 * work; }
-    P.slot_task_ptr[slot + 1]++;
-    ubytes += 16.0 * double(tk.tm) * double(tk.tn);
-    P.slot_flops[slot] += 2.0 * work;
-    P.slot_pieces[slot] += (int64_t)(e - q);
-    P.slot_maxpn[slot] = std::max<int32_t>(P.slot_maxpn[slot], (int32_t)(e - q));
-    P.slot_maxwork[slot] = std::max(P.slot_maxwork[slot], work);
-    q = e;
+  };
+  {
+    std::vector<int> gerr((size_t)gthr, 0);
+    auto guarded = [&](int t) { try { group(t); } catch (const std::bad_alloc&) { gerr[(size_t)t] = PASTIX_AMD_ERR_ALLOC; } };
+    std::vector<std::thread> th;
+    for (int t = 1; t < gthr; t++) th.emplace_back(guarded, t);
+    guarded(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < gthr; t++) if (gerr[(size_t)t]) return gerr[(size_t)t];
+  }
+  {
+    size_t nt = 0;
+    for (const GOut& O : gout) nt += O.tasks.size();
+    P.tasks.reserve(nt);
+    task_work.reserve(nt);
+    task_slot.reserve(nt);
+    task_urgent.reserve(nt);
+    for (GOut& O : gout) {
+      P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
+      task_work.insert(task_work.end(), O.work.begin(), O.work.end());
+      task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
+      task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
+      P.urgent_flops += O.urgent_flops;
+      P.full_flops += O.full_flops;
+      ubytes += O.ubytes;
+      for (int sl = 0; sl < NL; sl++) {
+        P.slot_flops[sl] += O.slot_flops[sl];
+        P.slot_urgent_flops[sl] += O.slot_urgent_flops[sl];
+        P.slot_pieces[sl] += O.slot_pieces[sl];
+        P.slot_task_ptr[sl + 1] += O.slot_cnt[sl];
+        P.slot_maxpn[sl] = std::max(P.slot_maxpn[sl], O.slot_maxpn[sl]);
+        P.slot_maxwork[sl] = std::max(P.slot_maxwork[sl], O.slot_maxwork[sl]);
+      }
+      GOut().tasks.swap(O.tasks);
+    }
   }
   P.update_bytes = ubytes;
   if (raw.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
@@ -682,14 +747,29 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // bound by operand traffic, the tail matters more.
   {
     const int order_mode = getenv("PASTIX_AMD_TASK_ORDER") ? atoi(getenv("PASTIX_AMD_TASK_ORDER")) : 0;
+    // bucket by slot (counting sort, keeps the creation order), then every slot's range sorted on its own, slots dealt
+    // to the host threads: the comparison is a total order, the result does not depend on the thread count
     std::vector<int64_t> idx(P.tasks.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
-      if (task_slot[a] != task_slot[b]) return task_slot[a] < task_slot[b];
-      if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];   // urgent tasks first
-      if (order_mode == 0) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
-      return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
-    });
+    {
+      std::vector<int64_t> pos(P.slot_task_ptr.begin(), P.slot_task_ptr.end() - 1);
+      for (size_t q = 0; q < P.tasks.size(); q++) idx[(size_t)pos[(size_t)task_slot[q]]++] = (int64_t)q;
+      std::atomic<int> nexts{0};
+      auto sort_slots = [&](int) {
+        for (;;) {
+          const int sl = nexts.fetch_add(1);
+          if (sl >= NL) break;
+          std::sort(idx.begin() + P.slot_task_ptr[sl], idx.begin() + P.slot_task_ptr[sl + 1], [&](int64_t a, int64_t b) {
+            if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];   // urgent tasks first
+            if (order_mode == 0 || order_mode == 3) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
+            return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
+          });
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthr; t++) th.emplace_back(sort_slots, t);
+      sort_slots(0);
+      for (auto& x : th) x.join();
+    }
     if (hist_on) {
       fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
@@ -827,7 +907,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       }
     }
     if (order_mode == 0 || order_mode == 2 || order_mode == 3) {
-      for (size_t q = 0; q < idx.size(); q++) sorted[q] = P.tasks[idx[q]];
+      std::vector<std::thread> th;
+      const size_t nq = idx.size(), per = (nq + (size_t)nthr - 1) / (size_t)nthr;
+      auto cp = [&](int t) { for (size_t q = (size_t)t * per; q < std::min(nq, ((size_t)t + 1) * per); q++) sorted[q] = P.tasks[idx[q]]; };
+      for (int t = 1; t < nthr; t++) th.emplace_back(cp, t);
+      cp(0);
+      for (auto& x : th) x.join();
     } else {
       // the urgent tasks [slot_task_ptr, slot_urgent_end) and the bulk of a slot are launched separately by the
       // two-stream driver (api.cpp): interleave each range on its own so that the split points stay valid

@@ -15,6 +15,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -280,6 +283,10 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       }
     }
     const int64_t nnz = colptr[n] - 1;
+    const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tph = tnow();
+    auto phase = [&](const char* name) { if (ptime) { const double t = tnow(); fprintf(stderr, "[symbolic] %-28s %.2f s\n", name, t - tph); tph = t; } };
 
     // symmetric adjacency (no diagonal) in the numbering given by `lab` (old -> label)
     std::vector<int64_t> xadj;
@@ -325,6 +332,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
     };
     build_adj(perm);
     etree();
+    phase("adjacency + etree");
     // ---- postorder; relabel ----------------------------------------------------------------------
     {
       std::vector<idx> head((size_t)n, -1), next((size_t)n, -1), post((size_t)n), stack;
@@ -348,6 +356,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
         etree();
       }
     }
+    phase("postorder + relabel");
     // ---- column counts (Gilbert, Ng, Peyton); labels are a postorder -----------------------------
     std::vector<int64_t> cc((size_t)n, 0);
     {
@@ -377,6 +386,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       }
       for (idx j = 0; j < n; j++) if (parent[j] != -1) cc[parent[j]] += cc[j];
     }
+    phase("column counts");
     // ---- supernodes ---------------------------------------------------------------------------------
     std::vector<idx> sfirst;   // first column of each supernode
     {
@@ -403,52 +413,58 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       sbelow[s] = cc[sfirst[s]] - sw[s];
       nnz0 += 0.5 * (double)sw[s] * (double)(sw[s] + 1) + (double)sw[s] * (double)sbelow[s];
     }
+    phase("supernodes");
     // ---- amalgamation: cheapest merges first until the fill budget is spent ----------------------
     // merged node keeps the parent's id; `rep` = union-find to the surviving node
     std::vector<idx> rep((size_t)ns0);
     std::iota(rep.begin(), rep.end(), 0);
-    std::function<idx(idx)> find = [&](idx x) { while (rep[x] != x) { rep[x] = rep[rep[x]]; x = rep[x]; } return x; };
+    auto find = [&](idx x) { while (rep[x] != x) { rep[x] = rep[rep[x]]; x = rep[x]; } return x; };
     {
-      std::vector<int32_t> ver((size_t)ns0, 0);
-      struct Ent { double cost; idx c; int32_t vc, vp; };
-      auto cmp = [](const Ent& a, const Ent& b) { return a.cost > b.cost; };
+      // Lazy heap: the cost of merging c into its (surviving) parent p, w_c (w_p + below_p - below_c) extra entries of L,
+      // only GROWS while the algorithm runs (c and p widen as they absorb nodes; a parent merged into its own parent hands
+      // c a wider one), so a popped entry whose stored cost is stale is a lower bound: re-evaluate, push back, go on.
+      // No per-merge refresh of all the children of the merged node (that was quadratic in the fan-out).
+      struct Ent { double cost; idx c; };
+      auto cmp = [](const Ent& a, const Ent& b) { return a.cost > b.cost || (a.cost == b.cost && a.c < b.c); };   // (ties: the node nearer the root first)
       std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp);
       auto cost_of = [&](idx c, idx p) {
-        double wc = (double)sw[c], wp = (double)sw[p], bp = (double)sbelow[p], bc = (double)sbelow[c];
-        (void)wp;
-        return wc * (wp + bp - bc);   // extra entries of L (lower storage) created by the merge
+        return (double)sw[c] * ((double)sw[p] + (double)sbelow[p] - (double)sbelow[c]);
       };
-      std::vector<std::vector<idx>> kids((size_t)ns0);
-      for (idx s = 0; s < ns0; s++) if (sparent[s] != -1) kids[sparent[s]].push_back(s);
+      // first every merge that adds no fill (kass does the same before it starts its heap, amalgamate.c:318-372);
+      // children before parents, so chains collapse in one pass
+      for (idx s = 0; s < ns0; s++) {
+        if (sparent[s] == -1) continue;
+        const idx p = find(sparent[s]);
+        if (cost_of(s, p) > 0) continue;
+        if (o.schur_n > 0 && (sfirst[s] >= n - o.schur_n) != (sfirst[p] >= n - o.schur_n)) continue;
+        rep[s] = p;
+        sw[p] += sw[s];
+      }
       for (idx s = 0; s < ns0; s++)
-        if (sparent[s] != -1) pq.push(Ent{cost_of(s, sparent[s]), s, ver[s], ver[sparent[s]]});
-      double budget = ratio * nnz0, spent = 0;
+        if (rep[s] == s && sparent[s] != -1) pq.push(Ent{cost_of(s, find(sparent[s])), s});
+      const double budget = ratio * nnz0;
+      double spent = 0;
       const int64_t maxw_merge = o.max_merge_width > 0 ? o.max_merge_width : (int64_t)1 << 40;
       while (!pq.empty()) {
-        Ent e = pq.top();
+        const Ent e = pq.top();
         pq.pop();
-        idx c = e.c;
-        if (rep[c] != c) continue;
-        idx p = sparent[c];
-        if (p == -1) continue;
-        p = find(p);
-        if (e.vc != ver[c] || e.vp != ver[p]) continue;
+        const idx c = e.c;
+        if (rep[c] != c || sparent[c] == -1) continue;
+        const idx p = find(sparent[c]);
+        sparent[c] = p;
+        const double cost = cost_of(c, p);
+        if (cost > e.cost) { pq.push(Ent{cost, c}); continue; }                     // stale: a lower bound, see above
         if (o.schur_n > 0 && (sfirst[c] >= n - o.schur_n) != (sfirst[p] >= n - o.schur_n)) continue;   // never across the Schur boundary
-        if (e.cost > 0 && spent + e.cost > budget) break;      // cheapest remaining does not fit
-        if (e.cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
-        // merge c into p
-        spent += std::max(0.0, e.cost);
-        rep[c] = p;
+        if (cost > 0 && spent + cost > budget) break;          // cheapest remaining does not fit
+        if (cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
+        spent += std::max(0.0, cost);
+        rep[c] = p;                                            // merge c into p
         sw[p] += sw[c];
-        ver[p]++;
-        ver[c]++;
-        for (idx k : kids[c]) { idx kk = find(k); if (kk != p && rep[kk] == kk) { sparent[kk] = p; kids[p].push_back(kk); } }
-        std::vector<idx>().swap(kids[c]);
-        // refresh the costs that involve p
-        for (idx k : kids[p]) { idx kk = find(k); if (kk != p && rep[kk] == kk) pq.push(Ent{cost_of(kk, p), kk, ver[kk], ver[p]}); }
-        if (sparent[p] != -1) { idx gp = find(sparent[p]); sparent[p] = gp; pq.push(Ent{cost_of(p, gp), p, ver[p], ver[gp]}); }
       }
+      for (idx s = 0; s < ns0; s++)
+        if (rep[s] == s && sparent[s] != -1) sparent[s] = find(sparent[s]);
     }
+    phase("amalgamation");
     // ---- new ordering: postorder of the amalgamated tree, members in original order --------------
     std::vector<idx> aid((size_t)ns0, -1);      // fundamental supernode -> amalgamated node (dense ids)
     std::vector<idx> afirst;                    // first new column of each amalgamated node
@@ -487,6 +503,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
     std::vector<idx> col2a((size_t)n);
     for (idx a = 0; a < na; a++) for (idx j = afirst[a]; j < afirst[a + 1]; j++) col2a[j] = a;
 
+    phase("reorder + adjacency");
     // ---- supernodal symbolic factorization on interval lists -------------------------------------
     // struct(a) = rows > last col of a reached from A's columns of a or from children's structs
     std::vector<std::vector<idx>> akids((size_t)na);
@@ -515,6 +532,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
     std::vector<int64_t>().swap(xadj);
     std::vector<idx>().swap(adj);
 
+    phase("interval symbolic");
     // ---- split wide nodes; final cblk boundaries -------------------------------------------------
     const idx maxbs = (idx)o.max_blocksize;
     std::vector<idx> cfirst;            // first column of each final cblk
@@ -556,6 +574,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
     std::vector<idx> col2c((size_t)n);
     for (idx c = 0; c < ncb; c++) for (idx j = cfirst[c]; j < cfirst[c + 1]; j++) col2c[j] = c;
 
+    phase("split");
     // ---- bloks -------------------------------------------------------------------------------------
     S->cblk.resize((size_t)ncb + 1);
     int64_t nnzl = 0;
@@ -585,6 +604,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       std::vector<Interval>().swap(keep[a]);
     }
     S->cblk[ncb].fcolnum = n; S->cblk[ncb].lcolnum = n; S->cblk[ncb].bloknum = (int64_t)S->blok.size(); S->cblk[ncb].stride = 0;
+    phase("bloks");
     S->nnzl = nnzl;
     S->perm.resize((size_t)n);
     S->invp.resize((size_t)n);
