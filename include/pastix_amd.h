@@ -257,6 +257,21 @@ int pastix_amd_download_cblk(pastix_amd_plan_t *plan, pastix_amd_int_t cblk, voi
  * numbering, n x nrhs, ld n; `double`, or interleaved `double complex` for complex plans) in place.  Not available
  * on distributed or Schur-mode plans (PASTIX_AMD_ERR_UNSUPPORTED). */
 int pastix_amd_solve(pastix_amd_plan_t *plan, void *x, pastix_amd_int_t nrhs);
+/* the same on a vector that already lives on the plan's device (device pointer, same layout): no host transfers */
+int pastix_amd_solve_device(pastix_amd_plan_t *plan, void *dx, pastix_amd_int_t nrhs);
+
+/* Iterative refinement on the device (csrc/refine.hip; pastix_task_raff, pastix.c:4300-4500): mode = IPARM_REFINEMENT
+ * (api.h:353-365: 0 GMRES raff_gmres.c, 1 conjugate gradient raff_grad.c, 2 simple iterative refinement raff_pivot.c,
+ * 3 BiCGStab raff_bicgstab.c), preconditioned by the device solve on the factors; Krylov vectors, the sparse
+ * matrix-vector product and the dot products stay on the GPU.  CSC 1-based in the caller's numbering (sym: 0 full
+ * pattern stored, 1 lower triangle of a symmetric matrix, 2 lower triangle of a Hermitian matrix), perm 0-based
+ * old -> new (the factor's numbering), b: right-hand sides, x: in the solution to improve / out the refined one (host,
+ * n x nrhs, `double` or interleaved `double complex` like the plan).  Stops at ||b - A x|| / ||b|| < eps or after
+ * itermax iterations; *iters -> IPARM_NBITER, *relerr -> DPARM_RELATIVE_ERROR. */
+int pastix_amd_refine(pastix_amd_plan_t *plan, int mode, int sym, pastix_amd_int_t n, const pastix_amd_int_t *colptr,
+                      const pastix_amd_int_t *rows, const void *vals, const pastix_amd_int_t *perm, const void *b, void *x,
+                      pastix_amd_int_t nrhs, double eps, pastix_amd_int_t itermax, int gmres_im, pastix_amd_int_t *iters,
+                      double *relerr);
 
 /* raw device pointers of the arenas (for callers that own device-side pipelines, e.g. RCCL fan-in) */
 int pastix_amd_device_arenas(pastix_amd_plan_t *plan, void **dL, void **dU);

@@ -68,7 +68,7 @@ EXPORTS = [
     "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",
     "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats",
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
-    "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve",
+    "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve", "pastix_amd_solve_device", "pastix_amd_refine",
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
     "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena",
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",

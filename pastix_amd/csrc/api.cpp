@@ -988,7 +988,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
 
 // Forward / (diagonal) / backward substitution on the device-resident factors (real LLt, LDLt, LU; the data
 // flow of up_down_smp, updo.c:114), x in permuted numbering.
-int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
+static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, bool x_on_device) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (p->distributed || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
@@ -1052,6 +1052,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
     }
     p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
   }
+  const int mode = x_on_device ? 2 : 1;
   if (p->cplx) {
     // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device
     const size_t needz = (size_t)H.ncol * 4;
@@ -1061,11 +1062,14 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
       HIPCHK(hipMalloc((void**)&p->dXws, needz * sizeof(double)));
       p->nXws = needz;
     }
-    double *dz = p->dXws, *dxr = p->dXws + 2 * (size_t)H.ncol, *dxi = p->dXws + 3 * (size_t)H.ncol;
+    double *dzs = p->dXws, *dxr = p->dXws + 2 * (size_t)H.ncol, *dxi = p->dXws + 3 * (size_t)H.ncol;
     double* xz = (double*)x_;
     const bool scale = H.factotype == PASTIX_AMD_FACT_LDLT || H.factotype == PASTIX_AMD_FACT_LDLH;
+    p->stats.solve_time = 0.0;
     for (int64_t j = 0; j < nrhs; j++) {
-      HIPCHK(hipMemcpyAsync(dz, xz + 2 * j * H.ncol, H.ncol * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+      double* dz = mode == 2 ? xz + 2 * j * H.ncol : dzs;          // interleaved vector on the device
+      if (mode == 1) HIPCHK(hipMemcpyAsync(dz, xz + 2 * j * H.ncol, H.ncol * 2 * sizeof(double), hipMemcpyHostToDevice, p->stream));
+      HIPCHK(hipEventRecord(p->ev0, p->stream));
       launch_split(p->stream, dz, dxr, dxi, H.ncol);
       for (int l = 0; l < H.nlevels; l++)
         launch_zsolve_level(p->stream, true, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l],
@@ -1077,8 +1081,12 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
                             H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
                             p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dxr, dxi, p->maxw);
       launch_merge(p->stream, dz, dxr, dxi, H.ncol);
-      HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+      HIPCHK(hipEventRecord(p->ev1, p->stream));
+      if (mode == 1) HIPCHK(hipMemcpyAsync(xz + 2 * j * H.ncol, dz, H.ncol * 2 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
       HIPCHK(hipStreamSynchronize(p->stream));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+      p->stats.solve_time += 1e-3 * ms;
     }
     HIPCHK(hipGetLastError());
     return PASTIX_AMD_OK;
@@ -1086,18 +1094,18 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes)
   const int64_t NRB = std::min<int64_t>(nrhs, 4);
   const size_t need = (size_t)H.ncol * (size_t)NRB;
-  if (p->nXws < need) {
+  if (mode == 1 && p->nXws < need) {
     (void)hipFree(p->dXws);
     p->dXws = nullptr; p->nXws = 0;
     HIPCHK(hipMalloc((void**)&p->dXws, need * sizeof(double)));
     p->nXws = need;
   }
-  double* dx = p->dXws;
   double* x = (double*)x_;
   p->stats.solve_time = 0.0;
   for (int64_t j = 0; j < nrhs;) {
     const int nr = nrhs - j >= 4 ? 4 : nrhs - j >= 2 ? 2 : 1;
-    HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
+    if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
     for (int l = 0; l < H.nlevels; l++)
       launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
@@ -1110,7 +1118,7 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
                          H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
                          p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
     HIPCHK(hipEventRecord(p->ev1, p->stream));
-    HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    if (mode == 1) HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
@@ -1120,6 +1128,11 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs) {
   HIPCHK(hipGetLastError());
   return PASTIX_AMD_OK;
 }
+
+int pastix_amd_solve(pastix_amd_plan_t* p, void* x, pastix_amd_int_t nrhs) { return solve_impl(p, x, nrhs, false); }
+// the same on a vector that already lives on the plan's device (device pointer, same layout): no host transfers --
+// what the device-resident refinement (refine.hip) preconditions with
+int pastix_amd_solve_device(pastix_amd_plan_t* p, void* dx, pastix_amd_int_t nrhs) { return solve_impl(p, dx, nrhs, true); }
 
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,

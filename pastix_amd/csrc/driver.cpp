@@ -8,8 +8,8 @@
 // dparm slots and enum values of api.h:124-234) so that the reference's example call sequence
 // (src/example/src/simple.c:59-256) runs unchanged on a box without PaStiX: ordering and symbolic
 // steps use this repo's producer (symbolic.cpp), the numerical factorization and the solves run on
-// the device.  Refinement: GMRES(m), conjugate gradient and plain iterative refinement, all
-// preconditioned by the device solve; vectors and SpMV on the host.
+// the device.  Refinement: GMRES(m), conjugate gradient, BiCGStab and plain iterative
+// refinement, preconditioned by the device solve, vectors and SpMV on the device (refine.hip).
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -279,126 +279,16 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         // pastix_task_raff (pastix.c:4300-4500) picks the refiner from IPARM_REFINEMENT (api.h:353-365): GMRES
         // (raff_gmres.c), conjugate gradient for the symmetric factorizations (raff_grad.c), plain iterative
         // refinement (raff_pivot.c).  All three are preconditioned by the device solve with the factors and stop at
-        // ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT or after IPARM_ITERMAX iterations; BICGSTAB requests run
-        // GMRES.  The vectors and the SpMV stay on the host (the matrix is the caller's CSC).
+        // ||b - A x|| / ||b|| < DPARM_EPSILON_REFINEMENT or after IPARM_ITERMAX iterations; all four run on
+        // the device (csrc/refine.hip): Krylov vectors, SpMV, dot products; the host sees scalars.
         if (D->schur_on) FAIL(PASTIX_AMD_ERR_UNSUPPORTED);
         if (!D->factorized || !b || !avals || D->rhs.size() != (size_t)(n * rhs) * TW) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
-        const double eps = dparm[DPARM_EPSILON_REFINEMENT];
-        const int64_t itermax = iparm[IPARM_ITERMAX];
-        int mode = (int)iparm[IPARM_REFINEMENT];
-        if (mode == API_RAF_BICGSTAB) mode = API_RAF_GMRES;
-        if (mode == API_RAF_GRAD && (facto == PASTIX_AMD_FACT_LU || (CPLX && !herm))) mode = API_RAF_GMRES;   // CG needs A = A^H
-        auto ax = [&](const T* x, T* y) {           // y = A x  (symmetric input: lower triangle stored)
-          for (int64_t i = 0; i < n; i++) y[i] = 0.0;
-          for (int64_t j = 0; j < n; j++)
-            for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
-              const int64_t i = row[q] - 1;
-              y[i] += avals[q] * x[j];
-              if (sym && i != j) y[j] += (herm ? conj_(avals[q]) : avals[q]) * x[i];
-            }
-        };
-        std::vector<T> pbuf((size_t)n);
-        auto precond = [&](const T* r, T* z) -> int {   // z = (factors)^-1 r
-          for (int64_t i = 0; i < n; i++) pbuf[D->perm[i]] = r[i];
-          const int rc2 = pastix_amd_solve(D->plan, pbuf.data(), 1);
-          if (rc2) return rc2;
-          for (int64_t i = 0; i < n; i++) z[i] = pbuf[D->perm[i]];
-          return 0;
-        };
-        auto dot = [&](const T* u, const T* w) { T t = 0; for (int64_t i = 0; i < n; i++) t += conj_(u[i]) * w[i]; return t; };   // <u, w> = u^H w
-        auto nrm = [&](const T* u) { return std::sqrt(real_(dot(u, u))); };
-        int64_t iters = 0;
+        pastix_amd_int_t iters = 0;
         double relerr = 0;
-        std::vector<T> r((size_t)n), z((size_t)n), w((size_t)n);
-        for (int64_t c = 0; c < rhs; c++) {
-          T* x = b + c * n;
-          const T* f = reinterpret_cast<const T*>(D->rhs.data()) + c * n;
-          double nb = nrm(f);
-          if (nb == 0) nb = 1;
-          auto residual = [&]() { ax(x, r.data()); for (int64_t i = 0; i < n; i++) r[i] = f[i] - r[i]; return nrm(r.data()) / nb; };
-          int64_t it = 0;
-          relerr = residual();
-          if (mode == API_RAF_PIVOT) {
-            while (relerr >= eps && it < itermax) {
-              if ((rc = precond(r.data(), z.data()))) FAIL(rc);
-              for (int64_t i = 0; i < n; i++) x[i] += z[i];
-              it++;
-              relerr = residual();
-            }
-          } else if (mode == API_RAF_GRAD) {
-            std::vector<T> pdir((size_t)n);
-            if ((rc = precond(r.data(), z.data()))) FAIL(rc);
-            pdir = z;
-            T rz = dot(r.data(), z.data());
-            while (relerr >= eps && it < itermax) {
-              ax(pdir.data(), w.data());
-              const T alpha = rz / dot(pdir.data(), w.data());
-              for (int64_t i = 0; i < n; i++) { x[i] += alpha * pdir[i]; r[i] -= alpha * w[i]; }
-              it++;
-              relerr = nrm(r.data()) / nb;
-              if (relerr < eps) break;
-              if ((rc = precond(r.data(), z.data()))) FAIL(rc);
-              const T rz2 = dot(r.data(), z.data());
-              const T beta = rz2 / rz;
-              rz = rz2;
-              for (int64_t i = 0; i < n; i++) pdir[i] = z[i] + beta * pdir[i];
-            }
-            relerr = residual();
-          } else {
-            // right-preconditioned GMRES(m): A M^-1 u = b, x = M^-1 u
-            const int m = (int)std::max<int64_t>(1, std::min<int64_t>(iparm[IPARM_GMRES_IM] > 0 ? iparm[IPARM_GMRES_IM] : 25, 200));
-            std::vector<std::vector<T>> V((size_t)m + 1, std::vector<T>((size_t)n));
-            std::vector<T> H((size_t)(m + 1) * m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
-            std::vector<double> cs((size_t)m);
-            while (relerr >= eps && it < itermax) {
-              const double beta = relerr * nb;
-              for (int64_t i = 0; i < n; i++) V[0][i] = r[i] / beta;
-              std::fill(g.begin(), g.end(), T(0.0));
-              g[0] = beta;
-              int j = 0;
-              for (; j < m && it < itermax; j++) {
-                if ((rc = precond(V[j].data(), z.data()))) FAIL(rc);
-                ax(z.data(), w.data());
-                for (int i = 0; i <= j; i++) {                       // modified Gram-Schmidt
-                  const T h = dot(V[i].data(), w.data());
-                  H[(size_t)i * m + j] = h;
-                  for (int64_t q = 0; q < n; q++) w[q] -= h * V[i][q];
-                }
-                const double hn = nrm(w.data());
-                H[(size_t)(j + 1) * m + j] = hn;
-                if (hn > 0) for (int64_t q = 0; q < n; q++) V[j + 1][q] = w[q] / hn;
-                for (int i = 0; i < j; i++) {                        // previous Givens rotations on the new column
-                  const T t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
-                  H[(size_t)(i + 1) * m + j] = -conj_(sn[i]) * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
-                  H[(size_t)i * m + j] = t;
-                }
-                // rotation [c s; -conj(s) c] with real c that zeroes H(j+1,j) (which is real, = hn)
-                const T a0 = H[(size_t)j * m + j];
-                const double a1 = hn, rr = std::sqrt(std::norm(std::complex<double>(a0)) + a1 * a1);
-                const double a0abs = std::abs(a0);
-                cs[j] = rr > 0 ? a0abs / rr : 1.0;
-                sn[j] = rr > 0 ? (a0abs > 0 ? (a0 / a0abs) * (a1 / rr) : T(a1 / rr)) : T(0.0);
-                H[(size_t)j * m + j] = cs[j] * a0 + sn[j] * a1;
-                H[(size_t)(j + 1) * m + j] = 0.0;
-                g[j + 1] = -conj_(sn[j]) * g[j];
-                g[j] = cs[j] * g[j];
-                it++;
-                if (std::abs(g[j + 1]) / nb < eps || hn == 0) { j++; break; }
-              }
-              for (int i = j - 1; i >= 0; i--) {                     // back substitution H y = g
-                T t = g[i];
-                for (int q = i + 1; q < j; q++) t -= H[(size_t)i * m + q] * y[q];
-                y[i] = t / H[(size_t)i * m + i];
-              }
-              for (int64_t q = 0; q < n; q++) w[q] = 0.0;
-              for (int i = 0; i < j; i++) for (int64_t q = 0; q < n; q++) w[q] += y[i] * V[i][q];
-              if ((rc = precond(w.data(), z.data()))) FAIL(rc);
-              for (int64_t q = 0; q < n; q++) x[q] += z[q];
-              relerr = residual();
-            }
-          }
-          iters = std::max(iters, it);
-        }
+        rc = pastix_amd_refine(D->plan, (int)iparm[IPARM_REFINEMENT], sym ? (herm ? 2 : 1) : 0, n, colptr, row, avals,
+                               D->perm.data(), D->rhs.data(), b, rhs, dparm[DPARM_EPSILON_REFINEMENT],
+                               iparm[IPARM_ITERMAX], (int)iparm[IPARM_GMRES_IM], &iters, &relerr);
+        if (rc) FAIL(rc);
         iparm[IPARM_NBITER] = iters;
         dparm[DPARM_RELATIVE_ERROR] = relerr;
         break;

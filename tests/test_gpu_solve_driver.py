@@ -318,7 +318,7 @@ def test_pastix_ldlt_and_lu_through_the_entry_point(facto):
     _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v, perm, invp, b, 1, iparm, dparm)
 
 
-@pytest.mark.parametrize("mode", ["GMRES", "GRAD", "PIVOT"])
+@pytest.mark.parametrize("mode", ["GMRES", "GRAD", "PIVOT", "BICGSTAB"])
 def test_pastix_refinement_modes_recover_from_static_pivoting(mode):
     """IPARM_REFINEMENT (api.h:353-365).  A huge DPARM_EPSILON_MAGN_CTRL makes the factorization clamp pivots
     (static pivoting perturbs the factors), so the first solve is inaccurate and the refiner has real work."""
@@ -513,3 +513,45 @@ def test_pastix_default_ordering_on_a_general_graph(name, facto, base, golden):
     assert iparm[px.IPARM["NNZEROS"]] < (0.8 if name.startswith("orsirr") else 0.5) * nat
     iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
     px.pastix(pd, n, cpb, rb, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", ["rlap3d_12_lu", "zrlap3d_12_ldlt", "zrlap3d_12_ldlh", "zrlap3d_8_lu"])
+def test_device_refinement_all_modes_all_arithmetics(name, mode, golden):
+    """pastix_amd_refine (csrc/refine.hip) directly: GMRES / CG / simple refinement / BiCGStab with vectors, SpMV and dot
+    products on the device, on unsymmetric real, complex symmetric, complex Hermitian and complex unsymmetric matrices.
+    The factors are perturbed by a large static-pivot threshold so that there is something to refine."""
+    import ctypes
+    from pastix_amd import COMPLEXDOUBLE, _lib
+    g = golden(name)
+    n = int(g["n"])
+    cz = np.iscomplexobj(g["L0"])
+    dt = np.complex128 if cz else np.float64
+    cp, r = g["colptr"].astype(np.int64), g["rows"].astype(np.int64)
+    v = np.ascontiguousarray(g["vals"], dtype=dt)
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    herm = g["facto"] == 3
+    if g["sym"]:
+        A = A + (sp.tril(A, -1).conj().T if herm else sp.tril(A, -1).T)
+    rng = np.random.default_rng(9)
+    x0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cz else 0)).astype(dt)
+    b = np.ascontiguousarray(A @ x0, dtype=dt)
+    perm = g["perm"].astype(np.int64)
+    crit = 0.3 * np.abs(g["L1"]).max() if g["facto"] != 0 else g["critere"]
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE if cz else 1) as p:
+        p.fill_csc(g["sym"], n, cp, r, v, perm)
+        st = p.factorize(crit)
+        assert st["nbpivot"] > 0                                   # perturbed factors
+        bp = np.empty(n, dtype=dt)
+        bp[perm] = b
+        x = np.ascontiguousarray(p.solve(bp)[perm], dtype=dt)
+        first = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+        it = ctypes.c_int64(0)
+        err = ctypes.c_double(0)
+        rc = _lib.lib().pastix_amd_refine(p._h, mode, 2 if (g["sym"] and herm) else int(g["sym"]), ctypes.c_int64(n),
+                                          _lib.ptr(cp), _lib.ptr(r), _lib.ptr(v), _lib.ptr(perm), _lib.ptr(b), _lib.ptr(x),
+                                          ctypes.c_int64(1), ctypes.c_double(1e-12), ctypes.c_int64(250), 25,
+                                          ctypes.byref(it), ctypes.byref(err))
+        assert rc == 0
+    res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
+    assert first > 1e-8 and res < 1e-11 and err.value < 1e-11 and 0 < it.value <= 250
