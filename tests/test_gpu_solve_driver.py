@@ -537,7 +537,11 @@ def test_device_refinement_all_modes_all_arithmetics(name, mode, golden):
     x0 = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if cz else 0)).astype(dt)
     b = np.ascontiguousarray(A @ x0, dtype=dt)
     perm = g["perm"].astype(np.int64)
-    crit = 0.3 * np.abs(g["L1"]).max() if g["facto"] != 0 else g["critere"]
+    c4 = g["cblk4"]
+    wid = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(wid * c4[:-1, 3])])
+    piv = np.concatenate([np.abs(g["L1"][off[k] + np.arange(wid[k]) * (c4[k, 3] + 1)]) for k in range(len(wid))])
+    crit = float(np.sort(piv)[n // 8])             # an eighth of the reference's pivots lie below: they get clamped
     with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE if cz else 1) as p:
         p.fill_csc(g["sym"], n, cp, r, v, perm)
         st = p.factorize(crit)
