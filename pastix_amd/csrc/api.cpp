@@ -804,7 +804,7 @@ static int launch_panels(pastix_amd_plan_t* p, int l) {
     launch_diag_llt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->dErr, p->maxw);
     launch_trsm_llt(s, p->dL, tt, ntt, p->dDinv, p->maxw);
   } else if (H.factotype == PASTIX_AMD_FACT_LDLT) {
-    launch_diag_ldlt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot);
+    launch_diag_ldlt(s, p->dL, pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->maxw);
     launch_trsm_ldlt(s, p->dL, p->dU, tt, ntt, p->dDinv, p->maxw);
   } else {
     launch_diag_lu(s, p->dL, p->dU, pt, npt, p->dDinv, p->crit_run, p->dNbpivot);

@@ -34,7 +34,7 @@ void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
 void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
-                      long long* nbpivot);
+                      long long* nbpivot, int maxw);
 void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
                     double critere, long long* nbpivot);
 void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,

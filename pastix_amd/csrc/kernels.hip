@@ -723,6 +723,172 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
     if (bad) atomicOr(errflag, 1);
   }
 }
+
+// k_diag_ldlt_w : the same organisation for the LDLt diagonal blok (PASTIX_sytrf_block, compute_diag.c:262-307), w <= 128:
+// packed lower triangle resident in LDS, the 16 x 16 tile factorized by wave 0 in registers (unit L, D on the diagonal,
+// static-pivot clamp and the count of positive pivots for IPARM_INERTIA), rows below solved thread-per-row, trailing
+// update (L D) L^T on the MFMA pipe with L D formed on the fly from L and the tile's diagonal.
+__global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                     double* __restrict__ dinv_ws, double critere,
+                                                     long long* __restrict__ nbpivot) {
+  // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
+  // only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
+  // size fits beside one k_update workgroup.  Entries outside the w x w part are zero.
+  __shared__ double D[128 * 129 / 2];
+#define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
+  __shared__ double Ri[16];            // reciprocals of the tile's diagonal (1 / d)
+  __shared__ double Dd[16];            // the tile's diagonal d
+  const PanelTask tk = tasks[blockIdx.x];
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  {
+    // blok -> LDS: thread = (row r, column parity); 32 columns per pass, loads issued before the stores
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c0 = 0; c0 < 128; c0 += 64) {
+      double v[32];
+#pragma unroll
+      for (int q = 0; q < 32; q++) {                     // unconditional loads from clamped addresses
+        const int c = min(c0 + ch + 2 * q, w - 1);
+        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      }
+#pragma unroll
+      for (int q = 0; q < 32; q++) {
+        const int c = c0 + ch + 2 * q;
+        if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
+      }
+    }
+  }
+  int npiv = 0, npos = 0;
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    __syncthreads();
+    double a[16];                                        // wave 0: row l15 of the tile
+    double ri[16], dd[16];                               // (uniform) reciprocals of the diagonal, the diagonal
+    if (wave == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) {                     // PASTIX_potrf (compute_diag.c:124-153)
+        if (j < nb) {
+          double d = readlane_f64(a[j], j);                // PASTIX_sytrf (compute_diag.c:223-242)
+          if (fabs(d) < critere) { d = critere; npiv++; }
+          if (d > 0.0) npos++;                             // inertia (sopalin3d.c:1144-1160)
+          const double inv = fast_rcp(d);
+          ri[j] = inv;
+          dd[j] = d;
+          const double t = a[j];                           // (L D)(i, j), unscaled
+          a[j] = (l15 == j) ? d : t * inv;                 // unit L below, D on the diagonal
+#pragma unroll
+          for (int k = j + 1; k < 16; k++) {
+            const double lkj = readlane_f64(a[j], k);      // L(k, j)
+            a[k] = __builtin_fma(-t, lkj, a[k]);           // SYR alpha = -d: a(i,k) -= (L D)(i,j) L(k,j)
+          }
+        } else {
+          ri[j] = 1.0;
+          dd[j] = 1.0;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+          if (c <= l15) DP(kb + c, kb + l15) = a[c];
+        double rmine = 1.0, dmine = 1.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) if (c == l15) { rmine = ri[c]; dmine = dd[c]; }
+        Ri[l15] = rmine;
+        Dd[l15] = dmine;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // (B') column c = l15 of inv(tile) by forward substitution; L(i,p) comes from lane i's registers
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double sacc = (i == l15) ? 1.0 : 0.0;
+#pragma unroll
+        for (int p2 = 0; p2 < 16; p2++)
+          if (p2 < i) {
+            const double lip = (i < nb) ? readlane_f64(a[p2], i) : 0.0;
+            sacc = __builtin_fma(-lip, x[p2], sacc);
+          }
+        x[i] = (i < nb && l15 < nb) ? ((i >= l15) ? sacc : 0.0) : ((i == l15) ? 1.0 : 0.0);      // unit diagonal
+      }
+      if (lane < 16) {
+        double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+      }
+    } else if (tid - 64 < rem) {
+      // (B) rows below the tile: TRSM "R","L","T","U" gives L D (compute_diag.c:284-288), scaled by 1/d it is L (:289-298)
+      const int rr = kb + nb + tid - 64;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (c < nb) {
+          double sacc = x[c];
+#pragma unroll
+          for (int p2 = 0; p2 < 16; p2++)
+            if (p2 < c) sacc = __builtin_fma(-x[p2], DP(kb + p2, kb + c), sacc);
+          x[c] = sacc;                                   // (L D)(rr, c)
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c < nb) DP(kb + c, rr) = x[c] * Ri[c];        // L(rr, c)
+    }
+    __syncthreads();
+    if (rem > 0) {
+      // (C) A22 -= (L D) L^T on the lower 16x16 tiles (GEMM with the L D copy, compute_diag.c:299-304); MFMA "i" = column,
+      // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros; L D is L times the tile's diagonal
+      const int nbd = (rem + 15) >> 4, r0 = kb + nb;
+      const int ntile = nbd * (nbd + 1) / 2;
+      for (int t = wave; t < ntile; t += 4) {
+        int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
+        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
+        const int bi = bj + rest;
+        const int rb = r0 + bi * 16, cb = r0 + bj * 16;
+        d4 c;
+        const int row = rb + l15;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int col = cb + g + 4 * q;
+          c[q] = (row >= col) ? DP(col, row) : 0.0;          // (diagonal tiles: the upper part is not stored)
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          const double xc = DP(kb + 4 * ks + g, cb + l15);
+          const double xr = DP(kb + 4 * ks + g, rb + l15) * Dd[4 * ks + g];
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc, xr, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int col = cb + g + 4 * q;
+          if (row >= col) DP(col, row) = c[q];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c = ch; c < w; c += 2)
+      if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
+  }
+  if (wave == 0 && lane == 0) {
+    if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+    if (npos) atomicAdd((unsigned long long*)nbpivot + 1, (unsigned long long)npos);
+  }
+}
+
+void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                        long long* nbpivot) {
+  hipLaunchKernelGGL(k_diag_ldlt_w, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
+}
 #undef DP
 
 // ------------------------------------------------------------------------------------------------

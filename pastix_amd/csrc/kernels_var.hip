@@ -9,6 +9,8 @@
 //         factor_trsm1d = kernel_trsm (ge)     compute_trsm.c:58-67    (L_off = A U_d^-1 ; U_off^T = A' L_d^-T unit)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "plan.h"
 #include "devmath.h"
 
@@ -346,10 +348,14 @@ __global__ __launch_bounds__(256) void k_trsm_var(double* __restrict__ L, double
   }
 }
 
+void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
+                        long long* nbpivot);      // kernels.hip: LDS-resident blok, MFMA trailing update (w <= 128)
 void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
-                      long long* nbpivot) {
+                      long long* nbpivot, int maxw) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_diag_ldlt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
+  static const bool old = getenv("PASTIX_AMD_DIAG_LDLT_OLD") != nullptr;
+  if (maxw <= 128 && !old) launch_diag_ldlt_w(s, L, tasks, n, dinv, critere, nbpivot);
+  else hipLaunchKernelGGL(k_diag_ldlt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
 }
 
 void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
