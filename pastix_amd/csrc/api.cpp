@@ -141,6 +141,8 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically smallest = highest priority
       HIPCHK(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
       HIPCHK(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, lo));
+      HIPCHK(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, lo));
+      HIPCHK(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
     }
     p->distributed = owner != nullptr;
     p->own_arena = !(opts && opts->external_arena);
@@ -341,6 +343,8 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
+  if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
+  if (p->evJoin) (void)hipEventDestroy(p->evJoin);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -953,7 +957,18 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   // of level l (P).  stream2: the rest of slot l, whose sources are of level <= l-1 and whose targets are of
   // level l+1 or later (B); it runs beside A(l) and P(l).  Orders kept: B(l) after P(l-1); A(l+1) after
   // B(l): all writers of a tile stay ordered, results do not depend on timing.
-  int lastN = -1;
+  // Tails of SHORT bulk launches: a launch of a few thousand tasks runs ~10 rounds of 512 workgroups, and its ramp
+  // and its last, partly filled round cost 10 % and more (100^3: ~200 launches of ~0.7 ms).  B(l) only needs P(l-1);
+  // what orders it behind B(l-1) is tile ownership -- both may update the same tile.  The plan marks those tasks of a
+  // slot ("late": same tile in the previous slot's bulk launch); all others ("early") start beside the tail of B(l-1)
+  // on a second bulk stream, the late ones follow once B(l-1) is done.  Results do not depend on timing: every tile
+  // still sees its updates in slot order.  Opt-in: PASTIX_AMD_TAIL_FLOPS=<flop> overlaps launches below that size
+  // (measured with 3e11: 100^3 0.1535 -> 0.1507 s, 160^3 1.874 -> 1.860 s, 60^3 -4 %).  Off by default: the gain is
+  // small -- at those sizes the next launch mostly waits for the panel chain, not for a free slot -- and overlapped
+  // launches stretch each other's durations, which is what the roofline line of bench.py and rocprofv3 divide by.
+  static const double tail_flops = getenv("PASTIX_AMD_TAIL_FLOPS") ? atof(getenv("PASTIX_AMD_TAIL_FLOPS")) : 0.0;
+  hipStream_t sB[2] = {s2, p->stream3 ? p->stream3 : s2};
+  int lastN = -1, prevB = -1;                 // prevB: last slot that had a bulk launch
   bool s2_used = false;
   for (int l = 0; l < H.nlevels; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
@@ -967,21 +982,33 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     if ((rc = launch_panels(p, l))) return rc;
     HIPCHK(hipEventRecord(p->evP[l], s1));
     if (t1 > tu) {
-      if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
-      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-      // one launch; inside it the tasks for level l+1 (N) come first.  (Launching N and R separately so
-      // that A(l+1) waits for N only was measured slower: smaller launches, same chain.)
-      launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
-      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
-      HIPCHK(hipEventRecord(p->evB[l], s2));
+      const bool overlap = sB[1] != sB[0] && prevB >= 0 && H.slot_flops[l] < tail_flops && H.slot_flops[prevB] < tail_flops;
+      hipStream_t sx = sB[l & 1];
+      const int64_t tl = overlap ? std::max(tu, std::min(H.slot_late_begin[l], t1)) : tu;
+      if (l > 0) HIPCHK(hipStreamWaitEvent(sx, p->evP[l - 1], 0));
+      // (the same stream carried B(l-2): stream order; B(l-1) ran on the other one)
+      if (!overlap && prevB >= 0) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
+      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], sx));
+      // inside a launch the tasks for level l+1 come first.  (Launching them separately so that A(l+1) waits for
+      // them only was measured slower: smaller launches, same chain.)
+      if (tl > tu) launch_update(sx, p->arenas(), p->dTasks + tu, p->dPieces, tl - tu, false);
+      if (t1 > tl) {
+        if (overlap) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
+        launch_update(sx, p->arenas(), p->dTasks + tl, p->dPieces, t1 - tl, false);
+      }
+      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], sx));
+      HIPCHK(hipEventRecord(p->evB[l], sx));
       lastN = l;
+      prevB = l;
       p->nupdB_run++;
       s2_used = true;
     }
   }
   if (s2_used) {
-    HIPCHK(hipEventRecord(p->evB[0], s2));
-    HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
+    for (int q = 0; q < 2; q++) {
+      HIPCHK(hipEventRecord(q ? p->evJoin : p->evB[0], sB[q]));
+      HIPCHK(hipStreamWaitEvent(s1, q ? p->evJoin : p->evB[0], 0));
+    }
   }
   return pastix_amd_factorize_end(p, stats);
 }

@@ -72,6 +72,8 @@ struct pastix_amd_plan_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // second stream: non-urgent contributions overlap the panel kernels
+  hipStream_t stream3 = nullptr;      // third: bulk launches of odd slots (tails of short launches overlap, api.cpp)
+  hipEvent_t evJoin = nullptr;
   std::vector<hipEvent_t> evP, evB;   // per level: panels done (stream), bulk contributions done (stream2)
   std::vector<hipEvent_t> evT;        // timing pairs of the bulk launches
   int nupdB_run = 0;

@@ -517,7 +517,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_task_ptr.assign(NL + 1, 0);
   std::vector<double> task_work;
   std::vector<int32_t> task_slot;
-  std::vector<uint8_t> task_urgent;
+  std::vector<uint8_t> task_urgent, task_late;
   const bool hist_on = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
   double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0, hist_merged = 0, hist_valid = 0;
   int64_t hist_groups = 0, hist_nonfull = 0;
@@ -535,7 +535,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     std::vector<Task> tasks;
     std::vector<double> work;
     std::vector<int32_t> slot;
-    std::vector<uint8_t> urgent;
+    std::vector<uint8_t> urgent, late;
     std::vector<double> slot_flops, slot_urgent_flops, slot_maxwork;
     std::vector<int64_t> slot_pieces, slot_cnt;
     std::vector<int32_t> slot_maxpn;
@@ -560,6 +560,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     O.slot_pieces.assign(NL, 0);
     O.slot_cnt.assign(NL, 0);
     O.slot_maxpn.assign(NL, 0);
+    int64_t prev_tile = -1;                        // (a tile's tasks come out consecutively, in slot order)
+    int prev_slot = -2;
       for (size_t q = qb; q < qe;) {
       size_t e = q;
       double work = 0;
@@ -691,6 +693,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       O.work.push_back(work + 4096.0 * double(e - q));
       O.slot.push_back(slot);
       O.urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
+      // "late": the tile was also updated by the bulk launch of the previous slot -- this task may not start before that
+      // launch has finished, every other bulk task of the slot may (api.cpp overlaps consecutive bulk launches)
+      O.late.push_back(raw[q].tile == prev_tile && slot == prev_slot + 1 && P.level[t] != slot ? 1 : 0);
+      prev_tile = raw[q].tile;
+      prev_slot = slot;
       if (P.level[t] == slot) { O.urgent_flops += 2.0 * work; O.slot_urgent_flops[slot] += 2.0 * work; }
       O.slot_cnt[slot]++;
       O.ubytes += 16.0 * double(tk.tm) * double(tk.tn);
@@ -717,11 +724,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     task_work.reserve(nt);
     task_slot.reserve(nt);
     task_urgent.reserve(nt);
+    task_late.reserve(nt);
     for (GOut& O : gout) {
       P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
       task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
       task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
+      task_late.insert(task_late.end(), O.late.begin(), O.late.end());
       P.urgent_flops += O.urgent_flops;
       P.full_flops += O.full_flops;
       ubytes += O.ubytes;
@@ -759,7 +768,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           const int sl = nexts.fetch_add(1);
           if (sl >= NL) break;
           std::sort(idx.begin() + P.slot_task_ptr[sl], idx.begin() + P.slot_task_ptr[sl + 1], [&](int64_t a, int64_t b) {
-            if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];   // urgent tasks first
+            if ((task_urgent[a] == 2) != (task_urgent[b] == 2)) return task_urgent[a] == 2;   // urgent tasks first
+            if (task_late[a] != task_late[b]) return task_late[a] < task_late[b];             // then early, then late
+            if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];     // targets of the next level first
             if (order_mode == 0 || order_mode == 3) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
             return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
           });
@@ -778,12 +789,17 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     phase("task grouping");
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);
+    P.slot_late_begin.assign(NL, 0);
     for (int sl = 0; sl < NL; sl++) {
       int64_t q = P.slot_task_ptr[sl];
       while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 2) q++;
       P.slot_urgent_end[sl] = q;
       while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 1) q++;
       P.slot_next_end[sl] = q;
+      int64_t ql = P.slot_urgent_end[sl];
+      while (ql < P.slot_task_ptr[sl + 1] && !task_late[idx[ql]]) ql++;
+      // (the locality orders 1-3 rearrange the bulk range: there the whole bulk launch waits for the previous one)
+      P.slot_late_begin[sl] = order_mode == 0 ? ql : P.slot_urgent_end[sl];
     }
     std::vector<Task> sorted(P.tasks.size());
     if (order_mode == 2) {

@@ -121,6 +121,9 @@ struct Plan {
   std::vector<int64_t> slot_urgent_end;  // [nlevels] tasks [slot_task_ptr[s], slot_urgent_end[s]) target cblks of
                                          // level s itself (needed by this level's panel kernels); the rest of the
                                          // slot only feeds later levels and may overlap with the panel kernels
+  std::vector<int64_t> slot_late_begin;  // [nlevels] bulk tasks [slot_urgent_end, slot_late_begin) touch no tile of the
+                                         // previous slot's bulk launch and may run beside it; [slot_late_begin,
+                                         // slot_task_ptr[s+1]) must wait for it (same tile in consecutive slots)
   std::vector<Task> tasks;
   std::vector<Piece, NoInitAlloc<Piece>> pieces;   // (filled by parallel copies: no serial zero fill of ~10 GB first)
   double update_flops = 0;

@@ -1,5 +1,8 @@
-mkdir -p gpurun_out/r02k
-timeout 1200 python -m pytest tests -m gpu -q -k "ldlt or LDLT or sy or inertia or ref_caller or dist" > gpurun_out/r02k/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02k/pytest.log
-tail -5 gpurun_out/r02k/pytest.log
-for f in llt ldlt; do python bench.py --grid 100 --facto $f --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['metric'], d['value'], d['ms_per_step'], d['config']['residual'])"; done
-PASTIX_AMD_DIAG_LDLT_OLD=1 python bench.py --grid 100 --facto ldlt --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('old diag kernel:', d['metric'], d['value'], d['ms_per_step'])"
+mkdir -p gpurun_out/r02m
+for mp in 8 16 32; do for c in 1024 2048 4096; do
+echo "maxpieces=$mp chunk=$c"
+for n in 100; do
+PASTIX_AMD_MAXPIECES=$mp python tools/dev_bench.py -n $n --reps 4 --look $c 2>&1 | tail -1
+done
+done; done > gpurun_out/r02m/chunks2.txt 2>&1
+cat gpurun_out/r02m/chunks2.txt | cut -c1-110

@@ -34,6 +34,20 @@ int main(int argc, char** argv) {
     }
   printf("slot %lld: %zu tasks, %zu pieces, %.3e flops (%.1f%% in whole-tile pieces), arena %.1f GB\n", (long long)hdr[3],
          tasks.size(), pieces.size(), fl, 100 * full / fl, coefnbr * 8e-9);
+  {  // task mix: which instance of the update loop runs (0 full tile, 1 edge tile, 2 has partial pieces), K per task
+    double f[3] = {0, 0, 0}, kk[3] = {0, 0, 0}, exec2 = 0; long n[3] = {0, 0, 0};
+    long hist[6] = {0, 0, 0, 0, 0, 0};
+    for (const Task& t : tasks) {
+      const int m = (int)t.nfull == t.pn ? ((t.tm == 128 && t.tn == 128) ? 0 : 1) : 2;
+      double tf = 0, tk = 0;
+      for (int i = 0; i < t.pn; i++) { const Piece& p = pieces[(size_t)t.p0 + i]; tf += 2.0 * p.m * (double)p.n * p.k; tk += ((p.k + 15) / 16) * 16;
+        if (m == 2) { const int rs = (p.dr + p.m + 15) / 16 - p.dr / 16, cs = (p.dc + p.n + 15) / 16 - p.dc / 16; exec2 += 2.0 * 256.0 * rs * cs * ((p.k + 15) / 16 * 16); } }
+      f[m] += tf; kk[m] += tk; n[m]++;
+      hist[tk <= 128 ? 0 : tk <= 256 ? 1 : tk <= 512 ? 2 : tk <= 1024 ? 3 : tk <= 2048 ? 4 : 5]++;
+    }
+    for (int m = 0; m < 3; m++) printf("  mode %d: %ld tasks, %.1f%% of the flops, chunk-lines per task %.0f\n", m, n[m], 100 * f[m] / fl, n[m] ? kk[m] / n[m] : 0.0);
+    printf("  mode 2: executed band flops / useful = %.2f; tasks by K (<=128,256,512,1024,2048,more): %ld %ld %ld %ld %ld %ld\n", f[2] > 0 ? exec2 / f[2] : 0.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
+  }
   char* raw;
   CK(hipMalloc(&raw, (size_t)coefnbr * 8 + 512));
   double* d = (double*)(raw + 256);
