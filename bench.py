@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--blocksize", type=int, default=128)
     ap.add_argument("--chunk", type=int, default=0, help="update-schedule chunk (0 = engine default)")
     ap.add_argument("--facto", choices=["llt", "ldlt", "lu"], default="llt")
+    ap.add_argument("--workload", choices=["laplacian", "elasticity"], default="laplacian",
+                    help="laplacian: 3-D 7-point Laplacian grid^3, double (the metric); elasticity: BASELINE configs[4], "
+                         "complex double LDLt on the 3-dof elasticity pattern of a grid^3 node mesh (n = 3 grid^3)")
     ap.add_argument("--cpu-sample-grid", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -171,17 +174,30 @@ def main():
     else:
         N = a.grid
         t0 = time.time()
-        facto = {"llt": 0, "ldlt": 1, "lu": 2}[a.facto]
-        n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
-        perm, _ = sy.order_grid(N, N, N)
+        zel = a.workload == "elasticity"
+        if zel:
+            from pastix_amd import COMPLEXDOUBLE
+            if a.facto == "llt":
+                a.facto = "ldlt"                       # (complex symmetric: LDLt, the `sy` variant)
+            facto = {"ldlt": 1, "lu": 2}[a.facto]
+            if facto == 2:
+                raise SystemExit("bench.py: --workload elasticity is the complex-symmetric LDLt configuration")
+            n, cp, r, v, _ = sy.elasticity_3d(N)
+            perm, _ = sy.order_grid_dof(N, 3)
+            ftype = COMPLEXDOUBLE
+        else:
+            facto = {"llt": 0, "ldlt": 1, "lu": 2}[a.facto]
+            n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
+            perm, _ = sy.order_grid(N, N, N)
+            ftype = 1
         s = sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
         c4, b4 = s["cblk4"], s["blok4"]
-        flops = fact_flops(c4, b4, facto)
+        flops = fact_flops(c4, b4, facto, ftype)
         t_sym = time.time() - t0
         t0 = time.time()
-        plan = Plan(c4, b4, facto, device=local, lookahead=a.chunk)
+        plan = Plan(c4, b4, facto, floattype=ftype, device=local, lookahead=a.chunk)
         t_plan = time.time() - t0
-        crit = 6.0 * 2 * np.sqrt(1e-31)
+        crit = (1e-12 if zel else 6.0 * 2 * np.sqrt(1e-31))
         t0 = time.time()
         plan.fill_csc(0 if facto == 2 else 1, n, cp, r, v, s["perm"])
         t_fill = time.time() - t0
@@ -203,8 +219,8 @@ def main():
         wall = time.time() - t0
         # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
         rng = np.random.default_rng(1)
-        b = rng.random(n)
-        bp = np.empty(n)
+        b = rng.random(n) + (1j * rng.random(n) if zel else 0)
+        bp = np.empty(n, dtype=b.dtype)
         bp[s["perm"]] = b
         t1 = time.time()
         x = plan.solve(bp)[s["perm"]]
@@ -242,11 +258,14 @@ def main():
         upd_rate = bulk_flops * K / max(ut_sum, 1e-12)
         busy_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
         out = {
-            "metric": "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
+            "metric": ("factorization GFLOP/s (complex flops), 3-dof elasticity pattern %d^3 nodes zLDLt" % a.grid) if a.workload == "elasticity"
+                      else "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": round(res["wall"] / K * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D 7-point Laplacian %d^3 (n=%d), double %s, geometric ND, max blocksize %d"
+            "vs_baseline": None, "dtype": "c128 (f64 MFMA on split re/im planes)" if a.workload == "elasticity" else "f64", "data": "synthetic",
+            "config": {"workload": ("3-dof elasticity pattern on %d^3 nodes (n=%d), complex double symmetric %s, geometric ND, max blocksize %d"
+                                    if a.workload == "elasticity" else
+                                    "3-D 7-point Laplacian %d^3 (n=%d), double %s, geometric ND, max blocksize %d")
                                    % (a.grid, res["n"], a.facto, a.blocksize),
                        "cblknbr": res["cblk"], "bloknbr": res["blok"], "nnzL": res["nnzl"],
                        "fact_flops": res["flops"], "parallelism": res["parallelism"],
@@ -273,7 +292,7 @@ def main():
         if res.get("solve_dev_s"):
             # the next row of the path: forward + backward sweep, HBM-bound -- every panel entry is read
             # once per sweep (LU: L forward, U backward)
-            sb = 2.0 * 8.0 * res["nnzl"]
+            sb = 2.0 * (16.0 if a.workload == "elasticity" else 8.0) * res["nnzl"]
             out["solve"] = {"bound": "hbm", "achieved": round(sb / res["solve_dev_s"] * 1e-9, 1), "peak": 8000.0,
                             "unit": "GB/s", "frac": round(sb / res["solve_dev_s"] / 8e12, 4),
                             "device_s": round(res["solve_dev_s"], 4), "host_to_host_s": round(res["solve_s"], 4),
