@@ -781,6 +781,24 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       sort_slots(0);
       for (auto& x : th) x.join();
     }
+    if (getenv("PASTIX_AMD_TASK_MIX")) {      // flops by update-loop instance (kernels.hip: MODE 0 / 1 / 2)
+      double f[3] = {0, 0, 0}, fp[3] = {0, 0, 0};
+      int64_t nt[3] = {0, 0, 0};
+      for (const Task& t : P.tasks) {
+        const int m = (int)t.nfull == t.pn ? ((t.tm == TM && t.tn == TN) ? 0 : 1) : 2;
+        nt[m]++;
+        for (int i = 0; i < t.pn; i++) {
+          const Piece& pc = P.pieces[(size_t)t.p0 + i];
+          const double w2 = 2.0 * pc.m * (double)pc.n * pc.k;
+          f[m] += w2;
+          if (i >= (int)t.nfull) fp[m] += w2;
+        }
+      }
+      const double tot = f[0] + f[1] + f[2];
+      fprintf(stderr, "[task mix] mode 0: %lld tasks %.1f%% of the update flops | mode 1: %lld tasks %.1f%% | mode 2: %lld tasks %.1f%% "
+              "(of which in partial pieces %.1f%% of all flops)\n", (long long)nt[0], 100 * f[0] / tot, (long long)nt[1], 100 * f[1] / tot,
+              (long long)nt[2], 100 * f[2] / tot, 100 * fp[2] / tot);
+    }
     if (hist_on) {
       fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
