@@ -1,4 +1,4 @@
-( ./tools/bench_update 8192 16 128 64
-NOFAST=1 ./tools/bench_update 8192 16 128 64
-STRUCT=1 ROWS=40960 ./tools/bench_update 16384 16 128 16
-NOFAST=1 STRUCT=1 ROWS=40960 ./tools/bench_update 16384 16 128 16 ) 2>&1
+for bs in 128 96 64; do for g in 40 48; do
+python bench.py --workload elasticity --grid $g --blocksize $bs --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('bs=$bs grid=$g', d['value'], d['ms_per_step'], d['config']['residual'], d['config']['fact_flops'])"
+done; done
