@@ -237,6 +237,13 @@ int pastix_amd_factorize_dist(pastix_amd_plan_t *plan, double critere, pastix_am
 /* drives the plans of pastix_amd_dist_attach_local with one host thread per rank; stats / rcs: [world] or NULL */
 int pastix_amd_factorize_dist_local(pastix_amd_plan_t *const *plans, int32_t world, double critere,
                                     pastix_amd_stats_t *stats, int32_t *rcs);
+/* Triangular solves on the distributed factors (real arithmetic, one right-hand side; the data flow of updo.c with
+ * several processes, updo_sendrecv.c): x (host, permuted numbering): in the right-hand side (full length on every
+ * rank), out the solution on the columns of the cblks this rank owns and zeros elsewhere -- the sum over the ranks is
+ * the solution.  Forward sweep: fan-in of the vector contributions at the target's level; backward sweep: the same
+ * channels the other way (the owner sends the solved segment to the ranks whose panels have rows in it). */
+int pastix_amd_solve_dist(pastix_amd_plan_t *plan, double *x);
+int pastix_amd_solve_dist_local(pastix_amd_plan_t *const *plans, int32_t world, double *const *xs);
 /* host only: the fan-in blocks of one rank in the order both ends of every channel issue them, 6 integers each:
  * {level, peer, cblk, dir (0 send, 1 receive), nrows, width}.  out may be NULL (count only). */
 int pastix_amd_dist_schedule(const pastix_amd_layout_t *layout, int factotype, int floattype, const int32_t *owner,

@@ -1015,20 +1015,19 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
 
 // Forward / (diagonal) / backward substitution on the device-resident factors (real LLt, LDLt, LU; the data
 // flow of up_down_smp, updo.c:114), x in permuted numbering.
-static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, bool x_on_device) {
-  if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
+// device tables of the solve (built on first use): per factorized cblk a SolveTask, its off-diagonal rows in chunks
+// of 64 (forward) / 256 (backward) rows, the blok table and the panel-row -> global-row map
+int pai_solve_tables(pastix_amd_plan_t* p) {
   const Plan& H = p->host;
-  if (p->distributed || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
-  if (!p->factored) return PASTIX_AMD_ERR_BADPARAMETER;       // panels hold no factors (refill / upload since)
-  HIPCHK(hipSetDevice(p->device));
+  const int64_t nown = H.lvl_cblk_ptr[H.nlevels];          // cblks factorized here (all of them on one GPU)
   if (!p->dSolve) {
-    std::vector<SolveTask> st((size_t)H.cblknbr);
+    std::vector<SolveTask> st((size_t)nown);
     std::vector<SolveChunk> ch, chB;
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_maxw.assign((size_t)H.nlevels, 1);
-    std::vector<int64_t> roff((size_t)H.cblknbr + 1, 0);          // in level order, like st
-    for (int64_t q = 0; q < H.cblknbr; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
+    std::vector<int64_t> roff((size_t)nown + 1, 0);          // in level order, like st
+    for (int64_t q = 0; q < nown; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
     // panel rows per chunk: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly and
     // one set of atomics per 256 rows)
     const int32_t CH = 64;
@@ -1065,8 +1064,8 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
       if ((r = to_device(&dC, ch))) return r;
       if ((r = to_device(&dCB, chB))) return r;
       if ((r = to_device(&droff, roff))) return r;
-      HIPCHK(hipMalloc((void**)&dR, (size_t)std::max<int64_t>(roff[H.cblknbr], 1) * sizeof(int32_t)));
-      launch_solve_rowidx(p->stream, dS, H.cblknbr, droff, dB, dR);
+      HIPCHK(hipMalloc((void**)&dR, (size_t)std::max<int64_t>(roff[nown], 1) * sizeof(int32_t)));
+      launch_solve_rowidx(p->stream, dS, nown, droff, dB, dR);
       HIPCHK(hipStreamSynchronize(p->stream));
       HIPCHK(hipGetLastError());
       return 0;
@@ -1079,6 +1078,33 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     }
     p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
   }
+  return PASTIX_AMD_OK;
+}
+
+// one level of the forward (fwd) or backward sweep on nr right-hand sides (real arithmetic), on the plan's stream
+void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) {
+  const Plan& H = p->host;
+  if (fwd)
+    launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                       p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
+  else
+    launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
+                       p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
+}
+void pai_solve_dscale(pastix_amd_plan_t* p, double* dx, int nr) {     // LDLt: x <- D^-1 x on the cblks factorized here
+  const Plan& H = p->host;
+  for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx + k * H.ncol);
+}
+
+static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, bool x_on_device) {
+  if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
+  const Plan& H = p->host;
+  if (p->distributed || H.opts.schur) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (!p->factored) return PASTIX_AMD_ERR_BADPARAMETER;       // panels hold no factors (refill / upload since)
+  HIPCHK(hipSetDevice(p->device));
+  { const int rt = pai_solve_tables(p); if (rt) return rt; }
   const int mode = x_on_device ? 2 : 1;
   if (p->cplx) {
     // x is interleaved `double complex` (n x nrhs, column-major) like the reference's; planes on the device
@@ -1134,16 +1160,9 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
     if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
-    for (int l = 0; l < H.nlevels; l++)
-      launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
-                         p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
-    if (H.factotype == PASTIX_AMD_FACT_LDLT)
-      for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.cblknbr, dx + k * H.ncol);
-    for (int l = H.nlevels - 1; l >= 0; l--)
-      launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                         H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
-                         p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
+    for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
+    if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
+    for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
     HIPCHK(hipEventRecord(p->ev1, p->stream));
     if (mode == 1) HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));

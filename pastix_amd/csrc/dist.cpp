@@ -275,6 +275,9 @@ struct pastix_amd_dist_s {
   size_t nev_used = 0;
   double bytes_sent = 0, bytes_recv = 0;
   int64_t nsend = 0, nrecv = 0;
+  double* dXs = nullptr;                    // solve: the rank's copy of the vector
+  double* dSolveStage = nullptr;            // solve: received segments (forward sweep)
+  std::vector<int64_t> solve_stage_off;     // per message: offset in dSolveStage (receive messages)
 };
 
 static void dist_free(pastix_amd_dist_s* D) {
@@ -283,6 +286,8 @@ static void dist_free(pastix_amd_dist_s* D) {
   D->T.reset();
   (void)hipFree(D->dStage);
   (void)hipFree(D->dRows);
+  (void)hipFree(D->dXs);
+  (void)hipFree(D->dSolveStage);
   for (hipEvent_t e : D->events) (void)hipEventDestroy(e);
   delete D;
 }
@@ -547,6 +552,161 @@ int pastix_amd_factorize_dist(pastix_amd_plan_t* p, double critere, pastix_amd_s
     HIPCHK(hipStreamWaitEvent(s1, e, 0));
   }
   return pastix_amd_factorize_end(p, stats);
+}
+
+}  // extern "C"
+
+namespace {
+__global__ void k_vec_add(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+}  // namespace
+
+extern "C" {
+
+// Triangular solves on the distributed factors (the data flow of up_down_smp with several processes, updo.c:114 and
+// updo_sendrecv.c): every rank keeps a full-length copy of the vector.  Forward sweep: a rank's copy holds the
+// right-hand side on the columns of its own cblks and ZERO elsewhere, so what its panels subtract from the rows of a
+// remote cblk t accumulates there; at t's level that segment travels to t's owner, which adds it before it solves t --
+// the fan-in of the factorization, on vectors (same channels, same (level, peer, cblk) order).  Backward sweep: the
+// same messages run the other way: the owner of t sends the solved segment x_t to every rank that holds panel rows in
+// t, before they reach the levels below.  x (host, permuted numbering, one right-hand side): in b, out the solved
+// values on the columns this rank owns and zeros elsewhere -- the sum over the ranks is the solution.
+int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
+  if (!p || !x || !p->distributed || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (p->cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (!p->factored) return PASTIX_AMD_ERR_BADPARAMETER;
+  pastix_amd_dist_s* D = p->dist;
+  const DistSchedule& S = D->S;
+  const Plan& H = p->host;
+  HIPCHK(hipSetDevice(p->device));
+  int rc = pai_solve_tables(p);
+  if (rc) return rc;
+  const int64_t n = H.ncol;
+  if (!D->dXs) HIPCHK(hipMalloc((void**)&D->dXs, (size_t)n * sizeof(double)));
+  if (D->solve_stage_off.empty() && !S.msgs.empty()) {
+    D->solve_stage_off.assign(S.msgs.size(), 0);
+    int64_t off = 0;
+    for (size_t i = 0; i < S.msgs.size(); i++)
+      if (S.msgs[i].dir == 1) { D->solve_stage_off[i] = off; off += S.msgs[i].width; }
+    HIPCHK(hipMalloc((void**)&D->dSolveStage, (size_t)std::max<int64_t>(off, 1) * sizeof(double)));
+  }
+  // the rank's view of b: own columns only
+  std::vector<double> hx((size_t)n, 0.0);
+  for (int64_t k = 0; k < H.cblknbr; k++)
+    if (H.role[k] == 1)
+      std::memcpy(hx.data() + H.cblk[k].fcolnum, x + H.cblk[k].fcolnum,
+                  (size_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1) * sizeof(double));
+  hipStream_t s1 = p->stream;
+  double* dx = D->dXs;
+  HIPCHK(hipMemcpyAsync(dx, hx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s1));
+  D->nev_used = 0;
+  auto new_event = [&](hipEvent_t* out) -> int {
+    if (D->nev_used == D->events.size()) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      D->events.push_back(e);
+    }
+    *out = D->events[D->nev_used++];
+    return 0;
+  };
+  // one sweep over the levels; fwd: contributors send, owners receive and add; bwd: owners send, contributors receive
+  auto exchange = [&](int l, bool fwd, size_t m0, size_t m1) -> int {
+    if (m1 <= m0) return 0;
+    hipEvent_t evA;
+    int r;
+    if ((r = new_event(&evA))) return r;
+    HIPCHK(hipEventRecord(evA, s1));                      // everything this rank computed so far
+    for (size_t g0 = m0; g0 < m1;) {
+      size_t g1 = g0;
+      const int peer = S.msgs[g0].peer;
+      while (g1 < m1 && S.msgs[g1].peer == peer) g1++;
+      hipStream_t cs = D->chan[peer];
+      HIPCHK(hipStreamWaitEvent(cs, evA, 0));
+      if ((r = D->T->group_begin(peer))) return r;
+      bool gr = false;
+      for (size_t i = g0; i < g1; i++) {
+        const DistMsg& m = S.msgs[i];
+        double* seg = dx + H.cblk[m.cblk].fcolnum;
+        const bool send = fwd ? m.dir == 0 : m.dir == 1;
+        if (send) r = D->T->send(peer, seg, m.width, cs);
+        else { r = D->T->recv(peer, fwd ? D->dSolveStage + D->solve_stage_off[i] : seg, m.width, cs); gr = true; }
+        if (r) { (void)D->T->group_end(peer); return r; }
+      }
+      if ((r = D->T->group_end(peer))) return r;
+      if (gr) {
+        hipEvent_t evC;
+        if ((r = new_event(&evC))) return r;
+        HIPCHK(hipEventRecord(evC, cs));
+        HIPCHK(hipStreamWaitEvent(s1, evC, 0));
+      }
+      g0 = g1;
+    }
+    if (fwd)
+      for (size_t i = m0; i < m1; i++) {
+        const DistMsg& m = S.msgs[i];
+        if (m.dir != 1) continue;
+        hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((m.width + 255) / 256)), dim3(256), 0, s1,
+                           dx + H.cblk[m.cblk].fcolnum, D->dSolveStage + D->solve_stage_off[i], m.width);
+      }
+    (void)l;
+    return 0;
+  };
+  std::vector<size_t> lvl_m((size_t)H.nlevels + 1, S.msgs.size());
+  {
+    size_t mi = 0;
+    for (int l = 0; l < H.nlevels; l++) {
+      lvl_m[(size_t)l] = mi;
+      while (mi < S.msgs.size() && S.msgs[mi].level == l) mi++;
+    }
+    lvl_m[(size_t)H.nlevels] = mi;
+  }
+  for (int l = 0; l < H.nlevels; l++) {
+    if ((rc = exchange(l, true, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
+    pai_solve_level(p, true, l, dx, 1);
+  }
+  if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, 1);
+  for (int l = H.nlevels - 1; l >= 0; l--) {
+    pai_solve_level(p, false, l, dx, 1);
+    if ((rc = exchange(l, false, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
+  }
+  for (auto& c : D->chan) {                               // sends of the last levels have left
+    hipEvent_t e;
+    if ((rc = new_event(&e))) return rc;
+    HIPCHK(hipEventRecord(e, c.second));
+    HIPCHK(hipStreamWaitEvent(s1, e, 0));
+  }
+  HIPCHK(hipMemcpyAsync(hx.data(), dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s1));
+  HIPCHK(hipStreamSynchronize(s1));
+  HIPCHK(hipGetLastError());
+  std::memset(x, 0, (size_t)n * sizeof(double));
+  for (int64_t k = 0; k < H.cblknbr; k++)
+    if (H.role[k] == 1)
+      std::memcpy(x + H.cblk[k].fcolnum, hx.data() + H.cblk[k].fcolnum,
+                  (size_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1) * sizeof(double));
+  return PASTIX_AMD_OK;
+}
+
+// drives pastix_amd_solve_dist of the plans of pastix_amd_dist_attach_local with one host thread per rank;
+// xs[r]: rank r's vector (each a full copy of b on entry)
+int pastix_amd_solve_dist_local(pastix_amd_plan_t* const* plans, int32_t world, double* const* xs) {
+  if (!plans || !xs || world < 2) return PASTIX_AMD_ERR_BADPARAMETER;
+  std::vector<int> rc((size_t)world, 0);
+  std::vector<std::thread> th;
+  auto run = [&](int r) {
+    rc[(size_t)r] = pastix_amd_solve_dist(plans[r], xs[r]);
+    if (rc[(size_t)r])
+      if (auto* lt = dynamic_cast<LocalTransport*>(plans[r]->dist ? plans[r]->dist->T.get() : nullptr)) {
+        { std::lock_guard<std::mutex> g(lt->hub->mu); lt->hub->failed = true; }
+        lt->hub->cv.notify_all();
+      }
+  };
+  for (int r = 1; r < world; r++) th.emplace_back(run, r);
+  run(0);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < world; r++) if (rc[(size_t)r]) return rc[(size_t)r];
+  return PASTIX_AMD_OK;
 }
 
 // Single-process emulation of a whole job: the rank plans (attached with pastix_amd_dist_attach_local) are driven by

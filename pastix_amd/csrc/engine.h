@@ -123,6 +123,13 @@ struct pastix_amd_plan_s {
     }                                                                                    \
   } while (0)
 
+// api.cpp: pieces of the device solve shared with the multi-GPU driver (dist.cpp)
+extern "C" {
+int pai_solve_tables(pastix_amd_plan_s* p);
+void pai_solve_level(pastix_amd_plan_s* p, bool fwd, int l, double* dx, int nr);
+void pai_solve_dscale(pastix_amd_plan_s* p, double* dx, int nr);
+}
+
 static inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

@@ -544,6 +544,13 @@ class DistPlan:
               "pastix_amd_factorize_dist")
         return s.as_dict()
 
+    def solve(self, b):
+        """pastix_amd_solve_dist: b (permuted numbering, full length) -> this rank's part of the solution (zeros on the
+        columns of other ranks' cblks); collective over the job, the sum over the ranks is x."""
+        x = np.ascontiguousarray(b, dtype=np.float64).copy()
+        check(_lib.lib().pastix_amd_solve_dist(self._h, _lib.ptr(x)), "pastix_amd_solve_dist")
+        return x
+
     def diag_logsum(self):
         """sum of log of the diagonal entries of the owned factor panels (LLt: log det A = 2 x the job-wide sum)."""
         c4 = self.layout.cblk4
@@ -569,6 +576,16 @@ def factorize_local(plans, critere):
     check(_lib.lib().pastix_amd_factorize_dist_local(arr, ctypes.c_int32(n), ctypes.c_double(critere), st, rcs),
           "pastix_amd_factorize_dist_local")
     return [s.as_dict() for s in st]
+
+
+def solve_local(plans, b):
+    """Distributed solve of the rank plans of this process (attach_local): returns the assembled solution."""
+    n = len(plans)
+    xs = [np.ascontiguousarray(b, dtype=np.float64).copy() for _ in plans]
+    arr = (ctypes.c_void_p * n)(*[p._h for p in plans])
+    xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
+    check(_lib.lib().pastix_amd_solve_dist_local(arr, ctypes.c_int32(n), xp), "pastix_amd_solve_dist_local")
+    return np.sum(xs, axis=0)
 
 
 def exchange_unique_ids(cblk4, blok4, owner, rank, world):
@@ -691,7 +708,23 @@ def bench_distributed(a, rank, world, local):
     # size-independent check of the distributed factors: log det A = 2 sum log L_kk (LLt; LDLt: sum log d_k; LU: the
     # diagonal of L carries the pivots) over the owned cblks of all ranks, against the analytic spectrum of the 7-point
     # Dirichlet Laplacian (eigenvalues 6 - 2cos(i pi/(N+1)) - 2cos(j pi/(N+1)) - 2cos(k pi/(N+1)))
+    resid = None
     if native:
+        # end-to-end check: distributed solve, the parts summed over the ranks, ||Ax - b|| / ||b||
+        rng = np.random.default_rng(1)
+        b = rng.random(n)
+        bp = np.empty(n)
+        bp[s["perm"]] = b
+        xpart = torch.from_numpy(eng.solve(bp)).to(torch.device("cuda", local))
+        dist.all_reduce(xpart)
+        if rank == 0:
+            import scipy.sparse as sp
+            xs = xpart.cpu().numpy()[s["perm"]]
+            A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+            Ax = A @ xs if facto == 2 else A @ xs + sp.tril(A, -1).T @ xs
+            resid = float(np.linalg.norm(Ax - b) / np.linalg.norm(b))
+            if not resid < 1e-9:
+                raise RuntimeError("distributed solve: residual %.3e" % resid)
         ld_local = eng.diag_logsum() * (2.0 if facto == 0 else 1.0)
         info = eng.info()
         fanin_gb, arena_gb = info["fanin_buffer_bytes"] * 1e-9, 8e-9 * float(eng.poff[-1])
@@ -720,7 +753,7 @@ def bench_distributed(a, rank, world, local):
         raise RuntimeError("distributed factorization failed its log-det check: %.15g vs %.15g" % (float(sm[4]), ld_exact))
     res = dict(wall=float(mx[0]), flops=flops, logdet_rel_err=ld_err, fact_time=ft, update_time=float(sm[1]) / world,
                update_time_sum=float(sm[5]) / world, urgent_flops=0.0,
-               update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=None, nbpivot=st["nbpivot"],
+               update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"],
                n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
                t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
                parallelism="%d ranks, one per GPU: elimination-tree subtrees + asynchronous fan-in, transport %s "

@@ -1,4 +1,7 @@
-for bs in 128 96 64; do for g in 40 48; do
-python bench.py --workload elasticity --grid $g --blocksize $bs --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('bs=$bs grid=$g', d['value'], d['ms_per_step'], d['config']['residual'], d['config']['fact_flops'])"
-done; done
+mkdir -p gpurun_out/r02o
+for i in 1 2 3; do
+timeout 1200 python -m pytest tests/test_gpu_dist.py tests/test_gpu_solve_driver.py -q > gpurun_out/r02o/pytest$i.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02o/pytest$i.log
+tail -3 gpurun_out/r02o/pytest$i.log
+done
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r02o/pytest_all.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02o/pytest_all.log
+tail -3 gpurun_out/r02o/pytest_all.log
