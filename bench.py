@@ -304,6 +304,11 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+        # RCCL's exit-time teardown has been seen to abort ("double free") after everything was done and printed:
+        # the ranks leave without running it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
