@@ -74,6 +74,29 @@ __device__ double g_zero_line[128];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// The same through inline assembly (the 4-stage experiment): the compiler neither models these loads' LDS writes (it
+// puts a vmcnt(0) in front of every LDS read that may alias an LDS-DMA it knows of) nor forces vmcnt(0) in front of the
+// barrier, so several stages can stay in flight across barriers; ordering is by the explicit counts below.
+#define PASTIX_AMD_GLDS_ASM(gptr, lptr)                                                                       \
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"                                          \
+               :: "v"(gptr), "s"((unsigned)(size_t)(__attribute__((address_space(3))) void*)(lptr)) : "memory")
+#define PASTIX_AMD_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// A Piece fetched with dword loads only (two 16-byte loads, scalar when the address is wave-uniform): the 16-bit
+// fields read one by one compile to global_load_ushort -- vector loads whose vmcnt wait would drain the LDS-DMA stages
+// that are supposed to stay in flight across a piece switch.
+struct PieceW { int64_t a_off, b_off; int lda, k, flags; };
+__device__ __forceinline__ PieceW load_piece_w(const Piece* __restrict__ pp) {
+  const uint4 lo = ((const uint4*)pp)[0], hi = ((const uint4*)pp)[1];
+  PieceW w;
+  w.a_off = (int64_t)(((uint64_t)lo.y << 32) | lo.x);
+  w.b_off = (int64_t)(((uint64_t)lo.w << 32) | lo.z);
+  w.lda = (int)hi.x;
+  w.k = (int)(hi.y & 0xffffu);
+  w.flags = (int)(hi.w >> 16);
+  return w;
+}
+
 // KIND 0: the bulk launches.  KIND 1 (`k_update_urgent` in profiles): the same code for the few latency-critical
 // tasks of a level that the two-stream driver runs beside the bulk launch of the previous slot; a separate
 // instantiation so that per-kernel profiles of the two do not mix.
@@ -363,6 +386,118 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     };
     // instantiations: MODE x sign flips (Task flag bit 3, set by the plan; real factorizations never have them: 16
     // vector instructions per chunk less).  The plan puts the whole-tile pieces of a task first (Task::nfull).
+#ifdef UPDATE_S4
+    // EXPERIMENT (compile with -DUPDATE_S4): the branch-free loop with FOUR 8-line LDS stages instead of two
+    // 16-line buffers (same 73.7 KB): the DMA of stage s+3 is issued at the start of stage s, i.e. three stages (1.5
+    // chunks) of lead instead of one chunk; a barrier every 8 lines; counted vmcnt instead of __syncthreads' vmcnt(0)
+    // (DMA and barrier through inline assembly, Piece fetched with scalar loads only -- see the macros above).  Correct
+    // (parity suite green, bitwise reproducible) and NOT faster: from cache 67.9 against 68.4 TFLOP/s, long tasks 70.7 /
+    // 71.5, operands from HBM 59.3 / 59.6, a replayed 160^3 launch 63.1 / 63.7.  The loss with HBM-fed operands is
+    // therefore not exposed latency that more lead could hide.
+    auto fast_loop4 = [&](const int pbeg, const int pend) {
+      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      constexpr int SK = 8;                                  // k-lines per stage
+      double* shs = &sh[0][0][0];                            // stage b: A image at b * 2*SK*SLD, B image + SK*SLD
+      auto stA = [&](int b) { return shs + b * (2 * SK * SLD); };
+      auto stB = [&](int b) { return shs + b * (2 * SK * SLD) + SK * SLD; };
+      int pi = pbeg;
+      PieceW cur = load_piece_w(pieces + pi);
+      PieceW nextp = load_piece_w(pieces + min(pi + 1, pend - 1));
+      int64_t lda = cur.lda;
+      const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+      const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+      const int lo2 = 2 * lane;
+      int left = (cur.k + SK - 1) / SK;                 // stages left in the piece on the DMA side
+      int krem = cur.k;
+      const double* zl = g_zero_line;
+      bool more = true;                                      // the DMA cursor has not run off the piece list
+      int issued = 0, done = 0;                              // stages issued / computed
+      auto issue = [&](int b) {                              // DMA of the cursor's stage into stage buffer b, advance
+        if (wave < krem) {
+          PASTIX_AMD_GLDS_ASM(pa + lo2, stA(b) + wave * SLD);
+          PASTIX_AMD_GLDS_ASM(pb + lo2, stB(b) + wave * SLD);
+        } else {
+          PASTIX_AMD_GLDS_ASM(zl + lo2, stA(b) + wave * SLD);
+          PASTIX_AMD_GLDS_ASM(zl + lo2, stB(b) + wave * SLD);
+        }
+        krem -= SK;
+        issued++;
+        if (--left == 0) {
+          if (++pi < pend) {
+            cur = nextp;
+            lda = cur.lda;
+            pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+            pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+            left = (cur.k + SK - 1) / SK;
+            krem = cur.k;
+            nextp = load_piece_w(pieces + min(pi + 1, pend - 1));
+          } else {
+            more = false;
+          }
+        } else {
+          pa += (int64_t)SK * lda;
+          pb += (int64_t)SK * lda;
+        }
+      };
+      touched |= MALL | (0xFu << 4);
+      issue(0);
+      if (more) issue(1);
+      if (more) issue(2);
+      // wait for stage 0: everything issued after it may stay in flight (2 DMA instructions per stage and wave)
+      if (issued == 3) PASTIX_AMD_WAIT_BARRIER(4);
+      else if (issued == 2) PASTIX_AMD_WAIT_BARRIER(2);
+      else PASTIX_AMD_WAIT_BARRIER(0);
+      __builtin_amdgcn_sched_barrier(0);
+      double bm0[MI], an0[NI], bm1[MI], an1[NI];
+      const int woffA = row0 + l15 + g * SLD, woffB = col0 + l15 + g * SLD;
+      {
+        const double* a0 = stA(0) + woffA; const double* b0 = stB(0) + woffB;
+#pragma unroll
+        for (int s2 = 0; s2 < MI; s2++) bm0[s2] = a0[s2 * RS];
+#pragma unroll
+        for (int s2 = 0; s2 < NI; s2++) an0[s2] = b0[s2 * CS];
+      }
+      int buf = 0;
+      while (true) {
+        if (more) issue((buf + 3) & 3);                      // (stage buffer last read in the previous iteration)
+        const double* sA = stA(buf) + woffA;
+        const double* sB = stB(buf) + woffB;
+#pragma unroll
+        for (int s2 = 0; s2 < MI; s2++) bm1[s2] = sA[4 * SLD + s2 * RS];
+#pragma unroll
+        for (int s2 = 0; s2 < NI; s2++) an1[s2] = sB[4 * SLD + s2 * CS];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
+        done++;
+        const int ahead = issued - done;                     // stages issued beyond the one just computed (0..3)
+        // stage done+0 (the next one) must have landed: later ones (ahead - 1 of them) may stay in flight
+        if (ahead >= 3) PASTIX_AMD_WAIT_BARRIER(4);
+        else if (ahead == 2) PASTIX_AMD_WAIT_BARRIER(2);
+        else PASTIX_AMD_WAIT_BARRIER(0);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const double* nA = stA((buf + 1) & 3) + woffA;
+          const double* nB = stB((buf + 1) & 3) + woffB;
+#pragma unroll
+          for (int s2 = 0; s2 < MI; s2++) bm0[s2] = nA[s2 * RS];
+#pragma unroll
+          for (int s2 = 0; s2 < NI; s2++) an0[s2] = nB[s2 * CS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+          for (int ni = 0; ni < NI; ni++)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
+        if (ahead == 0) break;
+        buf = (buf + 1) & 3;
+      }
+      __syncthreads();
+    };
+#endif
     // Exactly one instance runs per task: tasks made of whole-tile pieces only (the bulk of the flops) take MODE 0 / 1,
     // a task with any partial piece runs all its pieces through MODE 2 (a whole-tile piece is its special case).
     const int plast = tk.p0 + tk.pn;
@@ -370,7 +505,11 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
     if ((int)tk.nfull == tk.pn) {
       if (tk.tm == TM && tk.tn == TN) {
         if (neg) fast_loop(std::integral_constant<int, 0>{}, std::true_type{}, tk.p0, plast);
+#ifdef UPDATE_S4
+        else fast_loop4(tk.p0, plast);
+#else
         else fast_loop(std::integral_constant<int, 0>{}, std::false_type{}, tk.p0, plast);
+#endif
       } else {
         if (neg) fast_loop(std::integral_constant<int, 1>{}, std::true_type{}, tk.p0, plast);
         else fast_loop(std::integral_constant<int, 1>{}, std::false_type{}, tk.p0, plast);

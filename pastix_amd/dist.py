@@ -728,7 +728,7 @@ def bench_distributed(a, rank, world, local):
         ld_local = eng.diag_logsum() * (2.0 if facto == 0 else 1.0)
         info = eng.info()
         fanin_gb, arena_gb = info["fanin_buffer_bytes"] * 1e-9, 8e-9 * float(eng.poff[-1])
-        nsend, transport = info["nsend"], info["transport"]
+        nsend, transport = info["nsend"], info["transport"] + " point-to-point, asynchronous (native driver)"
     else:
         wid = (c4[:-1, 1] - c4[:-1, 0] + 1).astype(np.int64)
         own = np.nonzero(eng.role == 1)[0]
@@ -756,7 +756,7 @@ def bench_distributed(a, rank, world, local):
                update_flops=float(sm[2]) / world, update_bytes=ps["update_bytes"], nlaunch=st["nupdate_launches"], resid=resid, nbpivot=st["nbpivot"],
                n=n, cblk=len(c4) - 1, blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym,
                t_plan=t_plan, t_fill=t_fill, ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"],
-               parallelism="%d ranks, one per GPU: elimination-tree subtrees + asynchronous fan-in, transport %s "
+               parallelism="%d ranks, one per GPU: elimination-tree subtrees + fan-in of aggregated contributions, transport %s "
                            "(rank 0: %.1f%% of the flops, %d fan-in blocks sent, arena %.1f GB of which fan-in buffers %.1f GB)"
                            % (world, transport, 100.0 * ps["local_flops"] / flops, nsend, arena_gb, fanin_gb))
     eng.close()
