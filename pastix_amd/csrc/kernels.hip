@@ -693,7 +693,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+__global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
                                                     double* __restrict__ dinv_ws, double critere,
                                                     long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
@@ -708,18 +708,22 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   {
-    // blok -> LDS: thread = (row r, column parity); 32 columns per pass, loads issued before the stores
-    const int r = tid & 127, ch = tid >> 7;
+    // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
+    // the kernel must stay within 128 VGPRs -- a workgroup on the panel stream only gets a slot beside a running bulk
+    // launch if its waves fit the 128-register holes a retiring k_update workgroup leaves)
+    // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
+    // the compiler honour the 128-register bound)
+    const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
     for (int c0 = 0; c0 < 128; c0 += 64) {
-      double v[32];
+      double v[16];
 #pragma unroll
-      for (int q = 0; q < 32; q++) {                     // unconditional loads from clamped addresses
-        const int c = min(c0 + ch + 2 * q, w - 1);
+      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        const int c = min(c0 + ch + 4 * q, w - 1);
         v[q] = A[min(r, w - 1) + (int64_t)c * ld];
       }
 #pragma unroll
-      for (int q = 0; q < 32; q++) {
-        const int c = c0 + ch + 2 * q;
+      for (int q = 0; q < 16; q++) {
+        const int c = c0 + ch + 4 * q;
         if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
       }
     }
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
       // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros
       const int nbd = (rem + 15) >> 4, r0 = kb + nb;
       const int ntile = nbd * (nbd + 1) / 2;
-      for (int t = wave; t < ntile; t += 4) {
+      for (int t = wave; t < ntile; t += 8) {
         int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
         while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
         const int bi = bj + rest;
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
   __syncthreads();
   {
     const int r = tid & 127, ch = tid >> 7;
-    for (int c = ch; c < w; c += 2)
+    for (int c = ch; c < w; c += 4)
       if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
   }
   STAMP(5)
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(256) void k_diag_llt_w(double* __restrict__ L, cons
 // packed lower triangle resident in LDS, the 16 x 16 tile factorized by wave 0 in registers (unit L, D on the diagonal,
 // static-pivot clamp and the count of positive pivots for IPARM_INERTIA), rows below solved thread-per-row, trailing
 // update (L D) L^T on the MFMA pipe with L D formed on the fly from L and the tile's diagonal.
-__global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+__global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
                                                      double* __restrict__ dinv_ws, double critere,
                                                      long long* __restrict__ nbpivot) {
   // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
@@ -883,18 +887,22 @@ __global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   {
-    // blok -> LDS: thread = (row r, column parity); 32 columns per pass, loads issued before the stores
-    const int r = tid & 127, ch = tid >> 7;
+    // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
+    // the kernel must stay within 128 VGPRs -- a workgroup on the panel stream only gets a slot beside a running bulk
+    // launch if its waves fit the 128-register holes a retiring k_update workgroup leaves)
+    // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
+    // the compiler honour the 128-register bound)
+    const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
     for (int c0 = 0; c0 < 128; c0 += 64) {
-      double v[32];
+      double v[16];
 #pragma unroll
-      for (int q = 0; q < 32; q++) {                     // unconditional loads from clamped addresses
-        const int c = min(c0 + ch + 2 * q, w - 1);
+      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        const int c = min(c0 + ch + 4 * q, w - 1);
         v[q] = A[min(r, w - 1) + (int64_t)c * ld];
       }
 #pragma unroll
-      for (int q = 0; q < 32; q++) {
-        const int c = c0 + ch + 2 * q;
+      for (int q = 0; q < 16; q++) {
+        const int c = c0 + ch + 4 * q;
         if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
       }
     }
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, con
       // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros; L D is L times the tile's diagonal
       const int nbd = (rem + 15) >> 4, r0 = kb + nb;
       const int ntile = nbd * (nbd + 1) / 2;
-      for (int t = wave; t < ntile; t += 4) {
+      for (int t = wave; t < ntile; t += 8) {
         int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
         while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
         const int bi = bj + rest;
@@ -1015,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, con
   __syncthreads();
   {
     const int r = tid & 127, ch = tid >> 7;
-    for (int c = ch; c < w; c += 2)
+    for (int c = ch; c < w; c += 4)
       if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
   }
   if (wave == 0 && lane == 0) {
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt_w(double* __restrict__ L, con
 
 void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                         long long* nbpivot) {
-  hipLaunchKernelGGL(k_diag_ldlt_w, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
+  hipLaunchKernelGGL(k_diag_ldlt_w, dim3((unsigned)n), dim3(512), 0, s, L, tasks, dinv, critere, nbpivot);
 }
 #undef DP
 
@@ -1656,7 +1664,7 @@ void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n
                      long long* nbpivot, int* errflag, int maxw) {
   if (n <= 0) return;
   if (maxw <= 128)
-    hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
+    hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(512), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
   else
     hipLaunchKernelGGL(k_diag_llt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
 }

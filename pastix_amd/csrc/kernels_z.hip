@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "plan.h"
+#include "devmath.h"
 
 namespace pastix_amd {
 
@@ -20,6 +21,16 @@ __device__ __forceinline__ cz cmul(cz a, cz b) { return cz{a.re * b.re - a.im * 
 __device__ __forceinline__ cz csub(cz a, cz b) { return cz{a.re - b.re, a.im - b.im}; }
 template <bool C>
 __device__ __forceinline__ cz cj(cz a) { return C ? cz{a.re, -a.im} : a; }
+// 1/a on the latency-critical chain of the diagonal-blok kernels: Smith's scaling with the Newton-refined hardware
+// reciprocal (devmath.h, <= 2 ulp) instead of three correctly rounded software divisions
+__device__ __forceinline__ cz cinv_fast(cz a) {
+  if (fabs(a.re) >= fabs(a.im)) {
+    const double r = a.im * fast_rcp(a.re), d = fast_rcp(a.re + a.im * r);
+    return cz{d, -r * d};
+  }
+  const double r = a.re * fast_rcp(a.im), d = fast_rcp(a.re * r + a.im);
+  return cz{r * d, -d};
+}
 __device__ __forceinline__ cz cinv(cz a) {
   // 1/a, scaled (Smith) to stay finite for large/small |a|
   if (fabs(a.re) >= fabs(a.im)) {
@@ -902,6 +913,7 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
   __shared__ cz Ti[16][17];
   __shared__ cz Xs[16][XR];
   __shared__ cz Ws[16][XR];
+  __shared__ cz Li[16];                 // reciprocals of the tile's pivots
   const PanelTask tk = tasks[blockIdx.x];
   double* Ar = ar.p[0] + tk.off;
   double* Ai = ar.p[2] + tk.off;
@@ -958,8 +970,9 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
       const int ti = tid & 15, tj = tid >> 4;
       for (int j = 0; j < nb; j++) {
         cz d = Ts[j][j];
-        if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // ABS_FLOAT = cabs
-        const cz inv = cinv(d);
+        if (d.re * d.re + d.im * d.im < critere * critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // |d| < critere (ABS_FLOAT = cabs)
+        const cz inv = cinv_fast(d);
+        if (tid == 0) Li[j] = inv;
         if (ti < nb && tj < nb) {
           if (tj == j) {
             if (ti == j) Lo[j][j] = d;
@@ -1019,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
       for (int cc = 0; cc < 16; cc++) {
         if (cc < nb) {
           const cz v = x[cc];
-          const cz sc = cmul(v, cinv(Lo[cc][cc]));
+          const cz sc = cmul(v, Li[cc]);
           Ws[cc][rr] = v;
           Xs[cc][rr] = sc;
           Ar[o0 + (int64_t)cc * ld] = sc.re;
@@ -1069,12 +1082,247 @@ __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const Panel
   if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_diag_zsy_w (round 2): the register-resident complex diagonal blok with ROLE-SPLIT waves.  What bounded
+// k_diag_zsy_r beside a bulk k_update launch was not arithmetic but the number of barrier-separated phases -- 22 per
+// 16-column step, 16 of them the per-column barriers of the tile factorization -- each costing several microseconds
+// when the workgroup's waves compete with the update waves of the same CU.  Here (256 threads, up to 256 VGPRs: one
+// wave per SIMD beside the two of a k_update workgroup) wave 0 factorizes the
+// 16 x 16 tile alone, in registers (row per lane, pivots and multipliers exchanged with v_readlane, no barrier), then
+// forms the tile's inverse for the panel solve while the other waves solve the rows below the tile; waves 1-3 hold
+// the blok (eleven 2 x 2 blocks per thread) and do the trailing update.  Four barriers per step.  The two roles are
+// separate code paths, so the row registers of wave 0 and the resident blocks of the others share the register file.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double zreadlane(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+template <bool HERM>
+__global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const PanelTask* __restrict__ tasks,
+                                                    double* __restrict__ dinv_ws, double critere,
+                                                    long long* __restrict__ nbpivot) {
+  constexpr int XR = 116, NBLK = 5, NT = 448;      // 64*65/2 = 2080 blocks of 2x2 <= 5 * 448
+  __shared__ cz Ts[16][17];
+  __shared__ cz Lo[16][17];
+  __shared__ cz Li[16];
+  __shared__ cz Xs[16][XR];
+  __shared__ cz Ws[16][XR];
+  const PanelTask tk = tasks[blockIdx.x];
+  double* Ar = ar.p[0] + tk.off;
+  double* Ai = ar.p[2] + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb2 = (w + 1) >> 1, nblk = nb2 * (nb2 + 1) / 2;
+  if (wave == 0) {
+    // ================= wave 0: tile factorization + tile inverse =================
+    const int lane = tid & 63, l15 = lane & 15;
+    int npiv = 0;
+    for (int kb = 0; kb < w; kb += 16) {
+      const int nb = min(16, w - kb);
+      __syncthreads();                                   // (A) the tile is in Ts
+      cz a[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[c] = (c <= l15 && l15 < nb && c < nb) ? Ts[l15][c] : cz{0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < 16; j++) {                     // PASTIX_sytrf / hetrf (compute_diag.c:223-242, :326-345)
+        if (j < nb) {
+          cz d = cz{zreadlane(a[j].re, j), zreadlane(a[j].im, j)};
+          if (d.re * d.re + d.im * d.im < critere * critere) { d = cz{critere, 0.0}; npiv++; }   // |d| < critere
+          const cz iv = cinv_fast(d);
+          if (lane == 0) Li[j] = iv;
+          const cz t = a[j];                             // (L D)(i, j)
+          const cz lj = cmul(t, iv);                     // L(i, j)
+          a[j] = (l15 == j) ? d : lj;
+#pragma unroll
+          for (int k = j + 1; k < 16; k++) {
+            const cz lkj = cz{zreadlane(lj.re, k), zreadlane(lj.im, k)};      // L(k, j)
+            if (!HERM) a[k] = csub(a[k], cmul(t, lkj));                       // GER alpha = -d: x x^T
+            else {                                                             // zher: alpha = -Re(d), x x^H
+              cz v = csub(a[k], cmul(cz{lj.re * d.re, lj.im * d.re}, cz{lkj.re, -lkj.im}));
+              if (l15 == k) v.im = 0.0;
+              a[k] = v;
+            }
+          }
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          if (c <= l15 && l15 < nb) {
+            Lo[l15][c] = a[c];
+            const int64_t o = (kb + l15) + (int64_t)(kb + c) * ld;
+            Ar[o] = a[c].re;
+            Ai[o] = a[c].im;
+          }
+        }
+      }
+      __syncthreads();                                   // (B) Lo / Li are there: the others solve the rows below
+      // inverse of the unit-lower tile by forward substitution, column l15 per lane (lanes 0-15), through LDS: the tile
+      // buffer Ts is free until the next step's S1 (behind barrier D), and the other waves are busy with the rows below and
+      // the trailing update meanwhile -- nothing waits for this before the panel-solve kernel
+      if (lane < 16) {
+        double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512;   // [256 re][256 im] per block
+#pragma unroll 1
+        for (int i = 0; i < 16; i++) {
+          cz x;
+          if (i >= nb || l15 >= nb) x = cz{(i == l15) ? 1.0 : 0.0, 0.0};
+          else if (i < l15) x = cz{0.0, 0.0};
+          else {
+            cz sacc = cz{(i == l15) ? 1.0 : 0.0, 0.0};
+#pragma unroll 1
+            for (int pp = l15; pp < i; pp++) sacc = csub(sacc, cmul(Lo[i][pp], Ts[pp][l15]));
+            x = sacc;
+          }
+          Ts[i][l15] = x;
+          dst[i + 16 * l15] = x.re;
+          dst[256 + i + 16 * l15] = x.im;
+        }
+      }
+      __syncthreads();                                   // (C) rows below solved
+      __syncthreads();                                   // (D) trailing update done
+    }
+    if (lane == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+    return;
+  }
+  // ================= waves 1-3: resident blok, rows below the tile, trailing update =================
+  const int t3 = tid - 64;
+  int brc[NBLK];                                  // (row block) << 8 | (column block), -1: unused slot
+  cz c[NBLK][2][2];
+#pragma unroll
+  for (int i = 0; i < NBLK; i++) {
+    const int q = t3 + NT * i;
+    int col = 0;
+    if (q < nblk) {
+      const double t = 2.0 * nb2 + 1.0;
+      col = (int)((t - sqrt(t * t - 8.0 * q)) * 0.5);
+      while (col > 0 && col * nb2 - col * (col - 1) / 2 > q) col--;
+      while ((col + 1) * nb2 - (col + 1) * col / 2 <= q) col++;
+    }
+    const int bci = q < nblk ? col : -1;
+    const int bri = q < nblk ? col + (q - (col * nb2 - col * (col - 1) / 2)) : -1;
+    brc[i] = q < nblk ? (bri << 8) | bci : -1;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int r = 2 * bri + a, cc = 2 * bci + b;
+        const bool v = q < nblk && r < w && cc < w && r >= cc;
+        const int64_t o = (int64_t)min(max(r, 0), w - 1) + (int64_t)min(max(cc, 0), w - 1) * ld;
+        const double re = Ar[o], im = Ai[o];
+        c[i][a][b] = v ? cz{re, im} : cz{0.0, 0.0};
+      }
+  }
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    const int b0 = kb >> 1, b1 = (kb + 16) >> 1;          // 2x2-block range of the tile
+    // ---- S1: the tile and the rows below it go to LDS ----
+#pragma unroll
+    for (int i = 0; i < NBLK; i++) {
+      const int bci = brc[i] < 0 ? -1 : (brc[i] & 255), bri = brc[i] >> 8;
+      if (bci < b0 || bci >= b1) continue;
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+          const int r = 2 * bri + a - kb, cc = 2 * bci + b - kb;
+          if (r + kb >= w || cc >= nb || r < cc) continue;
+          if (r < nb) Ts[r][cc] = c[i][a][b];
+          else Ws[cc][r - nb] = c[i][a][b];
+        }
+    }
+    __syncthreads();                                     // (A)
+    __syncthreads();                                     // (B) wave 0 has factorized the tile
+    // ---- S3: rows below the tile, one thread per row, four columns at a time (register budget: the resident blocks
+    // stay live); later quarters re-read the earlier L D values from Ws ----
+    if (t3 < rem) {
+      const int rr = t3;
+      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        cz x[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = Ws[min(4 * h + q, nb - 1)][rr];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int cc = 4 * h + q;
+          if (cc < nb) {
+            cz sacc = x[q];
+            for (int pp = 0; pp < 4 * h; pp++) sacc = csub(sacc, cmul(Ws[pp][rr], cj<HERM>(Lo[cc][pp])));
+#pragma unroll
+            for (int pq = 0; pq < 4; pq++)
+              if (pq < q) sacc = csub(sacc, cmul(x[pq], cj<HERM>(Lo[cc][4 * h + pq])));
+            x[q] = sacc;                                   // L*D  (TRSM "R","L","T"|"C","U")
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int cc = 4 * h + q;
+          if (cc < nb) {
+            const cz v = x[q];
+            const cz sc = cmul(v, Li[cc]);
+            Ws[cc][rr] = v;
+            Xs[cc][rr] = sc;
+            Ar[o0 + (int64_t)cc * ld] = sc.re;
+            Ai[o0 + (int64_t)cc * ld] = sc.im;
+          }
+        }
+      }
+    }
+    __syncthreads();                                     // (C)
+    // ---- S4: trailing update of the resident blocks ----
+    if (rem > 0) {
+#pragma unroll
+      for (int i = 0; i < NBLK; i++) {
+        const int bci = brc[i] < 0 ? -1 : (brc[i] & 255), bri = brc[i] >> 8;
+        if (bci < b1) continue;                              // (also skips the unused slots)
+        const int r0 = 2 * bri - kb - nb, c0 = 2 * bci - kb - nb;
+        cz acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) acc[a][b] = cz{0.0, 0.0};
+        for (int pp = 0; pp < nb; pp++) {
+          cz xa[2], xb[2];
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            xa[a] = Ws[pp][min(r0 + a, XR - 1)];
+            xb[a] = Xs[pp][min(c0 + a, XR - 1)];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+              const cz m = cmul(xa[a], cj<HERM>(xb[b]));
+              acc[a][b].re += m.re;
+              acc[a][b].im += m.im;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+          for (int b = 0; b < 2; b++) {
+            c[i][a][b].re -= acc[a][b].re;
+            c[i][a][b].im -= acc[a][b].im;
+          }
+      }
+    }
+    __syncthreads();                                     // (D)
+  }
+}
+
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv,
                      double critere, long long* nbpivot, int maxw) {
   if (n <= 0) return;
   const dim3 g((unsigned)n), b(256);
   static const bool gen1 = getenv("PASTIX_AMD_ZDIAG_GEN1") != nullptr;
-  if (maxw <= 128 && !gen1) {
+  static const bool gen2 = getenv("PASTIX_AMD_ZDIAG_GEN2") != nullptr;       // round 1's register-resident kernel
+  if (maxw <= 128 && !gen1 && !gen2) {
+    if (herm) hipLaunchKernelGGL((k_diag_zsy_w<true>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
+    else hipLaunchKernelGGL((k_diag_zsy_w<false>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
+  } else if (maxw <= 128 && !gen1) {
     if (herm) hipLaunchKernelGGL((k_diag_zsy_r<true>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
     else hipLaunchKernelGGL((k_diag_zsy_r<false>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
   } else if (maxw <= 128) {
