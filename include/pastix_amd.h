@@ -195,10 +195,14 @@ int pastix_amd_plan_fanin_add(pastix_amd_plan_t *plan, pastix_amd_int_t cblk, co
  * role[cblknbr]: 1 owned, 2 shadow, 0 absent.  Any pointer may be NULL. */
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *poff, int32_t *level,
                                 int8_t *role);
-/* with opts.external_arena.  The memory must be readable 16 bytes beyond both ends of the coefnbr doubles (allocate
- * 2 x 16 bytes more and pass base + 16): the update kernel's 16-byte DMA lanes touch the neighbouring element
- * when a contribution starts or ends on an odd row. */
-int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU);
+/* with opts.external_arena: the caller owns the device memory of the panels (e.g. a torch tensor it also hands to
+ * torch.distributed; real arithmetic only).  arena_info: *nelems = doubles each buffer must hold,
+ * *first = element index at which the engine places the first panel (panel of cblk k starts at first + poff[k] of
+ * pastix_amd_plan_layout_info; the elements before and after are slack for the update kernel's 16-byte DMA lanes, which
+ * touch the neighbouring element when a contribution starts or ends on an odd row).  set_arena takes the allocations
+ * themselves (dU NULL unless LU) and their size in elements; a buffer smaller than arena_info asks for is refused. */
+int pastix_amd_plan_arena_info(const pastix_amd_plan_t *plan, pastix_amd_int_t *nelems, pastix_amd_int_t *first);
+int pastix_amd_plan_set_arena(pastix_amd_plan_t *plan, void *dL, void *dU, pastix_amd_int_t nelems);
 /* host-only schedule statistics of one rank (no device needed): per launch slot the update flops, the
  * largest task (multiply-adds), the task count, per level the panel (diag+trsm) flops, and the part of the slot's
  * flops whose targets are of the slot's own level (the urgent tasks the level's panel kernels wait for) */

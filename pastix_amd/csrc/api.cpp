@@ -299,11 +299,24 @@ int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const
   return PASTIX_AMD_OK;
 }
 
-int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU) {
+// The update kernel's 16-byte DMA lanes touch the element next to a panel when a contribution starts or ends on an
+// odd row, so the panels sit EXT_ARENA_PAD elements inside the caller's buffer; the caller allocates what
+// pastix_amd_plan_arena_info reports and passes the allocation itself (the size is checked here).
+static const int64_t EXT_ARENA_PAD = 32;
+int pastix_amd_plan_arena_info(const pastix_amd_plan_t* p, pastix_amd_int_t* nelems, pastix_amd_int_t* first) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (nelems) *nelems = std::max<int64_t>(p->host.poff[p->host.cblknbr], 1) + 2 * EXT_ARENA_PAD;   // (real plans only)
+  if (first) *first = EXT_ARENA_PAD;
+  return PASTIX_AMD_OK;
+}
+int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU, pastix_amd_int_t nelems) {
   if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !dL || p->own_arena) return PASTIX_AMD_ERR_BADPARAMETER;
-  p->dL = (double*)dL;
-  p->dU = (double*)dU;
+  pastix_amd_int_t need = 0;
+  (void)pastix_amd_plan_arena_info(p, &need, nullptr);
+  if (nelems < need) return PASTIX_AMD_ERR_BADPARAMETER;
+  p->dL = (double*)dL + EXT_ARENA_PAD;
+  p->dU = dU ? (double*)dU + EXT_ARENA_PAD : nullptr;
   return PASTIX_AMD_OK;
 }
 
@@ -729,6 +742,7 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
   p->nupd_run = 0;
+  p->launch_events = true;
   p->nupdB_run = 0;
   p->crit_run = critere;
   // Level-stepped use (distributed plans): the same urgent / bulk split over two streams as pastix_amd_factorize's
@@ -833,6 +847,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   p->stats.fact_time = ms * 1e-3;
   double upd = 0;
+  if (!p->launch_events) { p->nupd_run = 0; p->nupdB_run = 0; }     // (no per-launch events were recorded)
   {
     int i = 0;
     for (int l = 0; l < H.nlevels && i < p->nupd_run; l++) {
@@ -967,16 +982,22 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   // small -- at those sizes the next launch mostly waits for the panel chain, not for a free slot -- and overlapped
   // launches stretch each other's durations, which is what the roofline line of bench.py and rocprofv3 divide by.
   static const double tail_flops = getenv("PASTIX_AMD_TAIL_FLOPS") ? atof(getenv("PASTIX_AMD_TAIL_FLOPS")) : 0.0;
-  hipStream_t sB[2] = {s2, p->stream3 ? p->stream3 : s2};
+  // Per-launch timing events (statistics, bench.py's roofline line) are markers the command processor handles one by
+  // one: PASTIX_AMD_LAUNCH_EVENTS=0 leaves them out (update_time / update_time_sum then read 0).
+  static const bool ev_env = !getenv("PASTIX_AMD_LAUNCH_EVENTS") || atoi(getenv("PASTIX_AMD_LAUNCH_EVENTS")) != 0;
+  p->launch_events = ev_env;
+  const bool tev = p->launch_events;
+  // without tail overlap every bulk launch goes to stream2: consecutive launches are ordered by the stream itself
+  hipStream_t sB[2] = {s2, (tail_flops > 0 && p->stream3) ? p->stream3 : s2};
   int lastN = -1, prevB = -1;                 // prevB: last slot that had a bulk launch
   bool s2_used = false;
   for (int l = 0; l < H.nlevels; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
     if (lastN >= 0) { HIPCHK(hipStreamWaitEvent(s1, p->evB[lastN], 0)); lastN = -1; }
     if (tu > t0) {
-      HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s1));
+      if (tev) HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s1));
       launch_update(s1, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, true);
-      HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s1));
+      if (tev) HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s1));
       p->nupd_run++;
     }
     if ((rc = launch_panels(p, l))) return rc;
@@ -987,8 +1008,8 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       const int64_t tl = overlap ? std::max(tu, std::min(H.slot_late_begin[l], t1)) : tu;
       if (l > 0) HIPCHK(hipStreamWaitEvent(sx, p->evP[l - 1], 0));
       // (the same stream carried B(l-2): stream order; B(l-1) ran on the other one)
-      if (!overlap && prevB >= 0) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
-      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], sx));
+      if (!overlap && prevB >= 0 && sB[1] != sB[0]) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
+      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], sx));
       // inside a launch the tasks for level l+1 come first.  (Launching them separately so that A(l+1) waits for
       // them only was measured slower: smaller launches, same chain.)
       if (tl > tu) launch_update(sx, p->arenas(), p->dTasks + tu, p->dPieces, tl - tu, false);
@@ -996,7 +1017,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
         if (overlap) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
         launch_update(sx, p->arenas(), p->dTasks + tl, p->dPieces, t1 - tl, false);
       }
-      HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], sx));
+      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], sx));
       HIPCHK(hipEventRecord(p->evB[l], sx));
       lastN = l;
       prevB = l;
@@ -1022,9 +1043,11 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
   const int64_t nown = H.lvl_cblk_ptr[H.nlevels];          // cblks factorized here (all of them on one GPU)
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)nown);
-    std::vector<SolveChunk> ch, chB;
+    std::vector<SolveChunk> ch, chB, chF, chBF;
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
+    p->lvl_chunk_far.assign((size_t)H.nlevels, 0);          // [lvl_chunk_ptr[l], far[l]) near, [far[l], ptr[l+1]) far
+    p->lvl_chunkB_far.assign((size_t)H.nlevels, 0);
     p->lvl_maxw.assign((size_t)H.nlevels, 1);
     std::vector<int64_t> roff((size_t)nown + 1, 0);          // in level order, like st
     for (int64_t q = 0; q < nown; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
@@ -1041,13 +1064,35 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
         st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
                           (int32_t)H.cblk[k + 1].bloknum};
         p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
-        for (int32_t r = w; r < sd; r += CH)
-          ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                  (int32_t)H.cblk[k + 1].bloknum, r, std::min(CH, sd - r), roff[q]});
-        for (int32_t r = w; r < sd; r += CHB)
-          chB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                   (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q]});
+        // rows facing a cblk of the next level are "near": the next level's diagonal solves wait for exactly these
+        // chunks (forward) / these chunks wait for exactly the previous diagonal solves (backward); the far chunks
+        // go to the second stream (solve_sweeps below).  The bloks of a panel are sorted by row, and so are the
+        // levels they face only loosely, hence the scan.
+        const int64_t fb = H.cblk[k].bloknum + 1, lb = H.cblk[k + 1].bloknum;
+        auto near_rows = [&](int32_t r0, int32_t r1) {         // does [r0, r1) hold a row facing level l+1?
+          for (int64_t b = fb; b < lb; b++) {
+            const int32_t c0 = (int32_t)H.blok[b].coefind, c1 = c0 + (int32_t)(H.blok[b].lrownum - H.blok[b].frownum + 1);
+            if (c1 <= r0 || c0 >= r1) continue;
+            if (H.level[H.blok[b].cblknum] == l + 1) return true;
+          }
+          return false;
+        };
+        for (int32_t r = w; r < sd; r += CH) {
+          const int32_t n = std::min(CH, sd - r);
+          (near_rows(r, r + n) ? ch : chF).push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
+        }
+        for (int32_t r = w; r < sd; r += CHB) {
+          const int32_t n = std::min(CHB, sd - r);
+          (near_rows(r, r + n) ? chB : chBF).push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
+        }
       }
+      p->lvl_chunk_far[l] = (int64_t)ch.size();
+      p->lvl_chunkB_far[l] = (int64_t)chB.size();
+      ch.insert(ch.end(), chF.begin(), chF.end());
+      chB.insert(chB.end(), chBF.begin(), chBF.end());
+      chF.clear(); chBF.clear();
     }
     p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
     p->lvl_chunkB_ptr[H.nlevels] = (int64_t)chB.size();
@@ -1098,6 +1143,58 @@ void pai_solve_dscale(pastix_amd_plan_t* p, double* dx, int nr) {     // LDLt: x
   for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx + k * H.ncol);
 }
 
+// Both sweeps of one group of right-hand sides on two streams.  The chain of a sweep is diagonal solve -> the panel
+// rows facing the next level -> next diagonal solve; the rest of a panel (rows facing later levels: most of the
+// bytes at the top of the tree) only has to land before the level after next, so it runs on the second stream beside
+// the next level's chain.  Forward: far(l) starts after diag(l) and ends before diag(l+2).  Backward (levels
+// descending): far(l) needs x of the levels >= l+2, i.e. starts after diag(l+2), and ends before diag(l).  The
+// adds into x are atomic, so the two streams may touch the same rows.  Events: the factorization's per-level pairs.
+static int solve_sweeps(pastix_amd_plan_t* p, double* dx, int nr) {
+  const Plan& H = p->host;
+  hipStream_t sA = p->stream, sB = p->stream2;
+  const int nl = H.nlevels;
+  auto part = [&](hipStream_t s, bool fwd, int l, int what) {     // what: 1 diag, 2 near chunks, 4 far chunks
+    const SolveChunk* base = fwd ? p->dChunk : p->dChunkB;
+    const int64_t c0 = (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l], c2 = (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l + 1];
+    const int64_t c1 = (fwd ? p->lvl_chunk_far : p->lvl_chunkB_far)[l];
+    const int64_t b = what == 4 ? c1 : c0, e = what == 4 ? c2 : c1;
+    launch_solve_level(s, fwd, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], base + b, e - b, p->dBlok, p->dRidx, dx, H.ncol, nr,
+                       p->maxw, p->lvl_maxw[l], what == 1 ? 1 : 2);
+  };
+  auto has_far = [&](bool fwd, int l) {
+    return (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l + 1] > (fwd ? p->lvl_chunk_far : p->lvl_chunkB_far)[l];
+  };
+  for (int l = 0; l < nl; l++) {
+    if (l >= 2 && has_far(true, l - 2)) HIPCHK(hipStreamWaitEvent(sA, p->evB[l - 2], 0));
+    part(sA, true, l, 1);
+    if (has_far(true, l)) {
+      HIPCHK(hipEventRecord(p->evP[l], sA));
+      HIPCHK(hipStreamWaitEvent(sB, p->evP[l], 0));
+      part(sB, true, l, 4);
+      HIPCHK(hipEventRecord(p->evB[l], sB));
+    }
+    part(sA, true, l, 2);
+  }
+  // every far launch has been waited for except those of the last two levels, which have no far rows (nothing
+  // lies two levels above them)
+  if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
+  if (nl > 0) HIPCHK(hipEventRecord(p->evP[nl - 1], sA));       // x complete (forward sweep + scaling)
+  for (int l = nl - 1; l >= 0; l--) {
+    if (has_far(false, l)) {
+      // x of the levels >= l+2 is final after diag(l+2); for the topmost far launch that is the forward sweep's end
+      HIPCHK(hipStreamWaitEvent(sB, l + 2 < nl ? p->evP[l + 2] : p->evP[nl - 1], 0));
+      part(sB, false, l, 4);
+      HIPCHK(hipEventRecord(p->evB[l], sB));
+    }
+    part(sA, false, l, 2);
+    if (has_far(false, l)) HIPCHK(hipStreamWaitEvent(sA, p->evB[l], 0));
+    part(sA, false, l, 1);
+    HIPCHK(hipEventRecord(p->evP[l], sA));
+  }
+  return PASTIX_AMD_OK;
+}
+
 static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, bool x_on_device) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
@@ -1145,6 +1242,10 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     return PASTIX_AMD_OK;
   }
   // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes)
+  // (measured slower: 200^3 154 ms against 111 ms -- a cross-stream event per level costs more than the overlap
+  // gains on 753 levels of 10-40 us; kept for experiments)
+  static const bool want_two = getenv("PASTIX_AMD_SOLVE_TWO_STREAM") != nullptr;
+  const bool two_stream = want_two && p->stream2 && H.nlevels > 2;
   const int64_t NRB = std::min<int64_t>(nrhs, 4);
   const size_t need = (size_t)H.ncol * (size_t)NRB;
   if (mode == 1 && p->nXws < need) {
@@ -1160,9 +1261,12 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
     if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
-    for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
-    if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
-    for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
+    if (two_stream) { const int rs = solve_sweeps(p, dx, nr); if (rs) return rs; }
+    else {
+      for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
+      if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
+      for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
+    }
     HIPCHK(hipEventRecord(p->ev1, p->stream));
     if (mode == 1) HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));

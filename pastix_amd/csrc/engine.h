@@ -43,7 +43,8 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw,
+                        int part = 3);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -72,6 +73,7 @@ struct pastix_amd_plan_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // second stream: non-urgent contributions overlap the panel kernels
+  bool launch_events = true;          // per-launch timing events recorded (api.cpp, mode-1 driver)
   hipStream_t stream3 = nullptr;      // third: bulk launches of odd slots (tails of short launches overlap, api.cpp)
   hipEvent_t evJoin = nullptr;
   std::vector<hipEvent_t> evP, evB;   // per level: panels done (stream), bulk contributions done (stream2)
@@ -108,6 +110,7 @@ struct pastix_amd_plan_s {
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
   std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
+  std::vector<int64_t> lvl_chunk_far, lvl_chunkB_far;   // per level: where the chunks facing only levels > l+1 begin
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

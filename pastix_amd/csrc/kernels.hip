@@ -524,6 +524,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
   // 16-row band are issued together from clamped addresses (one latency per band, not per element).
   double* C = ar.p[tk.flags & 3] + tk.c_off;
   const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
+#ifdef EXP_NO_EPI
+  if (acc[0][0][0] != 12345.678) return;
+#endif
   if (tk.flags & 4) {
     epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, RS, CS, l15, g, tm1, tn1, tk.ldc);
     return;
@@ -1724,9 +1727,11 @@ static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* t
 template <int NR>
 static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw, int lvlw) {
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw, int lvlw, int part) {
   static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;     // the first-generation kernels
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
+  if (!(part & 1)) ntask = 0;          // part: 1 = the diagonal solves, 2 = the panel chunks (two-stream sweeps)
+  if (!(part & 2)) nchunk = 0;
   const dim3 gt((unsigned)ntask), gc((unsigned)nchunk);
   if (fwd) {
     if (ntask > 0) {
@@ -1753,10 +1758,11 @@ static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L,
 }
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw) {
-  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
-  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
-  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw,
+                        int part) {
+  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
+  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
+  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {

@@ -799,6 +799,28 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
               "(of which in partial pieces %.1f%% of all flops)\n", (long long)nt[0], 100 * f[0] / tot, (long long)nt[1], 100 * f[1] / tot,
               (long long)nt[2], 100 * f[2] / tot, 100 * fp[2] / tot);
     }
+    if (getenv("PASTIX_AMD_SLOT_MIX")) {      // per slot: tasks, pieces, mean piece shape (diagnostic of the leaf-side launches)
+      const int upto = atoi(getenv("PASTIX_AMD_SLOT_MIX"));
+      for (int sl = 0; sl < std::min<int>(NL, upto); sl++) {
+        int64_t nt = 0, np = 0, nfullp = 0;
+        double sm = 0, sn = 0, sk = 0, fl = 0, boxes = 0;
+        for (int64_t q = P.slot_task_ptr[sl]; q < P.slot_task_ptr[sl + 1]; q++) {
+          const Task& t = P.tasks[(size_t)idx[q]];
+          nt++; np += t.pn; nfullp += t.nfull;
+          int r0 = 999, r1 = 0, c0 = 999, c1 = 0;
+          for (int i = 0; i < t.pn; i++) {
+            const Piece& pc = P.pieces[(size_t)t.p0 + i];
+            sm += pc.m; sn += pc.n; sk += pc.k; fl += 2.0 * pc.m * (double)pc.n * pc.k;
+            r0 = std::min<int>(r0, pc.dr); r1 = std::max<int>(r1, pc.dr + pc.m);
+            c0 = std::min<int>(c0, pc.dc); c1 = std::max<int>(c1, pc.dc + pc.n);
+          }
+          boxes += double(r1 - r0) * (c1 - c0);
+        }
+        if (nt) fprintf(stderr, "[slot mix] slot %3d: %6lld tasks, %5.1f pieces each (%4.1f%% whole-tile), mean piece %5.1f x %5.1f x %5.1f, "
+                        "%.2f GF, bounding box of a task %.0f elements\n", sl, (long long)nt, double(np) / nt, 100.0 * nfullp / np,
+                        sm / np, sn / np, sk / np, fl * 1e-9, boxes / nt);
+      }
+    }
     if (hist_on) {
       fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
       for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);

@@ -320,12 +320,15 @@ class GpuEngine:
         check(_lib.lib().pastix_amd_plan_layout_info(self._h, _lib.ptr(self.poff), _lib.ptr(self.level),
                                                      _lib.ptr(self.role)), "pastix_amd_plan_layout_info")
         self.device = torch.device("cuda", device_index)
-        # 32 doubles of slack on both sides (pastix_amd_plan_set_arena: the update kernel's DMA lanes may touch
-        # the element next to a panel); self.arena is the view the panels live in
-        self._arena_store = torch.zeros(max(int(self.poff[-1]), 1) + 64, dtype=torch.float64, device=self.device)
-        self.arena = self._arena_store[32:-32]
-        check(_lib.lib().pastix_amd_plan_set_arena(self._h, ctypes.c_void_p(self.arena.data_ptr()), None),
-              "pastix_amd_plan_set_arena")
+        # the caller's allocation holds the panels `first` elements in (pastix_amd_plan_arena_info: slack for the update
+        # kernel's DMA lanes); self.arena is the view the panels live in
+        ne, first = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(_lib.lib().pastix_amd_plan_arena_info(self._h, ctypes.byref(ne), ctypes.byref(first)),
+              "pastix_amd_plan_arena_info")
+        self._arena_store = torch.zeros(ne.value, dtype=torch.float64, device=self.device)
+        self.arena = self._arena_store[first.value:first.value + max(int(self.poff[-1]), 1)]
+        check(_lib.lib().pastix_amd_plan_set_arena(self._h, ctypes.c_void_p(self._arena_store.data_ptr()), None,
+                                                   ctypes.c_int64(ne.value)), "pastix_amd_plan_set_arena")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         check(_lib.lib().pastix_amd_plan_set_stream(self._h, ctypes.c_void_p(stream)), "pastix_amd_plan_set_stream")
         # receive side of the fan-in: row map of every (cblk owned here, sending rank) block, on the device

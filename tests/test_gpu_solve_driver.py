@@ -166,6 +166,15 @@ def test_distributed_plans_emulated_on_one_gpu(world, golden):
     engs = [pd.GpuEngine(c4, b4, owner, r, 0) for r in range(world)]
     exch = [pd.Exchange(c4, b4, owner, level, r) for r in range(world)]
     assert sum(len(x) for e in exch for x in e.sends) > 0
+    # a caller-owned arena smaller than pastix_amd_plan_arena_info asks for is refused (the DMA slack is checked,
+    # not a convention)
+    import ctypes
+    from pastix_amd import _lib
+    ne, first = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert _lib.lib().pastix_amd_plan_arena_info(engs[0]._h, ctypes.byref(ne), ctypes.byref(first)) == 0
+    assert first.value > 0 and ne.value >= int(engs[0].poff[-1]) + 2 * first.value
+    assert _lib.lib().pastix_amd_plan_set_arena(engs[0]._h, ctypes.c_void_p(engs[0]._arena_store.data_ptr()), None,
+                                                ctypes.c_int64(ne.value - 1)) == -1      # PASTIX_AMD_ERR_BADPARAMETER
     for e in engs:
         assert np.array_equal(e.level, level)
         e.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
