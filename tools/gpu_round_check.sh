@@ -1,4 +1,12 @@
 export TMPDIR=/tmp
-for leaf in 4 6 8 10 12 16; do for am in 5 12; do
-echo -n "leaf $leaf amalg $am: "; python tools/dev_bench.py -n 100 --leaf $leaf --amalg $am --reps 3 2>&1 | awk '/^N=/{printf "%s %s %s | ", $2, $4, $5} /^plan/{printf "%s | ", $3} /^rep 2/{print $6, $7, $9, $10}'
-done; done
+bash tools/profile_round.sh 200 > gpurun_out/profile_200.log 2>&1
+bash tools/profile_round.sh 100 > gpurun_out/profile_100.log 2>&1
+NO_PMC=1 bash tools/profile_round.sh 48 --workload elasticity > gpurun_out/profile_48.log 2>&1
+tail -3 gpurun_out/profile_200.log
+python bench.py --grid 100 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100.json 2>/dev/null
+python bench.py --grid 100 --facto ldlt --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100_ldlt.json 2>/dev/null
+python bench.py --grid 100 --facto lu --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100_lu.json 2>/dev/null
+python bench.py --grid 40 --workload elasticity --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_z40.json 2>/dev/null
+python bench.py --grid 56 --workload elasticity --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_z56.json 2>/dev/null
+for f in gpurun_out/bench_*.json; do python3 -c "
+import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'])"; done

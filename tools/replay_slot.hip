@@ -8,6 +8,7 @@
 #include "../pastix_amd/csrc/kernels.hip"
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <numeric>
 #include <random>
 #include <vector>
@@ -25,6 +26,14 @@ int main(int argc, char** argv) {
   if (fread(pieces.data(), sizeof(Piece), pieces.size(), f) != pieces.size()) return 1;
   fclose(f);
   const int64_t coefnbr = hdr[0];
+  if (const char* fm = getenv("MODES")) {        // MODES=02: keep only the tasks run by these instances of the update loop
+    std::vector<Task> keep;
+    for (const Task& t : tasks) {
+      const int m = (int)t.nfull == t.pn ? ((t.tm == 128 && t.tn == 128) ? 0 : 1) : 2;
+      if (strchr(fm, '0' + m)) keep.push_back(t);
+    }
+    tasks.swap(keep);
+  }
   double fl = 0, full = 0;
   for (const Task& t : tasks)
     for (int i = 0; i < t.pn; i++) {
