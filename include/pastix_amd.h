@@ -100,7 +100,7 @@ typedef struct pastix_amd_stats_s {
   double urgent_time_sum;  /* sum of their durations */
   pastix_amd_int_t nurgent_launches;
   double solve_time;         /* s, device time of the last pastix_amd_solve call's sweeps (no host transfers) */
-  double reserved[1];
+  double nquadrant_tasks;    /* tasks of the plan that are 64x64 quadrant tasks (run by k_update_small) */
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;

@@ -198,6 +198,8 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.coefnbr = H.coefnbr;
   S.nlevels = H.nlevels;
   S.ntasks = (int64_t)H.tasks.size();
+  S.nquadrant_tasks = 0;
+  for (const Task& t : H.tasks) if (t.flags & 32u) S.nquadrant_tasks += 1.0;
   S.npieces = (int64_t)H.pieces.size();
   S.update_flops = H.update_flops;
   S.update_bytes = H.update_bytes;
@@ -734,6 +736,24 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   return PASTIX_AMD_OK;
 }
 
+// tasks [b, e) of launch slot `slot`: the quadrant tasks at the end of the slot's urgent range and at the end of its bulk
+// range go to k_update_small, the rest to k_update (PASTIX_AMD_SMALL_KERNEL=0: everything to k_update, which runs a
+// quadrant task as an edge tile)
+static void launch_update_range(pastix_amd_plan_t* p, hipStream_t s, int slot, int64_t b, int64_t e, bool urgent) {
+  static const bool small_on = !getenv("PASTIX_AMD_SMALL_KERNEL") || atoi(getenv("PASTIX_AMD_SMALL_KERNEL")) != 0;
+  const Plan& H = p->host;
+  if (!small_on) { launch_update(s, p->arenas(), p->dTasks + b, p->dPieces, e - b, urgent); return; }
+  // the slot's ranges: [t0, us) urgent, [us, tu) urgent quadrants, [tu, sb) bulk, [sb, t1) bulk quadrants
+  const int64_t cut[5] = {H.slot_task_ptr[(size_t)slot], H.slot_usmall_begin[(size_t)slot], H.slot_urgent_end[(size_t)slot],
+                          H.slot_small_begin[(size_t)slot], H.slot_task_ptr[(size_t)slot + 1]};
+  for (int k = 0; k < 4; k++) {
+    const int64_t lo = std::max(b, cut[k]), hi = std::min(e, cut[k + 1]);
+    if (hi <= lo) continue;
+    if (k & 1) launch_update_small(s, p->arenas(), p->dTasks + lo, p->dPieces, hi - lo, urgent);
+    else launch_update(s, p->arenas(), p->dTasks + lo, p->dPieces, hi - lo, urgent);
+  }
+}
+
 int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   if (!p || !p->dL || (p->host.factotype != PASTIX_AMD_FACT_LLT && !p->dU)) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
@@ -772,7 +792,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
       if (p->staged_lastB >= 0) { HIPCHK(hipStreamWaitEvent(s, p->evB[p->staged_lastB], 0)); p->staged_lastB = -1; }
       if (tu > t0) {
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
-        launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, true);
+        launch_update_range(p, s, l, t0, tu, true);
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
         p->nupd_run++;
       }
@@ -780,7 +800,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
         if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
         else HIPCHK(hipStreamWaitEvent(s2, p->ev0, 0));
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
+        launch_update_range(p, s2, l, tu, t1, false);
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
         HIPCHK(hipEventRecord(p->evB[l], s2));
         p->staged_lastB = l;
@@ -794,7 +814,7 @@ int pastix_amd_factorize_level(pastix_amd_plan_t* p, int l, int phase) {
   }
   if (t1 > t0 && phase != 2) {
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s));
-    launch_update(s, p->arenas(), p->dTasks + t0, p->dPieces, t1 - t0, false);
+    launch_update_range(p, s, l, t0, t1, false);
     HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s));
     p->nupd_run++;
   }
@@ -949,7 +969,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
       if (tu > t0) {
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s2));
-        launch_update(s2, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, false);
+        launch_update_range(p, s2, l, t0, tu, false);
         HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s2));
         p->nupd_run++;
       }
@@ -959,7 +979,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       HIPCHK(hipEventRecord(p->evP[l], s1));
       if (t1 > tu) {
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-        launch_update(s2, p->arenas(), p->dTasks + tu, p->dPieces, t1 - tu, false);
+        launch_update_range(p, s2, l, tu, t1, false);
         HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
         p->nupdB_run++;
       }
@@ -996,7 +1016,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     if (lastN >= 0) { HIPCHK(hipStreamWaitEvent(s1, p->evB[lastN], 0)); lastN = -1; }
     if (tu > t0) {
       if (tev) HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s1));
-      launch_update(s1, p->arenas(), p->dTasks + t0, p->dPieces, tu - t0, true);
+      launch_update_range(p, s1, l, t0, tu, true);
       if (tev) HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s1));
       p->nupd_run++;
     }
@@ -1012,10 +1032,10 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], sx));
       // inside a launch the tasks for level l+1 come first.  (Launching them separately so that A(l+1) waits for
       // them only was measured slower: smaller launches, same chain.)
-      if (tl > tu) launch_update(sx, p->arenas(), p->dTasks + tu, p->dPieces, tl - tu, false);
+      if (tl > tu) launch_update_range(p, sx, l, tu, tl, false);
       if (t1 > tl) {
         if (overlap) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
-        launch_update(sx, p->arenas(), p->dTasks + tl, p->dPieces, t1 - tl, false);
+        launch_update_range(p, sx, l, tl, t1, false);
       }
       if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], sx));
       HIPCHK(hipEventRecord(p->evB[l], sx));

@@ -14,6 +14,9 @@
 namespace pastix_amd {
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
                    bool urgent);
+// the quadrant tasks of a slot (Task flag 32, kernels_small.hip)
+void launch_update_small(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
+                         bool urgent);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,

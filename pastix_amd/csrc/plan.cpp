@@ -502,6 +502,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }
   for (int t = 0; t < nthr; t++) if (terr[(size_t)t]) return terr[(size_t)t];
   phase("piece sort");
+  // (room for the clipped copies the quadrant tasks below append, without touching the memory now)
+  P.pieces.reserve(raw.size() + raw.size() / 3 + 1024);
   P.pieces.resize(raw.size());
   {
     std::vector<std::thread> th;
@@ -527,6 +529,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
+  // quadrant tasks (below): on unless PASTIX_AMD_QUADRANTS=0; a task qualifies when its pieces fill less than
+  // PASTIX_AMD_QUAD_FILL (default 0.25) of the 128 x 128 x 16 chunks k_update would run for them
+  // (not with the diagnostic task orders 1-3: they rearrange the bulk range of a slot)
+  const bool quad_on = (!getenv("PASTIX_AMD_QUADRANTS") || atoi(getenv("PASTIX_AMD_QUADRANTS")) != 0) &&
+                       !(getenv("PASTIX_AMD_TASK_ORDER") && atoi(getenv("PASTIX_AMD_TASK_ORDER")) != 0);
+  const double quad_fill = getenv("PASTIX_AMD_QUAD_FILL") ? atof(getenv("PASTIX_AMD_QUAD_FILL")) : 0.25;
+  const int64_t quad_min = getenv("PASTIX_AMD_QUAD_MIN") ? atoll(getenv("PASTIX_AMD_QUAD_MIN")) : 1024;
   const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
                                                                : true;
   // The tiles are independent: the sorted piece list is cut at tile boundaries into one range per host thread, every
@@ -689,22 +698,30 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           }
         }
       }
-      O.tasks.push_back(tk);
-      O.work.push_back(work + 4096.0 * double(e - q));
-      O.slot.push_back(slot);
-      O.urgent.push_back(P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0);
+      const uint8_t urg = P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0;
       // "late": the tile was also updated by the bulk launch of the previous slot -- this task may not start before that
       // launch has finished, every other bulk task of the slot may (api.cpp overlaps consecutive bulk launches)
-      O.late.push_back(raw[q].tile == prev_tile && slot == prev_slot + 1 && P.level[t] != slot ? 1 : 0);
+      const uint8_t late = raw[q].tile == prev_tile && slot == prev_slot + 1 && P.level[t] != slot ? 1 : 0;
       prev_tile = raw[q].tile;
       prev_slot = slot;
       if (P.level[t] == slot) { O.urgent_flops += 2.0 * work; O.slot_urgent_flops[slot] += 2.0 * work; }
+      O.slot_flops[slot] += 2.0 * work;
+      O.slot_maxwork[slot] = std::max(O.slot_maxwork[slot], work);
+      // candidate for quadrant tasks (split after the grouping, once the number of candidates per slot is known)
+      if (quad_on && !raw[q].shared && tk.nfull == 0) {
+        double iters = 0;
+        for (size_t z = q; z < e; z++) iters += double((P.pieces[z].k + 15) / 16);
+        if (work < quad_fill * iters * 16.0 * double(TM) * double(TN)) tk.flags |= 64u;
+      }
+      O.tasks.push_back(tk);
+      O.work.push_back(work + 4096.0 * double(e - q));
+      O.slot.push_back(slot);
+      O.urgent.push_back(urg);
+      O.late.push_back(late);
       O.slot_cnt[slot]++;
       O.ubytes += 16.0 * double(tk.tm) * double(tk.tn);
-      O.slot_flops[slot] += 2.0 * work;
       O.slot_pieces[slot] += (int64_t)(e - q);
       O.slot_maxpn[slot] = std::max<int32_t>(O.slot_maxpn[slot], (int32_t)(e - q));
-      O.slot_maxwork[slot] = std::max(O.slot_maxwork[slot], work);
       q = e;
     }
   };
@@ -745,8 +762,73 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       GOut().tasks.swap(O.tasks);
     }
   }
-  P.update_bytes = ubytes;
   if (raw.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+  // ---- quadrant tasks ----------------------------------------------------------------------------
+  // A task of small pieces (the chains inside the leaf domains: a handful of pieces of 10-40 rows and columns, K of
+  // 30-60) is latency-bound in k_update -- a chunk iteration costs the same whatever the piece covers, and two
+  // workgroups fit a CU.  Where a launch has many of them (>= quad_min candidates among the urgent / among the bulk
+  // tasks of a slot; a handful would only add a launch), each is cut into the four 64x64 quadrants of its tile, its
+  // pieces clipped to them: ordinary tasks on a tile of valid extent <= 64 (Task flag 32), which k_update_small
+  // (kernels_small.hip: four waves, eight workgroups per CU) runs right behind the slot's k_update launch.  Ownership
+  // is unchanged: the quadrants are disjoint, every one sees its pieces in the order of the list.  The parent leaves
+  // the schedule (slot -1); its pieces stay where they are, the clipped copies are appended.
+  if (quad_on) {
+    std::vector<int64_t> cand((size_t)NL * 2, 0);
+    const size_t nt0 = P.tasks.size();
+    for (size_t i = 0; i < nt0; i++)
+      if (P.tasks[i].flags & 64u) cand[(size_t)task_slot[i] * 2 + (task_urgent[i] == 2 ? 1 : 0)]++;
+    for (size_t i = 0; i < nt0; i++) {
+      if (!(P.tasks[i].flags & 64u)) continue;
+      P.tasks[i].flags &= ~64u;
+      const int slot = task_slot[i];
+      if (cand[(size_t)slot * 2 + (task_urgent[i] == 2 ? 1 : 0)] < quad_min) continue;
+      const Task tk = P.tasks[i];
+      int made = 0;
+      for (int qd = 0; qd < 4; qd++) {
+        const int qr = (qd & 1) * 64, qc = (qd >> 1) * 64;
+        if (qr >= (int)tk.tm || qc >= (int)tk.tn) continue;
+        const size_t sp0 = P.pieces.size();
+        double wq = 0;
+        bool neg = false;
+        for (int z = 0; z < tk.pn; z++) {
+          const Piece pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+          const int r0 = std::max<int>(pc.dr, qr), r1 = std::min<int>(pc.dr + pc.m, qr + 64);
+          const int c0 = std::max<int>(pc.dc, qc), c1 = std::min<int>(pc.dc + pc.n, qc + 64);
+          if (r1 <= r0 || c1 <= c0) continue;
+          Piece cp = pc;
+          cp.a_off += r0 - pc.dr;
+          cp.b_off += c0 - pc.dc;
+          cp.dr = (uint16_t)(r0 - qr); cp.m = (uint16_t)(r1 - r0);
+          cp.dc = (uint16_t)(c0 - qc); cp.n = (uint16_t)(c1 - c0);
+          P.pieces.push_back(cp);
+          wq += double(cp.m) * cp.n * cp.k;
+          neg = neg || (cp.flags & 16);
+        }
+        const size_t np = P.pieces.size() - sp0;
+        if (np == 0) continue;
+        if (P.pieces.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+        Task tq = tk;
+        tq.c_off = tk.c_off + qr + (int64_t)qc * tk.ldc;
+        tq.tm = (uint16_t)std::min<int>(64, (int)tk.tm - qr);
+        tq.tn = (uint16_t)std::min<int>(64, (int)tk.tn - qc);
+        tq.p0 = (int32_t)sp0;
+        tq.pn = (int32_t)np;
+        tq.nfull = 0;
+        tq.flags = (tk.flags & ~(8u | 64u)) | (neg ? 8u : 0u) | 32u;
+        P.tasks.push_back(tq);
+        task_work.push_back(wq + 4096.0 * double(np));
+        task_slot.push_back(slot);
+        task_urgent.push_back(task_urgent[i]);
+        task_late.push_back(task_late[i]);
+        ubytes += 16.0 * double(tq.tm) * double(tq.tn);
+        made++;
+      }
+      ubytes -= 16.0 * double(tk.tm) * double(tk.tn);
+      P.slot_task_ptr[(size_t)slot + 1] += made - 1;
+      task_slot[i] = -1;                            // the parent is not launched
+    }
+  }
+  P.update_bytes = ubytes;
   for (int s = 0; s < NL; s++) P.slot_task_ptr[s + 1] += P.slot_task_ptr[s];
   // Order inside a slot: heaviest task first (mode 0, default: shortest tail of the launch).
   // Mode 1 (PASTIX_AMD_TASK_ORDER=1) is the XCD-locality order: workgroups are dealt round-robin over
@@ -758,10 +840,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     const int order_mode = getenv("PASTIX_AMD_TASK_ORDER") ? atoi(getenv("PASTIX_AMD_TASK_ORDER")) : 0;
     // bucket by slot (counting sort, keeps the creation order), then every slot's range sorted on its own, slots dealt
     // to the host threads: the comparison is a total order, the result does not depend on the thread count
-    std::vector<int64_t> idx(P.tasks.size());
+    std::vector<int64_t> idx((size_t)P.slot_task_ptr[NL]);
     {
       std::vector<int64_t> pos(P.slot_task_ptr.begin(), P.slot_task_ptr.end() - 1);
-      for (size_t q = 0; q < P.tasks.size(); q++) idx[(size_t)pos[(size_t)task_slot[q]]++] = (int64_t)q;
+      for (size_t q = 0; q < P.tasks.size(); q++)
+        if (task_slot[q] >= 0) idx[(size_t)pos[(size_t)task_slot[q]]++] = (int64_t)q;
       std::atomic<int> nexts{0};
       auto sort_slots = [&](int) {
         for (;;) {
@@ -769,6 +852,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           if (sl >= NL) break;
           std::sort(idx.begin() + P.slot_task_ptr[sl], idx.begin() + P.slot_task_ptr[sl + 1], [&](int64_t a, int64_t b) {
             if ((task_urgent[a] == 2) != (task_urgent[b] == 2)) return task_urgent[a] == 2;   // urgent tasks first
+            if (((P.tasks[a].flags ^ P.tasks[b].flags) & 32u) != 0) return (P.tasks[a].flags & 32u) == 0;   // quadrant tasks last
             if (task_late[a] != task_late[b]) return task_late[a] < task_late[b];             // then early, then late
             if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];     // targets of the next level first
             if (order_mode == 0 || order_mode == 3) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
@@ -830,6 +914,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);
     P.slot_late_begin.assign(NL, 0);
+    P.slot_small_begin.assign(NL, 0);
+    P.slot_usmall_begin.assign(NL, 0);
     for (int sl = 0; sl < NL; sl++) {
       int64_t q = P.slot_task_ptr[sl];
       while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 2) q++;
@@ -840,8 +926,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       while (ql < P.slot_task_ptr[sl + 1] && !task_late[idx[ql]]) ql++;
       // (the locality orders 1-3 rearrange the bulk range: there the whole bulk launch waits for the previous one)
       P.slot_late_begin[sl] = order_mode == 0 ? ql : P.slot_urgent_end[sl];
+      int64_t qs = P.slot_task_ptr[sl + 1];
+      while (qs > P.slot_urgent_end[sl] && (P.tasks[(size_t)idx[qs - 1]].flags & 32u)) qs--;
+      P.slot_small_begin[sl] = qs;
+      qs = P.slot_urgent_end[sl];
+      while (qs > P.slot_task_ptr[sl] && (P.tasks[(size_t)idx[qs - 1]].flags & 32u)) qs--;
+      P.slot_usmall_begin[sl] = qs;
     }
-    std::vector<Task> sorted(P.tasks.size());
+    std::vector<Task> sorted(idx.size());
     if (order_mode == 2) {
       // XCD-locality order of the bulk launch (everything after the urgent tasks of a slot).  Workgroup g of a launch
       // runs on XCD g % 8, and an XCD keeps 64 of these workgroups resident: give every XCD 8x8 blocks of tasks that

@@ -40,7 +40,7 @@ struct Task {
   uint16_t tm, tn;    // valid extent of the tile (<= TM, TN)
   int32_t p0, pn;     // piece range
   uint32_t flags;     // bits 0-1: arena of C, bit 2: combine with atomics (tile shared by several tasks),
-                      // bit 3: some of the leading full pieces are "+=" pieces (Piece flag 16)
+                      // bit 3: some pieces are "+=" pieces (Piece flag 16), bit 5: quadrant task (plan.cpp)
   uint32_t nfull;     // the first nfull pieces are full 128x128 tiles with K % 16 == 0 (specialized loop)
 };
 static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
@@ -124,6 +124,9 @@ struct Plan {
   std::vector<int64_t> slot_late_begin;  // [nlevels] bulk tasks [slot_urgent_end, slot_late_begin) touch no tile of the
                                          // previous slot's bulk launch and may run beside it; [slot_late_begin,
                                          // slot_task_ptr[s+1]) must wait for it (same tile in consecutive slots)
+  std::vector<int64_t> slot_small_begin; // [nlevels] bulk tasks [slot_small_begin[s], slot_task_ptr[s+1]) are quadrant tasks (Task
+                                         // flag 32: tile = a 64x64 quadrant, small pieces) for k_update_small
+  std::vector<int64_t> slot_usmall_begin;// [nlevels] urgent tasks [slot_usmall_begin[s], slot_urgent_end[s]): the same
   std::vector<Task> tasks;
   std::vector<Piece, NoInitAlloc<Piece>> pieces;   // (filled by parallel copies: no serial zero fill of ~10 GB first)
   double update_flops = 0;

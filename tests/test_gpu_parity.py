@@ -267,3 +267,33 @@ def test_task_orders_keep_the_urgent_split(name, order, golden, monkeypatch):
     assert np.abs(L1 - g["L1"]).max() <= TOL * np.abs(g["L1"]).max()
     if g["facto"] == 2:
         assert np.abs(U1 - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()
+
+
+QUAD = (golden_names("llt")[:4] + ["rlap3d_20_llt_bs128"] + golden_names("ldlt")[:2] + golden_names("lu")[:2] +
+        ["orsirr_1030_lu"] + golden_names("ldlt", prec="z")[:2] + golden_names("ldlh", prec="z")[:1] +
+        golden_names("lu", prec="z")[:1])
+
+
+@pytest.mark.parametrize("fill", ["0.25", "2.0"])
+@pytest.mark.parametrize("name", sorted(set(QUAD)))
+def test_quadrant_tasks_match_reference_golden(name, fill, golden, monkeypatch):
+    """Quadrant tasks (plan.cpp) + k_update_small (kernels_small.hip): with PASTIX_AMD_QUAD_MIN=1 every slot of these small
+    layouts cuts its qualifying tasks into 64x64 quadrants (fill 2.0: every task without whole-tile pieces, urgent ones
+    included), for every factorization kind and both arithmetics; and the same plan run through k_update alone
+    (PASTIX_AMD_SMALL_KERNEL=0 is read once per process, so that half is covered by the kernel's own edge-tile cases)."""
+    from pastix_amd import COMPLEXDOUBLE, REALDOUBLE
+    monkeypatch.setenv("PASTIX_AMD_QUAD_MIN", "1")
+    monkeypatch.setenv("PASTIX_AMD_QUAD_FILL", fill)
+    g = golden(name)
+    cplx = np.iscomplexobj(g["L1"])
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE if cplx else REALDOUBLE) as p:
+        assert p.stats()["nquadrant_tasks"] > 0
+        p.upload(g["L0"], g["U0"] if g["facto"] == 2 else None)
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+    m = _lower_mask(g["cblk4"]) if g["facto"] in (1, 3) else np.ones(g["L1"].shape, dtype=bool)
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    if g["facto"] == 2:
+        assert np.abs(U1 - g["U1"]).max() <= TOL * max(scale, np.abs(g["U1"]).max())
+    assert st["nbpivot"] == g["nbpivot"]
