@@ -737,11 +737,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   {
     size_t nt = 0;
     for (const GOut& O : gout) nt += O.tasks.size();
-    P.tasks.reserve(nt);
-    task_work.reserve(nt);
-    task_slot.reserve(nt);
-    task_urgent.reserve(nt);
-    task_late.reserve(nt);
+    const size_t ntr = quad_on ? nt + nt / 2 : nt;   // (room for the quadrant tasks appended below)
+    P.tasks.reserve(ntr);
+    task_work.reserve(ntr);
+    task_slot.reserve(ntr);
+    task_urgent.reserve(ntr);
+    task_late.reserve(ntr);
     for (GOut& O : gout) {
       P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
@@ -775,57 +776,103 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   if (quad_on) {
     std::vector<int64_t> cand((size_t)NL * 2, 0);
     const size_t nt0 = P.tasks.size();
+    bool any = false;
     for (size_t i = 0; i < nt0; i++)
       if (P.tasks[i].flags & 64u) cand[(size_t)task_slot[i] * 2 + (task_urgent[i] == 2 ? 1 : 0)]++;
-    for (size_t i = 0; i < nt0; i++) {
-      if (!(P.tasks[i].flags & 64u)) continue;
-      P.tasks[i].flags &= ~64u;
-      const int slot = task_slot[i];
-      if (cand[(size_t)slot * 2 + (task_urgent[i] == 2 ? 1 : 0)] < quad_min) continue;
-      const Task tk = P.tasks[i];
-      int made = 0;
-      for (int qd = 0; qd < 4; qd++) {
-        const int qr = (qd & 1) * 64, qc = (qd >> 1) * 64;
-        if (qr >= (int)tk.tm || qc >= (int)tk.tn) continue;
-        const size_t sp0 = P.pieces.size();
-        double wq = 0;
-        bool neg = false;
-        for (int z = 0; z < tk.pn; z++) {
-          const Piece pc = P.pieces[(size_t)tk.p0 + (size_t)z];
-          const int r0 = std::max<int>(pc.dr, qr), r1 = std::min<int>(pc.dr + pc.m, qr + 64);
-          const int c0 = std::max<int>(pc.dc, qc), c1 = std::min<int>(pc.dc + pc.n, qc + 64);
-          if (r1 <= r0 || c1 <= c0) continue;
-          Piece cp = pc;
-          cp.a_off += r0 - pc.dr;
-          cp.b_off += c0 - pc.dc;
-          cp.dr = (uint16_t)(r0 - qr); cp.m = (uint16_t)(r1 - r0);
-          cp.dc = (uint16_t)(c0 - qc); cp.n = (uint16_t)(c1 - c0);
-          P.pieces.push_back(cp);
-          wq += double(cp.m) * cp.n * cp.k;
-          neg = neg || (cp.flags & 16);
+    for (int64_t c : cand) any = any || c >= quad_min;
+    // the candidates are cut on the host threads (ranges of the task list, every thread into lists of its own, which
+    // are appended in range order: the result does not depend on the thread count)
+    struct QOut {
+      std::vector<Task> tasks;
+      std::vector<double> work;
+      std::vector<int32_t> slot;
+      std::vector<uint8_t> urgent, late;
+      std::vector<Piece> pieces;                   // Task::p0 is relative to this list until it is appended to P.pieces
+      std::vector<std::pair<int32_t, int32_t>> dcnt;   // (slot, change of its task count)
+      double dbytes = 0;
+      int err = 0;
+    };
+    const int qthr = any ? nthr : 1;
+    std::vector<QOut> qout((size_t)qthr);
+    auto cut = [&](int qt) {
+      QOut& O = qout[(size_t)qt];
+      const size_t per = (nt0 + (size_t)qthr - 1) / (size_t)qthr;
+      const size_t ib = (size_t)qt * per, ie = std::min(nt0, ib + per);
+      for (size_t i = ib; i < ie; i++) {
+        if (!(P.tasks[i].flags & 64u)) continue;
+        P.tasks[i].flags &= ~64u;
+        const int slot = task_slot[i];
+        if (cand[(size_t)slot * 2 + (task_urgent[i] == 2 ? 1 : 0)] < quad_min) continue;
+        const Task tk = P.tasks[i];
+        int made = 0;
+        for (int qd = 0; qd < 4; qd++) {
+          const int qr = (qd & 1) * 64, qc = (qd >> 1) * 64;
+          if (qr >= (int)tk.tm || qc >= (int)tk.tn) continue;
+          const size_t sp0 = O.pieces.size();
+          double wq = 0;
+          bool neg = false;
+          for (int z = 0; z < tk.pn; z++) {
+            const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+            const int r0 = std::max<int>(pc.dr, qr), r1 = std::min<int>(pc.dr + pc.m, qr + 64);
+            const int c0 = std::max<int>(pc.dc, qc), c1 = std::min<int>(pc.dc + pc.n, qc + 64);
+            if (r1 <= r0 || c1 <= c0) continue;
+            Piece cp = pc;
+            cp.a_off += r0 - pc.dr;
+            cp.b_off += c0 - pc.dc;
+            cp.dr = (uint16_t)(r0 - qr); cp.m = (uint16_t)(r1 - r0);
+            cp.dc = (uint16_t)(c0 - qc); cp.n = (uint16_t)(c1 - c0);
+            O.pieces.push_back(cp);
+            wq += double(cp.m) * cp.n * cp.k;
+            neg = neg || (cp.flags & 16);
+          }
+          const size_t np = O.pieces.size() - sp0;
+          if (np == 0) continue;
+          if (O.pieces.size() > 0x7fffffffULL) { O.err = PASTIX_AMD_ERR_UNSUPPORTED; return; }
+          Task tq = tk;
+          tq.c_off = tk.c_off + qr + (int64_t)qc * tk.ldc;
+          tq.tm = (uint16_t)std::min<int>(64, (int)tk.tm - qr);
+          tq.tn = (uint16_t)std::min<int>(64, (int)tk.tn - qc);
+          tq.p0 = (int32_t)sp0;
+          tq.pn = (int32_t)np;
+          tq.nfull = 0;
+          tq.flags = (tk.flags & ~(8u | 64u)) | (neg ? 8u : 0u) | 32u;
+          O.tasks.push_back(tq);
+          O.work.push_back(wq + 4096.0 * double(np));
+          O.slot.push_back(slot);
+          O.urgent.push_back(task_urgent[i]);
+          O.late.push_back(task_late[i]);
+          O.dbytes += 16.0 * double(tq.tm) * double(tq.tn);
+          made++;
         }
-        const size_t np = P.pieces.size() - sp0;
-        if (np == 0) continue;
-        if (P.pieces.size() > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
-        Task tq = tk;
-        tq.c_off = tk.c_off + qr + (int64_t)qc * tk.ldc;
-        tq.tm = (uint16_t)std::min<int>(64, (int)tk.tm - qr);
-        tq.tn = (uint16_t)std::min<int>(64, (int)tk.tn - qc);
-        tq.p0 = (int32_t)sp0;
-        tq.pn = (int32_t)np;
-        tq.nfull = 0;
-        tq.flags = (tk.flags & ~(8u | 64u)) | (neg ? 8u : 0u) | 32u;
-        P.tasks.push_back(tq);
-        task_work.push_back(wq + 4096.0 * double(np));
-        task_slot.push_back(slot);
-        task_urgent.push_back(task_urgent[i]);
-        task_late.push_back(task_late[i]);
-        ubytes += 16.0 * double(tq.tm) * double(tq.tn);
-        made++;
+        O.dbytes -= 16.0 * double(tk.tm) * double(tk.tn);
+        O.dcnt.emplace_back(slot, made - 1);
+        task_slot[i] = -1;                          // the parent is not launched
       }
-      ubytes -= 16.0 * double(tk.tm) * double(tk.tn);
-      P.slot_task_ptr[(size_t)slot + 1] += made - 1;
-      task_slot[i] = -1;                            // the parent is not launched
+    };
+    {
+      auto guarded = [&](int t) { try { cut(t); } catch (const std::bad_alloc&) { qout[(size_t)t].err = PASTIX_AMD_ERR_ALLOC; } };
+      std::vector<std::thread> th;
+      for (int t = 1; t < qthr; t++) th.emplace_back(guarded, t);
+      guarded(0);
+      for (auto& x : th) x.join();
+    }
+    size_t nq = 0;
+    for (const QOut& O : qout) { if (O.err) return O.err; nq += O.pieces.size(); }
+    if (P.pieces.size() + nq > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+    size_t base = P.pieces.size();
+    P.pieces.resize(base + nq);
+    for (QOut& O : qout) {
+      std::copy(O.pieces.begin(), O.pieces.end(), P.pieces.begin() + base);
+      for (Task& tq : O.tasks) tq.p0 += (int32_t)base;
+      base += O.pieces.size();
+      P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
+      task_work.insert(task_work.end(), O.work.begin(), O.work.end());
+      task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
+      task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
+      task_late.insert(task_late.end(), O.late.begin(), O.late.end());
+      for (auto& d : O.dcnt) P.slot_task_ptr[(size_t)d.first + 1] += d.second;
+      ubytes += O.dbytes;
+      QOut().pieces.swap(O.pieces);
     }
   }
   P.update_bytes = ubytes;
