@@ -1,12 +1,7 @@
 export TMPDIR=/tmp
-bash tools/profile_round.sh 200 > gpurun_out/profile_200.log 2>&1
-bash tools/profile_round.sh 100 > gpurun_out/profile_100.log 2>&1
-NO_PMC=1 bash tools/profile_round.sh 48 --workload elasticity > gpurun_out/profile_48.log 2>&1
-python bench.py --grid 100 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100.json 2>/dev/null
-python bench.py --grid 100 --facto ldlt --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100_ldlt.json 2>/dev/null
-python bench.py --grid 100 --facto lu --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_100_lu.json 2>/dev/null
-python bench.py --grid 40 --workload elasticity --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_z40.json 2>/dev/null
-python bench.py --grid 56 --workload elasticity --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_z56.json 2>/dev/null
-python bench.py --grid 192 --facto lu --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_192_lu.json 2>/dev/null
-for f in gpurun_out/bench_*.json gpurun_out/profile_200/bench_under_rocprof.json gpurun_out/profile_100/bench_under_rocprof.json; do python3 -c "
-import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['config'].get('residual'))"; done
+for ov in 1 0; do
+rm -rf /tmp/le
+PASTIX_AMD_OVERLAP=$ov rocprofv3 --kernel-trace --output-format csv -d /tmp/le -- python3 tools/dev_bench.py -n 100 --reps 2 > /tmp/le.log 2>&1
+echo "OVERLAP=$ov: $(tail -1 /tmp/le.log | cut -c1-60)"
+python3 tools/gap_stats.py /tmp/le
+done
