@@ -165,6 +165,11 @@ int pastix_amd_download_tabs(pastix_amd_plan_t *plan, void *const *coeftab, void
 int pastix_amd_fill_csc(pastix_amd_plan_t *plan, int sym, pastix_amd_int_t n, const pastix_amd_int_t *colptr,
                         const pastix_amd_int_t *rows, const void *vals, const pastix_amd_int_t *perm);
 
+/* IPARM_FILL_MATRIX = API_YES, the reference's structure-only "fake factorisation" fill (CoefMatrix_Init,
+ * coefinit.c:343-443): no CSC; coeftab all 1, ucoeftab all 2, diagonals gnodenbr^2, LU: strictly upper part of
+ * coeftab's diagonal bloks 2.  The matching pivot threshold is (gnodenbr^2 + gnodenbr) sqrt(eps)
+ * (sopalin3d.c:597-598).  Cached like pastix_amd_fill_csc.  One-GPU plans with cblks <= 256 wide. */
+int pastix_amd_fill_fake(pastix_amd_plan_t *plan, pastix_amd_int_t gnodenbr);
 /* re-apply the fill cached by the last pastix_amd_fill_csc (device only: memset + scatter). */
 int pastix_amd_refill(pastix_amd_plan_t *plan);
 

@@ -22,7 +22,7 @@ enum {
   IPARM_ORDERING = 14, IPARM_STATIC_PIVOTING = 20, IPARM_NNZEROS = 22, IPARM_BASEVAL = 24,
   IPARM_MIN_BLOCKSIZE = 25, IPARM_MAX_BLOCKSIZE = 26, IPARM_SCHUR = 27, IPARM_FACTORIZATION = 30, IPARM_THREAD_NBR = 34,
   IPARM_LEVEL_OF_FILL = 36, IPARM_RHS_MAKING = 38, IPARM_REFINEMENT = 39, IPARM_SYM = 40, IPARM_GMRES_IM = 44,
-  IPARM_INERTIA = 54,
+  IPARM_FILL_MATRIX = 53, IPARM_INERTIA = 54,
   IPARM_ESP_NBTASKS = 55, IPARM_FLOAT = 61, IPARM_ERROR_NUMBER = 63, IPARM_CUDA_NBR = 64
 };
 /* DPARM_ACCESS (api.h:219-234) */

@@ -333,6 +333,10 @@ int main(int argc, char **argv)
   iparm[IPARM_RHS_MAKING] = API_RHS_B;
   iparm[IPARM_ITERMAX] = 0;
   if (minbs > 0) { iparm[IPARM_MIN_BLOCKSIZE] = minbs; iparm[IPARM_MAX_BLOCKSIZE] = maxbs; }
+  /* REF_FAKE=1: the reference's structure-only "fake factorisation" (IPARM_FILL_MATRIX = API_YES, coefinit.c:343-443):
+   * the CSC values are not used by the numerical step */
+  const int fake = getenv("REF_FAKE") != NULL;
+  if (fake) iparm[IPARM_FILL_MATRIX] = API_YES;
   iparm[IPARM_START_TASK] = API_TASK_ORDERING;
   iparm[IPARM_END_TASK] = API_TASK_ANALYSE;
   pastix(&pd, 0, n, A.colptr, A.rows, A.vals, perm, invp, b, 1, iparm, dparm);
@@ -375,6 +379,27 @@ int main(int argc, char **argv)
       w64(f, sm->tasktab[k].cblknum); w64(f, sm->tasktab[k].prionum); w64(f, sm->tasktab[k].ctrbcnt);
     }
 
+    if (fake) {
+      /* input panels of a fake run: what CoefMatrix_Init's else-branch produces inside the sopalin threads (all 1 / all
+       * 2, gnodenbr^2 on the diagonals, LU: upper part of coeftab's diagonal bloks = 2); the pin of this case is the
+       * factor dump below, which comes from the reference's own fill + factorization */
+      critere = dparm[DPARM_EPSILON_MAGN_CTRL] < 0 ? -dparm[DPARM_EPSILON_MAGN_CTRL]
+              : ((double)n * (double)n + (double)n) * sqrt(dparm[DPARM_EPSILON_MAGN_CTRL]);
+      w64(f, 0);                                   /* no internal CSC: zero entries, n zero column counts */
+      for (k = 0; k < n; k++) w64(f, 0);
+      for (k = 0; k < sm->cblknbr; k++) {
+        long w = sm->cblktab[k].lcolnum - sm->cblktab[k].fcolnum + 1, sd = sm->cblktab[k].stride, sz = sd * w, c, r;
+        PASTIX_FLOAT *tl = malloc(sz * sizeof(PASTIX_FLOAT)), *tu = malloc(sz * sizeof(PASTIX_FLOAT));
+        for (c = 0; c < sz; c++) { tl[c] = 1; tu[c] = 2; }
+        for (c = 0; c < w; c++) {
+          tl[c + c * sd] = (PASTIX_FLOAT)((double)n * (double)n);
+          if (facto == API_FACT_LU) for (r = c + 1; r < w; r++) tl[c + r * sd] = tu[r + c * sd];
+        }
+        fwrite(tl, sizeof(PASTIX_FLOAT), sz, f);
+        if (facto == API_FACT_LU) fwrite(tu, sizeof(PASTIX_FLOAT), sz, f);
+        free(tl); free(tu);
+      }
+    } else {
     /* pre-factor panels through the reference's own fill code */
     pastix_fillin_csc(pd, pd->pastix_comm, n, A.colptr, A.rows, A.vals, b, 1, NULL);
     pd->cscInternFilled = API_YES;
@@ -424,6 +449,7 @@ int main(int argc, char **argv)
       if (facto == API_FACT_LU) fwrite(tu, sizeof(PASTIX_FLOAT), sz, f);
       sm->cblktab[k].coeftab = sv; sm->cblktab[k].ucoeftab = su;
       free(tl); free(tu);
+    }
     }
   }
 

@@ -12,7 +12,7 @@
  * tests/golden/ (.npz files) by tests/golden/make_golden.py (tests/test_oracle_golden.py).
  *
  * Exports (C ABI, i64 = int64_t everywhere):
- *   oracle_{d,z}sopalin / oracle_{d,z}fill / oracle_{d,z}solve   (sopalin_oracle_impl.h)
+ *   oracle_{d,z}sopalin / oracle_{d,z}fill / oracle_{d,z}fill_fake / oracle_{d,z}solve   (sopalin_oracle_impl.h)
  *   oracle_fact_flops                                            (below)
  */
 #include <stdlib.h>

@@ -382,6 +382,29 @@ int NAME(fill)(int facto, int sym, i64 n, const i64 *colptr, const i64 *rows, co
 }
 
 /*
+ * "Fake factorisation" fill: CoefMatrix_Init with IPARM_FILL_MATRIX = API_YES (coefinit.c:343-443), the reference's
+ * structure-only benchmark mode -- no CSC: every panel entry of coeftab is 1 (:411), of ucoeftab 2 (:413), the diagonal
+ * of every diagonal blok is gnodenbr^2 (:425-428: "on s'assure que la matrice est diagonale dominante"), and for LU the
+ * strictly upper part of coeftab's diagonal blok is a copy of ucoeftab's strictly lower part, i.e. 2 (:431-441).  The
+ * pivot threshold of such a run is (gnodenbr^2 + gnodenbr) sqrt(eps) (sopalin3d.c:597-598).
+ */
+int NAME(fill_fake)(int facto, i64 gnodenbr, i64 cblknbr, const i64 *cblk4, T *L, T *U)
+{
+  i64 k, p, off = 0, r, c;
+  for (k = 0; k < cblknbr; k++) {
+    i64 w = cblk4[4 * k + 1] - cblk4[4 * k] + 1, s = cblk4[4 * k + 3];
+    for (p = 0; p < s * w; p++) { L[off + p] = 1; if (U && facto == 2) U[off + p] = 2; }
+    for (c = 0; c < w; c++) {
+      L[off + c + c * s] = (T)((double)gnodenbr * (double)gnodenbr);
+      if (U && facto == 2)
+        for (r = c + 1; r < w; r++) L[off + c + r * s] = U[off + r + c * s];
+    }
+    off += s * w;
+  }
+  return 0;
+}
+
+/*
  * Triangular solves on the factored panels (context only: restates the data flow of
  * up_down_smp, updo.c:114, for a single right-hand side in permuted numbering):
  * forward L y = b (unit diagonal for LDLt/LU... LU uses L with the U diagonal, see below),

@@ -70,7 +70,7 @@ EXPORTS = [
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
     "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve", "pastix_amd_solve_device", "pastix_amd_refine",
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
-    "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena", "pastix_amd_plan_arena_info",
+    "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena", "pastix_amd_plan_arena_info", "pastix_amd_fill_fake",
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
     "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add", "pastix_amd_download_cblk",
     "pastix_amd_dist_unique_id", "pastix_amd_dist_selftest_rccl", "pastix_amd_dist_attach_rccl", "pastix_amd_dist_attach_local", "pastix_amd_dist_info",

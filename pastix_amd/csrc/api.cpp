@@ -699,6 +699,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
     return 0;
   };
   int r;
+  p->fillBaseL = p->fillBaseU = 0.0;
   if ((r = cache(idxL, valL, &p->dFillIdxL, &p->dFillValL, &p->nFillL))) return r;
   if ((r = cache(idxU, valU, &p->dFillIdxU, &p->dFillValU, &p->nFillU))) return r;
   if (p->cplx) {
@@ -718,14 +719,52 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   return pastix_amd_refill(p);
 }
 
+// The reference's "fake factorisation" fill (CoefMatrix_Init with IPARM_FILL_MATRIX = API_YES, coefinit.c:343-443): no
+// CSC -- every entry of coeftab is 1, of ucoeftab 2, the diagonal of every diagonal blok gnodenbr^2, and for LU the
+// strictly upper part of coeftab's diagonal blok is 2 (the copy of ucoeftab's lower part, :431-441).  Cached like
+// pastix_amd_fill_csc (pastix_amd_refill re-applies it).  One GPU, cblks <= 256 wide.
+int pastix_amd_fill_fake(pastix_amd_plan_t* p, pastix_amd_int_t gnodenbr) {
+  if (!p || gnodenbr < 1) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (p->distributed || p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;
+  const Plan& H = p->host;
+  HIPCHK(hipSetDevice(p->device));
+  const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
+  std::vector<int64_t> idx;
+  std::vector<double> val;
+  for (int64_t k = 0; k < H.cblknbr; k++) {
+    const int64_t w = H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1, sd = H.cblk[k].stride;
+    for (int64_t c = 0; c < w; c++) {
+      idx.push_back(H.poff[k] + c + c * sd);
+      val.push_back((double)gnodenbr * (double)gnodenbr);
+      if (lu)
+        for (int64_t r = c + 1; r < w; r++) { idx.push_back(H.poff[k] + c + r * sd); val.push_back(2.0); }
+    }
+  }
+  (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
+  (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi);
+  p->dFillIdxL = p->dFillIdxU = nullptr;
+  p->dFillValL = p->dFillValU = p->dFillValLi = p->dFillValUi = nullptr;
+  p->nFillL = p->nFillU = 0;
+  HIPCHK(hipMalloc((void**)&p->dFillIdxL, idx.size() * sizeof(int64_t)));
+  HIPCHK(hipMalloc((void**)&p->dFillValL, val.size() * sizeof(double)));
+  HIPCHK(hipMemcpy(p->dFillIdxL, idx.data(), idx.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(p->dFillValL, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+  p->nFillL = (int64_t)idx.size();
+  p->fillBaseL = 1.0;
+  p->fillBaseU = lu ? 2.0 : 0.0;
+  return pastix_amd_refill(p);
+}
+
 // Re-apply the cached coefficient fill (device only): zero the panels, scatter the values.
 int pastix_amd_refill(pastix_amd_plan_t* p) {
   if (!p || (!p->dFillIdxL && p->nFillL != 0) || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   p->factored = false;
   HIPCHK(hipSetDevice(p->device));
-  HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
-  if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->fillBaseL != 0.0) launch_fill_const(p->stream, p->dL, H.coefnbr, p->fillBaseL);
+  else HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
+  if (p->dU && p->fillBaseU != 0.0) launch_fill_const(p->stream, p->dU, H.coefnbr, p->fillBaseU);
+  else if (p->dU) HIPCHK(hipMemsetAsync(p->dU, 0, H.coefnbr * sizeof(double), p->stream));
   if (p->dLi) HIPCHK(hipMemsetAsync(p->dLi, 0, H.coefnbr * sizeof(double), p->stream));
   if (p->dUi) HIPCHK(hipMemsetAsync(p->dUi, 0, H.coefnbr * sizeof(double), p->stream));
   launch_scatter(p->stream, p->dL, p->dFillIdxL, p->dFillValL, p->nFillL);

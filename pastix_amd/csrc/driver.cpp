@@ -235,6 +235,22 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         break;
       }
       case API_TASK_NUMFACT: {
+        if (D->plan && iparm[IPARM_FILL_MATRIX] == API_YES) {
+          // "fake factorisation" (pastix.c:3282, coefinit.c:343-443): no CSC values; critere from the node count
+          // (sopalin3d.c:597-598)
+          const double eps = dparm[DPARM_EPSILON_MAGN_CTRL];
+          const double critere = eps < 0 ? -eps : ((double)n * (double)n + (double)n) * std::sqrt(eps);
+          rc = pastix_amd_fill_fake(D->plan, n);
+          if (rc) FAIL(rc);
+          pastix_amd_stats_t st{};
+          rc = pastix_amd_factorize(D->plan, critere, &st);
+          dparm[DPARM_FACT_TIME] = st.fact_time;
+          iparm[IPARM_STATIC_PIVOTING] = st.nbpivot;
+          iparm[IPARM_INERTIA] = st.inertia;
+          if (rc) FAIL(rc);
+          D->factorized = true;
+          break;
+        }
         if (!D->plan || !avals) FAIL(PASTIX_AMD_ERR_BADPARAMETER);
         // critere = ||A||_1 * sqrt(eps)   (sopalin3d.c:586-606, CscNorm1 csc_intern_compute.c:120)
         std::vector<double> colsum((size_t)n, 0.0);

@@ -35,6 +35,7 @@ void launch_merge(hipStream_t s, double* z, const double* re, const double* im, 
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag, int maxw);
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw);
+void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v);
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n);
 void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                       long long* nbpivot, int maxw);
@@ -76,6 +77,8 @@ struct pastix_amd_plan_s {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;      // second stream: non-urgent contributions overlap the panel kernels
+  double fillBaseL = 0.0, fillBaseU = 0.0;   // value every panel entry starts from in pastix_amd_refill (0; 1 / 2 after
+                                             // pastix_amd_fill_fake)
   bool launch_events = true;          // per-launch timing events recorded (api.cpp, mode-1 driver)
   hipStream_t stream3 = nullptr;      // third: bulk launches of odd slots (tails of short launches overlap, api.cpp)
   hipEvent_t evJoin = nullptr;

@@ -1769,6 +1769,14 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
   if (ntask > 0) hipLaunchKernelGGL(k_solve_dscale, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
 }
 
+__global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = v;
+}
+void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_const, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, s, dst, n, v);
+}
+
 void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double* val, int64_t n) {
   if (n <= 0) return;
   int64_t blocks = (n + 255) / 256;

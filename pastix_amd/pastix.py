@@ -11,7 +11,7 @@ IPARM_SIZE, DPARM_SIZE = 128, 64
 IPARM = dict(MODIFY_PARAMETER=0, START_TASK=1, END_TASK=2, VERBOSE=3, DOF_NBR=4, ITERMAX=5,
              MATRIX_VERIFICATION=6, NBITER=10, AMALGAMATION_LEVEL=13, ORDERING=14, STATIC_PIVOTING=20,
              NNZEROS=22, BASEVAL=24, MIN_BLOCKSIZE=25, MAX_BLOCKSIZE=26, SCHUR=27, FACTORIZATION=30, THREAD_NBR=34,
-             LEVEL_OF_FILL=36, RHS_MAKING=38, REFINEMENT=39, SYM=40, GMRES_IM=44, INERTIA=54, FLOAT=61, ERROR_NUMBER=63,
+             LEVEL_OF_FILL=36, RHS_MAKING=38, REFINEMENT=39, SYM=40, GMRES_IM=44, FILL_MATRIX=53, INERTIA=54, FLOAT=61, ERROR_NUMBER=63,
              CUDA_NBR=64)
 DPARM = dict(EPSILON_REFINEMENT=5, RELATIVE_ERROR=6, EPSILON_MAGN_CTRL=10, FACT_TIME=20, FACT_FLOPS=22)
 API_TASK = dict(INIT=0, ORDERING=1, SYMBFACT=2, ANALYSE=3, NUMFACT=4, SOLVE=5, REFINE=6, CLEAN=7)

@@ -81,6 +81,10 @@ class Plan:
                                              _lib.ptr(rows), _lib.ptr(vals), _lib.ptr(perm)),
               "pastix_amd_fill_csc")
 
+    def fill_fake(self, gnodenbr):
+        """IPARM_FILL_MATRIX = API_YES: the reference's structure-only fill (coefinit.c:343-443)."""
+        check(_lib.lib().pastix_amd_fill_fake(self._h, ctypes.c_int64(gnodenbr)), "pastix_amd_fill_fake")
+
     def refill(self):
         check(_lib.lib().pastix_amd_refill(self._h), "pastix_amd_refill")
 

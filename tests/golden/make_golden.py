@@ -45,6 +45,12 @@ CASES = [
     ("rlap3d_20_llt_bs128", "d", "rlap3d", "20", "llt", ["64", "128"]),
     ("rlap3d_20_lu_bs128", "d", "rlap3d", "20", "lu", ["64", "128"]),
     ("zrlap3d_20_ldlt_bs128", "z", "rlap3d", "20", "ldlt", ["64", "128"]),
+    # IPARM_FILL_MATRIX = API_YES, the reference's structure-only "fake factorisation" (coefinit.c:343-443, critere
+    # sopalin3d.c:597-598): the CSC is only a pattern; harness run with REF_FAKE=1.  (Names outside the
+    # kind_size_facto scheme on purpose: the CSC-based tests do not apply to them.)
+    ("fake_rlap3d_8_llt", "d", "rlap3d", "8", "llt", []),
+    ("fake_rlap3d_8_ldlt", "d", "rlap3d", "8", "ldlt", []),
+    ("fake_rlap3d_8_lu", "d", "rlap3d", "8", "lu", []),
 ]
 
 
@@ -91,7 +97,8 @@ def main():
         if kind == "hb":
             hb_to_mtx(arg, "/tmp/%s.mtx" % name)
             kind, arg = "mtx", "/tmp/%s.mtx" % name
-        out = subprocess.run([exe, "dump", kind, arg, facto, "1", raw] + extra, env=env,
+        out = subprocess.run([exe, "dump", kind, arg, facto, "1", raw] + extra,
+                             env=dict(env, REF_FAKE="1") if name.startswith("fake_") else env,
                              capture_output=True, text=True, check=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = fixture_io.read_raw(raw)

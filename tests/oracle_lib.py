@@ -56,6 +56,19 @@ def fill(facto, sym, n, colptr, rows, vals, perm, cblk4, blok4):
     return L, U
 
 
+def fill_fake(facto, gnodenbr, cblk4, cz=False):
+    """coefinit.c:343-443 (IPARM_FILL_MATRIX = API_YES)."""
+    c4 = _i64(cblk4)
+    dt = np.complex128 if cz else np.float64
+    coefnbr = int(((c4[:-1, 1] - c4[:-1, 0] + 1) * c4[:-1, 3]).sum())
+    L = np.zeros(coefnbr, dtype=dt)
+    U = np.zeros(coefnbr, dtype=dt) if facto == 2 else None
+    fn = lib().oracle_zfill_fake if cz else lib().oracle_dfill_fake
+    rc = fn(ctypes.c_int(facto), ctypes.c_int64(gnodenbr), ctypes.c_int64(len(c4) - 1), _p(c4), _p(L), _p(U))
+    assert rc == 0
+    return L, U
+
+
 def sopalin(facto, cblk4, blok4, L, U, critere):
     """Factorize a copy of the panels; returns (L, U, nbpivot)."""
     c4, b4 = _i64(cblk4), _i64(blok4)

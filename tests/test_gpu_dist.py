@@ -124,11 +124,12 @@ def test_native_driver_loopback_is_repeatable(golden):
             p.close()
 
 
-def test_native_driver_on_own_layout_at_scale():
-    """36^3 on the repo's own layout (128-wide cblks), 4 emulated ranks: log det A from the distributed factors against
-    the analytic spectrum of the Dirichlet Laplacian (size-independent check, as bench.py --gpus N uses it)."""
+@pytest.mark.parametrize("N,world", [(36, 4), (40, 8)])
+def test_native_driver_on_own_layout_at_scale(N, world):
+    """36^3 / 40^3 on the repo's own layout (128-wide cblks), 4 / 8 emulated ranks (8 = the metric's largest job): log det A
+    from the distributed factors against the analytic spectrum of the Dirichlet Laplacian (size-independent check, as
+    bench.py --gpus N uses it)."""
     from pastix_amd import symbolic as sy
-    N, world = 36, 4
     n, cp, r, v = sy.laplacian_3d(N)
     perm, _ = sy.order_grid(N, N, N)
     s = sy.symbolic(n, cp, r, perm, max_blocksize=128)

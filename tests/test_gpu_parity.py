@@ -297,3 +297,28 @@ def test_quadrant_tasks_match_reference_golden(name, fill, golden, monkeypatch):
     if g["facto"] == 2:
         assert np.abs(U1 - g["U1"]).max() <= TOL * max(scale, np.abs(g["U1"]).max())
     assert st["nbpivot"] == g["nbpivot"]
+
+
+@pytest.mark.parametrize("name", ["fake_rlap3d_8_llt", "fake_rlap3d_8_ldlt", "fake_rlap3d_8_lu"])
+def test_fake_fill_matches_reference(name, golden):
+    """IPARM_FILL_MATRIX = API_YES (CoefMatrix_Init's structure-only fill, coefinit.c:343-443): the device fill is
+    bit-exact against the input panels, the factors of the reference's own fake run are reproduced, refill re-applies
+    the fill."""
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"]) as p:
+        p.fill_fake(g["n"])
+        L0, U0 = p.download()
+        assert np.array_equal(L0, g["L0"])
+        if g["facto"] == 2:
+            assert np.array_equal(U0, g["U0"])
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+        p.refill()
+        L0b, _ = p.download()
+    assert np.array_equal(L0b, g["L0"])
+    m = _lower_mask(g["cblk4"]) if g["facto"] == 1 else np.ones(g["L1"].shape, dtype=bool)
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    if g["facto"] == 2:
+        assert np.abs(U1 - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()
+    assert st["nbpivot"] == g["nbpivot"] == 0

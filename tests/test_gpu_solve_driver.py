@@ -568,3 +568,27 @@ def test_device_refinement_all_modes_all_arithmetics(name, mode, golden):
         assert rc == 0
     res = np.linalg.norm(A @ x - b) / np.linalg.norm(b)
     assert first > 1e-8 and res < 1e-11 and err.value < 1e-11 and 0 < it.value <= 250
+
+
+@pytest.mark.parametrize("facto", ["LLT", "LU"])
+def test_pastix_fill_matrix_mode(facto):
+    """iparm[IPARM_FILL_MATRIX] = API_YES through pastix(): a structure-only run of the reference (pastix.c:3282,
+    coefinit.c:343-443, critere sopalin3d.c:597-598) -- the values of the CSC must not be read (they are NaN here), the
+    run succeeds without static pivots and reports its time.  (Factor values of this mode: test_fake_fill_matches_reference.)"""
+    N = 8
+    n, cp, r, v = sy.laplacian_3d(N, full=(facto == "LU"))
+    perm0, invp0 = sy.order_grid(N, N, N)
+    perm, invp = perm0 + 1, invp0 + 1
+    b = np.ones(n)
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if facto == "LU" else px.API_SYM_YES
+    iparm[px.IPARM["ORDERING"]] = px.API_ORDER_PERSONAL
+    iparm[px.IPARM["FILL_MATRIX"]] = px.API_YES
+    iparm[px.IPARM["START_TASK"]] = px.API_TASK["ORDERING"]
+    iparm[px.IPARM["END_TASK"]] = px.API_TASK["NUMFACT"]
+    pd = px.pastix(None, n, cp, r, np.full_like(v, np.nan), perm, invp, b, 1, iparm, dparm)   # values must not be read
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0
+    assert iparm[px.IPARM["STATIC_PIVOTING"]] == 0 and dparm[px.DPARM["FACT_TIME"]] > 0
+    iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
+    px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
