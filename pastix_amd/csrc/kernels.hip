@@ -717,17 +717,21 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
     // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
     // the compiler honour the 128-register bound)
     const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
-    for (int c0 = 0; c0 < 128; c0 += 64) {
+    const int w16 = (w + 15) & ~15;                       // (nothing reads LDS rows or columns beyond the last 16-band of w:
+                                                          // narrow cblks -- the leaf levels have thousands -- skip the rest)
+    for (int c0 = 0; c0 < w16; c0 += 64) {
       double v[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        if (c0 + 4 * q >= w16) break;
         const int c = min(c0 + ch + 4 * q, w - 1);
         v[q] = A[min(r, w - 1) + (int64_t)c * ld];
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) {
+        if (c0 + 4 * q >= w16) break;
         const int c = c0 + ch + 4 * q;
-        if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
+        if (c <= r && r < w16) DP(c, r) = (r < w) ? v[q] : 0.0;
       }
     }
   }
@@ -896,17 +900,21 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
     // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
     // the compiler honour the 128-register bound)
     const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
-    for (int c0 = 0; c0 < 128; c0 += 64) {
+    const int w16 = (w + 15) & ~15;                       // (nothing reads LDS rows or columns beyond the last 16-band of w:
+                                                          // narrow cblks -- the leaf levels have thousands -- skip the rest)
+    for (int c0 = 0; c0 < w16; c0 += 64) {
       double v[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        if (c0 + 4 * q >= w16) break;
         const int c = min(c0 + ch + 4 * q, w - 1);
         v[q] = A[min(r, w - 1) + (int64_t)c * ld];
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) {
+        if (c0 + 4 * q >= w16) break;
         const int c = c0 + ch + 4 * q;
-        if (c <= r) DP(c, r) = (r < w) ? v[q] : 0.0;
+        if (c <= r && r < w16) DP(c, r) = (r < w) ? v[q] : 0.0;
       }
     }
   }
