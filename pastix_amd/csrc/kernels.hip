@@ -704,7 +704,8 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
   // size fits beside one k_update workgroup.  Entries outside the w x w part are zero.
   __shared__ double D[128 * 129 / 2];
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
-  __shared__ double Ri[16];            // reciprocals of the tile's diagonal
+  __shared__ double Ri[2][16];         // reciprocals of the tile's diagonal (two tiles: wave 1 inverts the previous tile
+                                       // while wave 0 factorizes the next one)
   const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
@@ -745,12 +746,42 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
   STAMP(0)
   int npiv = 0;
   bool bad = false;
+  // (B') inverse of the factored tile at column kt for k_trsm: lane c = l15 computes column c of inv(tile) by forward
+  // substitution; L(i, p) is register t[p] of lane i.  Run by WAVE 1 from the tile in LDS while wave 0 factorizes the
+  // next tile (the inverse feeds only the panel solve of a later kernel: off the critical path of this one, where it
+  // used to cost as much as the factorization of the tile itself, ~11 k cycles of a dependent fp64 chain).
+  auto tile_inverse = [&](const int kt) {
+    const int nbt = min(16, w - kt);
+    double t[16], rt[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) t[c] = (c <= l15) ? DP(kt + c, kt + l15) : 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) rt[c] = Ri[(kt >> 4) & 1][c];
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double sacc = (i == l15) ? 1.0 : 0.0;
+#pragma unroll
+      for (int p2 = 0; p2 < 16; p2++)
+        if (p2 < i) {
+          const double lip = (i < nbt) ? readlane_f64(t[p2], i) : 0.0;
+          sacc = __builtin_fma(-lip, x[p2], sacc);
+        }
+      x[i] = (i < nbt && l15 < nbt) ? ((i >= l15) ? sacc * rt[i] : 0.0) : ((i == l15) ? 1.0 : 0.0);
+    }
+    if (lane < 16) {
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
+#pragma unroll
+      for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+    }
+  };
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
-    double a[16];                                        // wave 0: row l15 of the tile
-    double ri[16];                                       // (uniform) reciprocals of the diagonal
+    if (wave == 1 && kb > 0) tile_inverse(kb - 16);
     if (wave == 0) {
+      double a[16];                                      // row l15 of the tile
+      double ri[16];                                     // (uniform) reciprocals of the diagonal
 #pragma unroll
       for (int c = 0; c < 16; c++) a[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
 #pragma unroll
@@ -779,49 +810,43 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
         double rmine = 1.0;
 #pragma unroll
         for (int c = 0; c < 16; c++) if (c == l15) rmine = ri[c];
-        Ri[l15] = rmine;
+        Ri[(kb >> 4) & 1][l15] = rmine;
       }
     }
     STAMP(1)
     __syncthreads();
-    if (wave == 0) {
-      // (B') column c = l15 of inv(tile) by forward substitution; L(i,p) comes from lane i's registers
-      double x[16];
+    if (wave >= 1 && (wave - 1) * 64 < rem) {
+      // (B) rows below the tile: x = A21 L11^-T, one thread per row (TRSM "R","L","T","N", compute_diag.c:191-195).
+      // The tile's entries are wave-uniform operands: every wave with rows keeps row l15 of the tile in registers and
+      // broadcasts L(c, p) with v_readlane (a dependent LDS read per multiply-add cost ~10 k cycles per tile).
+      double tl[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double sacc = (i == l15) ? 1.0 : 0.0;
+      for (int c = 0; c < 16; c++) tl[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
+      double rmine = Ri[(kb >> 4) & 1][l15];
+      // (pin the loads here, with every lane of the wave active: v_readlane reads lanes that are inactive inside the
+      // divergent part below, and the compiler would otherwise sink the loads into it -- they are only "used" there)
 #pragma unroll
-        for (int p2 = 0; p2 < 16; p2++)
-          if (p2 < i) {
-            const double lip = (i < nb) ? readlane_f64(a[p2], i) : 0.0;
-            sacc = __builtin_fma(-lip, x[p2], sacc);
+      for (int c = 0; c < 16; c++) asm volatile("" : "+v"(tl[c]));
+      asm volatile("" : "+v"(rmine));
+      if (tid - 64 < rem) {
+        const int rr = kb + nb + tid - 64;
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          if (c < nb) {
+            double sacc = x[c];
+#pragma unroll
+            for (int p2 = 0; p2 < 16; p2++)
+              if (p2 < c) sacc = __builtin_fma(-x[p2], readlane_f64(tl[p2], c), sacc);
+            x[c] = sacc * readlane_f64(rmine, c);
           }
-        x[i] = (i < nb && l15 < nb) ? ((i >= l15) ? sacc * ri[i] : 0.0) : ((i == l15) ? 1.0 : 0.0);
-      }
-      if (lane < 16) {
-        double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
-      }
-    } else if (tid - 64 < rem) {
-      // (B) rows below the tile: x = A21 L11^-T, one thread per row (TRSM "R","L","T","N", compute_diag.c:191-195)
-      const int rr = kb + nb + tid - 64;
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          double sacc = x[c];
-#pragma unroll
-          for (int p2 = 0; p2 < 16; p2++)
-            if (p2 < c) sacc = __builtin_fma(-x[p2], DP(kb + p2, kb + c), sacc);
-          x[c] = sacc * Ri[c];
         }
-      }
 #pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < nb) DP(kb + c, rr) = x[c];
+        for (int c = 0; c < 16; c++)
+          if (c < nb) DP(kb + c, rr) = x[c];
+      }
     }
     STAMP(2)
     __syncthreads();
@@ -859,6 +884,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
   }
   STAMP(4)
   __syncthreads();
+  if (wave == 1) tile_inverse(((w - 1) >> 4) << 4);      // the last tile's
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
