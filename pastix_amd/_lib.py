@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpastix_amd.so")
+# (PASTIX_AMD_LIB: another build of the same library, for A/B timing of compile-time switches)
+LIB_PATH = os.environ.get("PASTIX_AMD_LIB") or os.path.join(_HERE, "lib", "libpastix_amd.so")
 
 i64 = ctypes.c_int64
 

@@ -1,6 +1,14 @@
 // devmath.h -- device-only scalar helpers (include after <hip/hip_runtime.h>)
 #pragma once
 
+// The kernels of the panel stream (urgent updates, diagonal bloks, panel solves) share their CUs with a bulk k_update
+// workgroup; their waves are dependent chains, the bulk waves are MFMA-bound: the instruction arbiter is told so.
+#ifndef PASTIX_AMD_NO_PRIO
+#define PANEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define PANEL_PRIO() ((void)0)
+#endif
+
 namespace pastix_amd {
 
 // Latency-critical scalar math of the diagonal-blok kernels: hardware estimate (v_rcp_f64 / v_rsq_f64)

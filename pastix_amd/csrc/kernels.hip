@@ -34,6 +34,7 @@ namespace pastix_amd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+
 // ------------------------------------------------------------------------------------------------
 // k_update
 // ------------------------------------------------------------------------------------------------
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 #ifdef PASTIX_AMD_DESYNC_BIT
   if ((blockIdx.x >> PASTIX_AMD_DESYNC_BIT) & 1) { __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); }
 #endif
+  if (KIND == 1) PANEL_PRIO();
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*16*MI.., cols wc*64..
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
 __global__ __launch_bounds__(256) void k_diag_llt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
                                                   double* __restrict__ dinv_ws, double critere,
                                                   long long* __restrict__ nbpivot, int* __restrict__ errflag) {
+  PANEL_PRIO();
   __shared__ double Ts[16][17];
   __shared__ double Lo[16][17];
   __shared__ double Ti[16][17];
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
   __shared__ double Ri[2][16];         // reciprocals of the tile's diagonal (two tiles: wave 1 inverts the previous tile
                                        // while wave 0 factorizes the next one)
+  PANEL_PRIO();
   const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
@@ -914,6 +918,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
   __shared__ double Ri[16];            // reciprocals of the tile's diagonal (1 / d)
   __shared__ double Dd[16];            // the tile's diagonal d
+  PANEL_PRIO();
   const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
@@ -1084,6 +1089,7 @@ void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_
 template <int NT>
 __global__ __launch_bounds__(256) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
+  PANEL_PRIO();
   const TrsmTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;

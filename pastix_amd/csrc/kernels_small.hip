@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "plan.h"
+#include "devmath.h"
 
 namespace pastix_amd {
 
@@ -34,6 +35,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, 8) void k_update_small(const Arenas ar, const Task* __restrict__ tasks,
                                                       const Piece* __restrict__ pieces) {
   __shared__ double sh[2][QK * QLD];             // [A | B] image of one chunk: 20 KB
+  if (KIND == 1) PANEL_PRIO();
   const Task tk = tasks[blockIdx.x];
   if (tk.pn <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -42,6 +42,7 @@ __device__ __forceinline__ void tile_inverse(F lower, bool unit, int nb, int c, 
 __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
                                                    double* __restrict__ dinv_ws, double critere,
                                                    long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   __shared__ double Ts[16][17];
   __shared__ double Lo[16][17];
   __shared__ double Ti[16][17];
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const
 __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double* __restrict__ U,
                                                  const PanelTask* __restrict__ tasks, double* __restrict__ dinv_ws,
                                                  double critere, long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   __shared__ double Ts[16][17];
   __shared__ double Lo[16][17];    // tile after getrf: unit L strictly below, U on and above the diagonal
   __shared__ double Ti[16][17];
@@ -282,6 +284,7 @@ template <int NT, int MODE>
 __global__ __launch_bounds__(256) void k_trsm_var(double* __restrict__ L, double* __restrict__ U,
                                                   const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
+  PANEL_PRIO();
   const TrsmTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;

@@ -45,6 +45,7 @@ template <bool HERM, int XR>
 __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                   double* __restrict__ dinv_ws, double critere,
                                                   long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   __shared__ cz Ts[16][17];
   __shared__ cz Lo[16][17];
   __shared__ cz Ti[16][17];
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTa
 template <int NT, bool HERM>
 __global__ __launch_bounds__(256) void k_trsm_zsy(const Arenas ar, const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
+  PANEL_PRIO();
   const TrsmTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -293,6 +295,7 @@ template <int XR>
 __global__ __launch_bounds__(256) void k_diag_zlu(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                   double* __restrict__ dinv_ws, double critere,
                                                   long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   __shared__ cz Ts[16][17];
   __shared__ cz Lo[16][17];
   __shared__ cz Ti[16][17];
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(256) void k_diag_zlu(const Arenas ar, const PanelTa
 template <int NT, int MODE>
 __global__ __launch_bounds__(256) void k_trsm_zlu(const Arenas ar, const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
+  PANEL_PRIO();
   const TrsmTask tk = tasks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -907,6 +911,7 @@ template <bool HERM>
 __global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                     double* __restrict__ dinv_ws, double critere,
                                                     long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   constexpr int XR = 116, NBLK = 9;               // 64*65/2 = 2080 blocks of 2x2 <= 9 * 256
   __shared__ cz Ts[16][17];
   __shared__ cz Lo[16][17];
@@ -1103,6 +1108,7 @@ template <bool HERM>
 __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                     double* __restrict__ dinv_ws, double critere,
                                                     long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
   constexpr int XR = 116, NBLK = 5, NT = 448;      // 64*65/2 = 2080 blocks of 2x2 <= 5 * 448
   __shared__ cz Ts[16][17];
   __shared__ cz Lo[16][17];
