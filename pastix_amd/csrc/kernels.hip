@@ -1087,7 +1087,7 @@ void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_
 // operand supplies the matching column g+4q of L[ct,p], so no lane shuffles or LDS are needed.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
+__global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
   PANEL_PRIO();
   const TrsmTask tk = tasks[blockIdx.x];

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
 //   MODE 3 (LU, U): T = unit-lower L_d (from the L arena), in/out = U arena
 // ------------------------------------------------------------------------------------------------
 template <int NT, int MODE>
-__global__ __launch_bounds__(256) void k_trsm_var(double* __restrict__ L, double* __restrict__ U,
+__global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_var(double* __restrict__ L, double* __restrict__ U,
                                                   const TrsmTask* __restrict__ tasks,
                                                   const double* __restrict__ dinv_ws) {
   PANEL_PRIO();
