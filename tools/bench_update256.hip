@@ -14,14 +14,18 @@ struct Piece { int64_t a_off, b_off; int32_t lda; int32_t k; };
 struct Task { int64_t c_off; int32_t ldc, p0, pn; };
 constexpr int KC = 16, SLA = 272, SLB = 144;   // LDS line lengths (doubles): 256 + 16, 128 + 16
 
-__global__ __launch_bounds__(512, 2) void k_upd256(const double* __restrict__ src, double* __restrict__ dst,
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void k_upd256(const double* __restrict__ src, double* __restrict__ dst,
                                                     const Task* __restrict__ tasks, const Piece* __restrict__ pieces) {
   __shared__ double sA[2][KC * SLA];
   __shared__ double sB[2][KC * SLB];
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, l15 = lane & 15, g = lane >> 4;
-  constexpr int MI = 4, NI = 4, RS = 64, CS = 32;     // row bands wr + 4 s (16 bands), col bands wc + 2 s (8 bands)
+  // NWV = 8: row bands wr + 4 s (16 bands, MI = 4); NWV = 16: wr + 8 s (MI = 2, 64 accumulator VGPRs, four waves per SIMD
+  // at one workgroup per CU); col bands wc + 2 s (8 bands)
+  constexpr int MI = 32 / NWV, NI = 4, RS = 8 * NWV, CS = 32;
+  constexpr int LW = 16 / NWV;                         // k-lines per wave and operand
   const int row0 = wr * 16, col0 = wc * 16;
   d4 acc[MI][NI];
 #pragma unroll
@@ -35,15 +39,15 @@ __global__ __launch_bounds__(512, 2) void k_upd256(const double* __restrict__ sr
   int64_t lda = cur.lda;
   // A: 16 k-lines x 2 KiB = 32 wave-instructions; B: 16 x 1 KiB = 16: wave w copies A lines 2w, 2w+1 (both halves)
   // and B lines 2w, 2w+1
-  const double* pa = src + cur.a_off + (int64_t)(2 * wave) * lda + 2 * lane;
-  const double* pb = src + cur.b_off + (int64_t)(2 * wave) * lda + 2 * lane;
+  const double* pa = src + cur.a_off + (int64_t)(LW * wave) * lda + 2 * lane;
+  const double* pb = src + cur.b_off + (int64_t)(LW * wave) * lda + 2 * lane;
   int left = cur.k / KC;
   auto dma = [&](int b) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      GLDS(pa + (int64_t)q * lda, sA[b] + (2 * wave + q) * SLA);
-      GLDS(pa + (int64_t)q * lda + 128, sA[b] + (2 * wave + q) * SLA + 128);
-      GLDS(pb + (int64_t)q * lda, sB[b] + (2 * wave + q) * SLB);
+    for (int q = 0; q < LW; q++) {
+      GLDS(pa + (int64_t)q * lda, sA[b] + (LW * wave + q) * SLA);
+      GLDS(pa + (int64_t)q * lda + 128, sA[b] + (LW * wave + q) * SLA + 128);
+      GLDS(pb + (int64_t)q * lda, sB[b] + (LW * wave + q) * SLB);
     }
   };
   dma(0);
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(512, 2) void k_upd256(const double* __restrict__ sr
       if (++pi < pend) {
         cur = nextp;
         lda = cur.lda;
-        pa = src + cur.a_off + (int64_t)(2 * wave) * lda + 2 * lane;
-        pb = src + cur.b_off + (int64_t)(2 * wave) * lda + 2 * lane;
+        pa = src + cur.a_off + (int64_t)(LW * wave) * lda + 2 * lane;
+        pb = src + cur.b_off + (int64_t)(LW * wave) * lda + 2 * lane;
         left = cur.k / KC;
         nextp = pieces[min(pi + 1, pend - 1)];
       } else has_next = false;
@@ -146,7 +150,12 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dt, tasks.data(), tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
   CK(hipMemcpy(dp, pieces.data(), pieces.size() * sizeof(Piece), hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_upd256, dim3(ntask), dim3(512), 0, 0, ds, dc, dt, dp); CK(hipDeviceSynchronize());
+  const int nwv = getenv("NWV") ? atoi(getenv("NWV")) : 8;
+  auto launch = [&]() {
+    if (nwv == 16) hipLaunchKernelGGL(k_upd256<16>, dim3(ntask), dim3(1024), 0, 0, ds, dc, dt, dp);
+    else hipLaunchKernelGGL(k_upd256<8>, dim3(ntask), dim3(512), 0, 0, ds, dc, dt, dp);
+  };
+  launch(); CK(hipDeviceSynchronize()); CK(hipGetLastError());
   // spot check of one element against a host dot product (one launch: C = -sum_p A_p B_p^T)
   {
     std::vector<double> ha((size_t)P * K), hb((size_t)P * K); double c;
@@ -161,10 +170,10 @@ int main(int argc, char** argv) {
     printf("check C[%d,%d] of task %d: %.12e vs %.12e\n", r, col, t, c, ref);
   }
   int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5; CK(hipEventRecord(e0));
-  for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_upd256, dim3(ntask), dim3(512), 0, 0, ds, dc, dt, dp);
+  for (int r = 0; r < reps; r++) launch();
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double fl = 2.0 * 256 * 128 * K * (double)P * ntask * reps;
-  printf("256x128 tiles: tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,
+  printf("256x128 tiles, %d waves: tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", nwv, ntask, P, K, pool, ms / reps,
          fl / (ms * 1e-3) * 1e-12, fl / (ms * 1e-3) / 78.6e12 * 100);
   return 0;
 }

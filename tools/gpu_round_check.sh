@@ -1,3 +1,3 @@
-export TMPDIR=/tmp
-PASTIX_AMD_QUAD_MIN=1 PASTIX_AMD_QUAD_FILL=2.0 timeout 1200 python -m pytest tests/test_gpu_dist.py tests/test_gpu_solve_driver.py tests/test_gpu_edges.py tests/test_gpu_ref_caller.py -q 2>&1 | tail -3 | cut -c1-200
-PASTIX_AMD_QUAD_MIN=1 timeout 600 python tools/dev_bench_dist_local.py 60 4 2>&1 | tail -1
+cd tools
+echo "cache-fed (pool 64):"; ./bench_update 8192 16 128 64 | tail -1; NWV=8 ./bench_update256 4096 16 128 64 | tail -2; NWV=16 ./bench_update256 4096 16 128 64 | tail -2
+echo "HBM-fed (pool 4096):"; ./bench_update 8192 16 128 4096 | tail -1; NWV=8 ./bench_update256 4096 16 128 4096 | tail -1; NWV=16 ./bench_update256 4096 16 128 4096 | tail -1
