@@ -950,9 +950,35 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
     }
   }
   int npiv = 0, npos = 0;
+  // (B') inverse of the factored (unit lower) tile at column kt for k_trsm, by WAVE 1 from the tile in LDS while wave 0
+  // factorizes the next tile -- as in k_diag_llt_w
+  auto tile_inverse = [&](const int kt) {
+    const int nbt = min(16, w - kt);
+    double t[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) t[c] = (c < l15) ? DP(kt + c, kt + l15) : 0.0;
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      double sacc = (i == l15) ? 1.0 : 0.0;
+#pragma unroll
+      for (int p2 = 0; p2 < 16; p2++)
+        if (p2 < i) {
+          const double lip = (i < nbt) ? readlane_f64(t[p2], i) : 0.0;
+          sacc = __builtin_fma(-lip, x[p2], sacc);
+        }
+      x[i] = (i < nbt && l15 < nbt) ? ((i >= l15) ? sacc : 0.0) : ((i == l15) ? 1.0 : 0.0);      // unit diagonal
+    }
+    if (lane < 16) {
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
+#pragma unroll
+      for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+    }
+  };
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
+    if (wave == 1 && kb > 0) tile_inverse(kb - 16);
     double a[16];                                        // wave 0: row l15 of the tile
     double ri[16], dd[16];                               // (uniform) reciprocals of the diagonal, the diagonal
     if (wave == 0) {
@@ -991,44 +1017,35 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
       }
     }
     __syncthreads();
-    if (wave == 0) {
-      // (B') column c = l15 of inv(tile) by forward substitution; L(i,p) comes from lane i's registers
-      double x[16];
+    if (wave >= 1 && (wave - 1) * 64 < rem) {
+      // (B) rows below the tile: TRSM "R","L","T","U" gives L D (compute_diag.c:284-288), scaled by 1/d it is L (:289-298).
+      // Tile entries by v_readlane from registers (loads pinned in front of the divergent part), as in k_diag_llt_w.
+      double tl[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        double sacc = (i == l15) ? 1.0 : 0.0;
+      for (int c = 0; c < 16; c++) tl[c] = (c < l15) ? DP(kb + c, kb + l15) : 0.0;
+      double rmine = Ri[l15];
 #pragma unroll
-        for (int p2 = 0; p2 < 16; p2++)
-          if (p2 < i) {
-            const double lip = (i < nb) ? readlane_f64(a[p2], i) : 0.0;
-            sacc = __builtin_fma(-lip, x[p2], sacc);
+      for (int c = 0; c < 16; c++) asm volatile("" : "+v"(tl[c]));
+      asm volatile("" : "+v"(rmine));
+      if (tid - 64 < rem) {
+        const int rr = kb + nb + tid - 64;
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          if (c < nb) {
+            double sacc = x[c];
+#pragma unroll
+            for (int p2 = 0; p2 < 16; p2++)
+              if (p2 < c) sacc = __builtin_fma(-x[p2], readlane_f64(tl[p2], c), sacc);
+            x[c] = sacc;                                   // (L D)(rr, c)
           }
-        x[i] = (i < nb && l15 < nb) ? ((i >= l15) ? sacc : 0.0) : ((i == l15) ? 1.0 : 0.0);      // unit diagonal
-      }
-      if (lane < 16) {
-        double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
-      }
-    } else if (tid - 64 < rem) {
-      // (B) rows below the tile: TRSM "R","L","T","U" gives L D (compute_diag.c:284-288), scaled by 1/d it is L (:289-298)
-      const int rr = kb + nb + tid - 64;
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          double sacc = x[c];
-#pragma unroll
-          for (int p2 = 0; p2 < 16; p2++)
-            if (p2 < c) sacc = __builtin_fma(-x[p2], DP(kb + p2, kb + c), sacc);
-          x[c] = sacc;                                   // (L D)(rr, c)
         }
-      }
 #pragma unroll
-      for (int c = 0; c < 16; c++)
-        if (c < nb) DP(kb + c, rr) = x[c] * Ri[c];        // L(rr, c)
+        for (int c = 0; c < 16; c++)
+          if (c < nb) DP(kb + c, rr) = x[c] * readlane_f64(rmine, c);        // L(rr, c)
+      }
     }
     __syncthreads();
     if (rem > 0) {
@@ -1063,6 +1080,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
     }
   }
   __syncthreads();
+  if (wave == 1) tile_inverse(((w - 1) >> 4) << 4);      // the last tile's
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
