@@ -62,14 +62,23 @@ def cpu_baseline(sample_grid, threads):
 
 
 def engine_source_sha():
-    """Identity of the code the HBM-traffic counters were collected on: sha256 over the engine sources that shape
-    k_update and its schedule.  profiles/*/traffic_k_update.json records it (tools/profile_round.sh); a traffic
-    figure measured on other sources is stale and is reported as null."""
+    """Identity of the code the HBM-traffic counters were collected on: sha256 over EVERY engine source
+    (pastix_amd/csrc/*.hip, *.cpp, *.h, the Makefile) and the values of the PASTIX_AMD_* environment knobs that shape the
+    schedule.  profiles/*/traffic_k_update.json records it (tools/profile_round.sh); a traffic figure measured on other
+    sources or under other knobs is stale and is reported as null."""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "plan.cpp", "plan.h", "api.cpp"):
-        with open(os.path.join(ROOT, "pastix_amd", "csrc", f), "rb") as fh:
+    d = os.path.join(ROOT, "pastix_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp")) + glob.glob(os.path.join(d, "*.h"))
+                    + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
             h.update(fh.read())
+    for k in sorted(os.environ):
+        if k.startswith("PASTIX_AMD_") and k not in ("PASTIX_AMD_BENCH_GRID", "PASTIX_AMD_LIB", "PASTIX_AMD_DIST_TIMEOUT",
+                                                    "PASTIX_AMD_BENCH_PREFLIGHT", "PASTIX_AMD_VERBOSE"):
+            h.update(("%s=%s" % (k, os.environ[k])).encode())
     return h.hexdigest()[:16]
 
 
@@ -108,6 +117,126 @@ def self_launch(a, argv):
     raise SystemExit(subprocess.call(cmd))
 
 
+def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, local):
+    """One configuration on one GPU: analysis, plan, device fill, `warmup` untimed and `steps` timed steps (a step =
+    device re-fill + factorization, inputs resident in HBM), then the end-to-end check ||Ax - b|| / ||b|| with the device
+    solve on the last factors.  Returns the raw figures the JSON line is made of."""
+    import numpy as np
+    import torch
+    from pastix_amd import Plan, fact_flops
+    from pastix_amd import symbolic as sy
+    N = grid
+    t0 = time.time()
+    zel = workload == "elasticity"
+    if zel:
+        from pastix_amd import COMPLEXDOUBLE
+        if facto_name == "llt":
+            facto_name = "ldlt"                    # (complex symmetric: LDLt, the `sy` variant)
+        facto = {"ldlt": 1, "lu": 2}[facto_name]
+        if facto == 2:
+            raise SystemExit("bench.py: --workload elasticity is the complex-symmetric LDLt configuration")
+        n, cp, r, v, _ = sy.elasticity_3d(N)
+        perm, _ = sy.order_grid_dof(N, 3)
+        ftype = COMPLEXDOUBLE
+    else:
+        facto = {"llt": 0, "ldlt": 1, "lu": 2}[facto_name]
+        n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
+        perm, _ = sy.order_grid(N, N, N)
+        ftype = 1
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=blocksize)
+    c4, b4 = s["cblk4"], s["blok4"]
+    flops = fact_flops(c4, b4, facto, ftype)
+    t_sym = time.time() - t0
+    t0 = time.time()
+    plan = Plan(c4, b4, facto, floattype=ftype, device=local, lookahead=chunk)
+    t_plan = time.time() - t0
+    crit = (1e-12 if zel else 6.0 * 2 * np.sqrt(1e-31))
+    t0 = time.time()
+    plan.fill_csc(0 if facto == 2 else 1, n, cp, r, v, s["perm"])
+    t_fill = time.time() - t0
+    for _ in range(warmup):
+        plan.refill()
+        plan.factorize(crit)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ft = ut = uts = urt = 0.0
+    st = None
+    for _ in range(steps):
+        plan.refill()
+        st = plan.factorize(crit)
+        ft += st["fact_time"]
+        ut += st["update_time"]
+        uts += st["update_time_sum"]
+        urt += st["urgent_time_sum"]
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
+    rng = np.random.default_rng(1)
+    b = rng.random(n) + (1j * rng.random(n) if zel else 0)
+    bp = np.empty(n, dtype=b.dtype)
+    bp[s["perm"]] = b
+    t1 = time.time()
+    x = plan.solve(bp)[s["perm"]]
+    solve_s = time.time() - t1          # host vector in -> host vector out (first call also builds the solve tables)
+    t1 = time.time()
+    plan.solve(bp.copy())
+    solve_s = min(solve_s, time.time() - t1)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    Ax = A @ x if facto == 2 else A @ x + sp.tril(A, -1).T @ x
+    resid = float(np.linalg.norm(Ax - b) / np.linalg.norm(b))
+    ps = plan.stats()
+    res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_time_sum=uts, urgent_time_sum=urt, urgent_flops=st["urgent_flops"],
+               nurgent=st["nurgent_launches"], update_flops=ps["update_flops"],
+               update_bytes=ps["update_bytes"],
+               nlaunch=st["nupdate_launches"], solve_s=solve_s, solve_dev_s=ps["solve_time"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
+               blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
+               ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu", facto=facto_name)
+    plan.close()
+    del plan, A, Ax, x, b, bp, s, c4, b4
+    import gc
+    gc.collect()
+    return res
+
+
+# BASELINE.json configs[1], [2], [4] beside the headline (configs[3] at N = 1): run AFTER the headline's timed region and
+# reported in "other_configs"; the headline's numbers are untouched.  configs[2] is 200^3 dLU, which needs 2 x 150 GB
+# of panels: 192^3 (2 x 127 GB) is the largest grid that fits one 288 GB device, and is named as such.
+OTHER_CONFIGS = [
+    dict(config="configs[1]", workload="laplacian", grid=100, facto="llt", steps=3, warmup=1),
+    dict(config="configs[2] at the largest grid one GPU holds (200^3 dLU: 2 x 150 GB of panels + tables > 288 GB)",
+         workload="laplacian", grid=192, facto="lu", steps=1, warmup=0),
+    dict(config="configs[4]", workload="elasticity", grid=48, facto="ldlt", steps=3, warmup=1),
+]
+
+
+def other_configs(blocksize, local):
+    out = []
+    for c in OTHER_CONFIGS:
+        t0 = time.time()
+        try:
+            r = single_gpu_job(c["grid"], c["workload"], c["facto"], c["steps"], c["warmup"], blocksize, 0, local)
+        except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+            out.append({"config": c["config"], "error": repr(e)[:300]})
+            continue
+        K = c["steps"]
+        zel = c["workload"] == "elasticity"
+        bulk_flops = r["update_flops"] - r["urgent_flops"]
+        out.append({
+            "config": c["config"],
+            "workload": ("3-dof elasticity pattern on %d^3 nodes (n=%d), complex double symmetric LDLt" if zel else
+                         "3-D 7-point Laplacian %%d^3 (n=%%d), double %s" % {"llt": "LLt", "ldlt": "LDLt", "lu": "LU static pivoting"}[c["facto"]])
+                        % (c["grid"], r["n"]),
+            "dtype": "c128 (f64 MFMA on split re/im planes)" if zel else "f64",
+            "value": round(r["flops"] * K / r["wall"] * 1e-9, 1), "unit": "GFLOP/s" + (" (complex flops)" if zel else ""),
+            "steps": K, "warmup": c["warmup"], "ms_per_step": round(r["wall"] / K * 1e3, 2),
+            "pct_of_mfma_f64_peak": round(r["flops"] * K / r["wall"] / MFMA_F64_PEAK * 100, 2),
+            "roofline_frac": round(bulk_flops * K / max(r["update_time_sum"], 1e-12) / MFMA_F64_PEAK, 4),
+            "residual": r["resid"], "static_pivots": r["nbpivot"], "fact_flops": r["flops"],
+            "solve_device_s": round(r["solve_dev_s"], 4), "total_s_incl_analysis": round(time.time() - t0, 1)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +251,9 @@ def main():
                          "complex double LDLt on the 3-dof elasticity pattern of a grid^3 node mesh (n = 3 grid^3)")
     ap.add_argument("--cpu-sample-grid", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip BASELINE.json configs[1], [2], [4] after the headline (they run by default with the "
+                         "default workload on one GPU)")
     a = ap.parse_args()
 
     if a.gpus < 1:
@@ -138,6 +270,9 @@ def main():
         # every rank drives 2 compute streams + one channel stream per peer: give each its own hardware queue (the HIP
         # runtime multiplexes streams over 4 by default; a channel waiting for its peer must not stall a compute stream)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # a rank whose streams have not drained by then reports the first unmatched fan-in block of every channel,
+        # aborts its communicators and leaves with a non-zero code (csrc/dist.cpp: dist_finish)
+        os.environ.setdefault("PASTIX_AMD_DIST_TIMEOUT", "120")
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -153,93 +288,28 @@ def main():
         raise SystemExit("bench.py: %d ranks but %d GPU(s) on this box: one rank per GPU" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # (the bootstrap collectives -- layout broadcast, schedule hashes, unique ids, barriers -- get a deadline too)
+        tmo = datetime.timedelta(seconds=600)
         if dist_test:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
             # RCCL's copy kernels go on a high-priority stream: they must get a CU slot between the bulk update
             # workgroups of the second stream, like the panel kernels do
             try:
                 pgo = dist.ProcessGroupNCCL.Options()
                 pgo.is_high_priority_stream = True
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=pgo)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=pgo, timeout=tmo)
             except (AttributeError, TypeError):
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
 
-    from pastix_amd import Plan, fact_flops
-    from pastix_amd import symbolic as sy
     if world > 1:
         from pastix_amd import dist as pdist
         res = pdist.bench_distributed(a, rank, world, local)
     else:
-        N = a.grid
-        t0 = time.time()
-        zel = a.workload == "elasticity"
-        if zel:
-            from pastix_amd import COMPLEXDOUBLE
-            if a.facto == "llt":
-                a.facto = "ldlt"                       # (complex symmetric: LDLt, the `sy` variant)
-            facto = {"ldlt": 1, "lu": 2}[a.facto]
-            if facto == 2:
-                raise SystemExit("bench.py: --workload elasticity is the complex-symmetric LDLt configuration")
-            n, cp, r, v, _ = sy.elasticity_3d(N)
-            perm, _ = sy.order_grid_dof(N, 3)
-            ftype = COMPLEXDOUBLE
-        else:
-            facto = {"llt": 0, "ldlt": 1, "lu": 2}[a.facto]
-            n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
-            perm, _ = sy.order_grid(N, N, N)
-            ftype = 1
-        s = sy.symbolic(n, cp, r, perm, max_blocksize=a.blocksize)
-        c4, b4 = s["cblk4"], s["blok4"]
-        flops = fact_flops(c4, b4, facto, ftype)
-        t_sym = time.time() - t0
-        t0 = time.time()
-        plan = Plan(c4, b4, facto, floattype=ftype, device=local, lookahead=a.chunk)
-        t_plan = time.time() - t0
-        crit = (1e-12 if zel else 6.0 * 2 * np.sqrt(1e-31))
-        t0 = time.time()
-        plan.fill_csc(0 if facto == 2 else 1, n, cp, r, v, s["perm"])
-        t_fill = time.time() - t0
-        for _ in range(a.warmup):
-            plan.refill()
-            plan.factorize(crit)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        ft = ut = uts = urt = 0.0
-        st = None
-        for _ in range(a.steps):
-            plan.refill()
-            st = plan.factorize(crit)
-            ft += st["fact_time"]
-            ut += st["update_time"]
-            uts += st["update_time_sum"]
-            urt += st["urgent_time_sum"]
-        torch.cuda.synchronize()
-        wall = time.time() - t0
-        # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
-        rng = np.random.default_rng(1)
-        b = rng.random(n) + (1j * rng.random(n) if zel else 0)
-        bp = np.empty(n, dtype=b.dtype)
-        bp[s["perm"]] = b
-        t1 = time.time()
-        x = plan.solve(bp)[s["perm"]]
-        solve_s = time.time() - t1          # host vector in -> host vector out (first call also builds the solve tables)
-        t1 = time.time()
-        plan.solve(bp.copy())
-        solve_s = min(solve_s, time.time() - t1)
-        import scipy.sparse as sp
-        A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
-        Ax = A @ x if facto == 2 else A @ x + sp.tril(A, -1).T @ x
-        resid = float(np.linalg.norm(Ax - b) / np.linalg.norm(b))
-        ps = plan.stats()
-        res = dict(wall=wall, flops=flops, fact_time=ft, update_time=ut, update_time_sum=uts, urgent_time_sum=urt, urgent_flops=st["urgent_flops"],
-                   nurgent=st["nurgent_launches"], update_flops=ps["update_flops"],
-                   update_bytes=ps["update_bytes"],
-                   nlaunch=st["nupdate_launches"], solve_s=solve_s, solve_dev_s=ps["solve_time"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
-                   blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
-                   ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu")
-        plan.close()
+        res = single_gpu_job(a.grid, a.workload, a.facto, a.steps, a.warmup, a.blocksize, a.chunk, local)
+        a.facto = res["facto"]
 
     if rank == 0:
         K = a.steps
@@ -249,10 +319,10 @@ def main():
         traffic, traffic_src = (None, None)
         if world == 1:
             traffic, traffic_src = measured_traffic(a.grid, a.facto, a.blocksize)
-        # Dominant kernel: k_update<8,0>, the bulk contribution launches.  achieved = its flops / the sum of its
+        # Dominant kernel: k_update<0>, the bulk contribution launches.  achieved = its flops / the sum of its
         # launches' durations (HIP events around every launch, on the stream it is launched on) = what
         # rocprofv3 --kernel-trace --stats reports for that kernel.  The few urgent tasks of every level run as
-        # k_update<8,1> on the other stream, beside the previous slot's bulk launch; they are reported apart.
+        # k_update<1> on the other stream, beside the previous slot's bulk launch; they are reported apart.
         ut_sum = res.get("update_time_sum", res["update_time"])
         bulk_flops = res["update_flops"] - res.get("urgent_flops", 0.0)
         upd_rate = bulk_flops * K / max(ut_sum, 1e-12)
@@ -285,7 +355,7 @@ def main():
                          "avg_launch_ms": round(ut_sum / K / max(res["nlaunch"], 1) * 1e3, 4),
                          "achieved_while_in_flight": round(busy_rate * 1e-12, 3),
                          "flops_per_launch": bulk_flops / max(res["nlaunch"], 1),
-                         "urgent_launches": {"kernel": "k_update<8,1>", "launches_per_step": res.get("nurgent", 0),
+                         "urgent_launches": {"kernel": "k_update<1>", "launches_per_step": res.get("nurgent", 0),
                                              "share_of_update_flops": round(res.get("urgent_flops", 0.0) / max(res["update_flops"], 1.0), 4),
                                              "avg_launch_ms": round(res.get("urgent_time_sum", 0.0) / K / max(res.get("nurgent", 0), 1) * 1e3, 4)}},
         }
@@ -297,6 +367,9 @@ def main():
                             "unit": "GB/s", "frac": round(sb / res["solve_dev_s"] / 8e12, 4),
                             "device_s": round(res["solve_dev_s"], 4), "host_to_host_s": round(res["solve_s"], 4),
                             "panel_bytes_per_solve": sb, "nrhs": 1}
+        if (world == 1 and not a.no_other_configs and a.grid == 200 and a.workload == "laplacian" and a.facto == "llt"
+                and a.chunk == 0):
+            out["other_configs"] = other_configs(a.blocksize, local)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_grid, min(os.cpu_count() or 1, 64))
         print(json.dumps(out), flush=True)
@@ -304,12 +377,35 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-        # RCCL's exit-time teardown has been seen to abort ("double free") after everything was done and printed:
-        # the ranks leave without running it
+
+
+def _main_guarded():
+    """Ranks of a multi-GPU job leave through os._exit with the code they earned: 0 after a complete run, 1 after ANY
+    exception (printed first).  A rank that failed may hold streams its aborted channels never drained, and a peer may
+    be waiting in a collective: interpreter teardown (torch / RCCL destructors, atexit hooks) must not get the chance
+    to hang the job or to turn a failure into exit code 0.  The engine itself keeps one librccl per process
+    (csrc/dist.cpp: rccl()), which is what the exit-time aborts of the first rounds came from."""
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    try:
+        main()
+        code = 0
+    except SystemExit as e:
+        if not multi:
+            raise
+        code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+        if code and not isinstance(e.code, int):
+            sys.stderr.write(str(e.code) + "\n")
+    except BaseException:  # noqa: BLE001
+        if not multi:
+            raise
+        import traceback
+        traceback.print_exc()
+        code = 1
+    if multi:
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(code)
 
 
 if __name__ == "__main__":
-    main()
+    _main_guarded()

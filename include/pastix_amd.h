@@ -36,7 +36,9 @@ enum {
   PASTIX_AMD_ERR_DEVICE = -3,         /* HIP runtime error / no gfx950 device */
   PASTIX_AMD_ERR_NUMERIC = -4,        /* non-finite pivot met (reference would produce NaNs, compute_diag.c:143) */
   PASTIX_AMD_ERR_UNSUPPORTED = -5,    /* precision/factorization variant not built yet */
-  PASTIX_AMD_ERR_LAYOUT = -6          /* layout violates the SolverMatrix invariants (solver_check.c) */
+  PASTIX_AMD_ERR_LAYOUT = -6,         /* layout violates the SolverMatrix invariants (solver_check.c) */
+  PASTIX_AMD_ERR_TIMEOUT = -7         /* multi-GPU driver: the streams did not drain within PASTIX_AMD_DIST_TIMEOUT seconds
+                                         (a peer is missing or the two ends of a channel disagree); channels aborted */
 };
 
 /* SolverCblk subset (solver.h:94-107). cblktab has cblknbr+1 entries (last: bloknum = bloknbr). */
@@ -74,8 +76,12 @@ typedef struct pastix_amd_options_s {
                             pastix_amd_plan_set_arena (e.g. a torch tensor used with torch.distributed) */
   int schur;             /* 1: IPARM_SCHUR semantics of compute_1d (sopalin_compute.c:767-772): the last cblk is not
                             factorized; on return its panel holds the Schur complement (what pastix_getSchur reads).
-                            That cblk may be wider than 256 columns.  Solves are not available on such a plan. */
-  int reserved[11];
+                            That cblk is never re-cut, whatever its width.  Solves are not available on such a plan. */
+  int quadrant_min;      /* leaf-side launches: a slot whose tasks of small pieces number at least this many has them cut
+                            into 64x64 quadrant tasks for k_update_small (plan.cpp); <= 0 = default (1024) */
+  int quadrant_fill_pct; /* ... a task qualifies when its pieces fill less than this many percent of the 128x128x16
+                            chunks k_update would run for them; <= 0 = default (25) */
+  int reserved[9];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */
@@ -242,6 +248,17 @@ int pastix_amd_dist_attach_rccl(pastix_amd_plan_t *plan, int32_t world, const vo
  * the tests to run the same driver where RCCL cannot (one GPU) */
 int pastix_amd_dist_attach_local(pastix_amd_plan_t *const *plans, int32_t world);
 int pastix_amd_dist_info(const pastix_amd_plan_t *plan, pastix_amd_dist_info_t *info);
+/* host only: out[2q] = hash of the fan-in blocks this rank SENDS to rank q, out[2q+1] of
+ * those it RECEIVES from q (level, cblk, rows, width, planes; channel order), q < world.  The two ends of a channel
+ * agree iff a's out[2b] == b's out[2a+1] for every pair: the launcher compares them over its bootstrap BEFORE
+ * pastix_amd_dist_attach_rccl (dist.py: check_schedule_hashes), attach_local compares them itself.  The reference has no
+ * such check: a mismatched MPI fan-in hangs in recv_waitone_fob (sopalin_sendrecv.c:1219-1556). */
+int pastix_amd_dist_schedule_hash(const pastix_amd_layout_t *layout, int factotype, int floattype, const int32_t *owner,
+                                  int32_t myrank, int32_t world, uint64_t *out /* [2*world] */);
+/* Both enqueue everything and wait at the end with a deadline (PASTIX_AMD_DIST_TIMEOUT seconds, default 300): on expiry,
+ * or on any error with work in flight, the rank prints the first unmatched (level, peer, cblk, direction) of every
+ * channel, aborts its communicators (ncclCommAbort), drains its streams and returns PASTIX_AMD_ERR_TIMEOUT / the error;
+ * the plan's distributed state is dead afterwards (later calls return PASTIX_AMD_ERR_BADPARAMETER). */
 int pastix_amd_factorize_dist(pastix_amd_plan_t *plan, double critere, pastix_amd_stats_t *stats);
 /* drives the plans of pastix_amd_dist_attach_local with one host thread per rank; stats / rcs: [world] or NULL */
 int pastix_amd_factorize_dist_local(pastix_amd_plan_t *const *plans, int32_t world, double critere,

@@ -31,7 +31,8 @@ class Layout(ctypes.Structure):
 
 class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
-                ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("reserved", ctypes.c_int * 11)]
+                ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("quadrant_min", ctypes.c_int),
+                ("quadrant_fill_pct", ctypes.c_int), ("reserved", ctypes.c_int * 9)]
 
 
 class Stats(ctypes.Structure):
@@ -50,7 +51,7 @@ class Stats(ctypes.Structure):
 
 
 ERRORS = {0: "OK", -1: "BADPARAMETER", -2: "ALLOC", -3: "DEVICE", -4: "NUMERIC", -5: "UNSUPPORTED",
-          -6: "LAYOUT"}
+          -6: "LAYOUT", -7: "TIMEOUT"}
 
 
 class PastixAmdError(RuntimeError):
@@ -67,7 +68,7 @@ EXPORTS = [
     "pastix_amd_z_he_sopalin", "pastix_amd_z_ge_sopalin",
     "pastix_amd_s_po_sopalin", "pastix_amd_s_sy_sopalin", "pastix_amd_s_ge_sopalin",
     "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",
-    "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats",
+    "pastix_amd_plan_create", "pastix_amd_plan_destroy", "pastix_amd_plan_stats", "pastix_amd_dist_schedule_hash",
     "pastix_amd_upload_packed", "pastix_amd_download_packed", "pastix_amd_upload_tabs",
     "pastix_amd_download_tabs", "pastix_amd_fill_csc", "pastix_amd_refill", "pastix_amd_factorize", "pastix_amd_solve", "pastix_amd_solve_device", "pastix_amd_refine",
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",

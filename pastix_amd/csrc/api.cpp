@@ -22,9 +22,12 @@ double pastix_amd_fact_flops(const pastix_amd_layout_t* layout, int factotype, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// cblks wider than MAXW (the reference's blend leaves such supernodes unsplit in places, e.g. 334 columns on its own
-// orsirr.rua fixture): the engine factorizes an equivalent layout in which every such cblk is cut into column
-// groups of about SPLITW columns.  Sub-cblk j keeps the columns [c_j, c_j+1) and the panel rows from its own
+// cblks wider than SPLITW = 128 columns: the engine factorizes an equivalent layout in which every such cblk is cut into
+// column groups of 128 columns and a remainder.  blend's splitOnProcs (splitpart.c:431-475) cuts a supernode into pieces
+// of width in [max, 2 max) -- 144 columns at its defaults, 152 with MAX_BLOCKSIZE 128, up to 239 -- and leaves some
+// supernodes whole (334 columns on the reference's own orsirr.rua fixture): with the re-cut every layout the real PaStiX
+// hands over runs on the kernels built for <= 128 columns (LDS-resident diagonal blok, whole 128-column update tiles),
+// and there are no others.  Sub-cblk j keeps the columns [c_j, c_j+1) and the panel rows from its own
 // diagonal blok down: the rest of the original diagonal blok becomes off-diagonal bloks facing the later
 // sub-cblks, and bloks facing a split cblk are cut at its column groups.  Mathematically the blocked algorithm
 // on the wide blok; only the host <-> device panel copies see the difference (split_io below).
@@ -47,15 +50,16 @@ static int build_split(const pastix_amd_layout_t* L, bool schur, SplitMap& M) {
     M.ostride[k] = L->cblktab[k].stride;
     M.ooff[k + 1] = M.ooff[k] + w * M.ostride[k];
     int64_t ns = 1;
-    if (w > MAXW && !(schur && k == nc - 1)) { ns = (w + SPLITW - 1) / SPLITW; any = true; }
+    if (w > SPLITW && !(schur && k == nc - 1)) { ns = (w + SPLITW - 1) / SPLITW; any = true; }
     M.first[k + 1] = M.first[k] + ns;
   }
   M.active = any;
   if (!any) return 0;
-  // first column of sub j of cblk k: widths as even as possible
+  // first column of sub j of cblk k: groups of SPLITW columns, the last one takes what is left (whole 128-column
+  // update tiles for all but one group; even widths -- 76 + 76 for 152 -- would make every tile an edge tile)
   auto subcol = [&](int64_t k, int64_t j) {
-    const int64_t ns = M.first[k + 1] - M.first[k], w = M.owidth[k], base = w / ns, rem = w % ns;
-    return L->cblktab[k].fcolnum + j * base + std::min(j, rem);
+    const int64_t ns = M.first[k + 1] - M.first[k];
+    return L->cblktab[k].fcolnum + (j >= ns ? M.owidth[k] : j * (ns == 1 ? M.owidth[k] : (int64_t)SPLITW));
   };
   M.cblk.clear();
   M.blok.clear();
@@ -111,8 +115,14 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     if (!layout || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1) { delete p; return PASTIX_AMD_ERR_BADPARAMETER; }
     rc = build_split(layout, opts && opts->schur, p->split);
     pastix_amd_layout_t sl;
+    std::vector<int32_t> sowner;
     if (!rc && p->split.active) {
-      if (owner) rc = PASTIX_AMD_ERR_UNSUPPORTED;          // (the multi-GPU engine addresses panels by original cblk)
+      if (owner) {                                         // the column groups of a cblk stay with its owner
+        sowner.resize(p->split.cblk.size() - 1);
+        for (int64_t k = 0; k < p->split.ocblknbr; k++)
+          for (int64_t q = p->split.first[k]; q < p->split.first[k + 1]; q++) sowner[(size_t)q] = owner[k];
+        owner = sowner.data();
+      }
       sl.cblknbr = (pastix_amd_int_t)p->split.cblk.size() - 1;
       sl.bloknbr = (pastix_amd_int_t)p->split.blok.size();
       sl.cblktab = p->split.cblk.data();
@@ -125,6 +135,16 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   }
   if (rc) { delete p; return rc; }
   if (p->split.active) p->host.fact_flops = p->host.local_flops = oflops;   // DPARM_FACT_FLOPS is the caller's layout's
+  if (p->split.active && p->host.factotype != PASTIX_AMD_FACT_LU) {
+    SplitMap& M = p->split;
+    try {
+      M.upper.resize((size_t)M.ocblknbr);
+      const int es = floattype == PASTIX_AMD_COMPLEXDOUBLE ? 2 : 1;
+      for (int64_t k = 0; k < M.ocblknbr; k++)
+        if (M.first[k + 1] - M.first[k] > 1 && p->host.role[(size_t)M.first[k]] == 1)
+          M.upper[(size_t)k].assign((size_t)(M.owidth[k] * M.owidth[k] * es), 0.0);
+    } catch (const std::bad_alloc&) { delete p; return PASTIX_AMD_ERR_ALLOC; }
+  }
   Plan& H = p->host;
   p->device = H.opts.device;
   int ndev = 0;
@@ -141,8 +161,6 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically smallest = highest priority
       HIPCHK(hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, hi));
       HIPCHK(hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, lo));
-      HIPCHK(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, lo));
-      HIPCHK(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
     }
     p->distributed = owner != nullptr;
     p->own_arena = !(opts && opts->external_arena);
@@ -229,6 +247,20 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
                 H.slot_flops[sl]);
       }
     }
+  }
+  if (H.opts.verbose >= 2) {
+    // developer aid: per bulk launch, the update flops by instance of the update loop (whole 128x128 tiles / edge tiles /
+    // tasks with partial pieces) -- printed beside the launch's duration by pastix_amd_factorize_end
+    H.slot_mode_flops.assign((size_t)H.nlevels * 3, 0.0);
+    for (int sl = 0; sl < H.nlevels; sl++)
+      for (int64_t q = H.slot_urgent_end[sl]; q < H.slot_task_ptr[sl + 1]; q++) {
+        const Task& t = H.tasks[(size_t)q];
+        const int m = (t.flags & 32u) ? 2 : (int)t.nfull == t.pn ? ((t.tm == TM && t.tn == TN) ? 0 : 1) : 2;
+        for (int i = 0; i < t.pn; i++) {
+          const Piece& pc = H.pieces[(size_t)t.p0 + i];
+          H.slot_mode_flops[(size_t)sl * 3 + m] += 2.0 * pc.m * (double)pc.n * pc.k;
+        }
+      }
   }
   // the piece/task tables now live on the device; keep only what the host driver reads
   decltype(H.pieces)().swap(H.pieces);
@@ -331,9 +363,19 @@ int pastix_amd_plan_set_stream(pastix_amd_plan_t* p, void* stream) {
 }
 
 int pastix_amd_plan_layout_info(const pastix_amd_plan_t* p, pastix_amd_int_t* poff, int32_t* level, int8_t* role) {
-  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
+  if (p->split.active) {
+    // by ORIGINAL cblk: offsets in the caller's packed layout, level and role of the first column group (the groups of
+    // a cblk share its owner; their levels follow each other)
+    const SplitMap& M = p->split;
+    if (poff) std::memcpy(poff, M.ooff.data(), (size_t)(M.ocblknbr + 1) * sizeof(int64_t));
+    for (int64_t k = 0; k < M.ocblknbr; k++) {
+      if (level) level[k] = H.level[(size_t)M.first[k]];
+      if (role) role[k] = H.role[(size_t)M.first[k]];
+    }
+    return PASTIX_AMD_OK;
+  }
   if (poff) std::memcpy(poff, H.poff.data(), (size_t)(H.cblknbr + 1) * sizeof(int64_t));
   if (level) std::memcpy(level, H.level.data(), (size_t)H.cblknbr * sizeof(int32_t));
   if (role) std::memcpy(role, H.role.data(), (size_t)H.cblknbr);
@@ -358,8 +400,6 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
-  if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
-  if (p->evJoin) (void)hipEventDestroy(p->evJoin);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -430,6 +470,15 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
     return r;
   }
   const int64_t fcol = H.cblk[s0].fcolnum;
+  std::vector<double>* keep = (!M.upper.empty() && !M.upper[(size_t)k].empty()) ? const_cast<std::vector<double>*>(&M.upper[(size_t)k]) : nullptr;
+  if (up && keep) {                               // the diagonal blok's blocks above the column groups (see SplitMap::upper)
+    const double* host = (const double*)hostL;
+    for (int64_t j = 1; j < ns; j++) {
+      const int64_t offj = H.cblk[s0 + j].fcolnum - fcol, wj = H.cblk[s0 + j].lcolnum - H.cblk[s0 + j].fcolnum + 1;
+      for (int64_t c = 0; c < wj; c++)
+        memcpy(keep->data() + (offj + c) * ow * es, host + (offj + c) * os * es, (size_t)(offj * es) * sizeof(double));
+    }
+  }
   std::vector<std::vector<double>> tmp[2];
   for (int a = 0; a < 2; a++) tmp[a].resize((size_t)ns);
   for (int a = 0; a < (haveU ? 2 : 1); a++) {
@@ -474,6 +523,7 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
         double* col[2] = {(double*)hostL + (offj + c) * os * es, haveU ? (double*)hostU + (offj + c) * os * es : nullptr};
         for (int a = 0; a < (haveU ? 2 : 1); a++) {
           memset(col[a], 0, (size_t)(offj * es) * sizeof(double));
+          if (a == 0 && keep) memcpy(col[0], keep->data() + (offj + c) * ow * es, (size_t)(offj * es) * sizeof(double));
           if (!lu || (a == 1 && !p->factored)) continue;
           for (int64_t i = 0; i < j; i++) {                      // rows of the earlier group i, from the OTHER arena's panel of i
             const int64_t offi = H.cblk[s0 + i].fcolnum - fcol, wi = H.cblk[s0 + i].lcolnum - H.cblk[s0 + i].fcolnum + 1;
@@ -498,6 +548,7 @@ static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* c
   for (int64_t k = 0; k < M.ocblknbr; k++) {
     void* hl = coeftab ? coeftab[k] : (void*)((double*)packedL + M.ooff[k] * es);
     void* hu = coeftab ? (ucoeftab ? ucoeftab[k] : nullptr) : (packedU ? (void*)((double*)packedU + M.ooff[k] * es) : nullptr);
+    if (p->host.role[(size_t)M.first[k]] != 1) continue;          // (distributed plans: only owned panels travel)
     if (!hl) return PASTIX_AMD_ERR_BADPARAMETER;
     int r = split_cblk_io(p, k, up, hl, hu);
     if (r) return r;
@@ -616,7 +667,12 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
 }
 
 int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, void* U) {
-  if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
+  if (p && p->split.active) {
+    if (!L || k < 0 || k >= p->split.ocblknbr || p->host.role[(size_t)p->split.first[k]] != 1) return PASTIX_AMD_ERR_BADPARAMETER;
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return split_cblk_io(p, k, false, L, U);
+  }
   if (!p || !L || k < 0 || k >= p->host.cblknbr || p->host.role[k] != 1) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
@@ -668,6 +724,15 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
     return H.poff[kc] + H.blok[lo].coefind + (pr - H.blok[lo].frownum) + (pc - H.cblk[kc].fcolnum) * H.cblk[kc].stride;
   };
   const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
+  const bool keep_upper = p->split.active && !lu && !p->split.upper.empty();
+  std::vector<int64_t> sub2orig;
+  if (keep_upper) {
+    sub2orig.resize((size_t)H.cblknbr);
+    for (int64_t k = 0; k < p->split.ocblknbr; k++) {
+      for (int64_t q = p->split.first[k]; q < p->split.first[k + 1]; q++) sub2orig[(size_t)q] = k;
+      std::fill(p->split.upper[(size_t)k].begin(), p->split.upper[(size_t)k].end(), 0.0);
+    }
+  }
   for (int64_t j = 0; j < n; j++)
     for (int64_t q = colptr[j] - 1; q < colptr[j + 1] - 1; q++) {
       const int64_t i = rows[q] - 1;
@@ -681,6 +746,17 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
           valL.push_back(vals[vs * q]);
           // Hermitian input: the mirrored entry is the conjugate (CscOrdistrib type 'H', pastix.c:3309)
           if (p->cplx) valLi.push_back((pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1]);
+        } else if (keep_upper) {
+          // a re-cut cblk: entries of its diagonal blok above the column group of their column stay on the host
+          // (SplitMap::upper) -- the reference's coeftab carries them, unread, from the fill to the caller
+          const int64_t ko = sub2orig[(size_t)col2cblk[pc]];
+          std::vector<double>& up = p->split.upper[(size_t)ko];
+          const int64_t of = H.cblk[(size_t)p->split.first[ko]].fcolnum, ow = p->split.owidth[ko];
+          if (!up.empty() && pr >= of && pr < H.cblk[col2cblk[pc]].fcolnum) {
+            const size_t e = (size_t)(((pc - of) * ow + (pr - of)) * vs);
+            up[e] = vals[vs * q];
+            if (p->cplx) up[e + 1] = (pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1];
+          }
         }
         if (lu) {
           d = locate(pc, pr, true);
@@ -725,7 +801,9 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
 // pastix_amd_fill_csc (pastix_amd_refill re-applies it).  One GPU, cblks <= 256 wide.
 int pastix_amd_fill_fake(pastix_amd_plan_t* p, pastix_amd_int_t gnodenbr) {
   if (!p || gnodenbr < 1) return PASTIX_AMD_ERR_BADPARAMETER;
-  if (p->distributed || p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (p->distributed) return PASTIX_AMD_ERR_UNSUPPORTED;
+  for (auto& up : p->split.upper)                  // (re-cut cblks, LLt / LDLt: every coeftab entry is 1, also above the groups)
+    for (size_t e = 0; e < up.size(); e++) up[e] = (p->cplx && (e & 1)) ? 0.0 : 1.0;
   const Plan& H = p->host;
   HIPCHK(hipSetDevice(p->device));
   const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
@@ -776,12 +854,9 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
 }
 
 // tasks [b, e) of launch slot `slot`: the quadrant tasks at the end of the slot's urgent range and at the end of its bulk
-// range go to k_update_small, the rest to k_update (PASTIX_AMD_SMALL_KERNEL=0: everything to k_update, which runs a
-// quadrant task as an edge tile)
+// range go to k_update_small, the rest to k_update
 static void launch_update_range(pastix_amd_plan_t* p, hipStream_t s, int slot, int64_t b, int64_t e, bool urgent) {
-  static const bool small_on = !getenv("PASTIX_AMD_SMALL_KERNEL") || atoi(getenv("PASTIX_AMD_SMALL_KERNEL")) != 0;
   const Plan& H = p->host;
-  if (!small_on) { launch_update(s, p->arenas(), p->dTasks + b, p->dPieces, e - b, urgent); return; }
   // the slot's ranges: [t0, us) urgent, [us, tu) urgent quadrants, [tu, sb) bulk, [sb, t1) bulk quadrants
   const int64_t cut[5] = {H.slot_task_ptr[(size_t)slot], H.slot_usmall_begin[(size_t)slot], H.slot_urgent_end[(size_t)slot],
                           H.slot_small_begin[(size_t)slot], H.slot_task_ptr[(size_t)slot + 1]};
@@ -805,10 +880,8 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   p->nupdB_run = 0;
   p->crit_run = critere;
   // Level-stepped use (distributed plans): the same urgent / bulk split over two streams as pastix_amd_factorize's
-  // mode 1, one level at a time; PASTIX_AMD_DIST_OVERLAP=0 keeps one stream.  (pastix_amd_factorize sets
-  // `overlapped` itself after this call.)
-  static const char* dov = getenv("PASTIX_AMD_DIST_OVERLAP");
-  p->staged_overlap = p->distributed && p->stream2 && !(dov && atoi(dov) == 0);
+  // two-stream driver, one level at a time.  (pastix_amd_factorize sets `overlapped` itself after this call.)
+  p->staged_overlap = p->distributed && p->stream2;
   p->staged_lastB = -1;
   if (p->staged_overlap) { p->overlapped = true; p->overlap_mode = 1; }
   return PASTIX_AMD_OK;
@@ -923,6 +996,21 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
       i++;
     }
   }
+  if (p->nupdB_run > 0 && H.opts.verbose >= 2 && p->overlap_mode == 1 && !H.slot_mode_flops.empty()) {
+    int i = 0;
+    for (int l = 0; l < H.nlevels && i < p->nupdB_run; l++) {
+      const int64_t tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
+      if (t1 <= tu) continue;
+      float m2 = 0;
+      HIPCHK(hipEventElapsedTime(&m2, p->evT[2 * i], p->evT[2 * i + 1]));
+      const double* mf = &H.slot_mode_flops[(size_t)l * 3];
+      const double fl = mf[0] + mf[1] + mf[2];
+      fprintf(stderr, "bulk %4d: tasks %7lld (quadrant %6lld) flops %.4e  full %.4f edge %.4f partial %.4f  %9.1f us  %8.1f GF/s\n", l,
+              (long long)(t1 - tu), (long long)(t1 - H.slot_small_begin[l]), fl, mf[0] / std::max(fl, 1.0), mf[1] / std::max(fl, 1.0),
+              mf[2] / std::max(fl, 1.0), m2 * 1e3, fl / (m2 * 1e-3) * 1e-9);
+      i++;
+    }
+  }
   if (p->nupdB_run > 0) {
     // the launches of the two streams overlap: count the time at least one of them was in flight
     std::vector<std::pair<float, float>> iv;
@@ -981,10 +1069,10 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
-  // Two streams (mode 1 below) unless PASTIX_AMD_OVERLAP=0 (one stream) or =2.  Measured gain over one stream:
-  // 60^3 +25 %, 100^3 +8 %, 160^3 +3 %, 200^3 +1 %.
+  // Two streams unless PASTIX_AMD_OVERLAP=0 (one stream).  Measured gain over one stream: 60^3 +25 %, 100^3 +8 %,
+  // 160^3 +3 %, 200^3 +1 %.
   static const char* ov_env = getenv("PASTIX_AMD_OVERLAP");
-  const int want = ov_env ? atoi(ov_env) : 1;
+  const int want = ov_env ? (atoi(ov_env) != 0) : 1;
   p->overlap_mode = want;
   p->overlapped = p->own_stream && p->stream2 && want != 0;
   int rc = pastix_amd_factorize_begin(p, critere);
@@ -996,59 +1084,18 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   }
   const Plan& H = p->host;
   hipStream_t s1 = p->stream, s2 = p->stream2;
-  if (p->overlap_mode == 2) {
-    // Two streams, update launches never beside each other.  stream2 carries every contribution launch in
-    // order: A(l) (slot l's tasks that target level l), then B(l) (the rest of slot l: sources of level <= l-1,
-    // targets of later levels).  stream carries the panel kernels P(l), which start when A(l) is done and run
-    // beside B(l); A(l+1) waits for P(l).  P(l) touches level-l panels only, B(l) never does.
-    HIPCHK(hipEventRecord(p->evP[0], s1));                 // begin()'s resets precede everything on stream2
-    HIPCHK(hipStreamWaitEvent(s2, p->evP[0], 0));
-    for (int l = 0; l < H.nlevels; l++) {
-      const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
-      if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
-      if (tu > t0) {
-        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run], s2));
-        launch_update_range(p, s2, l, t0, tu, false);
-        HIPCHK(hipEventRecord(p->ev[2 * p->nupd_run + 1], s2));
-        p->nupd_run++;
-      }
-      HIPCHK(hipEventRecord(p->evB[l], s2));               // level l's panels have every contribution
-      HIPCHK(hipStreamWaitEvent(s1, p->evB[l], 0));
-      if ((rc = launch_panels(p, l))) return rc;
-      HIPCHK(hipEventRecord(p->evP[l], s1));
-      if (t1 > tu) {
-        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-        launch_update_range(p, s2, l, tu, t1, false);
-        HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
-        p->nupdB_run++;
-      }
-    }
-    HIPCHK(hipEventRecord(p->evB[0], s2));
-    HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
-    return pastix_amd_factorize_end(p, stats);
-  }
-  // Mode 1.  stream (high priority): contributions of slot l to level l (A), then the panel kernels
-  // of level l (P).  stream2: the rest of slot l, whose sources are of level <= l-1 and whose targets are of
-  // level l+1 or later (B); it runs beside A(l) and P(l).  Orders kept: B(l) after P(l-1); A(l+1) after
-  // B(l): all writers of a tile stay ordered, results do not depend on timing.
-  // Tails of SHORT bulk launches: a launch of a few thousand tasks runs ~10 rounds of 512 workgroups, and its ramp
-  // and its last, partly filled round cost 10 % and more (100^3: ~200 launches of ~0.7 ms).  B(l) only needs P(l-1);
-  // what orders it behind B(l-1) is tile ownership -- both may update the same tile.  The plan marks those tasks of a
-  // slot ("late": same tile in the previous slot's bulk launch); all others ("early") start beside the tail of B(l-1)
-  // on a second bulk stream, the late ones follow once B(l-1) is done.  Results do not depend on timing: every tile
-  // still sees its updates in slot order.  Opt-in: PASTIX_AMD_TAIL_FLOPS=<flop> overlaps launches below that size
-  // (measured with 3e11: 100^3 0.1535 -> 0.1507 s, 160^3 1.874 -> 1.860 s, 60^3 -4 %).  Off by default: the gain is
-  // small -- at those sizes the next launch mostly waits for the panel chain, not for a free slot -- and overlapped
-  // launches stretch each other's durations, which is what the roofline line of bench.py and rocprofv3 divide by.
-  static const double tail_flops = getenv("PASTIX_AMD_TAIL_FLOPS") ? atof(getenv("PASTIX_AMD_TAIL_FLOPS")) : 0.0;
+  // stream (high priority): contributions of slot l to level l (A), then the panel kernels of level l (P).  stream2: the
+  // rest of slot l, whose sources are of level <= l-1 and whose targets are of level l+1 or later (B); it runs beside
+  // A(l) and P(l).  Orders kept: B(l) after P(l-1) and after B(l-1) (stream order); A(l+1) after B(l): all writers of a
+  // tile stay ordered, results do not depend on timing.  (Letting the tasks of B(l) whose tile B(l-1) does not touch
+  // start beside the tail of B(l-1) on a third stream was built and measured: +1.9 % at 100^3, +0.8 % at 160^3 -- the next
+  // launch mostly waits for the panel chain, not for a free slot -- and removed again.)
   // Per-launch timing events (statistics, bench.py's roofline line) are markers the command processor handles one by
-  // one: PASTIX_AMD_LAUNCH_EVENTS=0 leaves them out (update_time / update_time_sum then read 0).
+  // one: PASTIX_AMD_LAUNCH_EVENTS=0 leaves them out (update_time / update_time_sum then read 0; -1.3 % at 100^3).
   static const bool ev_env = !getenv("PASTIX_AMD_LAUNCH_EVENTS") || atoi(getenv("PASTIX_AMD_LAUNCH_EVENTS")) != 0;
   p->launch_events = ev_env;
   const bool tev = p->launch_events;
-  // without tail overlap every bulk launch goes to stream2: consecutive launches are ordered by the stream itself
-  hipStream_t sB[2] = {s2, (tail_flops > 0 && p->stream3) ? p->stream3 : s2};
-  int lastN = -1, prevB = -1;                 // prevB: last slot that had a bulk launch
+  int lastN = -1;
   bool s2_used = false;
   for (int l = 0; l < H.nlevels; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
@@ -1062,33 +1109,21 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     if ((rc = launch_panels(p, l))) return rc;
     HIPCHK(hipEventRecord(p->evP[l], s1));
     if (t1 > tu) {
-      const bool overlap = sB[1] != sB[0] && prevB >= 0 && H.slot_flops[l] < tail_flops && H.slot_flops[prevB] < tail_flops;
-      hipStream_t sx = sB[l & 1];
-      const int64_t tl = overlap ? std::max(tu, std::min(H.slot_late_begin[l], t1)) : tu;
-      if (l > 0) HIPCHK(hipStreamWaitEvent(sx, p->evP[l - 1], 0));
-      // (the same stream carried B(l-2): stream order; B(l-1) ran on the other one)
-      if (!overlap && prevB >= 0 && sB[1] != sB[0]) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
-      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], sx));
+      if (l > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[l - 1], 0));
+      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
       // inside a launch the tasks for level l+1 come first.  (Launching them separately so that A(l+1) waits for
       // them only was measured slower: smaller launches, same chain.)
-      if (tl > tu) launch_update_range(p, sx, l, tu, tl, false);
-      if (t1 > tl) {
-        if (overlap) HIPCHK(hipStreamWaitEvent(sx, p->evB[prevB], 0));
-        launch_update_range(p, sx, l, tl, t1, false);
-      }
-      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], sx));
-      HIPCHK(hipEventRecord(p->evB[l], sx));
+      launch_update_range(p, s2, l, tu, t1, false);
+      if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
+      HIPCHK(hipEventRecord(p->evB[l], s2));
       lastN = l;
-      prevB = l;
       p->nupdB_run++;
       s2_used = true;
     }
   }
   if (s2_used) {
-    for (int q = 0; q < 2; q++) {
-      HIPCHK(hipEventRecord(q ? p->evJoin : p->evB[0], sB[q]));
-      HIPCHK(hipStreamWaitEvent(s1, q ? p->evJoin : p->evB[0], 0));
-    }
+    HIPCHK(hipEventRecord(p->evB[0], s2));
+    HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
   }
   return pastix_amd_factorize_end(p, stats);
 }
@@ -1102,18 +1137,16 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
   const int64_t nown = H.lvl_cblk_ptr[H.nlevels];          // cblks factorized here (all of them on one GPU)
   if (!p->dSolve) {
     std::vector<SolveTask> st((size_t)nown);
-    std::vector<SolveChunk> ch, chB, chF, chBF;
+    std::vector<SolveChunk> ch, chB;
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
-    p->lvl_chunk_far.assign((size_t)H.nlevels, 0);          // [lvl_chunk_ptr[l], far[l]) near, [far[l], ptr[l+1]) far
-    p->lvl_chunkB_far.assign((size_t)H.nlevels, 0);
     p->lvl_maxw.assign((size_t)H.nlevels, 1);
     std::vector<int64_t> roff((size_t)nown + 1, 0);          // in level order, like st
     for (int64_t q = 0; q < nown; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
     // panel rows per chunk: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly and
     // one set of atomics per 256 rows)
     const int32_t CH = 64;
-    const int32_t CHB = getenv("PASTIX_AMD_SOLVE_BCH") ? atoi(getenv("PASTIX_AMD_SOLVE_BCH")) : 256;
+    const int32_t CHB = 256;
     for (int l = 0; l < H.nlevels; l++) {
       p->lvl_chunk_ptr[l] = (int64_t)ch.size();
       p->lvl_chunkB_ptr[l] = (int64_t)chB.size();
@@ -1123,35 +1156,17 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
         st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
                           (int32_t)H.cblk[k + 1].bloknum};
         p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
-        // rows facing a cblk of the next level are "near": the next level's diagonal solves wait for exactly these
-        // chunks (forward) / these chunks wait for exactly the previous diagonal solves (backward); the far chunks
-        // go to the second stream (solve_sweeps below).  The bloks of a panel are sorted by row, and so are the
-        // levels they face only loosely, hence the scan.
-        const int64_t fb = H.cblk[k].bloknum + 1, lb = H.cblk[k + 1].bloknum;
-        auto near_rows = [&](int32_t r0, int32_t r1) {         // does [r0, r1) hold a row facing level l+1?
-          for (int64_t b = fb; b < lb; b++) {
-            const int32_t c0 = (int32_t)H.blok[b].coefind, c1 = c0 + (int32_t)(H.blok[b].lrownum - H.blok[b].frownum + 1);
-            if (c1 <= r0 || c0 >= r1) continue;
-            if (H.level[H.blok[b].cblknum] == l + 1) return true;
-          }
-          return false;
-        };
         for (int32_t r = w; r < sd; r += CH) {
           const int32_t n = std::min(CH, sd - r);
-          (near_rows(r, r + n) ? ch : chF).push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
+          ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
               (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
         }
         for (int32_t r = w; r < sd; r += CHB) {
           const int32_t n = std::min(CHB, sd - r);
-          (near_rows(r, r + n) ? chB : chBF).push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
+          chB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
               (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
         }
       }
-      p->lvl_chunk_far[l] = (int64_t)ch.size();
-      p->lvl_chunkB_far[l] = (int64_t)chB.size();
-      ch.insert(ch.end(), chF.begin(), chF.end());
-      chB.insert(chB.end(), chBF.begin(), chBF.end());
-      chF.clear(); chBF.clear();
     }
     p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
     p->lvl_chunkB_ptr[H.nlevels] = (int64_t)chB.size();
@@ -1202,58 +1217,6 @@ void pai_solve_dscale(pastix_amd_plan_t* p, double* dx, int nr) {     // LDLt: x
   for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx + k * H.ncol);
 }
 
-// Both sweeps of one group of right-hand sides on two streams.  The chain of a sweep is diagonal solve -> the panel
-// rows facing the next level -> next diagonal solve; the rest of a panel (rows facing later levels: most of the
-// bytes at the top of the tree) only has to land before the level after next, so it runs on the second stream beside
-// the next level's chain.  Forward: far(l) starts after diag(l) and ends before diag(l+2).  Backward (levels
-// descending): far(l) needs x of the levels >= l+2, i.e. starts after diag(l+2), and ends before diag(l).  The
-// adds into x are atomic, so the two streams may touch the same rows.  Events: the factorization's per-level pairs.
-static int solve_sweeps(pastix_amd_plan_t* p, double* dx, int nr) {
-  const Plan& H = p->host;
-  hipStream_t sA = p->stream, sB = p->stream2;
-  const int nl = H.nlevels;
-  auto part = [&](hipStream_t s, bool fwd, int l, int what) {     // what: 1 diag, 2 near chunks, 4 far chunks
-    const SolveChunk* base = fwd ? p->dChunk : p->dChunkB;
-    const int64_t c0 = (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l], c2 = (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l + 1];
-    const int64_t c1 = (fwd ? p->lvl_chunk_far : p->lvl_chunkB_far)[l];
-    const int64_t b = what == 4 ? c1 : c0, e = what == 4 ? c2 : c1;
-    launch_solve_level(s, fwd, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], base + b, e - b, p->dBlok, p->dRidx, dx, H.ncol, nr,
-                       p->maxw, p->lvl_maxw[l], what == 1 ? 1 : 2);
-  };
-  auto has_far = [&](bool fwd, int l) {
-    return (fwd ? p->lvl_chunk_ptr : p->lvl_chunkB_ptr)[l + 1] > (fwd ? p->lvl_chunk_far : p->lvl_chunkB_far)[l];
-  };
-  for (int l = 0; l < nl; l++) {
-    if (l >= 2 && has_far(true, l - 2)) HIPCHK(hipStreamWaitEvent(sA, p->evB[l - 2], 0));
-    part(sA, true, l, 1);
-    if (has_far(true, l)) {
-      HIPCHK(hipEventRecord(p->evP[l], sA));
-      HIPCHK(hipStreamWaitEvent(sB, p->evP[l], 0));
-      part(sB, true, l, 4);
-      HIPCHK(hipEventRecord(p->evB[l], sB));
-    }
-    part(sA, true, l, 2);
-  }
-  // every far launch has been waited for except those of the last two levels, which have no far rows (nothing
-  // lies two levels above them)
-  if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
-  if (nl > 0) HIPCHK(hipEventRecord(p->evP[nl - 1], sA));       // x complete (forward sweep + scaling)
-  for (int l = nl - 1; l >= 0; l--) {
-    if (has_far(false, l)) {
-      // x of the levels >= l+2 is final after diag(l+2); for the topmost far launch that is the forward sweep's end
-      HIPCHK(hipStreamWaitEvent(sB, l + 2 < nl ? p->evP[l + 2] : p->evP[nl - 1], 0));
-      part(sB, false, l, 4);
-      HIPCHK(hipEventRecord(p->evB[l], sB));
-    }
-    part(sA, false, l, 2);
-    if (has_far(false, l)) HIPCHK(hipStreamWaitEvent(sA, p->evB[l], 0));
-    part(sA, false, l, 1);
-    HIPCHK(hipEventRecord(p->evP[l], sA));
-  }
-  return PASTIX_AMD_OK;
-}
-
 static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, bool x_on_device) {
   if (!p || !x_ || nrhs < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
@@ -1300,11 +1263,9 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     HIPCHK(hipGetLastError());
     return PASTIX_AMD_OK;
   }
-  // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes)
-  // (measured slower: 200^3 154 ms against 111 ms -- a cross-stream event per level costs more than the overlap
-  // gains on 753 levels of 10-40 us; kept for experiments)
-  static const bool want_two = getenv("PASTIX_AMD_SOLVE_TWO_STREAM") != nullptr;
-  const bool two_stream = want_two && p->stream2 && H.nlevels > 2;
+  // up to four right-hand sides per pass over the panels (the sweeps are HBM-bound on the panel bytes).  One stream:
+  // the far rows of a panel on a second stream beside the next level's chain were built and measured slower (200^3:
+  // 154 ms against 111 ms -- a cross-stream event per level costs more than the overlap returns on 753 levels).
   const int64_t NRB = std::min<int64_t>(nrhs, 4);
   const size_t need = (size_t)H.ncol * (size_t)NRB;
   if (mode == 1 && p->nXws < need) {
@@ -1320,12 +1281,9 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
     if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
-    if (two_stream) { const int rs = solve_sweeps(p, dx, nr); if (rs) return rs; }
-    else {
-      for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
-      if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
-      for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
-    }
+    for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
+    if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
+    for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
     HIPCHK(hipEventRecord(p->ev1, p->stream));
     if (mode == 1) HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));

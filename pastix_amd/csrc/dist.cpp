@@ -25,8 +25,10 @@
 // there is one) and an in-process loopback (several rank plans sharing one GPU, host threads, device-to-device copies)
 // used by the single-GPU tests to run the very same driver.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -131,6 +133,23 @@ int build_schedule(const Plan& P, int world, DistSchedule& S) {
   return PASTIX_AMD_OK;
 }
 
+// Deadline of one distributed factorization / solve on the host (seconds; PASTIX_AMD_DIST_TIMEOUT, default 300): a
+// rank whose streams have not drained by then reports where they are stuck, aborts its channels and returns
+// PASTIX_AMD_ERR_TIMEOUT instead of waiting for a peer for ever.
+double dist_timeout_s() {
+  static const double t = [] {
+    const char* e = getenv("PASTIX_AMD_DIST_TIMEOUT");
+    const double v = e ? atof(e) : 300.0;
+    return v > 0 ? v : 300.0;
+  }();
+  return t;
+}
+
+// FNV-1a over 64-bit words
+inline void fnv(uint64_t& h, uint64_t v) {
+  for (int i = 0; i < 8; i++) { h ^= (v >> (8 * i)) & 0xffu; h *= 1099511628211ull; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // transports
 // ------------------------------------------------------------------------------------------------
@@ -140,15 +159,19 @@ struct Transport {
   virtual int send(int peer, const double* buf, int64_t count, hipStream_t s) = 0;
   virtual int recv(int peer, double* buf, int64_t count, hipStream_t s) = 0;
   virtual int group_end(int peer) = 0;
+  // give up: make every operation already enqueued on the device return (peers see an error, not a hang)
+  virtual void abort() = 0;
   virtual const char* name() const = 0;
 };
 
 // --- RCCL, resolved at run time ---
 struct RcclApi {
   void* h = nullptr;
+  char path[512] = {0};              // the object the entry points were resolved in (dladdr)
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -156,30 +179,58 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// The library choice is deterministic: ONE copy of librccl per process.  If a librccl is already mapped (PyTorch's
+// torch/lib/librccl.so once torch.distributed has been imported), exactly that object is used -- found by walking the
+// loaded objects, reopened by its own path with RTLD_NOLOAD -- and a failure to do so is an error, not a reason to map
+// a second copy next to it (two copies = two sets of global state = the exit-time aborts the first rounds worked
+// around).  Only a process that has no librccl yet maps the ROCm installation's.
+struct FoundLib { char path[512]; int n; };
+int find_rccl_cb(struct dl_phdr_info* info, size_t, void* data) {
+  FoundLib* f = (FoundLib*)data;
+  if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) {
+    if (f->n == 0) std::snprintf(f->path, sizeof(f->path), "%s", info->dlpi_name);
+    f->n++;
+  }
+  return 0;
+}
+
 RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    // a copy that is already in the process (PyTorch's) first, then the ROCm installation's
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-      if (api.h) break;
+    FoundLib f{{0}, 0};
+    dl_iterate_phdr(find_rccl_cb, &f);
+    if (f.n > 1) {
+      fprintf(stderr, "pastix_amd: %d copies of librccl are mapped in this process (first: %s); refusing to pick one\n", f.n, f.path);
+      return;
     }
-    for (const char* n : names) {
-      if (api.h) break;
-      api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (f.n == 1) {
+      api.h = dlopen(f.path, RTLD_NOW | RTLD_NOLOAD);
+      if (!api.h) {
+        fprintf(stderr, "pastix_amd: librccl is mapped (%s) but cannot be reopened: %s\n", f.path, dlerror());
+        return;
+      }
+    } else {
+      const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char* n : names) {
+        api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.h) break;
+      }
+      if (!api.h) return;
     }
-    if (!api.h) return;
 #define SYM(f) api.f = (decltype(api.f))dlsym(api.h, "nccl" #f)
-    SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart); SYM(GroupEnd);
-    SYM(GetErrorString);
+    SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(CommAbort); SYM(Send); SYM(Recv); SYM(GroupStart);
+    SYM(GroupEnd); SYM(GetErrorString);
 #undef SYM
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Send || !api.Recv || !api.GroupStart ||
-        !api.GroupEnd) {
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.CommAbort || !api.Send || !api.Recv ||
+        !api.GroupStart || !api.GroupEnd) {
       dlclose(api.h);
       api.h = nullptr;
+      return;
     }
+    Dl_info di;
+    if (dladdr((void*)api.Send, &di) && di.dli_fname) std::snprintf(api.path, sizeof(api.path), "%s", di.dli_fname);
+    if (getenv("PASTIX_AMD_VERBOSE")) fprintf(stderr, "pastix_amd: librccl resolved in %s\n", api.path);
   });
   return api.h ? &api : nullptr;
 }
@@ -197,9 +248,18 @@ RcclApi* rccl() {
 struct RcclTransport : Transport {
   int me = 0;
   std::map<int, ncclComm_t> comm;     // per peer: a 2-rank communicator (rank 0 = the lower job rank)
+  bool aborted = false;
   ~RcclTransport() override {
+    if (aborted) return;
     if (RcclApi* a = rccl())
       for (auto& c : comm) if (c.second) (void)a->CommDestroy(c.second);
+  }
+  // ncclCommAbort: the kernels of pending sends / receives leave, the communicator is freed (no CommDestroy after it)
+  void abort() override {
+    if (aborted) return;
+    aborted = true;
+    if (RcclApi* a = rccl())
+      for (auto& c : comm) if (c.second) { (void)a->CommAbort(c.second); c.second = nullptr; }
   }
   int group_begin(int) override { NCCLCHK(rccl()->GroupStart()); return 0; }
   int group_end(int) override { NCCLCHK(rccl()->GroupEnd()); return 0; }
@@ -244,17 +304,30 @@ struct LocalTransport : Transport {
     hub->cv.notify_all();
     return 0;
   }
+  void abort() override {
+    { std::lock_guard<std::mutex> g(hub->mu); hub->failed = true; }
+    hub->cv.notify_all();
+  }
   int recv(int peer, double* buf, int64_t count, hipStream_t s) override {
     LocalHub::Posted p;
     {
       std::unique_lock<std::mutex> g(hub->mu);
       auto& dq = hub->q[{peer, me}];
-      hub->cv.wait(g, [&] { return !dq.empty() || hub->failed; });
+      // (the host-side rendezvous of the emulation has the same deadline as the device-side wait of the real driver)
+      if (!hub->cv.wait_for(g, std::chrono::duration<double>(dist_timeout_s()), [&] { return !dq.empty() || hub->failed; })) {
+        fprintf(stderr, "pastix_amd[rank %d]: loopback receive from rank %d (%lld doubles) not matched within %.0f s\n", me,
+                peer, (long long)count, dist_timeout_s());
+        return PASTIX_AMD_ERR_TIMEOUT;
+      }
       if (hub->failed) return PASTIX_AMD_ERR_DEVICE;
       p = dq.front();
       dq.pop_front();
     }
-    if (p.count != count) return PASTIX_AMD_ERR_LAYOUT;       // the two ends disagree on the schedule
+    if (p.count != count) {                                    // the two ends disagree on the schedule
+      fprintf(stderr, "pastix_amd[rank %d]: receive from rank %d expects %lld doubles, the matching send has %lld\n", me,
+              peer, (long long)count, (long long)p.count);
+      return PASTIX_AMD_ERR_LAYOUT;
+    }
     HIPCHK(hipStreamWaitEvent(s, p.ev, 0));
     HIPCHK(hipMemcpyAsync(buf, p.ptr, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, s));
     return 0;
@@ -278,6 +351,12 @@ struct pastix_amd_dist_s {
   double* dXs = nullptr;                    // solve: the rank's copy of the vector
   double* dSolveStage = nullptr;            // solve: received segments (forward sweep)
   std::vector<int64_t> solve_stage_off;     // per message: offset in dSolveStage (receive messages)
+  // progress marks of the run in flight: one event behind every (level, peer) group on its channel stream and one
+  // behind every level on the panel stream -- what the deadline handler reads to say where a rank is stuck
+  struct Mark { hipEvent_t ev; int level, peer; size_t m0, m1; };
+  std::vector<Mark> marks;
+  std::vector<std::pair<hipEvent_t, int>> level_marks;
+  bool failed = false;                      // a run was aborted: the channels are gone, later calls refuse
 };
 
 static void dist_free(pastix_amd_dist_s* D) {
@@ -321,6 +400,33 @@ static int dist_attach_common(pastix_amd_plan_t* p, int world, std::unique_ptr<T
 
 extern "C" {
 
+static int host_schedule(const pastix_amd_layout_t* layout, int factotype, int floattype, const int32_t* owner,
+                         int32_t myrank, int32_t world, DistSchedule& S) {
+  Plan P;
+  P.factotype = factotype;
+  P.floattype = floattype;
+  P.cblknbr = layout->cblknbr;
+  P.bloknbr = layout->bloknbr;
+  P.cblk.assign(layout->cblktab, layout->cblktab + layout->cblknbr + 1);
+  P.blok.assign(layout->bloktab, layout->bloktab + layout->bloknbr);
+  int rc = owner_view(layout, owner, myrank, P);
+  if (rc) return rc;
+  return build_schedule(P, world, S);
+}
+
+// What a rank expects of every channel, as two hashes per peer: [2q] over the blocks it SENDS to rank q, [2q+1] over the
+// blocks it RECEIVES from q, each over (level, cblk, nrows, width, planes) in channel order.  The two ends of a channel
+// agree iff rank a's [2b] equals rank b's [2a+1] and vice versa; compared at attach time (loopback: here; RCCL: by the
+// launcher over its bootstrap, dist.py) so that a disagreement is an error message, not a rendezvous that never ends.
+static void schedule_hashes(const DistSchedule& S, uint64_t* out) {
+  for (int q = 0; q < 2 * S.world; q++) out[q] = 14695981039346656037ull;
+  for (const DistMsg& m : S.msgs) {
+    uint64_t& h = out[2 * m.peer + (m.dir ? 1 : 0)];
+    fnv(h, (uint64_t)m.level); fnv(h, (uint64_t)m.cblk); fnv(h, (uint64_t)m.nrows); fnv(h, (uint64_t)m.width);
+    fnv(h, (uint64_t)S.nplanes);
+  }
+}
+
 // Host only: the fan-in messages of one rank, in the order both ends of every channel issue them.
 // out[i*6 .. i*6+5] = {level, peer, cblk, dir (0 send / 1 recv), nrows, width}; returns the count through *nmsg
 // (out may be NULL to size it; at most `cap` messages are written).  *nplanes = arenas per message.
@@ -330,17 +436,9 @@ int pastix_amd_dist_schedule(const pastix_amd_layout_t* layout, int factotype, i
   if (!layout || !owner || !nmsg || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1)
     return PASTIX_AMD_ERR_BADPARAMETER;
   try {
-    Plan P;
-    P.factotype = factotype;
-    P.floattype = floattype;
-    P.cblknbr = layout->cblknbr;
-    P.bloknbr = layout->bloknbr;
-    P.cblk.assign(layout->cblktab, layout->cblktab + layout->cblknbr + 1);
-    P.blok.assign(layout->bloktab, layout->bloktab + layout->bloknbr);
-    int rc = owner_view(layout, owner, myrank, P);
-    if (rc) return rc;
     DistSchedule S;
-    if ((rc = build_schedule(P, world, S))) return rc;
+    int rc = host_schedule(layout, factotype, floattype, owner, myrank, world, S);
+    if (rc) return rc;
     *nmsg = (pastix_amd_int_t)S.msgs.size();
     if (nplanes) *nplanes = S.nplanes;
     if (out)
@@ -349,6 +447,21 @@ int pastix_amd_dist_schedule(const pastix_amd_layout_t* layout, int factotype, i
         pastix_amd_int_t* o = out + 6 * i;
         o[0] = m.level; o[1] = m.peer; o[2] = m.cblk; o[3] = m.dir; o[4] = m.nrows; o[5] = m.width;
       }
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  return PASTIX_AMD_OK;
+}
+
+int pastix_amd_dist_schedule_hash(const pastix_amd_layout_t* layout, int factotype, int floattype, const int32_t* owner,
+                                  int32_t myrank, int32_t world, uint64_t* out) {
+  if (!layout || !owner || !out || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1 || world < 1)
+    return PASTIX_AMD_ERR_BADPARAMETER;
+  try {
+    DistSchedule S;
+    const int rc = host_schedule(layout, factotype, floattype, owner, myrank, world, S);
+    if (rc) return rc;
+    schedule_hashes(S, out);
   } catch (const std::bad_alloc&) {
     return PASTIX_AMD_ERR_ALLOC;
   }
@@ -435,6 +548,22 @@ int pastix_amd_dist_attach_local(pastix_amd_plan_t* const* plans, int32_t world)
   if (!plans || world < 2) return PASTIX_AMD_ERR_BADPARAMETER;
   std::shared_ptr<LocalHub> hub;
   try { hub = std::make_shared<LocalHub>(); } catch (const std::bad_alloc&) { return PASTIX_AMD_ERR_ALLOC; }
+  {
+    std::vector<uint64_t> hs((size_t)world * 2 * (size_t)world);
+    for (int r = 0; r < world; r++) {
+      if (!plans[r] || !plans[r]->distributed || plans[r]->host.myrank != r) return PASTIX_AMD_ERR_BADPARAMETER;
+      DistSchedule S;
+      const int rc = build_schedule(plans[r]->host, world, S);
+      if (rc) return rc;
+      schedule_hashes(S, hs.data() + (size_t)r * 2 * world);
+    }
+    for (int a = 0; a < world; a++)
+      for (int b = 0; b < world; b++)
+        if (a != b && hs[(size_t)a * 2 * world + 2 * b] != hs[(size_t)b * 2 * world + 2 * a + 1]) {
+          fprintf(stderr, "pastix_amd: ranks %d and %d disagree on the fan-in blocks %d sends to %d\n", a, b, a, b);
+          return PASTIX_AMD_ERR_LAYOUT;
+        }
+  }
   for (int r = 0; r < world; r++) {
     pastix_amd_plan_t* p = plans[r];
     if (!p || !p->distributed || p->host.myrank != r) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -471,17 +600,88 @@ int pastix_amd_dist_info(const pastix_amd_plan_t* p, pastix_amd_dist_info_t* inf
   return PASTIX_AMD_OK;
 }
 
+// ---- the end of a distributed run: wait with a deadline, or give up cleanly ---------------------------------------
+// `fin`: an event behind everything the run enqueued (recorded on the panel stream after every channel and the second
+// stream joined it); enqueue_rc: what the enqueueing loop returned.  Success: fin reached within the deadline.  Otherwise
+// -- an error while enqueueing, a HIP error, or the deadline -- the rank says where its streams stand (first unmatched
+// group per channel, last level the panel stream finished), ABORTS its channels (ncclCommAbort: operations peers have
+// already enqueued against this rank fail instead of spinning), drains its streams and marks the plan's distributed
+// state failed.  A one-rank failure thus becomes an error code on every rank within the deadline, not a job-wide hang.
+static int dist_finish(pastix_amd_plan_t* p, int enqueue_rc, hipEvent_t fin, const char* what) {
+  pastix_amd_dist_s* D = p->dist;
+  const DistSchedule& S = D->S;
+  int rc = enqueue_rc;
+  bool timed_out = false;
+  if (!rc) {
+    const double t0 = now_s(), limit = dist_timeout_s();
+    for (;;) {
+      const hipError_t e = hipEventQuery(fin);
+      if (e == hipSuccess) return PASTIX_AMD_OK;
+      if (e != hipErrorNotReady) {
+        fprintf(stderr, "pastix_amd[rank %d]: %s: HIP error '%s' while waiting\n", S.myrank, what, hipGetErrorString(e));
+        rc = PASTIX_AMD_ERR_DEVICE;
+        break;
+      }
+      if (now_s() - t0 > limit) { timed_out = true; rc = PASTIX_AMD_ERR_TIMEOUT; break; }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+  if (timed_out) {
+    int last_level = -1;
+    for (auto& lm : D->level_marks) {
+      if (hipEventQuery(lm.first) != hipSuccess) break;
+      last_level = lm.second;
+    }
+    fprintf(stderr, "pastix_amd[rank %d]: %s did not finish within %.0f s (PASTIX_AMD_DIST_TIMEOUT); panel stream finished "
+            "level %d of %d\n", S.myrank, what, dist_timeout_s(), last_level, p->host.nlevels);
+    std::map<int, bool> seen;
+    for (auto& mk : D->marks) {
+      if (seen[mk.peer]) continue;
+      if (hipEventQuery(mk.ev) == hipSuccess) continue;
+      seen[mk.peer] = true;
+      const DistMsg& m = S.msgs[mk.m0];
+      fprintf(stderr, "pastix_amd[rank %d]:   channel to rank %d: first unmatched group at level %d (%zu blocks), first block: "
+              "cblk %d, %s, %lld x %lld x %d planes\n", S.myrank, mk.peer, mk.level, mk.m1 - mk.m0, m.cblk,
+              m.dir == 0 ? "send" : "receive", (long long)m.nrows, (long long)m.width, S.nplanes);
+    }
+    if (seen.empty()) fprintf(stderr, "pastix_amd[rank %d]:   every channel group completed: the compute streams are stuck\n", S.myrank);
+  } else {
+    fprintf(stderr, "pastix_amd[rank %d]: %s failed (code %d) with work in flight: aborting the channels\n", S.myrank, what, rc);
+  }
+  D->failed = true;
+  D->T->abort();
+  // drain what is left (bounded: a stream that survives the abort is left to process exit)
+  std::vector<hipStream_t> ss{p->stream, p->stream2};
+  for (auto& c : D->chan) ss.push_back(c.second);
+  const double t1 = now_s();
+  for (hipStream_t st : ss) {
+    if (!st) continue;
+    while (hipStreamQuery(st) == hipErrorNotReady && now_s() - t1 < 10.0)
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  (void)hipGetLastError();
+  p->factored = false;
+  return rc;
+}
+
 // The numerical factorization of this rank's share (the device replacement of sopalin_smp + the communication thread,
-// sopalin3d.c:790-1025, sopalin_sendrecv.c:2393-2775).  Everything is enqueued; the host waits only at the end.
+// sopalin3d.c:790-1025, sopalin_sendrecv.c:2393-2775).  Everything is enqueued; the host waits only at the end, with a
+// deadline (dist_finish).
 int pastix_amd_factorize_dist(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p || !p->distributed || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
   pastix_amd_dist_s* D = p->dist;
+  if (D->failed) {
+    fprintf(stderr, "pastix_amd[rank %d]: the channels of this plan were aborted by an earlier failure\n", D->S.myrank);
+    return PASTIX_AMD_ERR_BADPARAMETER;
+  }
   const DistSchedule& S = D->S;
   const Plan& H = p->host;
   int rc = pastix_amd_factorize_begin(p, critere);
   if (rc) return rc;
   hipStream_t s1 = p->stream;
   D->nev_used = 0;
+  D->marks.clear();
+  D->level_marks.clear();
   auto new_event = [&](hipEvent_t* out) -> int {
     if (D->nev_used == D->events.size()) {
       hipEvent_t e;
@@ -492,65 +692,85 @@ int pastix_amd_factorize_dist(pastix_amd_plan_t* p, double critere, pastix_amd_s
     return 0;
   };
   double* const arena[4] = {p->dL, p->dU, p->dLi, p->dUi};
-  size_t mi = 0;
-  const size_t nm = S.msgs.size();
-  for (int l = 0; l < H.nlevels; l++) {
-    if ((rc = pastix_amd_factorize_level(p, l, 1))) return rc;            // A(l) on the panel stream, B(l) beside it
-    const size_t m0 = mi;
-    while (mi < nm && S.msgs[mi].level == l) mi++;
-    if (mi > m0) {
-      bool any_send = false;
-      for (size_t i = m0; i < mi; i++) any_send |= S.msgs[i].dir == 0;
-      hipEvent_t evA = nullptr;
-      if (any_send) {
-        if ((rc = new_event(&evA))) return rc;
-        HIPCHK(hipEventRecord(evA, s1));                                    // this rank's blocks for level l are complete
-      }
-      for (size_t g0 = m0; g0 < mi;) {                                      // one group per peer
-        size_t g1 = g0;
-        const int peer = S.msgs[g0].peer;
-        bool gs = false, gr = false;
-        while (g1 < mi && S.msgs[g1].peer == peer) { (S.msgs[g1].dir == 0 ? gs : gr) = true; g1++; }
-        hipStream_t cs = D->chan[peer];
-        if (gs) HIPCHK(hipStreamWaitEvent(cs, evA, 0));
-        if ((rc = D->T->group_begin(peer))) return rc;
-        for (size_t i = g0; i < g1; i++) {
-          const DistMsg& m = S.msgs[i];
-          const int64_t cnt = m.nrows * m.width;
-          for (int q = 0; q < S.nplanes; q++) {
-            if (m.dir == 0) rc = D->T->send(peer, arena[S.planes[q]] + m.off, cnt, cs);
-            else rc = D->T->recv(peer, D->dStage + m.off + q * cnt, cnt, cs);
-            if (rc) { (void)D->T->group_end(peer); return rc; }
+  hipEvent_t fin = nullptr;
+  auto enqueue = [&]() -> int {
+    int rc = 0;
+    size_t mi = 0;
+    const size_t nm = S.msgs.size();
+    for (int l = 0; l < H.nlevels; l++) {
+      if ((rc = pastix_amd_factorize_level(p, l, 1))) return rc;            // A(l) on the panel stream, B(l) beside it
+      const size_t m0 = mi;
+      while (mi < nm && S.msgs[mi].level == l) mi++;
+      if (mi > m0) {
+        bool any_send = false;
+        for (size_t i = m0; i < mi; i++) any_send |= S.msgs[i].dir == 0;
+        hipEvent_t evA = nullptr;
+        if (any_send) {
+          if ((rc = new_event(&evA))) return rc;
+          HIPCHK(hipEventRecord(evA, s1));                                    // this rank's blocks for level l are complete
+        }
+        for (size_t g0 = m0; g0 < mi;) {                                      // one group per peer
+          size_t g1 = g0;
+          const int peer = S.msgs[g0].peer;
+          bool gs = false, gr = false;
+          while (g1 < mi && S.msgs[g1].peer == peer) { (S.msgs[g1].dir == 0 ? gs : gr) = true; g1++; }
+          hipStream_t cs = D->chan[peer];
+          if (gs) HIPCHK(hipStreamWaitEvent(cs, evA, 0));
+          if ((rc = D->T->group_begin(peer))) return rc;
+          for (size_t i = g0; i < g1; i++) {
+            const DistMsg& m = S.msgs[i];
+            const int64_t cnt = m.nrows * m.width;
+            for (int q = 0; q < S.nplanes; q++) {
+              if (m.dir == 0) rc = D->T->send(peer, arena[S.planes[q]] + m.off, cnt, cs);
+              else rc = D->T->recv(peer, D->dStage + m.off + q * cnt, cnt, cs);
+              if (rc) { (void)D->T->group_end(peer); return rc; }
+            }
           }
-        }
-        if ((rc = D->T->group_end(peer))) return rc;
-        if (gr) {
-          hipEvent_t evC;
-          if ((rc = new_event(&evC))) return rc;
+          if ((rc = D->T->group_end(peer))) return rc;
+          hipEvent_t evC;                                                     // progress mark of the group; receives:
+          if ((rc = new_event(&evC))) return rc;                              // what the panel stream waits for
           HIPCHK(hipEventRecord(evC, cs));
-          HIPCHK(hipStreamWaitEvent(s1, evC, 0));                           // the panel stream needs these blocks now
+          D->marks.push_back({evC, l, peer, g0, g1});
+          if (gr) HIPCHK(hipStreamWaitEvent(s1, evC, 0));                     // the panel stream needs these blocks now
+          g0 = g1;
         }
-        g0 = g1;
+        // recv_handle_fanin (sopalin_sendrecv.c:384-404): the owner ADDS the aggregated blocks, in a fixed order
+        for (size_t i = m0; i < mi; i++) {
+          const DistMsg& m = S.msgs[i];
+          if (m.dir != 1) continue;
+          const int64_t cnt = m.nrows * m.width;
+          for (int q = 0; q < S.nplanes; q++)
+            launch_fanin_add(s1, arena[S.planes[q]] + H.poff[m.cblk], H.cblk[m.cblk].stride, D->dStage + m.off + q * cnt,
+                             D->dRows + m.rows_off, m.nrows, m.width);
+        }
       }
-      // recv_handle_fanin (sopalin_sendrecv.c:384-404): the owner ADDS the aggregated blocks, in a fixed order
-      for (size_t i = m0; i < mi; i++) {
-        const DistMsg& m = S.msgs[i];
-        if (m.dir != 1) continue;
-        const int64_t cnt = m.nrows * m.width;
-        for (int q = 0; q < S.nplanes; q++)
-          launch_fanin_add(s1, arena[S.planes[q]] + H.poff[m.cblk], H.cblk[m.cblk].stride, D->dStage + m.off + q * cnt,
-                           D->dRows + m.rows_off, m.nrows, m.width);
+      if ((rc = pastix_amd_factorize_level(p, l, 2))) return rc;            // P(l)
+      if (mi > m0 || l + 1 == H.nlevels) {                                  // (a mark behind the levels that exchange)
+        hipEvent_t evL;
+        if ((rc = new_event(&evL))) return rc;
+        HIPCHK(hipEventRecord(evL, s1));
+        D->level_marks.emplace_back(evL, l);
       }
     }
-    if ((rc = pastix_amd_factorize_level(p, l, 2))) return rc;            // P(l)
-  }
-  // the channels join the panel stream: every send has left before the caller may zero the fan-in buffers again
-  for (auto& c : D->chan) {
-    hipEvent_t e;
-    if ((rc = new_event(&e))) return rc;
-    HIPCHK(hipEventRecord(e, c.second));
-    HIPCHK(hipStreamWaitEvent(s1, e, 0));
-  }
+    // the channels join the panel stream: every send has left before the caller may zero the fan-in buffers again
+    for (auto& c : D->chan) {
+      hipEvent_t e;
+      if ((rc = new_event(&e))) return rc;
+      HIPCHK(hipEventRecord(e, c.second));
+      HIPCHK(hipStreamWaitEvent(s1, e, 0));
+    }
+    if (p->staged_overlap && p->stream2) {                                  // ... and so does the second stream
+      hipEvent_t e;
+      if ((rc = new_event(&e))) return rc;
+      HIPCHK(hipEventRecord(e, p->stream2));
+      HIPCHK(hipStreamWaitEvent(s1, e, 0));
+    }
+    if ((rc = new_event(&fin))) return rc;
+    HIPCHK(hipEventRecord(fin, s1));
+    return 0;
+  };
+  rc = enqueue();
+  if ((rc = dist_finish(p, rc, fin, "pastix_amd_factorize_dist"))) return rc;
   return pastix_amd_factorize_end(p, stats);
 }
 
@@ -576,7 +796,7 @@ extern "C" {
 int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
   if (!p || !x || !p->distributed || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
-  if (!p->factored) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (!p->factored || p->dist->failed) return PASTIX_AMD_ERR_BADPARAMETER;
   pastix_amd_dist_s* D = p->dist;
   const DistSchedule& S = D->S;
   const Plan& H = p->host;
@@ -592,7 +812,7 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
       if (S.msgs[i].dir == 1) { D->solve_stage_off[i] = off; off += S.msgs[i].width; }
     HIPCHK(hipMalloc((void**)&D->dSolveStage, (size_t)std::max<int64_t>(off, 1) * sizeof(double)));
   }
-  // the rank's view of b: own columns only
+  // the rank's view of b: own columns only.  (hx outlives every copy: dist_finish drains the streams on every path)
   std::vector<double> hx((size_t)n, 0.0);
   for (int64_t k = 0; k < H.cblknbr; k++)
     if (H.role[k] == 1)
@@ -600,8 +820,9 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
                   (size_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1) * sizeof(double));
   hipStream_t s1 = p->stream;
   double* dx = D->dXs;
-  HIPCHK(hipMemcpyAsync(dx, hx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s1));
   D->nev_used = 0;
+  D->marks.clear();
+  D->level_marks.clear();
   auto new_event = [&](hipEvent_t* out) -> int {
     if (D->nev_used == D->events.size()) {
       hipEvent_t e;
@@ -635,12 +856,11 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
         if (r) { (void)D->T->group_end(peer); return r; }
       }
       if ((r = D->T->group_end(peer))) return r;
-      if (gr) {
-        hipEvent_t evC;
-        if ((r = new_event(&evC))) return r;
-        HIPCHK(hipEventRecord(evC, cs));
-        HIPCHK(hipStreamWaitEvent(s1, evC, 0));
-      }
+      hipEvent_t evC;
+      if ((r = new_event(&evC))) return r;
+      HIPCHK(hipEventRecord(evC, cs));
+      D->marks.push_back({evC, l, peer, g0, g1});
+      if (gr) HIPCHK(hipStreamWaitEvent(s1, evC, 0));
       g0 = g1;
     }
     if (fwd)
@@ -650,7 +870,6 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
         hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((m.width + 255) / 256)), dim3(256), 0, s1,
                            dx + H.cblk[m.cblk].fcolnum, D->dSolveStage + D->solve_stage_off[i], m.width);
       }
-    (void)l;
     return 0;
   };
   std::vector<size_t> lvl_m((size_t)H.nlevels + 1, S.msgs.size());
@@ -662,22 +881,32 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
     }
     lvl_m[(size_t)H.nlevels] = mi;
   }
-  for (int l = 0; l < H.nlevels; l++) {
-    if ((rc = exchange(l, true, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
-    pai_solve_level(p, true, l, dx, 1);
-  }
-  if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, 1);
-  for (int l = H.nlevels - 1; l >= 0; l--) {
-    pai_solve_level(p, false, l, dx, 1);
-    if ((rc = exchange(l, false, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
-  }
-  for (auto& c : D->chan) {                               // sends of the last levels have left
-    hipEvent_t e;
-    if ((rc = new_event(&e))) return rc;
-    HIPCHK(hipEventRecord(e, c.second));
-    HIPCHK(hipStreamWaitEvent(s1, e, 0));
-  }
-  HIPCHK(hipMemcpyAsync(hx.data(), dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s1));
+  hipEvent_t fin = nullptr;
+  auto enqueue = [&]() -> int {
+    int rc = 0;
+    HIPCHK(hipMemcpyAsync(dx, hx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s1));
+    for (int l = 0; l < H.nlevels; l++) {
+      if ((rc = exchange(l, true, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
+      pai_solve_level(p, true, l, dx, 1);
+    }
+    if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, 1);
+    for (int l = H.nlevels - 1; l >= 0; l--) {
+      pai_solve_level(p, false, l, dx, 1);
+      if ((rc = exchange(l, false, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
+    }
+    for (auto& c : D->chan) {                               // sends of the last levels have left
+      hipEvent_t e;
+      if ((rc = new_event(&e))) return rc;
+      HIPCHK(hipEventRecord(e, c.second));
+      HIPCHK(hipStreamWaitEvent(s1, e, 0));
+    }
+    HIPCHK(hipMemcpyAsync(hx.data(), dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s1));
+    if ((rc = new_event(&fin))) return rc;
+    HIPCHK(hipEventRecord(fin, s1));
+    return 0;
+  };
+  rc = enqueue();
+  if ((rc = dist_finish(p, rc, fin, "pastix_amd_solve_dist"))) { p->factored = true; return rc; }
   HIPCHK(hipStreamSynchronize(s1));
   HIPCHK(hipGetLastError());
   std::memset(x, 0, (size_t)n * sizeof(double));

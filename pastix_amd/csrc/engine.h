@@ -47,8 +47,7 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw,
-                        int part = 3);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -66,6 +65,12 @@ struct SplitMap {
   std::vector<int64_t> owidth, ostride, ooff;    // original width, stride, offset in the packed original arena
   std::vector<pastix_amd_cblk_t> cblk;           // the split layout
   std::vector<pastix_amd_blok_t> blok;
+  // LLt / LDLt: the blocks of a re-cut cblk's diagonal blok ABOVE its column groups are not part of the factor and not on
+  // the device; the reference's buffers carry the input values there from fill to return (compute_diag.c:124-203 never
+  // touches the strict upper triangle), so they are kept here: per re-cut cblk the diagonal blok as a dense ow x ow
+  // array (ld ow; complex: interleaved), of which only those blocks are used -- recorded by the fills / uploads, written
+  // back by the downloads.
+  std::vector<std::vector<double>> upper;        // [ocblknbr], empty for cblks that are not re-cut
 };
 
 struct pastix_amd_dist_s;            // dist.cpp: fan-in schedule, channels, transport
@@ -80,8 +85,6 @@ struct pastix_amd_plan_s {
   double fillBaseL = 0.0, fillBaseU = 0.0;   // value every panel entry starts from in pastix_amd_refill (0; 1 / 2 after
                                              // pastix_amd_fill_fake)
   bool launch_events = true;          // per-launch timing events recorded (api.cpp, mode-1 driver)
-  hipStream_t stream3 = nullptr;      // third: bulk launches of odd slots (tails of short launches overlap, api.cpp)
-  hipEvent_t evJoin = nullptr;
   std::vector<hipEvent_t> evP, evB;   // per level: panels done (stream), bulk contributions done (stream2)
   std::vector<hipEvent_t> evT;        // timing pairs of the bulk launches
   int nupdB_run = 0;
@@ -116,7 +119,6 @@ struct pastix_amd_plan_s {
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
   std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
-  std::vector<int64_t> lvl_chunk_far, lvl_chunkB_far;   // per level: where the chunks facing only levels > l+1 begin
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -1,6 +1,7 @@
 // kernels.hip -- gfx950 (MI355X / CDNA4) device kernels of the sopalin numerical factorization.
 //
-// Three kernels replace the reference's per-cblk CPU step compute_1d (sopalin_compute.c:747-863):
+// Three kernels replace the reference's per-cblk CPU step compute_1d (sopalin_compute.c:747-863); k_diag and k_trsm
+// (real LLt; LDLt's diagonal kernel) and the triangular solves are in this file, k_update in kernels_update.hip:
 //   k_diag   : factor_diag  (compute_diag.c:538-605)  blocked LLt of the w x w diagonal blok with the
 //              static-pivot clamp (compute_diag.c:133-137), plus the 16x16 diagonal-block inverses
 //              the panel solve uses;
@@ -34,529 +35,6 @@ namespace pastix_amd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-
-// ------------------------------------------------------------------------------------------------
-// k_update
-// ------------------------------------------------------------------------------------------------
-constexpr int KC = 16;        // k-chunk staged per barrier
-constexpr int SLD = 144;      // LDS line length in doubles: 128 rows + 16 pad -> lanes 16-31 of a
-                              // ds_read_b64 land on banks 32-63 (conflict-free, MI355X_MICROARCH LDS)
-
-// NW waves per workgroup share one 128x128 target tile: NW=4 -> 2x2 waves of 64x64 (16 MFMA tiles per
-// wave), NW=8 -> 4x2 waves of 32x64 (8 MFMA tiles per wave, 4 waves per SIMD at 2 workgroups per CU).
-
-// Epilogue variant for tiles that several workgroups update in the same launch (split piece lists of
-// the multi-GPU fan-in schedule): accumulate with f64 atomics instead of an exclusive read-modify-write.
-template <int MI, int NI>
-__device__ __forceinline__ void epilogue_atomic(double* C, const d4 (&acc)[MI][NI], unsigned touched, int row0,
-                                                int col0, int RS, int CS, int l15, int g, int tm1, int tn1, int ldc) {
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++) {
-    if (!((touched >> mi) & 1u)) continue;
-    const int r = row0 + mi * RS + l15;
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-      if (!((touched >> (4 + ni)) & 1u)) continue;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = col0 + ni * CS + g + 4 * q;
-        if (r <= tm1 && c <= tn1) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -acc[mi][ni][q]);
-      }
-    }
-  }
-}
-
-
-// 1 KiB of zeros: the DMA source of k-lines beyond a piece's K (the last chunk of a piece with K % 16 != 0)
-__device__ double g_zero_line[128];
-
-// LDS-DMA helper: one wave-instruction copies 64 lanes x 16 B = one 128-row k-line straight into LDS (no VGPRs).
-#define PASTIX_AMD_GLDS(gptr, lptr)                                                              \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// The same through inline assembly (the 4-stage experiment): the compiler neither models these loads' LDS writes (it
-// puts a vmcnt(0) in front of every LDS read that may alias an LDS-DMA it knows of) nor forces vmcnt(0) in front of the
-// barrier, so several stages can stay in flight across barriers; ordering is by the explicit counts below.
-#define PASTIX_AMD_GLDS_ASM(gptr, lptr)                                                                       \
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off"                                          \
-               :: "v"(gptr), "s"((unsigned)(size_t)(__attribute__((address_space(3))) void*)(lptr)) : "memory")
-#define PASTIX_AMD_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// A Piece fetched with dword loads only (two 16-byte loads, scalar when the address is wave-uniform): the 16-bit
-// fields read one by one compile to global_load_ushort -- vector loads whose vmcnt wait would drain the LDS-DMA stages
-// that are supposed to stay in flight across a piece switch.
-struct PieceW { int64_t a_off, b_off; int lda, k, flags; };
-__device__ __forceinline__ PieceW load_piece_w(const Piece* __restrict__ pp) {
-  const uint4 lo = ((const uint4*)pp)[0], hi = ((const uint4*)pp)[1];
-  PieceW w;
-  w.a_off = (int64_t)(((uint64_t)lo.y << 32) | lo.x);
-  w.b_off = (int64_t)(((uint64_t)lo.w << 32) | lo.z);
-  w.lda = (int)hi.x;
-  w.k = (int)(hi.y & 0xffffu);
-  w.flags = (int)(hi.w >> 16);
-  return w;
-}
-
-// KIND 0: the bulk launches.  KIND 1 (`k_update_urgent` in profiles): the same code for the few latency-critical
-// tasks of a level that the two-stream driver runs beside the bulk launch of the previous slot; a separate
-// instantiation so that per-kernel profiles of the two do not mix.
-template <int NW, int KIND>
-__global__ __launch_bounds__(64 * NW, NW / 2) void k_update(const Arenas ar,
-                                                           const Task* __restrict__ tasks,
-                                                           const Piece* __restrict__ pieces) {
-  constexpr int WRN = NW / 2;                   // wave grid: WRN rows x 2 cols
-  constexpr int MI = 8 / WRN;                   // 16-row sub-tiles per wave (4 or 2)
-  constexpr int NI = 4;                         // 16-col sub-tiles per wave
-  constexpr unsigned MALL = (1u << MI) - 1u;
-  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
-#ifdef PASTIX_AMD_DESYNC_BIT
-  if ((blockIdx.x >> PASTIX_AMD_DESYNC_BIT) & 1) { __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); __builtin_amdgcn_s_sleep(PASTIX_AMD_DESYNC_SLEEP); }
-#endif
-  if (KIND == 1) PANEL_PRIO();
-  const Task tk = tasks[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;      // this wave: rows wr*16*MI.., cols wc*64..
-  const int l15 = lane & 15, g = lane >> 4;
-  // cyclic sub-tile ownership: wave (wr, wc) owns the 16-row bands wr, wr + WRN, ... and the 16-col bands
-  // wc, wc + 2, ...: a piece that covers only part of the tile still spreads over all waves
-  constexpr int RS = 16 * WRN, CS = 32;          // distance between a wave's consecutive row / col bands
-  const int row0 = wr * 16, col0 = wc * 16;
-
-  d4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) acc[mi][ni] = d4{0, 0, 0, 0};
-
-  unsigned touched = 0;                         // union of active (mi | ni<<4) masks
-  {
-    // One software-pipelined LDS-DMA loop for every kind of piece, three instantiations (MODE):
-    //   0  whole-tile pieces of a full 128 x 128 tile: branch-free;
-    //   1  whole-tile pieces of a smaller valid tile (last row tile of a panel, target cblks narrower than 128
-    //      columns): lane and band masks fixed per task;
-    //   2  partial pieces (any rectangle [dr, dr+m) x [dc, dc+n) of the tile): lane masks, band masks and the operand
-    //      shift are recomputed per piece (every K / 16 chunks), the stray element a 16-byte DMA lane drags in at an
-    //      odd piece boundary is zeroed in LDS before anything reads it.
-    auto fast_loop = [&](auto mode_c, auto neg_c, const int pbeg, const int pend) {
-    constexpr int MODE = decltype(mode_c)::value;
-    constexpr bool FULLT = MODE == 0;
-    constexpr bool PART = MODE == 2;
-    constexpr bool NEG = decltype(neg_c)::value;   // the task has "+=" pieces (complex cross terms): sign flips compiled in
-    // (wave-uniform copy: the k-line tests and the per-wave operand offsets go to the scalar unit.  Not row0 / col0:
-    // with scalar band masks the edge-tile variant branches per MFMA and the kernel spills)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ---- leading full pieces, LDS-DMA version: every wave copies KC/NW k-lines of A and of B per chunk with
-    // global_load_lds_dwordx4 (no staging registers, no ds_write), the MFMA operands are double-buffered in
-    // registers so that the ds_reads of k-step s+1 are in flight under the MFMAs of k-step s, and the chunk
-    // barrier sits in front of the LAST k-step's MFMAs (operands already in registers), so no wave leaves
-    // the barrier without matrix work.  Order: DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+barrier |
-    // read (i+1, ks0) | MFMA ks3.  RAW: own vmcnt(0), then the barrier, then the read.  WAR: buffer i is
-    // re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired.
-    constexpr int NL = KC / NW;                    // k-lines per wave per operand per chunk
-    int pi = pbeg;
-    Piece cur = pieces[pi];
-    Piece nextp = pieces[min(pi + 1, pend - 1)];
-    int64_t lda = cur.lda;
-    // (wave-uniform pointers: the address arithmetic of the DMA stays on the scalar unit, the lane's 16 bytes are the
-    // vector offset of the load).  Partial pieces: tile row r holds source row r - dr, so the pointers are shifted by
-    // -dr / -dc; lanes wholly outside the piece copy the zero line instead and never use them.
-    const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
-    const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
-    const int lo2 = 2 * lane;
-    int left = ((int)cur.k + KC - 1) / KC;
-    int krem = (int)cur.k;                          // k-lines of the piece not yet issued
-    bool negn = (cur.flags & 16) != 0, negc = negn;
-    const double* zl = g_zero_line;
-    // These pieces cover the whole VALID tile: tm x tn, smaller than 128 x 128 only for the last row tile of a panel
-    // and for target cblks narrower than 128 columns.  Lanes beyond tm / tn copy the zero line; with an odd tm
-    // (tn) the last lane brings one element of the next panel row along, which only reaches accumulator rows
-    // (columns) the epilogue never stores.  Bands beyond the valid tile are skipped on the MFMA pipe.
-    bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
-    unsigned amt = 0, ant = 0;                     // bands of the chunk in the MFMA section
-    unsigned amn = 0, ann = 0;                     // ... of the chunk being copied (PART: they change with the piece)
-    int fixn = -1;                                 // PART: LDS element (relative to the A image of a buffer) this lane zeroes
-    // per-piece set-up of a partial piece: lanes 2l, 2l+1 of a k-line intersect the piece; 16-row / 16-col bands it
-    // touches; stray elements: a lane that straddles an odd boundary brings the source row next to the piece along
-    // (lanes 0-15 / 16-31 / 32-47 / 48-63 look after the rows dr-1, dr+m of A and dc-1, dc+n of B, one k-line each)
-    auto piece_setup = [&](const Piece& pc) {
-      const int dr = pc.dr, re = (int)pc.dr + (int)pc.m, dc = pc.dc, ce = (int)pc.dc + (int)pc.n;
-      la = lo2 + 1 >= dr && lo2 < re;
-      lb = lo2 + 1 >= dc && lo2 < ce;
-      amn = 0;
-      ann = 0;
-#pragma unroll
-      for (int s = 0; s < MI; s++) if (row0 + s * RS < re && row0 + s * RS + 16 > dr) amn |= 1u << s;
-#pragma unroll
-      for (int s = 0; s < NI; s++) if (col0 + s * CS < ce && col0 + s * CS + 16 > dc) ann |= 1u << s;
-      const int j = lane >> 4;
-      const int e = j == 0 ? dr - 1 : j == 1 ? re : j == 2 ? dc - 1 : ce;      // the row next to the boundary
-      const bool odd = (j == 0 || j == 2) ? (e & 1) == 0 && e >= 0 : (e & 1) != 0 && e < 128;   // shares a lane with a piece row
-      fixn = odd ? (j >= 2 ? KC * SLD : 0) + (lane & 15) * SLD + e : -1;
-      touched |= amn | (ann << 4);
-    };
-    if (PART) {
-      piece_setup(cur);
-    } else {
-#pragma unroll
-      for (int s = 0; s < MI; s++) if (row0 + s * RS < (int)tk.tm) amn |= 1u << s;
-#pragma unroll
-      for (int s = 0; s < NI; s++) if (col0 + s * CS < (int)tk.tn) ann |= 1u << s;
-      touched |= amn | (ann << 4);
-    }
-    amt = amn;
-    ant = ann;
-    int fixc = fixn;
-    bool allb = FULLT || (amt == MALL && ant == 0xFu);
-#pragma unroll
-    for (int q = 0; q < NL; q++) {
-      const bool kv = wave + NW * q < krem;        // wave-uniform
-      PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, sh[0][0] + (wave + NW * q) * SLD);
-      PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * NW * lda : zl) + lo2, sh[0][1] + (wave + NW * q) * SLD);
-    }
-    krem -= KC;
-    const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
-    const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
-    double bm0[MI], an0[NI], bm1[MI], an1[NI];
-    __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
-    if (PART && fixc >= 0) sh[0][0][fixc] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
-#pragma unroll
-    for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
-#pragma unroll
-    for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
-    int buf = 0;
-    while (true) {
-      bool has_next = true;
-      negc = negn;
-      if (PART) { amt = amn; ant = ann; fixc = fixn; allb = amt == MALL && ant == 0xFu; }
-      if (--left == 0) {
-        if (++pi < pend) {
-          cur = nextp;
-          lda = cur.lda;
-          pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
-          pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
-          left = ((int)cur.k + KC - 1) / KC;
-          krem = (int)cur.k;
-          negn = (cur.flags & 16) != 0;
-          nextp = pieces[min(pi + 1, pend - 1)];
-          if (PART) piece_setup(cur);
-        } else {
-          has_next = false;
-        }
-      } else {
-        pa += (int64_t)KC * lda;
-        pb += (int64_t)KC * lda;
-      }
-#ifndef EXP_NO_DMA   /* EXP_*: timing-only ablation switches of tools/bench_update (results are wrong with them) */
-      if (has_next) {
-        double* dA = sh[buf ^ 1][0] + wave * SLD;
-        double* dB = sh[buf ^ 1][1] + wave * SLD;
-#pragma unroll
-        for (int q = 0; q < NL; q++) {
-          const bool kv = wave + NW * q < krem;
-#if defined(EXP_DMA_ZERO)
-          PASTIX_AMD_GLDS(zl + lo2, dA + NW * q * SLD);
-          PASTIX_AMD_GLDS(zl + lo2, dB + NW * q * SLD);
-#elif defined(EXP_DMA_HALF)
-          PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, dA + NW * q * SLD);
-#else
-          if (FULLT) {                     // kv is wave-uniform: a scalar branch instead of 64-bit vector selects
-            if (kv) {
-              PASTIX_AMD_GLDS(pa + (int64_t)q * NW * lda + lo2, dA + NW * q * SLD);
-              PASTIX_AMD_GLDS(pb + (int64_t)q * NW * lda + lo2, dB + NW * q * SLD);
-            } else {
-              PASTIX_AMD_GLDS(zl + lo2, dA + NW * q * SLD);
-              PASTIX_AMD_GLDS(zl + lo2, dB + NW * q * SLD);
-            }
-          } else {
-            PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * NW * lda : zl) + lo2, dA + NW * q * SLD);
-            PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * NW * lda : zl) + lo2, dB + NW * q * SLD);
-          }
-#endif
-        }
-        krem -= KC;
-      }
-#endif
-      const double* sA = sAw + buf * (2 * KC * SLD);
-      const double* sB = sBw + buf * (2 * KC * SLD);
-      if (NEG && negc) {
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
-      }
-      // ks0 (operands in *0), prefetch ks1 into *1
-#pragma unroll
-      for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
-#pragma unroll
-      for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
-      if (FULLT || allb) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            if ((amt >> mi) & (ant >> ni) & 1u)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
-      }
-      if (NEG && negc) {
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
-      }
-      // ks1, prefetch ks2 into *0
-#pragma unroll
-      for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
-#pragma unroll
-      for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
-      if (FULLT || allb) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            if ((amt >> mi) & (ant >> ni) & 1u)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
-      }
-      if (NEG && negc) {
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm0[s] = -bm0[s];
-      }
-      // ks2, prefetch ks3 into *1
-#pragma unroll
-      for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
-#pragma unroll
-      for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
-      if (FULLT || allb) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            if ((amt >> mi) & (ant >> ni) & 1u)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
-      }
-      if (NEG && negc) {
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm1[s] = -bm1[s];
-      }
-#ifndef EXP_NO_BARRIER
-      __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
-#endif
-      if (PART && has_next && fixn >= 0) sh[buf ^ 1][0][fixn] = 0.0;
-      {
-        // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
-        const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
-        const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
-#pragma unroll
-        for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
-#pragma unroll
-        for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
-      // ks3 from registers
-      if (FULLT || allb) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            if ((amt >> mi) & (ant >> ni) & 1u)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
-      }
-      if (!has_next) break;
-      buf ^= 1;
-    }
-    __syncthreads();         // the general loop below restarts on buffer 0
-    };
-    // instantiations: MODE x sign flips (Task flag bit 3, set by the plan; real factorizations never have them: 16
-    // vector instructions per chunk less).  The plan puts the whole-tile pieces of a task first (Task::nfull).
-#ifdef UPDATE_S4
-    // EXPERIMENT (compile with -DUPDATE_S4): the branch-free loop with FOUR 8-line LDS stages instead of two
-    // 16-line buffers (same 73.7 KB): the DMA of stage s+3 is issued at the start of stage s, i.e. three stages (1.5
-    // chunks) of lead instead of one chunk; a barrier every 8 lines; counted vmcnt instead of __syncthreads' vmcnt(0)
-    // (DMA and barrier through inline assembly, Piece fetched with scalar loads only -- see the macros above).  Correct
-    // (parity suite green, bitwise reproducible) and NOT faster: from cache 67.9 against 68.4 TFLOP/s, long tasks 70.7 /
-    // 71.5, operands from HBM 59.3 / 59.6, a replayed 160^3 launch 63.1 / 63.7.  The loss with HBM-fed operands is
-    // therefore not exposed latency that more lead could hide.
-    auto fast_loop4 = [&](const int pbeg, const int pend) {
-      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      constexpr int SK = 8;                                  // k-lines per stage
-      double* shs = &sh[0][0][0];                            // stage b: A image at b * 2*SK*SLD, B image + SK*SLD
-      auto stA = [&](int b) { return shs + b * (2 * SK * SLD); };
-      auto stB = [&](int b) { return shs + b * (2 * SK * SLD) + SK * SLD; };
-      int pi = pbeg;
-      PieceW cur = load_piece_w(pieces + pi);
-      PieceW nextp = load_piece_w(pieces + min(pi + 1, pend - 1));
-      int64_t lda = cur.lda;
-      const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-      const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
-      const int lo2 = 2 * lane;
-      int left = (cur.k + SK - 1) / SK;                 // stages left in the piece on the DMA side
-      int krem = cur.k;
-      const double* zl = g_zero_line;
-      bool more = true;                                      // the DMA cursor has not run off the piece list
-      int issued = 0, done = 0;                              // stages issued / computed
-      auto issue = [&](int b) {                              // DMA of the cursor's stage into stage buffer b, advance
-        if (wave < krem) {
-          PASTIX_AMD_GLDS_ASM(pa + lo2, stA(b) + wave * SLD);
-          PASTIX_AMD_GLDS_ASM(pb + lo2, stB(b) + wave * SLD);
-        } else {
-          PASTIX_AMD_GLDS_ASM(zl + lo2, stA(b) + wave * SLD);
-          PASTIX_AMD_GLDS_ASM(zl + lo2, stB(b) + wave * SLD);
-        }
-        krem -= SK;
-        issued++;
-        if (--left == 0) {
-          if (++pi < pend) {
-            cur = nextp;
-            lda = cur.lda;
-            pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-            pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
-            left = (cur.k + SK - 1) / SK;
-            krem = cur.k;
-            nextp = load_piece_w(pieces + min(pi + 1, pend - 1));
-          } else {
-            more = false;
-          }
-        } else {
-          pa += (int64_t)SK * lda;
-          pb += (int64_t)SK * lda;
-        }
-      };
-      touched |= MALL | (0xFu << 4);
-      issue(0);
-      if (more) issue(1);
-      if (more) issue(2);
-      // wait for stage 0: everything issued after it may stay in flight (2 DMA instructions per stage and wave)
-      if (issued == 3) PASTIX_AMD_WAIT_BARRIER(4);
-      else if (issued == 2) PASTIX_AMD_WAIT_BARRIER(2);
-      else PASTIX_AMD_WAIT_BARRIER(0);
-      __builtin_amdgcn_sched_barrier(0);
-      double bm0[MI], an0[NI], bm1[MI], an1[NI];
-      const int woffA = row0 + l15 + g * SLD, woffB = col0 + l15 + g * SLD;
-      {
-        const double* a0 = stA(0) + woffA; const double* b0 = stB(0) + woffB;
-#pragma unroll
-        for (int s2 = 0; s2 < MI; s2++) bm0[s2] = a0[s2 * RS];
-#pragma unroll
-        for (int s2 = 0; s2 < NI; s2++) an0[s2] = b0[s2 * CS];
-      }
-      int buf = 0;
-      while (true) {
-        if (more) issue((buf + 3) & 3);                      // (stage buffer last read in the previous iteration)
-        const double* sA = stA(buf) + woffA;
-        const double* sB = stB(buf) + woffB;
-#pragma unroll
-        for (int s2 = 0; s2 < MI; s2++) bm1[s2] = sA[4 * SLD + s2 * RS];
-#pragma unroll
-        for (int s2 = 0; s2 < NI; s2++) an1[s2] = sB[4 * SLD + s2 * CS];
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an0[ni], bm0[mi], acc[mi][ni], 0, 0, 0);
-        done++;
-        const int ahead = issued - done;                     // stages issued beyond the one just computed (0..3)
-        // stage done+0 (the next one) must have landed: later ones (ahead - 1 of them) may stay in flight
-        if (ahead >= 3) PASTIX_AMD_WAIT_BARRIER(4);
-        else if (ahead == 2) PASTIX_AMD_WAIT_BARRIER(2);
-        else PASTIX_AMD_WAIT_BARRIER(0);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          const double* nA = stA((buf + 1) & 3) + woffA;
-          const double* nB = stB((buf + 1) & 3) + woffB;
-#pragma unroll
-          for (int s2 = 0; s2 < MI; s2++) bm0[s2] = nA[s2 * RS];
-#pragma unroll
-          for (int s2 = 0; s2 < NI; s2++) an0[s2] = nB[s2 * CS];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-          for (int ni = 0; ni < NI; ni++)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(an1[ni], bm1[mi], acc[mi][ni], 0, 0, 0);
-        if (ahead == 0) break;
-        buf = (buf + 1) & 3;
-      }
-      __syncthreads();
-    };
-#endif
-    // Exactly one instance runs per task: tasks made of whole-tile pieces only (the bulk of the flops) take MODE 0 / 1,
-    // a task with any partial piece runs all its pieces through MODE 2 (a whole-tile piece is its special case).
-    const int plast = tk.p0 + tk.pn;
-    const bool neg = (tk.flags & 8u) != 0;
-    if ((int)tk.nfull == tk.pn) {
-      if (tk.tm == TM && tk.tn == TN) {
-        if (neg) fast_loop(std::integral_constant<int, 0>{}, std::true_type{}, tk.p0, plast);
-#ifdef UPDATE_S4
-        else fast_loop4(tk.p0, plast);
-#else
-        else fast_loop(std::integral_constant<int, 0>{}, std::false_type{}, tk.p0, plast);
-#endif
-      } else {
-        if (neg) fast_loop(std::integral_constant<int, 1>{}, std::true_type{}, tk.p0, plast);
-        else fast_loop(std::integral_constant<int, 1>{}, std::false_type{}, tk.p0, plast);
-      }
-    } else {
-      if (neg) fast_loop(std::integral_constant<int, 2>{}, std::true_type{}, tk.p0, plast);
-      else fast_loop(std::integral_constant<int, 2>{}, std::false_type{}, tk.p0, plast);
-    }
-  }
-
-  // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column).  Loads of one
-  // 16-row band are issued together from clamped addresses (one latency per band, not per element).
-  double* C = ar.p[tk.flags & 3] + tk.c_off;
-  const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
-#ifdef EXP_NO_EPI
-  if (acc[0][0][0] != 12345.678) return;
-#endif
-  if (tk.flags & 4) {
-    epilogue_atomic<MI, NI>(C, acc, touched, row0, col0, RS, CS, l15, g, tm1, tn1, tk.ldc);
-    return;
-  }
-#pragma unroll
-  for (int mi = 0; mi < MI; mi++) {
-    if (!((touched >> mi) & 1u)) continue;
-    const int r = row0 + mi * RS + l15;
-    const int rc = min(r, tm1);
-    double cv[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = min(col0 + ni * CS + g + 4 * q, tn1);
-        cv[ni][q] = C[rc + (int64_t)c * tk.ldc];
-      }
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-      if (!((touched >> (4 + ni)) & 1u)) continue;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = col0 + ni * CS + g + 4 * q;
-        if (r <= tm1 && c <= tn1) C[r + (int64_t)c * tk.ldc] = cv[ni][q] - acc[mi][ni][q];
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_diag : LLt of the diagonal blok, one workgroup (256 threads) per cblk, 16-column block steps
@@ -1707,20 +1185,6 @@ void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src
                      ldd, src, rows, nrows, total);
 }
 
-void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
-                   bool urgent) {
-  if (ntasks <= 0) return;
-  static const int nw = getenv("PASTIX_AMD_UPDATE_WAVES") ? atoi(getenv("PASTIX_AMD_UPDATE_WAVES")) : 8;
-  const dim3 g((unsigned)ntasks);
-  if (nw == 4) {
-    if (urgent) hipLaunchKernelGGL((k_update<4, 1>), g, dim3(256), 0, s, ar, tasks, pieces);
-    else hipLaunchKernelGGL((k_update<4, 0>), g, dim3(256), 0, s, ar, tasks, pieces);
-  } else {
-    if (urgent) hipLaunchKernelGGL((k_update<8, 1>), g, dim3(512), 0, s, ar, tasks, pieces);
-    else hipLaunchKernelGGL((k_update<8, 0>), g, dim3(512), 0, s, ar, tasks, pieces);
-  }
-}
-
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag, int maxw) {
   if (n <= 0) return;
@@ -1757,70 +1221,49 @@ static bool dyn_lds_attr_once(const void* fn, int bytes) {
 }
 
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
+// (cblks are at most 128 columns wide: wider ones are re-cut before planning, api.cpp build_split)
 template <int MODE, int NR>
 static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
-                              int64_t ldx, int unit, int maxw, int lvlw) {
-  static const bool onewave = getenv("PASTIX_AMD_SOLVE_ONEWAVE") != nullptr;
+                              int64_t ldx, int unit, int lvlw) {
   // MODE 1 turns the blok through dynamic LDS sized for the widest cblk of the level
   const size_t smem = MODE == 1 ? (size_t)lvlw * (lvlw | 1) * sizeof(double) : 0;
-  if (maxw <= 128 && !onewave && NR == 1) {            // one right-hand side: the copy without the systolic loop
+  if (NR == 1) {                                       // one right-hand side: the copy without the systolic loop
     if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE>, 128 * 129 * 8)) return;
     hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, unit);
     return;
   }
-  if (maxw <= 128 && !onewave) {
-    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
-    hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
-    return;
-  }
-  for (int k = 0; k < NR; k++) {            // cblks wider than 128: one right-hand side at a time
-    if (maxw <= 128)
-      hipLaunchKernelGGL((k_solve_diag_w<2, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x + k * ldx, unit);
-    else
-      hipLaunchKernelGGL((k_solve_diag_w<4, MODE>), dim3((unsigned)ntask), dim3(64), 0, s, L, tasks, x + k * ldx, unit);
-  }
+  if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
+  hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
 }
 // one level of the forward (fwd) or backward sweep for NR right-hand sides (x: n x NR, leading dimension ldx).
 // chunks: the 64-row list forward, the 256-row list backward.
 template <int NR>
 static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int maxw, int lvlw, int part) {
-  static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;     // the first-generation kernels
+                        const int32_t* ridx, double* x, int64_t ldx, int lvlw) {
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
-  if (!(part & 1)) ntask = 0;          // part: 1 = the diagonal solves, 2 = the panel chunks (two-stream sweeps)
-  if (!(part & 2)) nchunk = 0;
-  const dim3 gt((unsigned)ntask), gc((unsigned)nchunk);
+  const dim3 gc((unsigned)nchunk);
   if (fwd) {
-    if (ntask > 0) {
-      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_fwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, unit);
-      else launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, maxw, lvlw);
-    }
-    if (nchunk > 0) {
-      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_off_fwd, gc, dim3(256), 0, s, L, chunks, bl, x + k * ldx);
-      else hipLaunchKernelGGL(k_solve_off_fwd64<NR>, gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
-    }
+    if (ntask > 0) launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, lvlw);
+    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_fwd64<NR>, gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
   } else {
     const double* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
     const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
-    if (nchunk > 0) {
-      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_off_bwd, gc, dim3(256), 0, s, B, chunks, bl, x + k * ldx);
-      else hipLaunchKernelGGL(k_solve_off_bwd64<NR>, gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
-    }
+    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd64<NR>, gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
     if (ntask > 0) {
-      if (scalar) for (int k = 0; k < NR; k++) hipLaunchKernelGGL(k_solve_diag_bwd, gt, dim3(256), 0, s, L, tasks, x + k * ldx, mode);
-      else if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, maxw, lvlw);
-      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, maxw, lvlw);
+      if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, lvlw);
+      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, lvlw);
     }
   }
 }
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
-                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw,
-                        int part) {
-  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
-  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
-  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, bl, ridx, x, ldx, maxw, lvlw, part);
+                        const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw) {
+  (void)bl;
+  (void)maxw;
+  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {

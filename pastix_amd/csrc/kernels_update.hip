@@ -1,0 +1,398 @@
+// kernels_update.hip -- gfx950 (MI355X / CDNA4): k_update, the trailing-update kernel of the sopalin factorization.
+//
+// k_update = compute_1dgemm = compute_contrib_compact + add_contrib_local (sopalin_compute.c:865-1032, :270-374,
+// :391-598) fused: every workgroup owns one 128x128 tile of a target panel and accumulates all contributions
+// ("pieces", plan.h) that the plan scheduled into this launch, then subtracts them from the tile once.  Tile ownership
+// replaces mutex_blok[] and makes the result deterministic.  ~96 % of the factorization's time at 200^3.
+//
+// MFMA f64 16x16x4 lane maps (measured on gfx950, tools/probe_mfma_f64.hip):
+//   A operand: lane l holds A[i = l&15][k = l>>4];  B operand: lane l holds B[k = l>>4][j = l&15];
+//   C/D: lane l, register q holds D[i = (l>>4) + 4q][j = l&15].
+// The target COLUMN index is fed as MFMA "i" and the target ROW index as "j", so that each accumulator register maps to
+// 16 consecutive rows of the column-major panel (128-byte segments for the read-modify-write of the tile).
+//
+// Workgroup: 512 threads = 8 waves in a 4 x 2 grid; wave (wr, wc) owns the 16-row bands wr, wr + 4 and the 16-column
+// bands wc, wc + 2, wc + 4, wc + 6 of the tile (cyclic ownership: a piece that covers part of the tile still spreads
+// over all waves) = 2 x 4 MFMA sub-tiles.
+//
+// The ACCUMULATORS LIVE IN AGPRs a[0:63], outside the compiler's register allocation: sub-tile (mi, ni) is
+// a[8 (4 mi + ni) : +7], every MFMA is an inline-asm statement naming them.  Reason: pieces that cover only part of
+// the tile must skip the sub-tiles they do not touch.  With compiler-allocated accumulators that is an exec-mask guard
+// per MFMA (s_and_saveexec / s_cbranch / s_or: >100 scalar instructions per 16-deep chunk, and a SIMD issues one
+// scalar instruction per 4 cycles -- a 16x16 piece cost 0.42 of a whole-tile piece), and any attempt to branch ONCE per
+// k-step into straight-line code for the wave's pattern of active sub-tiles (a switch: 30 patterns) made the compiler
+// spill thousands of VGPRs on the phi copies of eight 256-bit accumulator tuples.  Accumulators the compiler does not
+// see have no phis: the switch costs a handful of scalar compares, each arm is exactly the MFMAs the pattern needs.
+// 64 AGPRs + < 64 VGPRs = the 128 registers of four waves per SIMD at two workgroups per CU, as before.
+// Wait states the compiler cannot insert for code it does not see (cdna_hip_programming.md 5.7) are in the strings:
+// accumulate chains need none; the zeroing writes and the epilogue's reads are padded.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "plan.h"
+#include "devmath.h"
+
+namespace pastix_amd {
+
+constexpr int KC = 16;        // k-chunk staged per barrier
+constexpr int SLD = 144;      // LDS line length in doubles: 128 rows + 16 pad -> lanes 16-31 of a
+                              // ds_read_b64 land on banks 32-63 (conflict-free, MI355X_MICROARCH LDS)
+constexpr int UW = 8;         // waves per workgroup
+constexpr int MI = 2, NI = 4; // 16-row / 16-col sub-tiles per wave
+constexpr int RS = 64, CS = 32;   // distance between a wave's consecutive row / col bands
+
+// 1 KiB of zeros: the DMA source of k-lines beyond a piece's K (the last chunk of a piece with K % 16 != 0)
+__device__ double g_zero_line[128];
+
+// LDS-DMA helper: one wave-instruction copies 64 lanes x 16 B = one 128-row k-line straight into LDS (no VGPRs).
+#define PASTIX_AMD_GLDS(gptr, lptr)                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// ---- accumulators in a[0:63] ---------------------------------------------------------------------
+#define PA_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define PA_ACC_CLOBBER                                                                                           \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", PA_A8(1), PA_A8(2), PA_A8(3), PA_A8(4), PA_A8(5), \
+      "a60", "a61", "a62", "a63"
+
+// sub-tile T = 4 mi + ni:  acc[T] += an (MFMA "A": target columns) x bm (MFMA "B": target rows)
+template <int T>
+__device__ __forceinline__ void acc_mfma(const double an, const double bm) {
+  asm volatile("v_mfma_f64_16x16x4_f64 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(an), "v"(bm), "n"(8 * T), "n"(8 * T + 7)
+               : PA_ACC_CLOBBER);
+}
+#define PA_Z4(i) "v_accvgpr_write_b32 a" #i "0, 0\n\tv_accvgpr_write_b32 a" #i "1, 0\n\tv_accvgpr_write_b32 a" #i "2, 0\n\tv_accvgpr_write_b32 a" #i "3, 0\n\t" \
+                 "v_accvgpr_write_b32 a" #i "4, 0\n\tv_accvgpr_write_b32 a" #i "5, 0\n\tv_accvgpr_write_b32 a" #i "6, 0\n\tv_accvgpr_write_b32 a" #i "7, 0\n\t" \
+                 "v_accvgpr_write_b32 a" #i "8, 0\n\tv_accvgpr_write_b32 a" #i "9, 0\n\t"
+__device__ __forceinline__ void acc_zero() {
+  asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\t"
+               "v_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\t"
+               "v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\t" PA_Z4(1) PA_Z4(2) PA_Z4(3) PA_Z4(4) PA_Z4(5)
+               "v_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\t"
+               "s_nop 7" ::: PA_ACC_CLOBBER);          // (v_accvgpr_write -> MFMA SrcC)
+}
+// every MFMA has retired its D before anything but an MFMA reads the accumulators (16-pass DGEMM: 19 states)
+__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: PA_ACC_CLOBBER); }
+// register q (0..3) of sub-tile T: rows l15 of band mi, column g + 4 q of band ni
+template <int T, int Q>
+__device__ __forceinline__ double acc_read() {
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]"
+               : "=v"(lo), "=v"(hi)
+               : "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
+               : PA_ACC_CLOBBER);
+  return __hiloint2double(hi, lo);
+}
+
+// the MFMAs of one k-step for the sub-tiles RM (row bands, MI bits) x CM (col bands, NI bits) of this wave
+template <unsigned RM, unsigned CM>
+__device__ __forceinline__ void mfma_sel(const double (&an)[NI], const double (&bm)[MI]) {
+  if constexpr ((RM & 1u) && (CM & 1u)) acc_mfma<0>(an[0], bm[0]);
+  if constexpr ((RM & 1u) && (CM & 2u)) acc_mfma<1>(an[1], bm[0]);
+  if constexpr ((RM & 1u) && (CM & 4u)) acc_mfma<2>(an[2], bm[0]);
+  if constexpr ((RM & 1u) && (CM & 8u)) acc_mfma<3>(an[3], bm[0]);
+  if constexpr ((RM & 2u) && (CM & 1u)) acc_mfma<4>(an[0], bm[1]);
+  if constexpr ((RM & 2u) && (CM & 2u)) acc_mfma<5>(an[1], bm[1]);
+  if constexpr ((RM & 2u) && (CM & 4u)) acc_mfma<6>(an[2], bm[1]);
+  if constexpr ((RM & 2u) && (CM & 8u)) acc_mfma<7>(an[3], bm[1]);
+}
+// A piece is a rectangle of the tile: the wave's active row bands are any subset of its two, its active column bands a
+// contiguous run of its four -- 3 x 10 non-empty patterns `pat` = row bits | col bits << 2 (wave-uniform, in an SGPR).
+__device__ __forceinline__ void mfma_pat(const int pat, const double (&an)[NI], const double (&bm)[MI]) {
+#define PA_PAT(RM, CM) case (RM | (CM << 2)): mfma_sel<RM, CM>(an, bm); break;
+#define PA_PAT_ROWS(CM) PA_PAT(3u, CM) PA_PAT(1u, CM) PA_PAT(2u, CM)
+  switch (pat) {
+    PA_PAT_ROWS(15u) PA_PAT_ROWS(3u) PA_PAT_ROWS(6u) PA_PAT_ROWS(12u) PA_PAT_ROWS(7u) PA_PAT_ROWS(14u)
+    PA_PAT_ROWS(1u) PA_PAT_ROWS(2u) PA_PAT_ROWS(4u) PA_PAT_ROWS(8u)
+    default: break;                            // the wave has no sub-tile in this chunk's piece
+  }
+#undef PA_PAT_ROWS
+#undef PA_PAT
+}
+
+// ---- epilogue ------------------------------------------------------------------------------------
+// C -= acc for the row band MIX of the wave: loads of one 16-row band are issued together from clamped addresses (one
+// latency per band, not per element); ATOMIC: tiles that several workgroups update in the same launch (split piece
+// lists of the multi-GPU fan-in schedule) combine with f64 atomics instead of an exclusive read-modify-write.
+template <int MIX, bool ATOMIC>
+__device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsigned touched, const int row0, const int col0,
+                                              const int l15, const int g, const int tm1, const int tn1, const int ldc) {
+  if (!((touched >> MIX) & 1u)) return;
+  const int r = row0 + MIX * RS + l15;
+  const int rc = min(r, tm1);
+  double cv[NI][4];
+  if (!ATOMIC) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = min(col0 + ni * CS + g + 4 * q, tn1);
+        cv[ni][q] = C[rc + (int64_t)c * ldc];
+      }
+  }
+  // (the accumulator registers are read one at a time, next to their use: 64 VGPRs are all there is beside the AGPRs)
+  auto put = [&](auto ni_c, auto q_c) {
+    constexpr int ni = decltype(ni_c)::value, q = decltype(q_c)::value;
+    if (!((touched >> (MI + ni)) & 1u)) return;
+    const int c = col0 + ni * CS + g + 4 * q;
+    if (r <= tm1 && c <= tn1) {
+      const double a = acc_read<4 * MIX + ni, q>();
+      if (ATOMIC) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -a);
+      else C[r + (int64_t)c * ldc] = cv[ni][q] - a;
+    }
+  };
+#define PA_PUT4(ni)                                                              \
+  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 0>{});      \
+  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 1>{});      \
+  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 2>{});      \
+  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 3>{});
+  PA_PUT4(0) PA_PUT4(1) PA_PUT4(2) PA_PUT4(3)
+#undef PA_PUT4
+}
+
+// ---- the piece loop ------------------------------------------------------------------------------
+// One software-pipelined LDS-DMA loop, three instantiations (MODE), each with and without sign flips (NEG: the task has
+// "+=" pieces, the cross terms of complex products; real factorizations never do):
+//   0  whole-tile pieces of a full 128 x 128 tile: no masks at all;
+//   1  whole-tile pieces of a smaller valid tile (last row tile of a panel, target cblks narrower than 128 columns):
+//      lane masks and the sub-tile pattern fixed per task;
+//   2  partial pieces (any rectangle [dr, dr+m) x [dc, dc+n) of the tile): lane masks, pattern and the operand shift are
+//      recomputed per piece (every K / 16 chunks), the stray element a 16-byte DMA lane drags in at an odd piece boundary
+//      is zeroed in LDS before anything reads it.
+// Every wave copies KC/UW k-lines of A and of B per chunk with global_load_lds_dwordx4 (no staging registers, no
+// ds_write), the MFMA operands are double-buffered in registers so that the ds_reads of k-step s+1 are in flight under
+// the MFMAs of k-step s, and the chunk barrier sits in front of the LAST k-step's MFMAs (operands already in
+// registers), so no wave leaves the barrier without matrix work.  Order: DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+
+// barrier | read (i+1, ks0) | MFMA ks3.  RAW: own vmcnt(0), then the barrier, then the read.  WAR: buffer i is
+// re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired.
+// Returns the union of the patterns (which sub-tiles the epilogue has to write).
+template <int MODE, bool NEG>
+__device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
+                                               const Piece* __restrict__ pieces, const int row0, const int col0,
+                                               const int lane, const int l15, const int g) {
+  constexpr bool FULLT = MODE == 0;
+  constexpr bool PART = MODE == 2;
+  constexpr int NL = KC / UW;                    // k-lines per wave per operand per chunk
+  constexpr int PALL = 0x3F;
+  // (wave-uniform copy: the k-line tests, the per-wave operand offsets and the pattern go to the scalar unit)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wrow0 = (wave >> 1) * 16, wcol0 = (wave & 1) * 16;       // = row0, col0, as scalars
+  const int pend = tk.p0 + tk.pn;
+  int pi = tk.p0;
+  Piece cur = pieces[pi];
+  Piece nextp = pieces[min(pi + 1, pend - 1)];
+  int64_t lda = cur.lda;
+  // (wave-uniform pointers: the address arithmetic of the DMA stays on the scalar unit, the lane's 16 bytes are the
+  // vector offset of the load).  Partial pieces: tile row r holds source row r - dr, so the pointers are shifted by
+  // -dr / -dc; lanes wholly outside the piece copy the zero line instead and never use them.
+  const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
+  const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
+  const int lo2 = 2 * lane;
+  int left = ((int)cur.k + KC - 1) / KC;
+  int krem = (int)cur.k;                          // k-lines of the piece not yet issued
+  bool negn = (cur.flags & 16) != 0, negc = negn;
+  const double* zl = g_zero_line;
+  // MODE 1 pieces cover the whole VALID tile: tm x tn.  Lanes beyond tm / tn copy the zero line; with an odd tm (tn)
+  // the last lane brings one element of the next panel row along, which only reaches accumulator rows (columns) the
+  // epilogue never stores.  Bands beyond the valid tile are skipped on the MFMA pipe.
+  bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
+  int patc = PALL, patn = PALL;                  // pattern of the chunk in the MFMA section / of the one being copied
+  int fixn = -1;                                 // PART: LDS element (relative to the A image of a buffer) this lane zeroes
+  unsigned touched = 0;
+  auto band_pattern = [&](const int r_lo, const int r_hi, const int c_lo, const int c_hi) {   // scalar arithmetic
+    int p = 0;
+#pragma unroll
+    for (int s = 0; s < MI; s++) if (wrow0 + s * RS < r_hi && wrow0 + s * RS + 16 > r_lo) p |= 1 << s;
+#pragma unroll
+    for (int s = 0; s < NI; s++) if (wcol0 + s * CS < c_hi && wcol0 + s * CS + 16 > c_lo) p |= 1 << (MI + s);
+    // (no sub-tile unless both a row band and a column band are active)
+    return ((p & 3) && (p >> MI)) ? p : 0;
+  };
+  // per-piece set-up of a partial piece: lanes 2l, 2l+1 of a k-line intersect the piece; the pattern; stray elements: a
+  // lane that straddles an odd boundary brings the source row next to the piece along (lanes 0-15 / 16-31 / 32-47 /
+  // 48-63 look after the rows dr-1, dr+m of A and dc-1, dc+n of B, one k-line each)
+  auto piece_setup = [&](const Piece& pc) {
+    const int dr = pc.dr, re = (int)pc.dr + (int)pc.m, dc = pc.dc, ce = (int)pc.dc + (int)pc.n;
+    la = lo2 + 1 >= dr && lo2 < re;
+    lb = lo2 + 1 >= dc && lo2 < ce;
+    patn = band_pattern(dr, re, dc, ce);
+    const int j = lane >> 4;
+    const int e = j == 0 ? dr - 1 : j == 1 ? re : j == 2 ? dc - 1 : ce;      // the row next to the boundary
+    const bool odd = (j == 0 || j == 2) ? (e & 1) == 0 && e >= 0 : (e & 1) != 0 && e < 128;   // shares a lane with a piece row
+    fixn = odd ? (j >= 2 ? KC * SLD : 0) + (lane & 15) * SLD + e : -1;
+    touched |= (unsigned)patn;
+  };
+  if (PART) {
+    piece_setup(cur);
+  } else {
+    patn = FULLT ? PALL : band_pattern(0, (int)tk.tm, 0, (int)tk.tn);
+    touched = (unsigned)patn;
+  }
+  patc = patn;
+  int fixc = fixn;
+#pragma unroll
+  for (int q = 0; q < NL; q++) {
+    const bool kv = wave + UW * q < krem;        // wave-uniform
+    PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * UW * lda : zl) + lo2, sh[0][0] + (wave + UW * q) * SLD);
+    PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * UW * lda : zl) + lo2, sh[0][1] + (wave + UW * q) * SLD);
+  }
+  krem -= KC;
+  const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
+  const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+  double bm0[MI], an0[NI], bm1[MI], an1[NI];
+  __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
+  if (PART && fixc >= 0) sh[0][0][fixc] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
+#pragma unroll
+  for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
+#pragma unroll
+  for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
+  int buf = 0;
+  while (true) {
+    bool has_next = true;
+    negc = negn;
+    if (PART) { patc = patn; fixc = fixn; }
+    if (--left == 0) {
+      if (++pi < pend) {
+        cur = nextp;
+        lda = cur.lda;
+        pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
+        pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
+        left = ((int)cur.k + KC - 1) / KC;
+        krem = (int)cur.k;
+        negn = (cur.flags & 16) != 0;
+        nextp = pieces[min(pi + 1, pend - 1)];
+        if (PART) piece_setup(cur);
+      } else {
+        has_next = false;
+      }
+    } else {
+      pa += (int64_t)KC * lda;
+      pb += (int64_t)KC * lda;
+    }
+    if (has_next) {
+      double* dA = sh[buf ^ 1][0] + wave * SLD;
+      double* dB = sh[buf ^ 1][1] + wave * SLD;
+#pragma unroll
+      for (int q = 0; q < NL; q++) {
+        const bool kv = wave + UW * q < krem;
+        if (FULLT) {                     // kv is wave-uniform: a scalar branch instead of 64-bit vector selects
+          if (kv) {
+            PASTIX_AMD_GLDS(pa + (int64_t)q * UW * lda + lo2, dA + UW * q * SLD);
+            PASTIX_AMD_GLDS(pb + (int64_t)q * UW * lda + lo2, dB + UW * q * SLD);
+          } else {
+            PASTIX_AMD_GLDS(zl + lo2, dA + UW * q * SLD);
+            PASTIX_AMD_GLDS(zl + lo2, dB + UW * q * SLD);
+          }
+        } else {
+          PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * UW * lda : zl) + lo2, dA + UW * q * SLD);
+          PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * UW * lda : zl) + lo2, dB + UW * q * SLD);
+        }
+      }
+      krem -= KC;
+    }
+    const double* sA = sAw + buf * (2 * KC * SLD);
+    const double* sB = sBw + buf * (2 * KC * SLD);
+    // (NEG: a v_xor result feeds the MFMA inside an asm statement: its wait states are ours)
+#define PA_NEGATE(bm)                                        \
+  if (NEG && negc) {                                         \
+    _Pragma("unroll") for (int s = 0; s < MI; s++) bm[s] = -bm[s]; \
+    asm volatile("s_nop 1");                                 \
+  }
+    PA_NEGATE(bm0)
+    // ks0 (operands in *0), prefetch ks1 into *1
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
+    if (FULLT) mfma_sel<3u, 15u>(an0, bm0); else mfma_pat(patc, an0, bm0);
+    PA_NEGATE(bm1)
+    // ks1, prefetch ks2 into *0
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
+    if (FULLT) mfma_sel<3u, 15u>(an1, bm1); else mfma_pat(patc, an1, bm1);
+    PA_NEGATE(bm0)
+    // ks2, prefetch ks3 into *1
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
+    if (FULLT) mfma_sel<3u, 15u>(an0, bm0); else mfma_pat(patc, an0, bm0);
+    PA_NEGATE(bm1)
+    __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+    if (PART && has_next && fixn >= 0) sh[buf ^ 1][0][fixn] = 0.0;
+    {
+      // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
+      const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
+      const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
+#pragma unroll
+      for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
+#pragma unroll
+      for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
+    // ks3 from registers
+    if (FULLT) mfma_sel<3u, 15u>(an1, bm1); else mfma_pat(patc, an1, bm1);
+    if (!has_next) break;
+    buf ^= 1;
+  }
+#undef PA_NEGATE
+  return touched;
+}
+
+// KIND 0: the bulk launches.  KIND 1 (`k_update<1>` in profiles): the same code for the few latency-critical tasks of a
+// level that the two-stream driver runs beside the bulk launch of the previous slot; a separate instantiation so that
+// per-kernel profiles of the two do not mix.
+template <int KIND>
+__global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, const Task* __restrict__ tasks,
+                                                           const Piece* __restrict__ pieces) {
+  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+  if (KIND == 1) PANEL_PRIO();
+  const Task tk = tasks[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;      // this wave's first row / col band
+  const int l15 = lane & 15, g = lane >> 4;
+  acc_zero();
+  // Exactly one instance of the loop runs per task: tasks made of whole-tile pieces only (the bulk of the flops) take
+  // MODE 0 / 1, a task with any partial piece runs all its pieces through MODE 2 (a whole-tile piece is its special
+  // case).  The plan puts the whole-tile pieces of a task first (Task::nfull) and sets Task flag 8 for sign flips.
+  unsigned touched;
+  const bool neg = (tk.flags & 8u) != 0;
+  if ((int)tk.nfull == tk.pn) {
+    if (tk.tm == TM && tk.tn == TN) {
+      if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    } else {
+      if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    }
+  } else {
+    if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+  }
+
+  // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column)
+  acc_settle();
+  double* C = ar.p[tk.flags & 3] + tk.c_off;
+  const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
+  if (tk.flags & 4) {
+    epilogue_band<0, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    epilogue_band<1, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    return;
+  }
+  epilogue_band<0, false>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+  epilogue_band<1, false>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+}
+
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
+                   bool urgent) {
+  if (ntasks <= 0) return;
+  const dim3 g((unsigned)ntasks);
+  if (urgent) hipLaunchKernelGGL((k_update<1>), g, dim3(64 * UW), 0, s, ar, tasks, pieces);
+  else hipLaunchKernelGGL((k_update<0>), g, dim3(64 * UW), 0, s, ar, tasks, pieces);
+}
+
+}  // namespace pastix_amd

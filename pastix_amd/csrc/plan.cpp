@@ -202,7 +202,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   const bool big = fl_total > 5e13;
   if (P.opts.lookahead <= 0) P.opts.lookahead = big ? 2048 : fl_total > 1e12 ? 1024 : 512;
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
-  const int max_pieces = getenv("PASTIX_AMD_MAXPIECES") ? atoi(getenv("PASTIX_AMD_MAXPIECES")) : (big ? 16 : 8);
+  const int max_pieces = big ? 16 : 8;
   const int64_t nc = L->cblknbr;
   P.cblknbr = nc;
   P.bloknbr = L->bloknbr;
@@ -519,39 +519,31 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.slot_task_ptr.assign(NL + 1, 0);
   std::vector<double> task_work;
   std::vector<int32_t> task_slot;
-  std::vector<uint8_t> task_urgent, task_late;
-  const bool hist_on = getenv("PASTIX_AMD_PIECE_HIST") != nullptr;
-  double hist_f[3][3] = {{0}}, hist_odd = 0, hist_exec = 0, hist_wave = 0, hist_cyc = 0, hist_merged = 0, hist_valid = 0;
-  int64_t hist_groups = 0, hist_nonfull = 0;
-  int64_t hist_c[3][3] = {{0}};
+  std::vector<uint8_t> task_urgent;
   P.slot_flops.assign(NL, 0.0);
   P.slot_urgent_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
   P.slot_maxpn.assign(NL, 0);
   P.slot_maxwork.assign(NL, 0.0);
-  // quadrant tasks (below): on unless PASTIX_AMD_QUADRANTS=0; a task qualifies when its pieces fill less than
-  // PASTIX_AMD_QUAD_FILL (default 0.25) of the 128 x 128 x 16 chunks k_update would run for them
-  // (not with the diagnostic task orders 1-3: they rearrange the bulk range of a slot)
-  const bool quad_on = (!getenv("PASTIX_AMD_QUADRANTS") || atoi(getenv("PASTIX_AMD_QUADRANTS")) != 0) &&
-                       !(getenv("PASTIX_AMD_TASK_ORDER") && atoi(getenv("PASTIX_AMD_TASK_ORDER")) != 0);
-  const double quad_fill = getenv("PASTIX_AMD_QUAD_FILL") ? atof(getenv("PASTIX_AMD_QUAD_FILL")) : 0.25;
-  const int64_t quad_min = getenv("PASTIX_AMD_QUAD_MIN") ? atoll(getenv("PASTIX_AMD_QUAD_MIN")) : 1024;
-  const bool urgent_split = getenv("PASTIX_AMD_URGENT_SPLIT") ? atoi(getenv("PASTIX_AMD_URGENT_SPLIT")) != 0
-                                                               : true;
+  // quadrant tasks (below): a task qualifies when its pieces fill less than quad_fill of the 128 x 128 x 16 chunks
+  // k_update would run for them, and a slot gets them when it has at least quad_min candidates
+  constexpr bool quad_on = true;
+  const double quad_fill = P.opts.quadrant_fill_pct > 0 ? 0.01 * P.opts.quadrant_fill_pct : 0.25;
+  const int64_t quad_min = P.opts.quadrant_min > 0 ? P.opts.quadrant_min : 1024;
   // The tiles are independent: the sorted piece list is cut at tile boundaries into one range per host thread, every
   // thread groups its tiles into its own lists, which are concatenated in range order (= the serial result).
   struct GOut {
     std::vector<Task> tasks;
     std::vector<double> work;
     std::vector<int32_t> slot;
-    std::vector<uint8_t> urgent, late;
+    std::vector<uint8_t> urgent;
     std::vector<double> slot_flops, slot_urgent_flops, slot_maxwork;
     std::vector<int64_t> slot_pieces, slot_cnt;
     std::vector<int32_t> slot_maxpn;
     std::vector<Piece> part_tmp;
     double urgent_flops = 0, full_flops = 0, ubytes = 0;
   };
-  const int gthr = hist_on ? 1 : nthr;             // (the shape histogram keeps one set of counters)
+  const int gthr = nthr;
   std::vector<GOut> gout((size_t)gthr);
   std::vector<size_t> gcut((size_t)gthr + 1, raw.size());
   gcut[0] = 0;
@@ -569,8 +561,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     O.slot_pieces.assign(NL, 0);
     O.slot_cnt.assign(NL, 0);
     O.slot_maxpn.assign(NL, 0);
-    int64_t prev_tile = -1;                        // (a tile's tasks come out consecutively, in slot order)
-    int prev_slot = -2;
       for (size_t q = qb; q < qe;) {
       size_t e = q;
       double work = 0;
@@ -599,7 +589,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         // contributions from the level right below the target's are the only ones that cannot be computed
         // before that level's panel kernels: keep them in tasks of their own (the urgent set of their slot) and
         // flush everything older one slot earlier, where it overlaps with the panel kernels (api.cpp, two streams)
-        if (urgent_split && e < qe && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
+        if (e < qe && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
             raw[e - 1].lvl < tlev - 1) break;
       }
       int slot = raw[e - 1].lvl + 1;
@@ -619,10 +609,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       tk.flags = carena | (raw[q].shared ? 4u : 0u);
       {   // pieces that cover the whole valid tile (any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
           // through its specialized loop; tk.nfull = how many
-        static const bool edge_fast = getenv("PASTIX_AMD_EDGE_FAST") ? atoi(getenv("PASTIX_AMD_EDGE_FAST")) != 0 : true;
         auto isfull = [&](const Piece& pc) {   // covers the whole valid tile (tm x tn; 128 x 128 except at the edges)
-          return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0 &&
-                 (edge_fast || (pc.m == TM && pc.n == TN));
+          return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0;
         };
         // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
         O.part_tmp.clear();
@@ -638,72 +626,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it)
           if (it->flags & 16) tk.flags |= 8u;            // the update kernel needs its sign-flipping variant
 
-        if (hist_on) {   // diagnostic: flops of the non-full pieces by shape
-          {   // how many non-full pieces share (tile, source cblk): candidates for multi-segment merged pieces
-            int64_t lastk = -1;
-            int rs_lo = 999, rs_hi = -1, cs_lo = 999, cs_hi = -1, kk = 0;
-            auto flushg = [&]() {
-              if (lastk < 0) return;
-              hist_groups++;
-              // merged piece: bounding sub-tile box, busiest-wave model with cyclic ownership
-              int mx = 0;
-              for (int wr = 0; wr < 4; wr++)
-                for (int wc = 0; wc < 2; wc++) {
-                  int r = 0, c = 0;
-                  for (int t = 0; t < 2; t++) { int b = wr + 4 * t; if (b >= rs_lo && b <= rs_hi) r++; }
-                  for (int t = 0; t < 4; t++) { int b = wc + 2 * t; if (b >= cs_lo && b <= cs_hi) c++; }
-                  mx = std::max(mx, r * c);
-                }
-              hist_merged += 2.0 * 256.0 * mx * 8 * ((kk + 15) / 16 * 16);
-            };
-            for (auto it = mid; it != P.pieces.begin() + e; ++it) {
-              const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), it->a_off) - P.poff.begin() - 1;
-              if (k != lastk) { flushg(); lastk = k; rs_lo = cs_lo = 999; rs_hi = cs_hi = -1; kk = it->k; }
-              rs_lo = std::min(rs_lo, it->dr / 16); rs_hi = std::max(rs_hi, (it->dr + it->m - 1) / 16);
-              cs_lo = std::min(cs_lo, it->dc / 16); cs_hi = std::max(cs_hi, (it->dc + it->n - 1) / 16);
-              hist_nonfull++;
-            }
-            flushg();
-          }
-          for (auto it = mid; it != P.pieces.begin() + e; ++it) {
-            const double f = 2.0 * it->m * (double)it->n * it->k;
-            const bool even = !((it->dr | it->dc | it->m | it->n) & 1);
-            const int cm = it->m >= 96 ? 2 : it->m >= 32 ? 1 : 0, cn = it->n >= 96 ? 2 : it->n >= 32 ? 1 : 0;
-            hist_f[cm][cn] += f;
-            hist_c[cm][cn] += 1;
-            if (!even) hist_odd += f;
-            if (it->dr == 0 && it->dc == 0 && (it->m == TM || it->m == tk.tm) && (it->n == TN || it->n == tk.tn)) hist_valid += f;
-            // 16x16 sub-tiles the piece touches x chunks of 16: what the MFMA pipe executes for it
-            const int rs = (it->dr + it->m + 15) / 16 - it->dr / 16, cs = (it->dc + it->n + 15) / 16 - it->dc / 16;
-            hist_exec += 2.0 * 256.0 * rs * cs * ((it->k + 15) / 16 * 16);
-            // time-like: the busiest wave (32x64 wave tiles) x 8 waves
-            int mx = 0;
-            for (int wr = 0; wr < 4; wr++)
-              for (int wc = 0; wc < 2; wc++) {
-                int r = 0, c = 0;
-                for (int t = 0; t < 2; t++) { int lo = wr * 32 + t * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
-                for (int t = 0; t < 4; t++) { int lo = wc * 64 + t * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
-                mx = std::max(mx, r * c);
-              }
-            hist_wave += 2.0 * 256.0 * mx * 8 * ((it->k + 15) / 16 * 16);
-            int mxc = 0;   // cyclic sub-tile ownership: wave (wr,wc) owns row sub-tiles wr, wr+4 and col sub-tiles wc, wc+2, wc+4, wc+6
-            for (int wr = 0; wr < 4; wr++)
-              for (int wc = 0; wc < 2; wc++) {
-                int r = 0, c = 0;
-                for (int t = 0; t < 2; t++) { int lo = (wr + 4 * t) * 16; if (lo < it->dr + it->m && lo + 16 > it->dr) r++; }
-                for (int t = 0; t < 4; t++) { int lo = (wc + 2 * t) * 16; if (lo < it->dc + it->n && lo + 16 > it->dc) c++; }
-                mxc = std::max(mxc, r * c);
-              }
-            hist_cyc += 2.0 * 256.0 * mxc * 8 * ((it->k + 15) / 16 * 16);
-          }
-        }
       }
       const uint8_t urg = P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0;
-      // "late": the tile was also updated by the bulk launch of the previous slot -- this task may not start before that
-      // launch has finished, every other bulk task of the slot may (api.cpp overlaps consecutive bulk launches)
-      const uint8_t late = raw[q].tile == prev_tile && slot == prev_slot + 1 && P.level[t] != slot ? 1 : 0;
-      prev_tile = raw[q].tile;
-      prev_slot = slot;
       if (P.level[t] == slot) { O.urgent_flops += 2.0 * work; O.slot_urgent_flops[slot] += 2.0 * work; }
       O.slot_flops[slot] += 2.0 * work;
       O.slot_maxwork[slot] = std::max(O.slot_maxwork[slot], work);
@@ -717,7 +641,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       O.work.push_back(work + 4096.0 * double(e - q));
       O.slot.push_back(slot);
       O.urgent.push_back(urg);
-      O.late.push_back(late);
       O.slot_cnt[slot]++;
       O.ubytes += 16.0 * double(tk.tm) * double(tk.tn);
       O.slot_pieces[slot] += (int64_t)(e - q);
@@ -742,13 +665,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     task_work.reserve(ntr);
     task_slot.reserve(ntr);
     task_urgent.reserve(ntr);
-    task_late.reserve(ntr);
     for (GOut& O : gout) {
       P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
       task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
       task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
-      task_late.insert(task_late.end(), O.late.begin(), O.late.end());
       P.urgent_flops += O.urgent_flops;
       P.full_flops += O.full_flops;
       ubytes += O.ubytes;
@@ -786,7 +707,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       std::vector<Task> tasks;
       std::vector<double> work;
       std::vector<int32_t> slot;
-      std::vector<uint8_t> urgent, late;
+      std::vector<uint8_t> urgent;
       std::vector<Piece> pieces;                   // Task::p0 is relative to this list until it is appended to P.pieces
       std::vector<std::pair<int32_t, int32_t>> dcnt;   // (slot, change of its task count)
       double dbytes = 0;
@@ -840,7 +761,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           O.work.push_back(wq + 4096.0 * double(np));
           O.slot.push_back(slot);
           O.urgent.push_back(task_urgent[i]);
-          O.late.push_back(task_late[i]);
           O.dbytes += 16.0 * double(tq.tm) * double(tq.tn);
           made++;
         }
@@ -869,7 +789,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
       task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
       task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
-      task_late.insert(task_late.end(), O.late.begin(), O.late.end());
       for (auto& d : O.dcnt) P.slot_task_ptr[(size_t)d.first + 1] += d.second;
       ubytes += O.dbytes;
       QOut().pieces.swap(O.pieces);
@@ -877,14 +796,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }
   P.update_bytes = ubytes;
   for (int s = 0; s < NL; s++) P.slot_task_ptr[s + 1] += P.slot_task_ptr[s];
-  // Order inside a slot: heaviest task first (mode 0, default: shortest tail of the launch).
-  // Mode 1 (PASTIX_AMD_TASK_ORDER=1) is the XCD-locality order: workgroups are dealt round-robin over
-  // the 8 XCDs (each with its own 4 MiB L2), so blocks b and b+8 share an L2; tasks are sorted by
-  // target panel position and each XCD gets a contiguous run: block = (pos % per) * 8 + pos / per.
-  // Measured on MI355X (160^3): mode 0 51.7 TFLOP/s in k_update, mode 1 48.8 -- the kernel is not
-  // bound by operand traffic, the tail matters more.
+  // Order inside a slot: the urgent tasks (targets of the slot's own level) first, the quadrant tasks at the end of
+  // the urgent and of the bulk range, and inside a range the targets of the next level, then the heaviest task first
+  // (the hardware dispatches workgroups in that order: shortest tail of the launch).  Measured alternatives (XCD-
+  // locality orders that give every L2 8 x 8 blocks of tasks sharing operands) raise the L2 hit rate from 34 % to 62 %
+  // and change nothing or lose: the kernel is not bound by operand traffic.
   {
-    const int order_mode = getenv("PASTIX_AMD_TASK_ORDER") ? atoi(getenv("PASTIX_AMD_TASK_ORDER")) : 0;
     // bucket by slot (counting sort, keeps the creation order), then every slot's range sorted on its own, slots dealt
     // to the host threads: the comparison is a total order, the result does not depend on the thread count
     std::vector<int64_t> idx((size_t)P.slot_task_ptr[NL]);
@@ -900,10 +817,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           std::sort(idx.begin() + P.slot_task_ptr[sl], idx.begin() + P.slot_task_ptr[sl + 1], [&](int64_t a, int64_t b) {
             if ((task_urgent[a] == 2) != (task_urgent[b] == 2)) return task_urgent[a] == 2;   // urgent tasks first
             if (((P.tasks[a].flags ^ P.tasks[b].flags) & 32u) != 0) return (P.tasks[a].flags & 32u) == 0;   // quadrant tasks last
-            if (task_late[a] != task_late[b]) return task_late[a] < task_late[b];             // then early, then late
             if (task_urgent[a] != task_urgent[b]) return task_urgent[a] > task_urgent[b];     // targets of the next level first
-            if (order_mode == 0 || order_mode == 3) return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
-            return P.tasks[a].c_off != P.tasks[b].c_off ? P.tasks[a].c_off < P.tasks[b].c_off : a < b;
+            return task_work[a] != task_work[b] ? task_work[a] > task_work[b] : a < b;
           });
         }
       };
@@ -912,55 +827,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       sort_slots(0);
       for (auto& x : th) x.join();
     }
-    if (getenv("PASTIX_AMD_TASK_MIX")) {      // flops by update-loop instance (kernels.hip: MODE 0 / 1 / 2)
-      double f[3] = {0, 0, 0}, fp[3] = {0, 0, 0};
-      int64_t nt[3] = {0, 0, 0};
-      for (const Task& t : P.tasks) {
-        const int m = (int)t.nfull == t.pn ? ((t.tm == TM && t.tn == TN) ? 0 : 1) : 2;
-        nt[m]++;
-        for (int i = 0; i < t.pn; i++) {
-          const Piece& pc = P.pieces[(size_t)t.p0 + i];
-          const double w2 = 2.0 * pc.m * (double)pc.n * pc.k;
-          f[m] += w2;
-          if (i >= (int)t.nfull) fp[m] += w2;
-        }
-      }
-      const double tot = f[0] + f[1] + f[2];
-      fprintf(stderr, "[task mix] mode 0: %lld tasks %.1f%% of the update flops | mode 1: %lld tasks %.1f%% | mode 2: %lld tasks %.1f%% "
-              "(of which in partial pieces %.1f%% of all flops)\n", (long long)nt[0], 100 * f[0] / tot, (long long)nt[1], 100 * f[1] / tot,
-              (long long)nt[2], 100 * f[2] / tot, 100 * fp[2] / tot);
-    }
-    if (getenv("PASTIX_AMD_SLOT_MIX")) {      // per slot: tasks, pieces, mean piece shape (diagnostic of the leaf-side launches)
-      const int upto = atoi(getenv("PASTIX_AMD_SLOT_MIX"));
-      for (int sl = 0; sl < std::min<int>(NL, upto); sl++) {
-        int64_t nt = 0, np = 0, nfullp = 0;
-        double sm = 0, sn = 0, sk = 0, fl = 0, boxes = 0;
-        for (int64_t q = P.slot_task_ptr[sl]; q < P.slot_task_ptr[sl + 1]; q++) {
-          const Task& t = P.tasks[(size_t)idx[q]];
-          nt++; np += t.pn; nfullp += t.nfull;
-          int r0 = 999, r1 = 0, c0 = 999, c1 = 0;
-          for (int i = 0; i < t.pn; i++) {
-            const Piece& pc = P.pieces[(size_t)t.p0 + i];
-            sm += pc.m; sn += pc.n; sk += pc.k; fl += 2.0 * pc.m * (double)pc.n * pc.k;
-            r0 = std::min<int>(r0, pc.dr); r1 = std::max<int>(r1, pc.dr + pc.m);
-            c0 = std::min<int>(c0, pc.dc); c1 = std::max<int>(c1, pc.dc + pc.n);
-          }
-          boxes += double(r1 - r0) * (c1 - c0);
-        }
-        if (nt) fprintf(stderr, "[slot mix] slot %3d: %6lld tasks, %5.1f pieces each (%4.1f%% whole-tile), mean piece %5.1f x %5.1f x %5.1f, "
-                        "%.2f GF, bounding box of a task %.0f elements\n", sl, (long long)nt, double(np) / nt, 100.0 * nfullp / np,
-                        sm / np, sn / np, sk / np, fl * 1e-9, boxes / nt);
-      }
-    }
-    if (hist_on) {
-      fprintf(stderr, "[piece hist] full %.3e ; non-full useful flops by (m,n) class {<32, 32-95, >=96}:\n", P.full_flops);
-      for (int a = 0; a < 3; a++) fprintf(stderr, "   m%d: %.3e (%lld)  %.3e (%lld)  %.3e (%lld)\n", a, hist_f[a][0], (long long)hist_c[a][0], hist_f[a][1], (long long)hist_c[a][1], hist_f[a][2], (long long)hist_c[a][2]);
-      fprintf(stderr, "   odd offsets/extents %.3e ; executed on touched 16x16 sub-tiles %.3e ; busiest-wave-bound %.3e (cyclic ownership %.3e)\n   non-full pieces %lld in %lld (tile, source cblk) groups; merged-piece bound %.3e\n   covering the whole VALID tile (m = tm, n = tn): %.3e\n", hist_odd, hist_exec, hist_wave, hist_cyc, (long long)hist_nonfull, (long long)hist_groups, hist_merged, hist_valid);
-    }
     phase("task grouping");
     P.slot_urgent_end.assign(NL, 0);
     P.slot_next_end.assign(NL, 0);
-    P.slot_late_begin.assign(NL, 0);
     P.slot_small_begin.assign(NL, 0);
     P.slot_usmall_begin.assign(NL, 0);
     for (int sl = 0; sl < NL; sl++) {
@@ -969,10 +838,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       P.slot_urgent_end[sl] = q;
       while (q < P.slot_task_ptr[sl + 1] && task_urgent[idx[q]] == 1) q++;
       P.slot_next_end[sl] = q;
-      int64_t ql = P.slot_urgent_end[sl];
-      while (ql < P.slot_task_ptr[sl + 1] && !task_late[idx[ql]]) ql++;
-      // (the locality orders 1-3 rearrange the bulk range: there the whole bulk launch waits for the previous one)
-      P.slot_late_begin[sl] = order_mode == 0 ? ql : P.slot_urgent_end[sl];
       int64_t qs = P.slot_task_ptr[sl + 1];
       while (qs > P.slot_urgent_end[sl] && (P.tasks[(size_t)idx[qs - 1]].flags & 32u)) qs--;
       P.slot_small_begin[sl] = qs;
@@ -981,148 +846,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       P.slot_usmall_begin[sl] = qs;
     }
     std::vector<Task> sorted(idx.size());
-    if (order_mode == 2) {
-      // XCD-locality order of the bulk launch (everything after the urgent tasks of a slot).  Workgroup g of a launch
-      // runs on XCD g % 8, and an XCD keeps 64 of these workgroups resident: give every XCD 8x8 blocks of tasks that
-      // share their A operands along one axis and their B operands along the other (first piece's source rows),
-      // heavy tasks (by eighths of the heaviest) still first.
-      std::vector<int64_t> ra, rb, tmp;
-      for (int sl = 0; sl < NL; sl++) {
-        const int64_t b0 = P.slot_urgent_end[sl], n = P.slot_task_ptr[sl + 1] - b0;
-        if (n <= 0) continue;
-        ra.assign((size_t)n, 0);
-        rb.assign((size_t)n, 0);
-        tmp.resize((size_t)n);
-        double wmax = 0;
-        for (int64_t q = 0; q < n; q++) wmax = std::max(wmax, task_work[idx[b0 + q]]);
-        auto rank_by = [&](bool useA, std::vector<int64_t>& out) {
-          std::iota(tmp.begin(), tmp.end(), 0);
-          auto key = [&](int64_t q) {
-            const Piece& pc = P.pieces[P.tasks[idx[b0 + q]].p0];
-            return useA ? pc.a_off : pc.b_off;
-          };
-          std::sort(tmp.begin(), tmp.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
-          int64_t r = -1, last = -1;
-          for (int64_t i = 0; i < n; i++) {
-            const int64_t k = key(tmp[i]);
-            if (i == 0 || k != last) { r++; last = k; }
-            out[tmp[i]] = r;
-          }
-        };
-        rank_by(true, ra);
-        rank_by(false, rb);
-        std::vector<int64_t> ord((size_t)n);
-        std::iota(ord.begin(), ord.end(), 0);
-        auto bucket = [&](int64_t q) { return std::min<int>(7, (int)(8.0 * task_work[idx[b0 + q]] / std::max(wmax, 1.0))); };
-        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
-          const int bx = bucket(x), by = bucket(y);
-          if (bx != by) return bx > by;
-          if ((ra[x] >> 3) != (ra[y] >> 3)) return (ra[x] >> 3) < (ra[y] >> 3);
-          if ((rb[x] >> 3) != (rb[y] >> 3)) return (rb[x] >> 3) < (rb[y] >> 3);
-          if (ra[x] != ra[y]) return ra[x] < ra[y];
-          if (rb[x] != rb[y]) return rb[x] < rb[y];
-          return x < y;
-        });
-        std::vector<int64_t> seq((size_t)n);
-        for (int64_t q = 0; q < n; q++) seq[q] = idx[b0 + ord[q]];
-        // chunk m (64 consecutive tasks of seq) -> XCD m % 8, resident slots (m / 8) * 64 ...
-        const int64_t nfull = (n / 512) * 512;
-        for (int64_t q = 0; q < nfull; q++) {
-          const int64_t m = q / 64, u = q % 64;
-          idx[b0 + ((m / 8) * 64 + u) * 8 + (m % 8)] = seq[q];
-        }
-        for (int64_t q = nfull; q < n; q++) idx[b0 + q] = seq[q];
-      }
-    }
-    if (order_mode == 3) {
-      // 2-D blocks over (A rows, B rows) of the tasks' first pieces, as tools/replay_slot.hip order 1 (measured on dumped
-      // launches of 160^3: +1 ... +4 % against heaviest-first in tile order, random order -10 %): inside a work class
-      // (quarters of the heaviest task, heavy first) runs of 512 tasks form 16 x 32 blocks -- the tasks a full chip runs
-      // together read 16 + 32 operand row blocks per source instead of ~256 + 2 -- and every block is dealt so that
-      // workgroup g (-> XCD g % 8, each with its own L2) belongs to one 8 x 8 sub-block.
-      std::vector<int64_t> ra, rb, tmp, ord, seq;
-      std::vector<std::vector<int64_t>> Lx(8);
-      for (int sl = 0; sl < NL; sl++) {
-        const int64_t b0 = P.slot_urgent_end[sl], n = P.slot_task_ptr[sl + 1] - b0;
-        if (n < 1024) continue;                    // (a launch that does not fill the chip twice keeps heaviest-first)
-        ra.assign((size_t)n, 0);
-        rb.assign((size_t)n, 0);
-        tmp.resize((size_t)n);
-        double wmax = 0;
-        for (int64_t q = 0; q < n; q++) wmax = std::max(wmax, task_work[idx[b0 + q]]);
-        auto rank_by = [&](bool useA, std::vector<int64_t>& out) {
-          std::iota(tmp.begin(), tmp.end(), 0);
-          auto key = [&](int64_t q) {
-            const Piece& pc = P.pieces[P.tasks[idx[b0 + q]].p0];
-            return useA ? pc.a_off : pc.b_off;
-          };
-          std::sort(tmp.begin(), tmp.end(), [&](int64_t x, int64_t y) { return key(x) < key(y); });
-          int64_t r = -1, last = -1;
-          for (int64_t i = 0; i < n; i++) {
-            const int64_t k = key(tmp[i]);
-            if (i == 0 || k != last) { r++; last = k; }
-            out[tmp[i]] = r;
-          }
-        };
-        rank_by(true, ra);
-        rank_by(false, rb);
-        ord.resize((size_t)n);
-        std::iota(ord.begin(), ord.end(), 0);
-        auto bucket = [&](int64_t q) { return std::min<int>(3, (int)(4.0 * task_work[idx[b0 + q]] / std::max(wmax, 1.0))); };
-        auto sub = [&](int64_t q) { return (int)(((ra[q] / 8) % 2) * 4 + (rb[q] / 8) % 4); };
-        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
-          const int bx = bucket(x), by = bucket(y);
-          if (bx != by) return bx > by;
-          if (rb[x] / 32 != rb[y] / 32) return rb[x] / 32 < rb[y] / 32;
-          if (ra[x] / 16 != ra[y] / 16) return ra[x] / 16 < ra[y] / 16;
-          const int sx = sub(x), sy = sub(y);
-          if (sx != sy) return sx < sy;
-          if (ra[x] != ra[y]) return ra[x] < ra[y];
-          if (rb[x] != rb[y]) return rb[x] < rb[y];
-          return x < y;
-        });
-        seq.clear();
-        for (int64_t i = 0; i < n;) {
-          int64_t j = i;
-          for (auto& l : Lx) l.clear();
-          while (j < n && bucket(ord[j]) == bucket(ord[i]) && rb[ord[j]] / 32 == rb[ord[i]] / 32 &&
-                 ra[ord[j]] / 16 == ra[ord[i]] / 16) {
-            Lx[(size_t)sub(ord[j])].push_back(ord[j]);
-            j++;
-          }
-          for (size_t v = 0;; v++) {
-            bool any = false;
-            for (int x = 0; x < 8; x++)
-              if (v < Lx[(size_t)x].size()) { seq.push_back(idx[b0 + Lx[(size_t)x][v]]); any = true; }
-            if (!any) break;
-          }
-          i = j;
-        }
-        for (int64_t q = 0; q < n; q++) idx[b0 + q] = seq[(size_t)q];
-      }
-    }
-    if (order_mode == 0 || order_mode == 2 || order_mode == 3) {
+    {
       std::vector<std::thread> th;
       const size_t nq = idx.size(), per = (nq + (size_t)nthr - 1) / (size_t)nthr;
       auto cp = [&](int t) { for (size_t q = (size_t)t * per; q < std::min(nq, ((size_t)t + 1) * per); q++) sorted[q] = P.tasks[idx[q]]; };
       for (int t = 1; t < nthr; t++) th.emplace_back(cp, t);
       cp(0);
       for (auto& x : th) x.join();
-    } else {
-      // the urgent tasks [slot_task_ptr, slot_urgent_end) and the bulk of a slot are launched separately by the
-      // two-stream driver (api.cpp): interleave each range on its own so that the split points stay valid
-      for (int s = 0; s < NL; s++) {
-        const int64_t cuts[3] = {P.slot_task_ptr[s], P.slot_urgent_end[s], P.slot_task_ptr[s + 1]};
-        for (int part = 0; part < 2; part++) {
-          const int64_t b0 = cuts[part], n = cuts[part + 1] - b0;
-          const int64_t q8 = n / 8, r8 = n % 8;        // XCD x gets q8 + (x < r8) tasks
-          int64_t pos = 0;
-          for (int64_t x = 0; x < 8; x++) {
-            const int64_t cnt = q8 + (x < r8 ? 1 : 0);
-            for (int64_t j = 0; j < cnt; j++) sorted[b0 + j * 8 + x] = P.tasks[idx[b0 + pos++]];
-          }
-        }
-      }
     }
     P.tasks.swap(sorted);
   }

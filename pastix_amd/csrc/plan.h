@@ -121,9 +121,6 @@ struct Plan {
   std::vector<int64_t> slot_urgent_end;  // [nlevels] tasks [slot_task_ptr[s], slot_urgent_end[s]) target cblks of
                                          // level s itself (needed by this level's panel kernels); the rest of the
                                          // slot only feeds later levels and may overlap with the panel kernels
-  std::vector<int64_t> slot_late_begin;  // [nlevels] bulk tasks [slot_urgent_end, slot_late_begin) touch no tile of the
-                                         // previous slot's bulk launch and may run beside it; [slot_late_begin,
-                                         // slot_task_ptr[s+1]) must wait for it (same tile in consecutive slots)
   std::vector<int64_t> slot_small_begin; // [nlevels] bulk tasks [slot_small_begin[s], slot_task_ptr[s+1]) are quadrant tasks (Task
                                          // flag 32: tile = a 64x64 quadrant, small pieces) for k_update_small
   std::vector<int64_t> slot_usmall_begin;// [nlevels] urgent tasks [slot_usmall_begin[s], slot_urgent_end[s]): the same
@@ -136,6 +133,7 @@ struct Plan {
                                          // piece (8k(m+n)) + one read-modify-write of the tile per task (16 tm tn)
   std::vector<double> slot_flops;        // [nlevels] update flops per slot
   std::vector<double> slot_urgent_flops; // [nlevels] part of slot_flops in the urgent tasks (targets of level == slot)
+  std::vector<double> slot_mode_flops;   // [nlevels][3] (verbose >= 2 only) bulk flops by update-loop instance
   std::vector<int64_t> slot_pieces;      // [nlevels]
   std::vector<int32_t> slot_maxpn;       // [nlevels] longest piece list of a task in the slot
   std::vector<double> slot_maxwork;      // [nlevels] largest task (multiply-adds)

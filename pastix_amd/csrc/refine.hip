@@ -181,6 +181,20 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
   if (D.rc) return D.rc;
   if (mode == 1 /* conjugate gradient */ && (p->host.factotype == PASTIX_AMD_FACT_LU || (!std::is_same<T, double>::value && !herm)))
     mode = 0;                                      // CG needs A = A^H
+  // the mode's work vectors, ONCE for all right-hand sides (GMRES: m + 1 basis vectors of n entries -- 1.7 GB at n = 8e6
+  // and the default m = 25 -- must not be allocated again per right-hand side beside the factor arenas)
+  const int gm = (int)std::max<int64_t>(1, std::min<int64_t>(gmres_im > 0 ? gmres_im : 25, 200));
+  T *pd = nullptr, *r0 = nullptr, *pv = nullptr, *v = nullptr, *sv = nullptr, *t = nullptr, *y = nullptr;
+  std::vector<T*> V;
+  if (mode == 1) {
+    pd = D.vec();
+  } else if (mode == 3) {
+    r0 = D.vec(); pv = D.vec(); v = D.vec(); sv = D.vec(); t = D.vec(); y = D.vec();
+  } else if (mode == 0) {
+    V.resize((size_t)gm + 1);
+    for (auto& q : V) q = D.vec();
+  }
+  if (D.rc) return D.rc;
   int64_t iters = 0;
   double relerr = 0;
   int rc = 0;
@@ -200,8 +214,6 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
         relerr = residual();
       }
     } else if (mode == 1) {                        // raff_grad.c: preconditioned conjugate gradient
-      T* pd = D.vec();
-      if (D.rc) return D.rc;
       if ((rc = D.precond(r, z))) break;
       D.copy(z, pd);
       H rz = D.dot(r, z);
@@ -221,8 +233,6 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
       }
       if (!rc) relerr = residual();
     } else if (mode == 3) {                        // raff_bicgstab.c: right-preconditioned BiCGStab
-      T *r0 = D.vec(), *pv = D.vec(), *v = D.vec(), *sv = D.vec(), *t = D.vec(), *y = D.vec();
-      if (D.rc) return D.rc;
       D.copy(r, r0);
       H rho = 1.0, alpha = 1.0, omega = 1.0;
       D.axpby(H(0.0), r, H(0.0), pv);              // p = 0
@@ -259,10 +269,7 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
       if (!rc) relerr = residual();
     } else {
       // raff_gmres.c: right-preconditioned GMRES(m): A M^-1 u = b, x = M^-1 u; modified Gram-Schmidt, Givens rotations
-      const int m = (int)std::max<int64_t>(1, std::min<int64_t>(gmres_im > 0 ? gmres_im : 25, 200));
-      std::vector<T*> V((size_t)m + 1);
-      for (auto& q : V) q = D.vec();
-      if (D.rc) return D.rc;
+      const int m = gm;
       std::vector<H> Hm((size_t)(m + 1) * m), sn((size_t)m), g((size_t)m + 1), y((size_t)m);
       std::vector<double> cs((size_t)m);
       while (relerr >= eps && it < itermax && !rc) {

@@ -422,6 +422,44 @@ def schedule(cblk4, blok4, owner, rank, world, factotype=0, floattype=1):
     return out[:n.value], npl.value
 
 
+def schedule_hashes(cblk4, blok4, owner, rank, world, factotype=0, floattype=1):
+    """uint64[2 * world]: [2q] hash of the blocks this rank sends to rank q, [2q+1] of those it receives from q
+    (pastix_amd_dist_schedule_hash, host only)."""
+    la = LayoutArrays(cblk4, blok4)
+    own = np.ascontiguousarray(owner, dtype=np.int32)
+    out = np.zeros(2 * world, dtype=np.uint64)
+    check(_lib.lib().pastix_amd_dist_schedule_hash(ctypes.byref(la.c), factotype, floattype, _lib.ptr(own),
+                                                   ctypes.c_int32(rank), ctypes.c_int32(world), _lib.ptr(out)),
+          "pastix_amd_dist_schedule_hash")
+    return out
+
+
+def mismatched_channels(table):
+    """table[a] = schedule_hashes of rank a, for every rank: the (sender, receiver) pairs whose two ends disagree."""
+    world = len(table)
+    return [(a, b) for a in range(world) for b in range(world)
+            if a != b and int(table[a][2 * b]) != int(table[b][2 * a + 1])]
+
+
+def check_schedule_hashes(cblk4, blok4, owner, rank, world, factotype=0, floattype=1):
+    """Collective over torch.distributed, BEFORE the RCCL channels exist: every rank publishes what it expects of each
+    of its channels and all of them compare both ends of every channel.  A disagreement (ranks that planned from
+    different layouts or owner maps) raises on EVERY rank here instead of hanging in the first unmatched ncclRecv."""
+    import torch
+    import torch.distributed as dist
+    h = schedule_hashes(cblk4, blok4, owner, rank, world, factotype, floattype)
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(h.view(np.int64).copy()).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    table = [o.cpu().numpy().view(np.uint64) for o in out]
+    bad = mismatched_channels(table)
+    if bad:
+        raise RuntimeError("rank %d: the two ends of %d fan-in channel(s) disagree on their schedule (sender, receiver): %s"
+                           % (rank, len(bad), bad[:8]))
+    return table
+
+
 def factorize_scheduled(engine, msgs, nlevels, rows_of, isend, irecv):
     """Python mirror of pastix_amd_factorize_dist's message flow, for the CPU tests: same schedule, same order per
     channel, sends leave right after the level's contributions, a rank waits only for the blocks its next panels need.
@@ -636,15 +674,32 @@ def _bcast_layout(rank, make):
 
 
 def bench_distributed(a, rank, world, local):
-    """bench.py's N>1 leg: rank 0 analyses the matrix, every rank plans and factorizes its share of the elimination
-    tree; fan-in over RCCL point-to-point through the native driver.  With PASTIX_AMD_DIST_TEST=1 (ranks time-slicing
-    fewer GPUs, gloo) the lockstep torch.distributed protocol runs instead, for validation only."""
+    """bench.py's N>1 leg.  A PREFLIGHT first: the whole job -- analysis, partition, schedule-hash handshake, RCCL
+    channels, one factorization, distributed solve, residual and log-det checks -- on a 60^3 grid, so that a rendezvous
+    or numerical problem costs seconds and an error message instead of the 200^3 run's minutes
+    (PASTIX_AMD_BENCH_PREFLIGHT=0 skips it).  Then the same job on the benchmark grid, timed."""
+    import os
+    import sys
+    import time
+    pre = int(os.environ.get("PASTIX_AMD_BENCH_PREFLIGHT", "60"))
+    if pre > 0 and pre < a.grid:
+        t0 = time.time()
+        r = _dist_job(a, min(pre, a.grid), rank, world, local, steps=1, warmup=1)
+        if rank == 0:
+            sys.stderr.write("bench.py: preflight %d^3 on %d ranks ok in %.1f s (residual %s, log-det rel. err %.1e)\n"
+                             % (min(pre, a.grid), world, time.time() - t0, r["resid"], r["logdet_rel_err"]))
+    return _dist_job(a, a.grid, rank, world, local, steps=a.steps, warmup=a.warmup)
+
+
+def _dist_job(a, N, rank, world, local, steps, warmup):
+    """Rank 0 analyses the matrix, every rank plans and factorizes its share of the elimination tree; fan-in over RCCL
+    point-to-point through the native driver.  With PASTIX_AMD_DIST_TEST=1 (ranks time-slicing fewer GPUs, gloo) the
+    lockstep torch.distributed protocol runs instead, for validation only."""
     import time
     import torch
     import torch.distributed as dist
     from . import fact_flops
     from . import symbolic as sy
-    N = a.grid
     facto = {"llt": 0, "ldlt": 1, "lu": 2}[a.facto]
     native = dist.get_backend() != "gloo"
     if not native and facto != 0:
@@ -663,6 +718,9 @@ def bench_distributed(a, rank, world, local):
     t_sym = time.time() - t0
     t0 = time.time()
     crit = 6.0 * 2 * np.sqrt(1e-31)
+    # both ends of every channel must have planned the same blocks in the same order: compared over the bootstrap
+    # before a communicator exists (a mismatch raises on every rank)
+    check_schedule_hashes(c4, b4, owner, rank, world, factotype=facto)
     if native:
         eng = DistPlan(c4, b4, owner, rank, local, factotype=facto, chunk=a.chunk)
         t_plan = time.time() - t0
@@ -693,14 +751,14 @@ def bench_distributed(a, rank, world, local):
 
     # one untimed factorization whatever --warmup is: RCCL sets a channel up on its first message
     step()
-    for _ in range(max(a.warmup - 1, 0)):
+    for _ in range(max(warmup - 1, 0)):
         step()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     ft = ut = 0.0
     st = None
-    for _ in range(a.steps):
+    for _ in range(steps):
         st = step()
         ft += st["fact_time"]
         ut += st["update_time"]

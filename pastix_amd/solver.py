@@ -22,7 +22,7 @@ def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
 
 class Plan:
     def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0,
-                 schur=False):
+                 schur=False, quadrant_min=0, quadrant_fill_pct=0):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
         self.dtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float64
@@ -32,6 +32,8 @@ class Plan:
         opts.lookahead = lookahead
         opts.verbose = verbose
         opts.schur = 1 if schur else 0
+        opts.quadrant_min = quadrant_min
+        opts.quadrant_fill_pct = quadrant_fill_pct
         check(_lib.lib().pastix_amd_plan_create(ctypes.byref(self.layout.c), factotype, floattype,
                                                 ctypes.byref(opts), ctypes.byref(self._h)),
               "pastix_amd_plan_create")

@@ -37,3 +37,24 @@ def golden():
             cache[name] = fixture_io.load_npz(os.path.join(HERE, "golden", name + ".npz"))
         return cache[name]
     return get
+
+
+def recut_mask(c4, group=128):
+    """True where a packed panel entry is compared for LLt.  Everything, except the strict upper triangle of the
+    diagonal blok of a cblk wider than 128 columns.  The strict upper triangle is not part of L and nothing reads it
+    (potrf, trsm and updo use the lower triangle); the reference leaves by-products of its rectangular scatter there
+    (add_contrib_local subtracts whole blok x blok rectangles, sopalin_compute.c:427-452) -- which the engine's tiles
+    reproduce for every cblk of at most 128 columns, so those are compared in full.  A wider cblk is re-cut into column
+    groups of 128 (api.cpp build_split): the blocks above the groups have no storage on the device (the engine hands the
+    INPUT values back there), and inside a group the upper triangle also receives the earlier groups' update, which the
+    reference's blocked potrf applies to the lower triangle only (SYRK "L", compute_diag.c:197-200)."""
+    import numpy as np
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    parts = []
+    for k in range(len(w)):
+        wk, sk = int(w[k]), int(c4[k, 3])
+        m = np.ones((wk, sk), dtype=bool)            # [col][row]
+        if wk > group:
+            m[:, :wk] = np.triu(np.ones((wk, wk), dtype=bool))     # row >= col
+        parts.append(m.ravel())
+    return np.concatenate(parts)

@@ -201,3 +201,70 @@ def test_native_schedule_is_consistent_between_ranks(facto, floattype, npl, gold
                 for lvl, _p, t, d, nr, wd in ab.tolist():
                     assert lvl == level[t] and owner[t] == (b if d == 0 else a)
         assert nsend == len(pd.fanin_pairs(c4, b4, owner))
+
+
+def test_schedule_hashes_detect_a_rank_that_planned_differently(golden):
+    """pastix_amd_dist_schedule_hash (host only): with one owner map the two ends of every channel hash alike; a rank that
+    planned from another owner map (a cblk given to someone else) is caught on exactly the channels it touches."""
+    g = golden("rlap3d_14_llt_bs24")
+    c4, b4 = g["cblk4"], g["blok4"]
+    for facto, ft in ((0, 1), (2, 1), (1, 3)):
+        for world in (2, 4, 8):
+            owner = pd.partition(c4, b4, world)
+            table = [pd.schedule_hashes(c4, b4, owner, r, world, facto, ft) for r in range(world)]
+            assert pd.mismatched_channels(table) == []
+    world = 4
+    owner = pd.partition(c4, b4, world)
+    table = [pd.schedule_hashes(c4, b4, owner, r, world) for r in range(world)]
+    pairs = pd.fanin_pairs(c4, b4, owner)
+    t = int(pairs[len(pairs) // 2, 1])                  # a cblk that receives a fan-in block
+    other = owner.copy()
+    other[t] = (owner[t] + 1) % world
+    bad_rank = int(owner[t])
+    table[bad_rank] = pd.schedule_hashes(c4, b4, other, bad_rank, world)
+    bad = pd.mismatched_channels(table)
+    assert bad and all(bad_rank in ab for ab in bad)
+
+
+def _worker_hash(rank, world, port, name, poison, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fixture_io
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = fixture_io.load_npz(os.path.join(HERE, "golden", name + ".npz"))
+    c4, b4 = g["cblk4"], g["blok4"]
+    owner = pd.partition(c4, b4, world)
+    if poison and rank == 1:                            # this rank analysed something else
+        t = int(pd.fanin_pairs(c4, b4, owner)[0, 1])
+        owner = owner.copy()
+        owner[t] = (owner[t] + 1) % world
+    try:
+        pd.check_schedule_hashes(c4, b4, owner, rank, world)
+        q.put((rank, True, ""))
+    except RuntimeError as e:
+        q.put((rank, False, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("poison", [False, True])
+def test_schedule_handshake_over_gloo(poison):
+    """check_schedule_hashes, the collective bench.py --gpus N runs before any RCCL communicator exists: world 2 over
+    gloo; a disagreement raises on EVERY rank (nobody is left waiting in a rendezvous)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    port = 33700 + (os.getpid() % 2000) + int(poison)
+    procs = [ctx.Process(target=_worker_hash, args=(r, world, port, "rlap3d_14_llt_bs24", poison, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok != poison for _r, ok, _m in res), res
+    if poison:
+        assert all("disagree" in m for _r, _ok, m in res)

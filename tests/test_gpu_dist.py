@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import HERE, ROOT
+from conftest import HERE, ROOT, recut_mask
 from pastix_amd import dist as pd
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
@@ -35,7 +35,8 @@ def _check_owned(g, plan, owner, rank):
     assert sorted(got) == sorted(np.nonzero(owner == rank)[0].tolist())
     for k, (L, U) in got.items():
         ref = g["L1"][off[k]:off[k + 1]]
-        m = _lower_mask_cblk(int(w[k]), int(c4[k, 3])) if g["facto"] in (1, 3) else np.ones(ref.size, bool)
+        m = (_lower_mask_cblk(int(w[k]), int(c4[k, 3])) if g["facto"] in (1, 3)
+             else recut_mask(c4[k:k + 2]) if g["facto"] == 0 else np.ones(ref.size, bool))
         assert np.abs(L - ref)[m].max() <= TOL * scale, k
         if g["facto"] == 2:
             assert np.abs(U - g["U1"][off[k]:off[k + 1]]).max() <= TOL * scale, k
@@ -182,6 +183,7 @@ def _rccl_worker(rank, world, port, name, q):
     owner = pdd.partition(c4, b4, world)
     ok, msg = True, ""
     try:
+        pdd.check_schedule_hashes(c4, b4, owner, rank, world, g["facto"], 3 if cz else 1)
         with pdd.DistPlan(c4, b4, owner, rank, rank, factotype=g["facto"], floattype=3 if cz else 1) as p:
             p.attach_rccl(world, pdd.exchange_unique_ids(c4, b4, owner, rank, world))
             assert p.info()["transport"] == "rccl"
@@ -204,11 +206,13 @@ def _rccl_worker(rank, world, port, name, q):
     except Exception as e:  # noqa: BLE001
         ok, msg = False, repr(e)
     q.put((rank, ok, msg))
-    dist.barrier()
-    dist.destroy_process_group()
     q.close()
     q.join_thread()
-    os._exit(0)                    # (skip RCCL's exit-time teardown, see test_rccl_binding_selftest)
+    if ok:
+        dist.barrier()
+        dist.destroy_process_group()
+    # (leave without interpreter teardown -- a failed rank may hold aborted channels -- with the code it earned)
+    os._exit(0 if ok else 1)
 
 
 @pytest.mark.parametrize("name", ["rlap3d_14_llt_bs24", "rlap3d_20_llt_bs128", "rlap3d_12_lu", "zrlap3d_12_ldlt"])
@@ -226,6 +230,66 @@ def test_native_driver_over_rccl_world2(name):
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=120)
-        assert p.exitcode == 0
     for rank, ok, msg in res:
         assert ok, (rank, msg)
+    for p in procs:
+        assert p.exitcode == 0
+
+
+def test_unmatched_rank_times_out_instead_of_hanging():
+    """Hang protection of the multi-GPU driver (csrc/dist.cpp: dist_finish): rank 1 of a 2-rank loopback job runs ALONE --
+    the peer it receives from never shows up.  Within PASTIX_AMD_DIST_TIMEOUT seconds it reports the unmatched receive on
+    stderr, aborts its channels, returns PASTIX_AMD_ERR_TIMEOUT (-7); its distributed state is dead afterwards (the next
+    call is refused, nothing hangs) while the plan can still be destroyed.  In a child process: the deadline is read
+    once per process."""
+    import subprocess
+    code = r'''
+import ctypes, os, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import fixture_io
+from pastix_amd import _lib
+from pastix_amd import dist as pd
+g = fixture_io.load_npz(os.path.join(%r, "golden", "rlap3d_14_llt_bs24.npz"))
+c4, b4 = g["cblk4"], g["blok4"]
+owner = pd.partition(c4, b4, 2)
+plans = [pd.DistPlan(c4, b4, owner, r, 0) for r in range(2)]
+pd.attach_local(plans)
+for p in plans:
+    p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+recv = [r for r in range(2) if plans[r].info()["nrecv"] > 0][0]
+t0 = time.time()
+st = _lib.Stats()
+rc = _lib.lib().pastix_amd_factorize_dist(plans[recv]._h, ctypes.c_double(g["critere"]), ctypes.byref(st))
+dt = time.time() - t0
+rc2 = _lib.lib().pastix_amd_factorize_dist(plans[recv]._h, ctypes.c_double(g["critere"]), ctypes.byref(st))
+for p in plans:
+    p.close()
+print("RESULT", rc, rc2, "%%.1f" %% dt, flush=True)
+''' % (ROOT, HERE, os.path.join(HERE, "golden"), HERE)
+    env = dict(os.environ, PASTIX_AMD_DIST_TIMEOUT="3")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, (out.stdout[-500:], out.stderr[-1500:])
+    _tag, rc, rc2, dt = line[0].split()
+    assert int(rc) == -7 and int(rc2) == -1, (line, out.stderr[-1500:])
+    assert 2.5 <= float(dt) < 60.0
+    assert "not matched within" in out.stderr and "aborting the channels" in out.stderr
+
+
+def test_loopback_attach_rejects_mismatched_schedules(golden):
+    """attach_local compares both ends of every channel (pastix_amd_dist_schedule_hash) before wiring them: rank plans
+    built from different owner maps are refused with PASTIX_AMD_ERR_LAYOUT."""
+    g = golden("rlap3d_14_llt_bs24")
+    c4, b4 = g["cblk4"], g["blok4"]
+    owner = pd.partition(c4, b4, 2)
+    t = int(pd.fanin_pairs(c4, b4, owner)[0, 1])
+    other = owner.copy()
+    other[t] = 1 - owner[t]
+    plans = [pd.DistPlan(c4, b4, owner, 0, 0), pd.DistPlan(c4, b4, other, 1, 0)]
+    try:
+        with pytest.raises(RuntimeError, match="-6"):
+            pd.attach_local(plans)
+    finally:
+        for p in plans:
+            p.close()

@@ -1,6 +1,6 @@
 // Synthetic micro-benchmark of k_update: N tasks x P full pieces (128x128xK), operands drawn from a
 // pool of `pool` source panels.  Build: hipcc --offload-arch=gfx950 -O3 -I pastix_amd/csrc -o tools/bench_update tools/bench_update.hip
-#include "../pastix_amd/csrc/kernels.hip"
+#include "../pastix_amd/csrc/kernels_update.hip"
 #include <cstdio>
 #include <vector>
 #include <random>

@@ -18,7 +18,7 @@ slots = [i for i in range(len(sf)) if bulk[i] > 0]
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = []
 for row in csv.DictReader(open(f)):
-    if "k_update<8, 0>" in row["Kernel_Name"]:
+    if "k_update<0>" in row["Kernel_Name"]:
         ev.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), int(row.get("Grid_Size_X", row.get("Grid_Size", 0)) or 0)))
 ev.sort()
 ev = ev[-len(slots):]

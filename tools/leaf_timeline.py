@@ -7,8 +7,8 @@ nk = int(sys.argv[2]) if len(sys.argv) > 2 else 90
 ev = []
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    k = ("small_u" if "k_update_small<1>" in n else "small" if "k_update_small" in n else "bulk" if "k_update<8, 0>" in n else
-         "urgent" if "k_update<8, 1>" in n else "trsm" if "k_trsm" in n else "diag" if "k_diag" in n else None)
+    k = ("small_u" if "k_update_small<1>" in n else "small" if "k_update_small" in n else "bulk" if "k_update<0>" in n else
+         "urgent" if "k_update<1>" in n else "trsm" if "k_trsm" in n else "diag" if "k_diag" in n else None)
     if k:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
                    int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 256)) or 256)))

@@ -6,7 +6,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = []
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    k = "bulk" if "k_update<8, 0>" in n else "urg" if "k_update<8, 1>" in n else "trsm" if "k_trsm" in n else "diag" if "k_diag" in n else None
+    k = "bulk" if "k_update<0>" in n else "urg" if "k_update<1>" in n else "trsm" if "k_trsm" in n else "diag" if "k_diag" in n else None
     if k: ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k))
 ev.sort()
 diag = [e for e in ev if e[2] == "diag"]

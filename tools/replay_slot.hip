@@ -5,7 +5,7 @@
 //      workgroup g (-> XCD g % 8) belongs to an 8 x 8 sub-block
 //   2  random
 // Build: hipcc --offload-arch=gfx950 -O3 -I pastix_amd/csrc -o tools/replay_slot tools/replay_slot.hip
-#include "../pastix_amd/csrc/kernels.hip"
+#include "../pastix_amd/csrc/kernels_update.hip"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
