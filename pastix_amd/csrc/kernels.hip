@@ -37,130 +37,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 
 // ------------------------------------------------------------------------------------------------
-// k_diag : LLt of the diagonal blok, one workgroup (256 threads) per cblk, 16-column block steps
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_diag_llt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
-                                                  double* __restrict__ dinv_ws, double critere,
-                                                  long long* __restrict__ nbpivot, int* __restrict__ errflag) {
-  PANEL_PRIO();
-  __shared__ double Ts[16][17];
-  __shared__ double Lo[16][17];
-  __shared__ double Ti[16][17];
-  __shared__ double Xs[16][244];
-  const PanelTask tk = tasks[blockIdx.x];
-  double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x;
-  const int ti = tid & 15, tc = tid >> 4;
-  int npiv = 0;
-
-  for (int kb = 0; kb < w; kb += 16) {
-    const int nb = min(16, w - kb);
-    const int rem = w - kb - nb;
-    // (1) diagonal tile -> LDS
-    if (ti < nb && tc < nb && ti >= tc) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
-    // (2) unblocked LLt of the tile: PASTIX_potrf (compute_diag.c:124-153), one barrier per column
-    for (int j = 0; j < nb; j++) {
-      __syncthreads();
-      double d = Ts[j][j];
-      if (fabs(d) < critere) {                     // compute_diag.c:133-137
-        d = critere;
-        if (tid == 0) npiv++;
-      }
-      if (!(d > 0.0) && tid == 0) atomicOr(errflag, 1);   // sqrt of a non-positive pivot
-      double inv;
-      fast_sqrt_rsqrt(d, d, inv);                  // sqrt (compute_diag.c:142) and SCAL by 1/d (:150)
-      if (ti < nb && tc < nb) {
-        if (tc == j) {
-          if (ti == j) Lo[j][j] = d;
-          else if (ti > j) Lo[ti][j] = Ts[ti][j] * inv;
-        } else if (tc > j && ti >= tc) {
-          Ts[ti][tc] -= (Ts[ti][j] * inv) * (Ts[tc][j] * inv);   // SYR "L" (compute_diag.c:151)
-        }
-      }
-    }
-    __syncthreads();
-    // (3) tile back to global; 16x16 inverse by 16 threads; rows below by the other threads
-    if (ti < nb && tc < nb && ti >= tc) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
-    if (tid < 16) {
-      // column c of inv(T): forward substitution; identity padding beyond nb
-      const int c = tid;
-      for (int i = 0; i < 16; i++) {
-        double x;
-        if (i >= nb || c >= nb) x = (i == c) ? 1.0 : 0.0;
-        else if (i < c) x = 0.0;
-        else {
-          double s = (i == c) ? 1.0 : 0.0;
-          for (int p = c; p < i; p++) s -= Lo[i][p] * Ti[p][c];
-          x = s / Lo[i][i];
-        }
-        Ti[i][c] = x;
-      }
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
-      for (int i = 0; i < 16; i++) dst[i + 16 * c] = Ti[i][c];
-    } else if (tid - 16 < rem) {
-      // TRSM "R","L","T","N" on the rows of the diagonal blok below the tile (compute_diag.c:191-195)
-      const int rr = tid - 16;
-      double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = (c < nb) ? ap[(int64_t)c * ld] : 0.0;
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          double s = x[c];
-#pragma unroll
-          for (int p = 0; p < 16; p++)
-            if (p < c) s -= x[p] * Lo[c][p];
-          x[c] = s / Lo[c][c];
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) ap[(int64_t)c * ld] = x[c];
-        Xs[c][rr] = x[c];
-      }
-    }
-    __syncthreads();
-    // (4) SYRK "L","N" on the trailing part of the diagonal blok (compute_diag.c:197-200)
-    if (rem > 0) {
-      const int nt = (rem + 3) >> 2;
-      double* Cb = A + (kb + nb) + (int64_t)(kb + nb) * ld;
-      for (int id = tid; id < nt * nt; id += 256) {
-        const int tr = id % nt, tcc = id / nt;
-        if (tr < tcc) continue;
-        double c[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
-        for (int p = 0; p < nb; p++) {
-          double xa[4], xb[4];
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            xa[a] = Xs[p][min(4 * tr + a, 243)];
-            xb[a] = Xs[p][min(4 * tcc + a, 243)];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            const int r = 4 * tr + a, cc = 4 * tcc + b;
-            if (r < rem && cc < rem && r >= cc) Cb[r + (int64_t)cc * ld] -= c[a][b];
-          }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_diag_llt_w : the diagonal-blok factorization for w <= 128 with the blok resident in LDS (the global-memory
 // version above spends ~170 us per 128-wide blok on dependent L2 accesses; this is the latency-critical kernel
 // of every level).  Per 16-column block step:
@@ -653,110 +529,6 @@ __global__ void k_scatter(double* __restrict__ dst, const int64_t* __restrict__ 
   for (; i < n; i += stride) dst[idx[i]] = val[i];
 }
 
-// ------------------------------------------------------------------------------------------------
-// triangular solves on the factored panels (the data flow of up_down_smp, updo.c:114, for LLt):
-// forward L y = b level by level (cblks of one level are independent; their off-diagonal
-// contributions collide on x rows -> f64 atomics), backward L^T x = y in reverse level order
-// (gather, no atomics).  One workgroup per cblk.  Memory-bound: every panel is read once.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int panel_row_to_global(const DevBlok* __restrict__ bl, int fb, int lb, int p) {
-  int lo = fb, hi = lb - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (bl[mid].coefind <= p) lo = mid; else hi = mid - 1;
-  }
-  return bl[lo].frow + (p - bl[lo].coefind);
-}
-
-// forward, step 1: x_k := L_kk^-1 x_k (one workgroup per cblk)
-// unit: LDLt and LU (unit-lower L); else LLt
-__global__ __launch_bounds__(256) void k_solve_diag_fwd(const double* __restrict__ L,
-                                                        const SolveTask* __restrict__ tasks,
-                                                        double* __restrict__ x, int unit) {
-  __shared__ double xs[MAXW];
-  const SolveTask tk = tasks[blockIdx.x];
-  const double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
-  __syncthreads();
-  for (int c = 0; c < w; c++) {            // column-oriented forward substitution
-    const double xc = unit ? xs[c] : xs[c] / A[c + (int64_t)c * ld];
-    __syncthreads();
-    if (tid == 0) xs[c] = xc;
-    for (int r = c + 1 + tid; r < w; r += 256) xs[r] -= A[r + (int64_t)c * ld] * xc;
-    __syncthreads();
-  }
-  for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
-}
-
-// Triangular solve with the diagonal blok, one WAVE per cblk: lane i keeps x rows i, i+64, ... in registers, the
-// pivot value travels by readlane, and the blok streams through registers 16 columns ahead of the dependent
-// chain (the loads do not depend on x).  ~25 cycles per column instead of two workgroup barriers.
-//   MODE 0: forward, lower triangle (column c updates the rows below)
-//   MODE 1: backward with L^T (row c of L updates the rows above)      MODE 2: backward with the upper triangle
-// `unit`: unit diagonal.  The diagonal enters as a reciprocal (1 ulp from the division of the scalar kernels).
-template <int NS, int MODE>
-__global__ __launch_bounds__(64) void k_solve_diag_w(const double* __restrict__ L,
-                                                     const SolveTask* __restrict__ tasks,
-                                                     double* __restrict__ x, int unit) {
-  const SolveTask tk = tasks[blockIdx.x];
-  const double* A = L + tk.off;
-  const int64_t ld = tk.stride;
-  const int w = tk.width, lane = threadIdx.x;
-  double xr[NS], rinv[NS];
-  int64_t rcl[NS];
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    const int r = lane + 64 * j, rc = min(r, w - 1);
-    rcl[j] = rc;
-    xr[j] = r < w ? x[tk.fcol + rc] : 0.0;
-    rinv[j] = unit ? 1.0 : 1.0 / A[rc + rc * ld];
-  }
-  const int nb = (w + 15) >> 4;
-  auto col_of = [&](int cb, int i) { return MODE == 0 ? cb * 16 + i : w - 1 - (cb * 16 + i); };
-  auto load = [&](double (&a)[16][NS], int cb) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int64_t c = min(max(col_of(cb, i), 0), w - 1);
-#pragma unroll
-      for (int j = 0; j < NS; j++) a[i][j] = MODE == 1 ? A[c + rcl[j] * ld] : A[rcl[j] + c * ld];
-    }
-  };
-  auto compute = [&](double (&a)[16][NS], int cb) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int c = col_of(cb, i);
-      if (c < 0 || c >= w) break;
-      const int slot = c >> 6, src = c & 63;
-      double v = 0.0;
-#pragma unroll
-      for (int j = 0; j < NS; j++)
-        if (j == slot) v = xr[j] * rinv[j];
-      const double xc = readlane_f64(v, src);
-#pragma unroll
-      for (int j = 0; j < NS; j++) {
-        const int r = lane + 64 * j;
-        const bool upd = MODE == 0 ? (r > c && r < w) : (r < c);
-        const double nx = upd ? __builtin_fma(-a[i][j], xc, xr[j]) : xr[j];
-        xr[j] = (r == c) ? xc : nx;
-      }
-    }
-  };
-  double a0[16][NS], a1[16][NS];
-  load(a0, 0);
-  for (int cb = 0; cb < nb; cb += 2) {
-    if (cb + 1 < nb) load(a1, cb + 1);
-    compute(a0, cb);
-    if (cb + 2 < nb) load(a0, cb + 2);
-    if (cb + 1 < nb) compute(a1, cb + 1);
-  }
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    const int r = lane + 64 * j;
-    if (r < w) x[tk.fcol + r] = xr[j];
-  }
-}
-
 // The same solve for cblks of at most 128 columns on four waves: wave q keeps the 32 columns it will process in
 // registers (one memory round trip for the whole blok, all loads in flight at once), the waves take turns on the
 // chain and hand x over through LDS.
@@ -1076,91 +848,12 @@ __global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restric
   }
 }
 
-// forward, step 2: x[row] -= L[row, :] . x_k for 256 panel rows per workgroup (one row per thread)
-__global__ __launch_bounds__(256) void k_solve_off_fwd(const double* __restrict__ L,
-                                                       const SolveChunk* __restrict__ chunks,
-                                                       const DevBlok* __restrict__ bl, double* __restrict__ x) {
-  __shared__ double xs[MAXW];
-  const SolveChunk ck = chunks[blockIdx.x];
-  const double* A = L + ck.off;
-  const int ld = ck.stride, w = ck.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = x[ck.fcol + c];
-  __syncthreads();
-  const int p = ck.row0 + tid;
-  if (tid < ck.nrows) {
-    double s = 0;
-    for (int c = 0; c < w; c++) s += A[p + (int64_t)c * ld] * xs[c];
-    unsafeAtomicAdd(&x[panel_row_to_global(bl, ck.fblok, ck.lblok, p)], -s);
-  }
-}
-
-// backward, step 1: x_k[c] -= sum over 256 panel rows of L[row, c] * x[row]
-// One row per thread (coalesced column reads); the sum over the 64 rows of a wave for 32 columns at a time is a
-// transposed butterfly: at every step a lane hands half of its partial sums to its partner and keeps the other
-// half, so 32 columns cost 32 shuffles instead of 192; lanes 2c, 2c+1 end with column c.
-__global__ __launch_bounds__(256) void k_solve_off_bwd(const double* __restrict__ L,
-                                                       const SolveChunk* __restrict__ chunks,
-                                                       const DevBlok* __restrict__ bl, double* __restrict__ x) {
-  __shared__ double part[4][MAXW];
-  const SolveChunk ck = chunks[blockIdx.x];
-  const double* A = L + ck.off;
-  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = ck.row0 + tid;
-  const bool valid = tid < ck.nrows;
-  const double xr = valid ? x[panel_row_to_global(bl, ck.fblok, ck.lblok, min(p, ld - 1))] : 0.0;
-  const double* Ap = A + min(p, ld - 1);
-  for (int c0 = 0; c0 < w; c0 += 32) {
-    double acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) acc[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld] * xr;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const int d = 32 >> k, half = 16 >> k;
-      const bool up = (lane & d) != 0;
-#pragma unroll
-      for (int i = 0; i < half; i++) {
-        const double send = up ? acc[i] : acc[i + half];
-        const double keep = up ? acc[i + half] : acc[i];
-        acc[i] = keep + __shfl_xor(send, d);
-      }
-    }
-    acc[0] += __shfl_xor(acc[0], 1);
-    const int c = c0 + ((lane >> 1) & 31);
-    if (!(lane & 1) && c < w) part[wave][c] = acc[0];
-  }
-  __syncthreads();
-  for (int c = tid; c < w; c += 256)
-    unsafeAtomicAdd(&x[ck.fcol + c], -(part[0][c] + part[1][c] + part[2][c] + part[3][c]));
-}
-
 // LDLt: x_k := D_k^-1 x_k between the forward and the backward sweep
 __global__ __launch_bounds__(256) void k_solve_dscale(const double* __restrict__ L,
                                                       const SolveTask* __restrict__ tasks, double* __restrict__ x) {
   const SolveTask tk = tasks[blockIdx.x];
   const double* A = L + tk.off;
   for (int c = threadIdx.x; c < tk.width; c += 256) x[tk.fcol + c] /= A[c + (int64_t)c * tk.stride];
-}
-
-// backward, step 2: L_kk^T x_k = rhs
-// mode 0: L^T non-unit (LLt); 1: L^T unit (LDLt); 2: U = upper triangle of the factored blok (LU)
-__global__ __launch_bounds__(256) void k_solve_diag_bwd(const double* __restrict__ L,
-                                                        const SolveTask* __restrict__ tasks,
-                                                        double* __restrict__ x, int mode) {
-  __shared__ double xs[MAXW];
-  const SolveTask tk = tasks[blockIdx.x];
-  const double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = x[tk.fcol + c];
-  __syncthreads();
-  for (int c = w - 1; c >= 0; c--) {        // row-oriented backward substitution
-    const double xc = (mode == 1) ? xs[c] : xs[c] / A[c + (int64_t)c * ld];
-    __syncthreads();
-    if (tid == 0) xs[c] = xc;
-    for (int r = tid; r < c; r += 256)
-      xs[r] -= (mode == 2 ? A[r + (int64_t)c * ld] : A[c + (int64_t)r * ld]) * xc;
-    __syncthreads();
-  }
-  for (int c = tid; c < w; c += 256) x[tk.fcol + c] = xs[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1185,21 +878,18 @@ void launch_fanin_add(hipStream_t s, double* dst, int64_t ldd, const double* src
                      ldd, src, rows, nrows, total);
 }
 
+// (cblks are at most 128 columns wide: wider ones are re-cut before planning, api.cpp build_split)
 void launch_diag_llt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int* errflag, int maxw) {
+  (void)maxw;
   if (n <= 0) return;
-  if (maxw <= 128)
-    hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(512), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
-  else
-    hipLaunchKernelGGL(k_diag_llt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
+  hipLaunchKernelGGL(k_diag_llt_w, dim3((unsigned)n), dim3(512), 0, s, L, tasks, dinv, critere, nbpivot, errflag);
 }
 
 void launch_trsm_llt(hipStream_t s, double* L, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw) {
+  (void)maxw;
   if (n <= 0) return;
-  if (maxw <= 128)
-    hipLaunchKernelGGL(k_trsm_llt<8>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
-  else
-    hipLaunchKernelGGL(k_trsm_llt<16>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
+  hipLaunchKernelGGL(k_trsm_llt<8>, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device

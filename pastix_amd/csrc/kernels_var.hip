@@ -37,111 +37,6 @@ __device__ __forceinline__ void tile_inverse(F lower, bool unit, int nb, int c, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDLt diagonal blok
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_diag_ldlt(double* __restrict__ L, const PanelTask* __restrict__ tasks,
-                                                   double* __restrict__ dinv_ws, double critere,
-                                                   long long* __restrict__ nbpivot) {
-  PANEL_PRIO();
-  __shared__ double Ts[16][17];
-  __shared__ double Lo[16][17];
-  __shared__ double Ti[16][17];
-  __shared__ double Xs[16][244];   // L  rows below the tile (scaled)
-  __shared__ double Ws[16][244];   // L*D rows below the tile
-  const PanelTask tk = tasks[blockIdx.x];
-  double* A = L + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
-  int npiv = 0, npos = 0;
-  for (int kb = 0; kb < w; kb += 16) {
-    const int nb = min(16, w - kb), rem = w - kb - nb;
-    if (ti < nb && tc < nb && ti >= tc) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
-    for (int j = 0; j < nb; j++) {                       // PASTIX_sytrf, compute_diag.c:223-242
-      __syncthreads();
-      double d = Ts[j][j];
-      if (fabs(d) < critere) { d = critere; if (tid == 0) npiv++; }
-      if (tid == 0 && d > 0.0) npos++;                     // inertia (sopalin3d.c:1144-1160)
-      const double inv = fast_rcp(d);
-      if (ti < nb && tc < nb) {
-        if (tc == j) {
-          if (ti == j) Lo[j][j] = d;
-          else if (ti > j) Lo[ti][j] = Ts[ti][j] * inv;
-        } else if (tc > j && ti >= tc) {
-          Ts[ti][tc] -= (Ts[ti][j] * inv) * (d * (Ts[tc][j] * inv));   // SYR alpha = -d
-        }
-      }
-    }
-    __syncthreads();
-    if (ti < nb && tc < nb && ti >= tc) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
-    if (tid < 16) {
-      tile_inverse([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
-                   dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256);
-    } else if (tid - 16 < rem) {
-      // TRSM "R","L","T","U" gives L*D (compute_diag.c:284-288), then scale by 1/d (:289-298)
-      const int rr = tid - 16;
-      double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
-      double x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = ap[(int64_t)min(c, nb - 1) * ld];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          double s = x[c];
-#pragma unroll
-          for (int p = 0; p < 16; p++)
-            if (p < c) s -= x[p] * Lo[c][p];
-          x[c] = s;
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const double v = (c < nb) ? x[c] : 0.0;
-        const double sc = (c < nb) ? v * fast_rcp(Lo[min(c, nb - 1)][min(c, nb - 1)]) : 0.0;
-        Ws[c][rr] = v;
-        Xs[c][rr] = sc;
-        if (c < nb) ap[(int64_t)c * ld] = sc;
-      }
-    }
-    __syncthreads();
-    if (rem > 0) {                                       // A22 -= (L D) L^T, lower part
-      const int nt = (rem + 3) >> 2;
-      double* Cb = A + (kb + nb) + (int64_t)(kb + nb) * ld;
-      for (int id = tid; id < nt * nt; id += 256) {
-        const int tr = id % nt, tcc = id / nt;
-        if (tr < tcc) continue;
-        double c[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++) c[a][b] = 0.0;
-        for (int p = 0; p < nb; p++) {
-          double xa[4], xb[4];
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            xa[a] = Ws[p][min(4 * tr + a, 243)];
-            xb[a] = Xs[p][min(4 * tcc + a, 243)];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) c[a][b] += xa[a] * xb[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            const int r = 4 * tr + a, cc = 4 * tcc + b;
-            if (r < rem && cc < rem && r >= cc) Cb[r + (int64_t)cc * ld] -= c[a][b];
-          }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
-  if (tid == 0 && npos) atomicAdd((unsigned long long*)nbpivot + 1, (unsigned long long)npos);
-}
-
-// ------------------------------------------------------------------------------------------------
 // LU diagonal blok (full w x w square in the L arena; transposed copy into the U arena at the end)
 // workspace: [nbk blocks: inverse of (U tile)^T, lower non-unit][nbk blocks: inverse of the unit L tile]
 // ------------------------------------------------------------------------------------------------
@@ -355,10 +250,9 @@ void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_
                         long long* nbpivot);      // kernels.hip: LDS-resident blok, MFMA trailing update (w <= 128)
 void launch_diag_ldlt(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                       long long* nbpivot, int maxw) {
+  (void)maxw;                                     // (cblks are at most 128 columns wide: api.cpp build_split)
   if (n <= 0) return;
-  static const bool old = getenv("PASTIX_AMD_DIAG_LDLT_OLD") != nullptr;
-  if (maxw <= 128 && !old) launch_diag_ldlt_w(s, L, tasks, n, dinv, critere, nbpivot);
-  else hipLaunchKernelGGL(k_diag_ldlt, dim3((unsigned)n), dim3(256), 0, s, L, tasks, dinv, critere, nbpivot);
+  launch_diag_ldlt_w(s, L, tasks, n, dinv, critere, nbpivot);
 }
 
 void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks, int64_t n, double* dinv,
@@ -370,10 +264,8 @@ void launch_diag_lu(hipStream_t s, double* L, double* U, const PanelTask* tasks,
 template <int MODE>
 static void launch_trsm_mode(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n,
                              const double* dinv, int maxw) {
-  if (maxw <= 128)
-    hipLaunchKernelGGL((k_trsm_var<8, MODE>), dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv);
-  else
-    hipLaunchKernelGGL((k_trsm_var<16, MODE>), dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv);
+  (void)maxw;
+  hipLaunchKernelGGL((k_trsm_var<8, MODE>), dim3((unsigned)n), dim3(256), 0, s, L, U, tasks, dinv);
 }
 
 void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,

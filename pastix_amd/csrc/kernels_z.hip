@@ -41,147 +41,6 @@ __device__ __forceinline__ cz cinv(cz a) {
   return cz{r / d, -1.0 / d};
 }
 
-template <bool HERM, int XR>
-__global__ __launch_bounds__(256) void k_diag_zsy(const Arenas ar, const PanelTask* __restrict__ tasks,
-                                                  double* __restrict__ dinv_ws, double critere,
-                                                  long long* __restrict__ nbpivot) {
-  PANEL_PRIO();
-  __shared__ cz Ts[16][17];
-  __shared__ cz Lo[16][17];
-  __shared__ cz Ti[16][17];
-  __shared__ cz Xs[16][XR];    // L   rows below the tile (XR >= widest cblk - 16)
-  __shared__ cz Ws[16][XR];    // L*D rows below the tile
-  const PanelTask tk = tasks[blockIdx.x];
-  double* Ar = ar.p[0] + tk.off;
-  double* Ai = ar.p[2] + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
-  int npiv = 0;
-  for (int kb = 0; kb < w; kb += 16) {
-    const int nb = min(16, w - kb), rem = w - kb - nb;
-    if (ti < nb && tc < nb && ti >= tc) {
-      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
-      Ts[ti][tc] = cz{Ar[o], Ai[o]};
-    }
-    for (int j = 0; j < nb; j++) {                       // PASTIX_sytrf, compute_diag.c:223-242
-      __syncthreads();
-      cz d = Ts[j][j];
-      if (hypot(d.re, d.im) < critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // ABS_FLOAT = cabs
-      const cz inv = cinv(d);
-      if (ti < nb && tc < nb) {
-        if (tc == j) {
-          if (ti == j) Lo[j][j] = d;
-          else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
-        } else if (tc > j && ti >= tc) {
-          const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tc][j], inv);
-          if (!HERM) Ts[ti][tc] = csub(Ts[ti][tc], cmul(xi, cmul(d, xc)));    // GER with alpha = -d (x x^T)
-          else {                                                               // zher: alpha = -Re(d), x x^H,
-            cz v = csub(Ts[ti][tc], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));   // diagonal kept real
-            if (ti == tc) v.im = 0.0;
-            Ts[ti][tc] = v;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (ti < nb && tc < nb && ti >= tc) {
-      const int64_t o = (kb + ti) + (int64_t)(kb + tc) * ld;
-      Ar[o] = Lo[ti][tc].re;
-      Ai[o] = Lo[ti][tc].im;
-    }
-    if (tid < 16) {
-      // inverse of the unit-lower tile (complex), column c by forward substitution
-      const int c = tid;
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512;   // [256 re][256 im] per block
-      for (int i = 0; i < 16; i++) {
-        cz x;
-        if (i >= nb || c >= nb) x = cz{(i == c) ? 1.0 : 0.0, 0.0};
-        else if (i < c) x = cz{0.0, 0.0};
-        else {
-          cz s = cz{(i == c) ? 1.0 : 0.0, 0.0};
-          for (int p = c; p < i; p++) s = csub(s, cmul(Lo[i][p], Ti[p][c]));
-          x = s;
-        }
-        Ti[i][c] = x;
-      }
-      for (int i = 0; i < 16; i++) { dst[i + 16 * c] = Ti[i][c].re; dst[256 + i + 16 * c] = Ti[i][c].im; }
-    } else if (tid - 16 < rem) {
-      const int rr = tid - 16;
-      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
-      cz x[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const int64_t o = o0 + (int64_t)min(c, nb - 1) * ld;
-        x[c] = cz{Ar[o], Ai[o]};
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (c < nb) {
-          cz s = x[c];
-#pragma unroll
-          for (int p = 0; p < 16; p++)
-            if (p < c) s = csub(s, cmul(x[p], cj<HERM>(Lo[c][p])));
-          x[c] = s;                                        // L*D  (TRSM "R","L","T"|"C","U")
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const cz v = (c < nb) ? x[c] : cz{0.0, 0.0};
-        const cz sc = (c < nb) ? cmul(v, cinv(Lo[min(c, nb - 1)][min(c, nb - 1)])) : cz{0.0, 0.0};
-        Ws[c][rr] = v;
-        Xs[c][rr] = sc;
-        if (c < nb) {
-          Ar[o0 + (int64_t)c * ld] = sc.re;
-          Ai[o0 + (int64_t)c * ld] = sc.im;
-        }
-      }
-    }
-    __syncthreads();
-    if (rem > 0) {                                         // A22 -= (L D) L^T, lower part
-      const int nt = (rem + 1) >> 1;                       // 2x2 register tiles (complex)
-      const int64_t ob = (kb + nb) + (int64_t)(kb + nb) * ld;
-      for (int id = tid; id < nt * nt; id += 256) {
-        const int tr = id % nt, tcc = id / nt;
-        if (tr < tcc) continue;
-        cz c[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int b = 0; b < 2; b++) c[a][b] = cz{0.0, 0.0};
-        for (int p = 0; p < nb; p++) {
-          cz xa[2], xb[2];
-#pragma unroll
-          for (int a = 0; a < 2; a++) {
-            xa[a] = Ws[p][min(2 * tr + a, XR - 1)];
-            xb[a] = Xs[p][min(2 * tcc + a, XR - 1)];
-          }
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-              const cz m = cmul(xa[a], cj<HERM>(xb[b]));
-              c[a][b].re += m.re;
-              c[a][b].im += m.im;
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-          for (int a = 0; a < 2; a++) {
-            const int r = 2 * tr + a, cc = 2 * tcc + b;
-            if (r < rem && cc < rem && r >= cc) {
-              const int64_t o = ob + r + (int64_t)cc * ld;
-              Ar[o] -= c[a][b].re;
-              Ai[o] -= c[a][b].im;
-            }
-          }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
-}
-
 // Panel solve Y = A L_d^-T (unit lower, complex symmetric), L = Y D^-1; Y^T tiles (re, im) live in MFMA
 // accumulators; complex products are four real MFMAs.  w <= 16 NT.
 template <int NT, bool HERM>
@@ -529,98 +388,6 @@ __global__ __launch_bounds__(256) void k_trsm_zlu(const Arenas ar, const TrsmTas
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// complex triangular solves on the split planes (the data flow of up_down_smp, updo.c:114): same level schedule
-// and task tables as the real kernels of kernels.hip.  CONJ: the backward sweep uses L^H (Hermitian LDL^H,
-// updo.c:1328-1340,1437-1453) instead of L^T.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int z_panel_row_to_global(const DevBlok* __restrict__ bl, int fb, int lb, int p) {
-  int lo = fb, hi = lb - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (bl[mid].coefind <= p) lo = mid; else hi = mid - 1;
-  }
-  return bl[lo].frow + (p - bl[lo].coefind);
-}
-
-__global__ __launch_bounds__(256) void k_zsolve_diag_fwd(const double* __restrict__ Lr, const double* __restrict__ Li,
-                                                         const SolveTask* __restrict__ tasks, double* __restrict__ xr,
-                                                         double* __restrict__ xi, int unit) {
-  __shared__ cz xs[MAXW];
-  const SolveTask tk = tasks[blockIdx.x];
-  const double* Ar = Lr + tk.off;
-  const double* Ai = Li + tk.off;
-  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[tk.fcol + c], xi[tk.fcol + c]};
-  __syncthreads();
-  for (int c = 0; c < w; c++) {
-    const int64_t dd = c + (int64_t)c * ld;
-    const cz xc = unit ? xs[c] : cmul(xs[c], cinv(cz{Ar[dd], Ai[dd]}));
-    __syncthreads();
-    if (tid == 0) xs[c] = xc;
-    for (int r = c + 1 + tid; r < w; r += 256) {
-      const int64_t o = r + (int64_t)c * ld;
-      xs[r] = csub(xs[r], cmul(cz{Ar[o], Ai[o]}, xc));
-    }
-    __syncthreads();
-  }
-  for (int c = tid; c < w; c += 256) { xr[tk.fcol + c] = xs[c].re; xi[tk.fcol + c] = xs[c].im; }
-}
-
-__global__ __launch_bounds__(256) void k_zsolve_off_fwd(const double* __restrict__ Lr, const double* __restrict__ Li,
-                                                        const SolveChunk* __restrict__ chunks,
-                                                        const DevBlok* __restrict__ bl, double* __restrict__ xr,
-                                                        double* __restrict__ xi) {
-  __shared__ cz xs[MAXW];
-  const SolveChunk ck = chunks[blockIdx.x];
-  const double* Ar = Lr + ck.off;
-  const double* Ai = Li + ck.off;
-  const int ld = ck.stride, w = ck.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[ck.fcol + c], xi[ck.fcol + c]};
-  __syncthreads();
-  const int p = ck.row0 + tid;
-  if (tid < ck.nrows) {
-    cz sacc = cz{0.0, 0.0};
-    for (int c = 0; c < w; c++) {
-      const int64_t o = p + (int64_t)c * ld;
-      const cz m = cmul(cz{Ar[o], Ai[o]}, xs[c]);
-      sacc.re += m.re;
-      sacc.im += m.im;
-    }
-    const int gr = z_panel_row_to_global(bl, ck.fblok, ck.lblok, p);
-    unsafeAtomicAdd(&xr[gr], -sacc.re);
-    unsafeAtomicAdd(&xi[gr], -sacc.im);
-  }
-}
-
-template <bool CONJ>
-__global__ __launch_bounds__(256) void k_zsolve_off_bwd(const double* __restrict__ Br, const double* __restrict__ Bi,
-                                                        const SolveChunk* __restrict__ chunks,
-                                                        const DevBlok* __restrict__ bl, double* __restrict__ xr,
-                                                        double* __restrict__ xi) {
-  __shared__ double part[2][4][MAXW];
-  const SolveChunk ck = chunks[blockIdx.x];
-  const double* Ar = Br + ck.off;
-  const double* Ai = Bi + ck.off;
-  const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p = ck.row0 + tid;
-  const bool valid = tid < ck.nrows;
-  const int gr = z_panel_row_to_global(bl, ck.fblok, ck.lblok, min(p, ld - 1));
-  const cz xrow = valid ? cz{xr[gr], xi[gr]} : cz{0.0, 0.0};
-  const int64_t po = min(p, ld - 1);
-  for (int c = 0; c < w; c++) {
-    const int64_t o = po + (int64_t)c * ld;
-    cz m = valid ? cmul(cj<CONJ>(cz{Ar[o], Ai[o]}), xrow) : cz{0.0, 0.0};
-    for (int o2 = 32; o2 > 0; o2 >>= 1) { m.re += __shfl_down(m.re, o2); m.im += __shfl_down(m.im, o2); }
-    if (lane == 0) { part[0][wave][c] = m.re; part[1][wave][c] = m.im; }
-  }
-  __syncthreads();
-  for (int c = tid; c < w; c += 256) {
-    unsafeAtomicAdd(&xr[ck.fcol + c], -(part[0][0][c] + part[0][1][c] + part[0][2][c] + part[0][3][c]));
-    unsafeAtomicAdd(&xi[ck.fcol + c], -(part[1][0][c] + part[1][1][c] + part[1][2][c] + part[1][3][c]));
-  }
-}
-
 __global__ __launch_bounds__(256) void k_zsolve_dscale(const double* __restrict__ Lr, const double* __restrict__ Li,
                                                        const SolveTask* __restrict__ tasks, double* __restrict__ xr,
                                                        double* __restrict__ xi) {
@@ -631,32 +398,6 @@ __global__ __launch_bounds__(256) void k_zsolve_dscale(const double* __restrict_
     xr[tk.fcol + c] = v.re;
     xi[tk.fcol + c] = v.im;
   }
-}
-
-// mode 1: unit L^T or L^H (LDLt / LDLh); 2: U = upper triangle of the factored blok (LU)
-template <bool CONJ>
-__global__ __launch_bounds__(256) void k_zsolve_diag_bwd(const double* __restrict__ Lr, const double* __restrict__ Li,
-                                                         const SolveTask* __restrict__ tasks, double* __restrict__ xr,
-                                                         double* __restrict__ xi, int mode) {
-  __shared__ cz xs[MAXW];
-  const SolveTask tk = tasks[blockIdx.x];
-  const double* Ar = Lr + tk.off;
-  const double* Ai = Li + tk.off;
-  const int ld = tk.stride, w = tk.width, tid = threadIdx.x;
-  for (int c = tid; c < w; c += 256) xs[c] = cz{xr[tk.fcol + c], xi[tk.fcol + c]};
-  __syncthreads();
-  for (int c = w - 1; c >= 0; c--) {
-    const int64_t dd = c + (int64_t)c * ld;
-    const cz xc = (mode == 1) ? xs[c] : cmul(xs[c], cinv(cz{Ar[dd], Ai[dd]}));
-    __syncthreads();
-    if (tid == 0) xs[c] = xc;
-    for (int r = tid; r < c; r += 256) {
-      const int64_t o = (mode == 2) ? r + (int64_t)c * ld : c + (int64_t)r * ld;
-      xs[r] = csub(xs[r], cmul(cj<CONJ>(cz{Ar[o], Ai[o]}), xc));
-    }
-    __syncthreads();
-  }
-  for (int c = tid; c < w; c += 256) { xr[tk.fcol + c] = xs[c].re; xi[tk.fcol + c] = xs[c].im; }
 }
 
 // ---- second generation (the complex counterparts of k_solve_diag_q1 / k_solve_off_fwd64 / k_solve_off_bwd64 of
@@ -838,44 +579,25 @@ __global__ __launch_bounds__(256) void k_zsolve_off_bwd64(const double* __restri
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
                          const SolveChunk* chunks, int64_t nchunk, const DevBlok* bl, const int32_t* ridx, double* xr,
                          double* xi, int maxw) {
-  static const bool scalar = getenv("PASTIX_AMD_SOLVE_SCALAR") != nullptr;      // the first-generation kernels
+  (void)bl;
+  (void)maxw;                              // (cblks are at most 128 columns wide: api.cpp build_split)
   const dim3 b(256), gt((unsigned)ntask), gc((unsigned)nchunk);
   const bool lu = factotype == PASTIX_AMD_FACT_LU, herm = factotype == PASTIX_AMD_FACT_LDLH;
-  const bool gen1 = scalar || maxw > 128;
   if (fwd) {
-    if (ntask > 0) {
-      if (gen1) hipLaunchKernelGGL(k_zsolve_diag_fwd, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, 1);
-      else hipLaunchKernelGGL((k_zsolve_diag_q1<0, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
-    }
-    if (nchunk > 0) {
-      if (scalar) hipLaunchKernelGGL(k_zsolve_off_fwd, gc, b, 0, s, ar.p[0], ar.p[2], chunks, bl, xr, xi);
-      else hipLaunchKernelGGL(k_zsolve_off_fwd64, gc, b, 0, s, ar.p[0], ar.p[2], chunks, ridx, xr, xi);
-    }
+    if (ntask > 0) hipLaunchKernelGGL((k_zsolve_diag_q1<0, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    if (nchunk > 0) hipLaunchKernelGGL(k_zsolve_off_fwd64, gc, b, 0, s, ar.p[0], ar.p[2], chunks, ridx, xr, xi);
     return;
   }
   const double* Br = lu ? ar.p[1] : ar.p[0];
   const double* Bi = lu ? ar.p[3] : ar.p[2];
-  const int mode = lu ? 2 : 1;
   if (nchunk > 0) {
-    if (scalar) {
-      if (herm) hipLaunchKernelGGL(k_zsolve_off_bwd<true>, gc, b, 0, s, Br, Bi, chunks, bl, xr, xi);
-      else hipLaunchKernelGGL(k_zsolve_off_bwd<false>, gc, b, 0, s, Br, Bi, chunks, bl, xr, xi);
-    } else {
-      if (herm) hipLaunchKernelGGL(k_zsolve_off_bwd64<true>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
-      else hipLaunchKernelGGL(k_zsolve_off_bwd64<false>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
-    }
+    if (herm) hipLaunchKernelGGL(k_zsolve_off_bwd64<true>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
+    else hipLaunchKernelGGL(k_zsolve_off_bwd64<false>, gc, b, 0, s, Br, Bi, chunks, ridx, xr, xi);
   }
   if (ntask > 0) {
-    if (gen1) {
-      if (herm) hipLaunchKernelGGL(k_zsolve_diag_bwd<true>, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
-      else hipLaunchKernelGGL(k_zsolve_diag_bwd<false>, gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi, mode);
-    } else if (lu) {
-      hipLaunchKernelGGL((k_zsolve_diag_q1<2, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
-    } else if (herm) {
-      hipLaunchKernelGGL((k_zsolve_diag_q1<1, true>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
-    } else {
-      hipLaunchKernelGGL((k_zsolve_diag_q1<1, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
-    }
+    if (lu) hipLaunchKernelGGL((k_zsolve_diag_q1<2, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    else if (herm) hipLaunchKernelGGL((k_zsolve_diag_q1<1, true>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
+    else hipLaunchKernelGGL((k_zsolve_diag_q1<1, false>), gt, b, 0, s, ar.p[0], ar.p[2], tasks, xr, xi);
   }
 }
 void launch_zsolve_dscale(hipStream_t s, const Arenas& ar, const SolveTask* tasks, int64_t ntask, double* xr, double* xi) {
@@ -892,199 +614,6 @@ __global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, c
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) { z[2 * i] = re[i]; z[2 * i + 1] = im[i]; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Second generation of k_diag_zsy for cblks of at most 128 columns: the lower triangle of the diagonal blok lives
-// in REGISTERS for the whole kernel (2x2 complex blocks, nine per thread, loaded once with coalesced reads); every
-// 16-column step exchanges only the tile and the panel below it through LDS:
-//   S1  owners put the 16x16 diagonal tile (Ts) and the rows below it (Ws, raw) into LDS
-//   S2  the tile is factorized in LDS, one (row, column) pair per thread and one barrier per column (PASTIX_sytrf /
-//       hetrf, compute_diag.c:223-242, 326-345), and stored
-//   S3  lanes 0-15 of wave 0 invert the unit-lower tile for the panel kernel (dinv_ws) while waves 1-3 solve the
-//       rows below (thread per row): Ws = L D, Xs = L, L stored
-//   S4  every thread updates the blocks it owns right of the step: C -= (L D) L^T (L^H) from Ws / Xs
-// No global read-modify-write and no reload per step (the first kernel does both): one memory round trip in,
-// results streamed out.
-// ------------------------------------------------------------------------------------------------
-template <bool HERM>
-__global__ __launch_bounds__(256) void k_diag_zsy_r(const Arenas ar, const PanelTask* __restrict__ tasks,
-                                                    double* __restrict__ dinv_ws, double critere,
-                                                    long long* __restrict__ nbpivot) {
-  PANEL_PRIO();
-  constexpr int XR = 116, NBLK = 9;               // 64*65/2 = 2080 blocks of 2x2 <= 9 * 256
-  __shared__ cz Ts[16][17];
-  __shared__ cz Lo[16][17];
-  __shared__ cz Ti[16][17];
-  __shared__ cz Xs[16][XR];
-  __shared__ cz Ws[16][XR];
-  __shared__ cz Li[16];                 // reciprocals of the tile's pivots
-  const PanelTask tk = tasks[blockIdx.x];
-  double* Ar = ar.p[0] + tk.off;
-  double* Ai = ar.p[2] + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x;
-  const int nb2 = (w + 1) >> 1, nblk = nb2 * (nb2 + 1) / 2;
-  // ---- block ownership: q = tid + 256 i -> (br, bc), packed lower by columns; load ----
-  int br[NBLK], bc[NBLK];
-  cz c[NBLK][2][2];
-#pragma unroll
-  for (int i = 0; i < NBLK; i++) {
-    const int q = tid + 256 * i;
-    int col = 0;
-    if (q < nblk) {
-      const double t = 2.0 * nb2 + 1.0;
-      col = (int)((t - sqrt(t * t - 8.0 * q)) * 0.5);
-      while (col > 0 && col * nb2 - col * (col - 1) / 2 > q) col--;
-      while ((col + 1) * nb2 - (col + 1) * col / 2 <= q) col++;
-    }
-    bc[i] = q < nblk ? col : -1;
-    br[i] = q < nblk ? col + (q - (col * nb2 - col * (col - 1) / 2)) : -1;
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-      for (int b = 0; b < 2; b++) {
-        const int r = 2 * br[i] + a, cc = 2 * bc[i] + b;
-        const bool v = q < nblk && r < w && cc < w && r >= cc;
-        const int64_t o = (int64_t)min(max(r, 0), w - 1) + (int64_t)min(max(cc, 0), w - 1) * ld;
-        const double re = Ar[o], im = Ai[o];
-        c[i][a][b] = v ? cz{re, im} : cz{0.0, 0.0};
-      }
-  }
-  int npiv = 0;
-  for (int kb = 0; kb < w; kb += 16) {
-    const int nb = min(16, w - kb), rem = w - kb - nb;
-    const int b0 = kb >> 1, b1 = (kb + 16) >> 1;          // 2x2-block range of the tile
-    // ---- S1 ----
-#pragma unroll
-    for (int i = 0; i < NBLK; i++) {
-      if (bc[i] < b0 || bc[i] >= b1) continue;
-#pragma unroll
-      for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) {
-          const int r = 2 * br[i] + a - kb, cc = 2 * bc[i] + b - kb;
-          if (r + kb >= w || cc >= nb || r < cc) continue;
-          if (r < nb) Ts[r][cc] = c[i][a][b];
-          else Ws[cc][r - nb] = c[i][a][b];
-        }
-    }
-    __syncthreads();
-    // ---- S2: tile factorization, one (ti, tj) pair per thread, one barrier per column (PASTIX_sytrf / hetrf) ----
-    {
-      const int ti = tid & 15, tj = tid >> 4;
-      for (int j = 0; j < nb; j++) {
-        cz d = Ts[j][j];
-        if (d.re * d.re + d.im * d.im < critere * critere) { d = cz{critere, 0.0}; if (tid == 0) npiv++; }   // |d| < critere (ABS_FLOAT = cabs)
-        const cz inv = cinv_fast(d);
-        if (tid == 0) Li[j] = inv;
-        if (ti < nb && tj < nb) {
-          if (tj == j) {
-            if (ti == j) Lo[j][j] = d;
-            else if (ti > j) Lo[ti][j] = cmul(Ts[ti][j], inv);
-          } else if (tj > j && ti >= tj) {                        // (column j is not written in step j)
-            const cz xi = cmul(Ts[ti][j], inv), xc = cmul(Ts[tj][j], inv);
-            if (!HERM) Ts[ti][tj] = csub(Ts[ti][tj], cmul(xi, cmul(d, xc)));     // GER with alpha = -d (x x^T)
-            else {                                                                 // zher: alpha = -Re(d), x x^H
-              cz v = csub(Ts[ti][tj], cmul(xi, cz{d.re * xc.re, -d.re * xc.im}));
-              if (ti == tj) v.im = 0.0;
-              Ts[ti][tj] = v;
-            }
-          }
-        }
-        __syncthreads();
-      }
-      if (ti < nb && tj < nb && ti >= tj) {
-        const int64_t o = (kb + ti) + (int64_t)(kb + tj) * ld;
-        Ar[o] = Lo[ti][tj].re;
-        Ai[o] = Lo[ti][tj].im;
-      }
-    }
-    __syncthreads();
-    // ---- S3 ----
-    if (tid < 16) {
-      const int cix = tid;
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 512;   // [256 re][256 im] per block
-      for (int i = 0; i < 16; i++) {
-        cz x;
-        if (i >= nb || cix >= nb) x = cz{(i == cix) ? 1.0 : 0.0, 0.0};
-        else if (i < cix) x = cz{0.0, 0.0};
-        else {
-          cz sacc = cz{(i == cix) ? 1.0 : 0.0, 0.0};
-          for (int pp = cix; pp < i; pp++) sacc = csub(sacc, cmul(Lo[i][pp], Ti[pp][cix]));
-          x = sacc;
-        }
-        Ti[i][cix] = x;
-      }
-      for (int i = 0; i < 16; i++) { dst[i + 16 * cix] = Ti[i][cix].re; dst[256 + i + 16 * cix] = Ti[i][cix].im; }
-    } else if (tid >= 64 && tid - 64 < rem) {
-      const int rr = tid - 64;
-      const int64_t o0 = (kb + nb + rr) + (int64_t)kb * ld;
-      cz x[16];
-#pragma unroll
-      for (int cc = 0; cc < 16; cc++) x[cc] = Ws[min(cc, nb - 1)][rr];
-#pragma unroll
-      for (int cc = 0; cc < 16; cc++) {
-        if (cc < nb) {
-          cz sacc = x[cc];
-#pragma unroll
-          for (int pp = 0; pp < 16; pp++)
-            if (pp < cc) sacc = csub(sacc, cmul(x[pp], cj<HERM>(Lo[cc][pp])));
-          x[cc] = sacc;                                    // L*D  (TRSM "R","L","T"|"C","U")
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < 16; cc++) {
-        if (cc < nb) {
-          const cz v = x[cc];
-          const cz sc = cmul(v, Li[cc]);
-          Ws[cc][rr] = v;
-          Xs[cc][rr] = sc;
-          Ar[o0 + (int64_t)cc * ld] = sc.re;
-          Ai[o0 + (int64_t)cc * ld] = sc.im;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- S4 ----
-    if (rem > 0) {
-#pragma unroll
-      for (int i = 0; i < NBLK; i++) {
-        if (bc[i] < b1) continue;                            // (also skips the unused slots, bc = -1)
-        const int r0 = 2 * br[i] - kb - nb, c0 = 2 * bc[i] - kb - nb;
-        cz acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int b = 0; b < 2; b++) acc[a][b] = cz{0.0, 0.0};
-        for (int pp = 0; pp < nb; pp++) {
-          cz xa[2], xb[2];
-#pragma unroll
-          for (int a = 0; a < 2; a++) {
-            xa[a] = Ws[pp][min(r0 + a, XR - 1)];
-            xb[a] = Xs[pp][min(c0 + a, XR - 1)];
-          }
-#pragma unroll
-          for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-              const cz m = cmul(xa[a], cj<HERM>(xb[b]));
-              acc[a][b].re += m.re;
-              acc[a][b].im += m.im;
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-          for (int b = 0; b < 2; b++) {
-            c[i][a][b].re -= acc[a][b].re;
-            c[i][a][b].im -= acc[a][b].im;
-          }
-      }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1319,54 +848,35 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
   }
 }
 
+// (cblks are at most 128 columns wide -- api.cpp build_split --: one kernel per role)
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv,
                      double critere, long long* nbpivot, int maxw) {
+  (void)maxw;
   if (n <= 0) return;
-  const dim3 g((unsigned)n), b(256);
-  static const bool gen1 = getenv("PASTIX_AMD_ZDIAG_GEN1") != nullptr;
-  static const bool gen2 = getenv("PASTIX_AMD_ZDIAG_GEN2") != nullptr;       // round 1's register-resident kernel
-  if (maxw <= 128 && !gen1 && !gen2) {
-    if (herm) hipLaunchKernelGGL((k_diag_zsy_w<true>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
-    else hipLaunchKernelGGL((k_diag_zsy_w<false>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
-  } else if (maxw <= 128 && !gen1) {
-    if (herm) hipLaunchKernelGGL((k_diag_zsy_r<true>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-    else hipLaunchKernelGGL((k_diag_zsy_r<false>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-  } else if (maxw <= 128) {
-    if (herm) hipLaunchKernelGGL((k_diag_zsy<true, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-    else hipLaunchKernelGGL((k_diag_zsy<false, 116>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-  } else {
-    if (herm) hipLaunchKernelGGL((k_diag_zsy<true, 244>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-    else hipLaunchKernelGGL((k_diag_zsy<false, 244>), g, b, 0, s, ar, tasks, dinv, critere, nbpivot);
-  }
+  const dim3 g((unsigned)n);
+  if (herm) hipLaunchKernelGGL((k_diag_zsy_w<true>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
+  else hipLaunchKernelGGL((k_diag_zsy_w<false>), g, dim3(512), 0, s, ar, tasks, dinv, critere, nbpivot);
 }
 void launch_trsm_zsy(hipStream_t s, bool herm, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv,
                      int maxw) {
+  (void)maxw;
   if (n <= 0) return;
   const dim3 g((unsigned)n), b(256);
-  if (maxw <= 128) {
-    if (herm) hipLaunchKernelGGL((k_trsm_zsy<8, true>), g, b, 0, s, ar, tasks, dinv);
-    else hipLaunchKernelGGL((k_trsm_zsy<8, false>), g, b, 0, s, ar, tasks, dinv);
-  } else {
-    if (herm) hipLaunchKernelGGL((k_trsm_zsy<16, true>), g, b, 0, s, ar, tasks, dinv);
-    else hipLaunchKernelGGL((k_trsm_zsy<16, false>), g, b, 0, s, ar, tasks, dinv);
-  }
+  if (herm) hipLaunchKernelGGL((k_trsm_zsy<8, true>), g, b, 0, s, ar, tasks, dinv);
+  else hipLaunchKernelGGL((k_trsm_zsy<8, false>), g, b, 0, s, ar, tasks, dinv);
 }
 void launch_diag_zlu(hipStream_t s, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw) {
+  (void)maxw;
   if (n <= 0) return;
-  if (maxw <= 128) hipLaunchKernelGGL(k_diag_zlu<116>, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
-  else hipLaunchKernelGGL(k_diag_zlu<244>, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
+  hipLaunchKernelGGL(k_diag_zlu<116>, dim3((unsigned)n), dim3(256), 0, s, ar, tasks, dinv, critere, nbpivot);
 }
 void launch_trsm_zlu(hipStream_t s, const Arenas& ar, const TrsmTask* tasks, int64_t n, const double* dinv, int maxw) {
+  (void)maxw;
   if (n <= 0) return;
   const dim3 g((unsigned)n), b(256);
-  if (maxw <= 128) {
-    hipLaunchKernelGGL((k_trsm_zlu<8, 2>), g, b, 0, s, ar, tasks, dinv);
-    hipLaunchKernelGGL((k_trsm_zlu<8, 3>), g, b, 0, s, ar, tasks, dinv);
-  } else {
-    hipLaunchKernelGGL((k_trsm_zlu<16, 2>), g, b, 0, s, ar, tasks, dinv);
-    hipLaunchKernelGGL((k_trsm_zlu<16, 3>), g, b, 0, s, ar, tasks, dinv);
-  }
+  hipLaunchKernelGGL((k_trsm_zlu<8, 2>), g, b, 0, s, ar, tasks, dinv);
+  hipLaunchKernelGGL((k_trsm_zlu<8, 3>), g, b, 0, s, ar, tasks, dinv);
 }
 void launch_split(hipStream_t s, const double* z, double* re, double* im, int64_t n) {
   if (n <= 0) return;
