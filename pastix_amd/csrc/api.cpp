@@ -394,6 +394,8 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
+  (void)hipFree(p->dThinF); (void)hipFree(p->dThinB); (void)hipFree(p->dThinTasks); (void)hipFree(p->dInvF); (void)hipFree(p->dInvB);
+  (void)hipFree(p->dTicket);
   (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk); (void)hipFree(p->dChunkB); (void)hipFree(p->dRidx); (void)hipFree(p->dXws);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evT) if (e) (void)hipEventDestroy(e);
@@ -975,6 +977,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   p->factored = true;
+  p->fact_gen++;
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
   p->stats.fact_time = ms * 1e-3;
@@ -1147,37 +1150,82 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     // one set of atomics per 256 rows)
     const int32_t CH = 64;
     const int32_t CHB = 256;
+    // thin levels: at most THIN cblks (real arithmetic, one GPU): explicit inverses + one launch per level and sweep
+    constexpr int64_t THIN = 16;
+    std::vector<SolveChunk> thF, thB;
+    std::vector<int32_t> thin_tasks;
+    p->lvl_thin.assign((size_t)H.nlevels, 0);
+    p->lvl_thinF_ptr.assign((size_t)H.nlevels + 1, 0);
+    p->lvl_thinB_ptr.assign((size_t)H.nlevels + 1, 0);
     for (int l = 0; l < H.nlevels; l++) {
       p->lvl_chunk_ptr[l] = (int64_t)ch.size();
       p->lvl_chunkB_ptr[l] = (int64_t)chB.size();
+      p->lvl_thinF_ptr[l] = (int64_t)thF.size();
+      p->lvl_thinB_ptr[l] = (int64_t)thB.size();
+      const int64_t ncl = H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l];
+      const bool thin = !p->cplx && !p->distributed && ncl > 0 && ncl <= THIN;
+      p->lvl_thin[l] = thin ? 1 : 0;
       for (int64_t q = H.lvl_cblk_ptr[l]; q < H.lvl_cblk_ptr[l + 1]; q++) {
         const int32_t k = H.lvl_cblk[q];
         const int32_t w = (int32_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1), sd = (int32_t)H.cblk[k].stride;
         st[q] = SolveTask{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                          (int32_t)H.cblk[k + 1].bloknum};
+                          (int32_t)H.cblk[k + 1].bloknum, thin ? (int32_t)thin_tasks.size() : -1};
+        const int32_t tix = st[q].thin;
+        if (thin) {
+          // the level's workgroup lists for the fused sweeps: the cblk's chunks and one workgroup without rows (so that
+          // a cblk without off-diagonal rows is solved too), each knowing how many there are (the ticket)
+          thin_tasks.push_back((int32_t)q);
+          // (256 rows per workgroup in both sweeps: every workgroup applies the inverse for itself)
+          const int32_t nf = (sd - w + CHB - 1) / CHB + 1, nb = nf;
+          for (int32_t r = w; r < sd; r += CHB)
+            thF.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nf});
+          thF.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nf});
+          for (int32_t r = w; r < sd; r += CHB)
+            thB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nb});
+          thB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
+                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nb});
+        }
         p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
         for (int32_t r = w; r < sd; r += CH) {
           const int32_t n = std::min(CH, sd - r);
           ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
-              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0});
         }
         for (int32_t r = w; r < sd; r += CHB) {
           const int32_t n = std::min(CHB, sd - r);
           chB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
-              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q]});
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0});
         }
       }
     }
     p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
     p->lvl_chunkB_ptr[H.nlevels] = (int64_t)chB.size();
+    p->lvl_thinF_ptr[H.nlevels] = (int64_t)thF.size();
+    p->lvl_thinB_ptr[H.nlevels] = (int64_t)thB.size();
     std::vector<DevBlok> bl((size_t)H.bloknbr);
     for (int64_t b = 0; b < H.bloknbr; b++)
       bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
     // built into locals and published only when complete: a failed build leaves the plan without solve tables
     SolveTask* dS = nullptr; DevBlok* dB = nullptr; SolveChunk *dC = nullptr, *dCB = nullptr; int32_t* dR = nullptr;
+    SolveChunk *dTF = nullptr, *dTB = nullptr; int32_t* dTT = nullptr; double *dIF = nullptr, *dIB = nullptr; int* dTk = nullptr;
     int64_t* droff = nullptr;
+    const int64_t nthin = (int64_t)thin_tasks.size();
     auto build = [&]() -> int {
       int r;
+      if ((r = to_device(&dTF, thF))) return r;
+      if ((r = to_device(&dTB, thB))) return r;
+      if ((r = to_device(&dTT, thin_tasks))) return r;
+      if (nthin > 0) {
+        const size_t ib = (size_t)nthin * 128 * 128 * sizeof(double);
+        HIPCHK(hipMalloc((void**)&dIF, ib));
+        HIPCHK(hipMalloc((void**)&dIB, ib));
+        HIPCHK(hipMemset(dIF, 0, ib));
+        HIPCHK(hipMemset(dIB, 0, ib));
+        HIPCHK(hipMalloc((void**)&dTk, (size_t)nthin * 2 * sizeof(int)));
+      }
       if ((r = to_device(&dS, st))) return r;
       if ((r = to_device(&dB, bl))) return r;
       if ((r = to_device(&dC, ch))) return r;
@@ -1193,9 +1241,22 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     (void)hipFree(droff);
     if (rb) {
       (void)hipFree(dS); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dCB); (void)hipFree(dR);
+      (void)hipFree(dTF); (void)hipFree(dTB); (void)hipFree(dTT); (void)hipFree(dIF); (void)hipFree(dIB); (void)hipFree(dTk);
       return rb;
     }
     p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
+    p->dThinF = dTF; p->dThinB = dTB; p->dThinTasks = dTT; p->dInvF = dIF; p->dInvB = dIB; p->dTicket = dTk;
+    p->nthin = nthin;
+    p->inv_gen = -1;
+  }
+  if (p->nthin > 0 && p->inv_gen != p->fact_gen) {
+    // the inverses of the thin cblks' diagonal bloks, once per factorization (k_solve_inv)
+    const int unit = H.factotype != PASTIX_AMD_FACT_LLT;
+    launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvF, 0, unit);
+    if (H.factotype == PASTIX_AMD_FACT_LU) launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 2, 0);
+    else launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 1, unit);
+    HIPCHK(hipGetLastError());
+    p->inv_gen = p->fact_gen;
   }
   return PASTIX_AMD_OK;
 }
@@ -1203,6 +1264,13 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
 // one level of the forward (fwd) or backward sweep on nr right-hand sides (real arithmetic), on the plan's stream
 void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) {
   const Plan& H = p->host;
+  if (nr == 1 && p->nthin > 0 && p->lvl_thin[(size_t)l]) {
+    const std::vector<int64_t>& ptr = fwd ? p->lvl_thinF_ptr : p->lvl_thinB_ptr;
+    const double* P = fwd ? p->dL : (H.factotype == PASTIX_AMD_FACT_LU ? p->dU : p->dL);
+    launch_solve_thin(p->stream, fwd, P, (fwd ? p->dThinF : p->dThinB) + ptr[(size_t)l], ptr[(size_t)l + 1] - ptr[(size_t)l],
+                      p->dRidx, fwd ? p->dInvF : p->dInvB, p->dTicket + (fwd ? 0 : p->nthin), dx);
+    return;
+  }
   if (fwd)
     launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
                        H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
@@ -1281,6 +1349,7 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
     if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
+    if (nr == 1 && p->nthin > 0) HIPCHK(hipMemsetAsync(p->dTicket, 0, (size_t)p->nthin * 2 * sizeof(int), p->stream));
     for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
     if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
     for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);

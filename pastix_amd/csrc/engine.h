@@ -48,6 +48,10 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
+void launch_solve_inv(hipStream_t s, const double* A, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
+                      double* inv, int which, int unit);
+void launch_solve_thin(hipStream_t s, bool fwd, const double* P, const SolveChunk* chunks, int64_t nchunk,
+                       const int32_t* ridx, const double* inv, int* ticket, double* x);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -119,6 +123,15 @@ struct pastix_amd_plan_s {
   int64_t* dFillIdxU = nullptr; double* dFillValU = nullptr; int64_t nFillU = 0;
   SolveTask* dSolve = nullptr; DevBlok* dBlok = nullptr; SolveChunk *dChunk = nullptr, *dChunkB = nullptr; int32_t* dRidx = nullptr;
   std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
+  // thin levels (kernels.hip, k_solve_inv): explicit inverses of their diagonal bloks, one launch per level and sweep
+  std::vector<uint8_t> lvl_thin;        // [nlevels]
+  std::vector<int64_t> lvl_thinF_ptr, lvl_thinB_ptr;    // [nlevels+1] into dThinF / dThinB (empty ranges for other levels)
+  SolveChunk *dThinF = nullptr, *dThinB = nullptr;      // the thin levels' workgroup lists (chunks + one per cblk)
+  int32_t* dThinTasks = nullptr;        // SolveTask index of every thin cblk
+  int64_t nthin = 0;
+  double *dInvF = nullptr, *dInvB = nullptr;            // nthin x 128 x 128: L^-1, and (L^-1)^T / U^-1 for the backward sweep
+  int* dTicket = nullptr;               // 2 x nthin
+  long long inv_gen = -1, fact_gen = 0; // the inverses belong to factorization number inv_gen
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -857,6 +857,181 @@ __global__ __launch_bounds__(256) void k_solve_dscale(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Thin levels of the solve (a handful of cblks per level: the separator chains at the top of the tree -- 200^3: 317
+// levels of one cblk, 157 of two): a level there is pure dependent latency -- a 128-step substitution chain in the
+// diagonal blok (7-12 us), a panel kernel of a few MB, two kernel boundaries -- and there are hundreds of them per
+// sweep.  For these cblks the inverses of the diagonal bloks are formed once per factorization (k_solve_inv), the
+// substitution becomes a 128 x 128 matrix-vector product every workgroup of the level does for itself, and a level is
+// ONE launch per sweep:
+//   forward : every workgroup of cblk k reads b_k, forms x_k = L_kk^-1 b_k, then subtracts its 64 panel rows times
+//             x_k from the rows below; the workgroup that draws the last ticket of the cblk -- by then every other
+//             one has read b_k -- writes x_k in place;
+//   backward: every workgroup subtracts its 256 panel rows' part of L_panel^T x_below from b_k (atomics), fences, draws
+//             a ticket; the last one of the cblk reads the complete b_k back and writes x_k = L_kk^-T b_k.
+// The reference's counterpart is the per-cblk TRSV + GEMV of up_down_smp (updo.c:114-1608).
+// ------------------------------------------------------------------------------------------------
+constexpr int INVLD = 128;          // leading dimension of a stored inverse
+
+// One workgroup per (thin cblk, which): the inverse M of a lower-triangular w x w matrix T, by rows:
+// M[i, :] = (e_i - sum_{k<i} T[i,k] M[k, :]) / T[i,i]; thread j owns column j, M lives in dynamic LDS (w x (w|1)).
+//   which 0: T = the lower triangle of the diagonal blok in arena A (unit diagonal if `unit`);   out = M      [r + c ld]
+//   which 1: the same T,                                                                        out = M^T    [c + r ld]
+//   which 2: T = U^T, U the upper triangle of the blok (LU: non-unit),                          out = M^T = U^-1 stored
+//            as [c + r ld] of M, i.e. x = U^-1 b is the row-wise product the backward kernel does
+__global__ __launch_bounds__(128) void k_solve_inv(const double* __restrict__ A, const SolveTask* __restrict__ tasks,
+                                                   const int32_t* __restrict__ thin_tasks, double* __restrict__ inv,
+                                                   int which, int unit) {
+  extern __shared__ double S[];                     // M: [i + j * ldl], then the row buffer
+  const SolveTask tk = tasks[thin_tasks[blockIdx.x]];
+  const double* T = A + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width, j = threadIdx.x, ldl = w | 1;
+  double* row = S + (size_t)ldl * w;
+  for (int i = 0; i < w; i++) {
+    // row i of T: T[i, k], k <= i
+    if (j <= i && j < w) row[j] = which == 2 ? T[j + (int64_t)i * ld] : T[i + (int64_t)j * ld];
+    __syncthreads();
+    if (j < w) {
+      double sum = 0.0;
+      for (int k = j; k < i; k++) sum = __builtin_fma(row[k], S[k + j * ldl], sum);
+      const double d = unit ? 1.0 : row[i];
+      S[i + j * ldl] = j <= i ? ((i == j ? 1.0 : 0.0) - sum) / d : 0.0;
+    }
+    __syncthreads();
+  }
+  double* out = inv + (int64_t)tk.thin * INVLD * INVLD;
+  for (int i = 0; i < w; i++)
+    if (j < w) out[which == 0 ? i + j * INVLD : j + i * INVLD] = S[i + j * ldl];      // M, or M^T
+}
+
+// y = M x for the w x w matrix M stored [r + c INVLD] (zeros outside its triangle and beyond w), 256 threads: thread t ->
+// row t & 127 and one half of the 128 columns, 32 loads in flight at a time; xs (zero beyond w), ys: LDS vectors of
+// 128, tmp of 256
+__device__ __forceinline__ void inv_apply(const double* __restrict__ M, const double* xs, double* ys, double* tmp, int tid) {
+  const int r = tid & 127, h = tid >> 7;
+  const double* Mr = M + r + (int64_t)(64 * h) * INVLD;
+  double acc = 0.0;
+#pragma unroll
+  for (int c0 = 0; c0 < 64; c0 += 32) {
+    double m[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) m[i] = Mr[(int64_t)(c0 + i) * INVLD];
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc = __builtin_fma(m[i], xs[64 * h + c0 + i], acc);
+  }
+  tmp[tid] = acc;
+  __syncthreads();
+  if (tid < 128) ys[tid] = tmp[tid] + tmp[tid + 128];
+  __syncthreads();
+}
+
+// forward, thin levels: 256 panel rows per workgroup (one per thread); see above
+__global__ __launch_bounds__(256) void k_solve_thin_fwd(const double* __restrict__ L, const SolveChunk* __restrict__ chunks,
+                                                        const int32_t* __restrict__ ridx, const double* __restrict__ inv,
+                                                        int* __restrict__ ticket, double* __restrict__ x) {
+  __shared__ double xs[128], ys[128], tmp[256];
+  __shared__ int last;
+  const SolveChunk ck = chunks[blockIdx.x];
+  const int w = ck.width, tid = threadIdx.x;
+  if (tid < 128) xs[tid] = tid < w ? x[ck.fcol + tid] : 0.0;
+  __syncthreads();
+  // (every read of b_k by this workgroup is complete: the ticket may be drawn)
+  if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
+  // the thread's panel row, first 32 columns: in flight under the inverse's matrix-vector product
+  const int ld = ck.stride;
+  const bool rowv = tid < ck.nrows;
+  const int p = ck.row0 + min(tid, max(ck.nrows - 1, 0));
+  const double* Ap = L + ck.off + p;
+  double a0[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) a0[i] = rowv ? Ap[(int64_t)min(i, w - 1) * ld] : 0.0;
+  const int32_t gr = rowv ? ridx[ck.roff + p] : 0;
+  inv_apply(inv + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
+  if (last && tid < w) x[ck.fcol + tid] = ys[tid];
+  if (!rowv) return;
+  double sacc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) sacc = __builtin_fma((i < w) ? a0[i] : 0.0, ys[i], sacc);
+  for (int c0 = 32; c0 < w; c0 += 32) {
+    double a[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+    for (int i = 0; i < 32; i++) sacc = __builtin_fma((c0 + i < w) ? a[i] : 0.0, ys[min(c0 + i, 127)], sacc);
+  }
+  unsafeAtomicAdd(&x[gr], -sacc);
+}
+
+__global__ __launch_bounds__(256) void k_solve_thin_bwd(const double* __restrict__ B, const SolveChunk* __restrict__ chunks,
+                                                        const int32_t* __restrict__ ridx, const double* __restrict__ invT,
+                                                        int* __restrict__ ticket, double* __restrict__ x) {
+  __shared__ double xs[128], ys[128], tmp[256];
+  __shared__ int last;
+  const SolveChunk ck = chunks[blockIdx.x];
+  const int w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (ck.nrows > 0) {
+    const double* A = B + ck.off;
+    const int ld = ck.stride;
+    const int p = ck.row0 + lane;
+    // x of the chunk's (at most 256) rows, gathered up front: two dependent loads that would otherwise sit in front of
+    // every 64-row step
+    double xrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const bool rv = lane + 64 * q < ck.nrows;
+      xrow[q] = rv ? x[ridx[ck.roff + min(p + 64 * q, ld - 1)]] : 0.0;
+    }
+    for (int c0 = wave * 32; c0 < w; c0 += 128) {
+      double acc[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) acc[i] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {                        // the chunk's rows, 64 at a time
+        const int rb = 64 * q;
+        if (rb >= ck.nrows) break;
+        const int pp = min(p + rb, ld - 1);
+        const double xr = xrow[q];
+        const double* Ap = A + pp;
+        double a[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+        for (int i = 0; i < 32; i++) acc[i] = __builtin_fma(a[i], xr, acc[i]);
+      }
+      // transposed butterfly: 32 column sums over the 64 lanes (as k_solve_off_bwd64)
+#pragma unroll
+      for (int n = 32, d = 32; n > 1; n >>= 1, d >>= 1) {
+        const int half = n >> 1;
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+          const double send = up ? acc[i] : acc[i + half];
+          const double keep = up ? acc[i + half] : acc[i];
+          acc[i] = keep + __shfl_xor(send, d);
+        }
+      }
+      acc[0] += __shfl_xor(acc[0], 1);
+      const int c = c0 + ((lane >> 1) & 31);
+      if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
+    }
+  }
+  // Hand-off without fences (MI355X_MICROARCH, inter-workgroup visibility): the contributions are agent-scope atomics --
+  // performed at the memory side, not parked in this XCD's L2 --, so what the ticket needs is that every wave's atomics
+  // have been acknowledged (vmcnt(0)) before one lane draws it behind a workgroup barrier; a __threadfence here (L2
+  // write-back + invalidate by all 256 threads of every workgroup) cost ~100 us per level.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
+  __syncthreads();
+  if (!last) return;
+  // every contribution to b_k has been performed: read it with agent-scope (sc1) loads, past L1 and this XCD's L2
+  if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  __syncthreads();
+  inv_apply(invT + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
+  if (tid < w) x[ck.fcol + tid] = ys[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 // fan-in receive: dst[rows[r] + c*ldd] += src[r + c*nrows]  (recv_handle_fanin, sopalin_sendrecv.c:384-404: the owner
@@ -973,6 +1148,21 @@ void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double
   int64_t blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(256), 0, s, dst, idx, val, n);
+}
+
+// thin levels (see k_solve_inv): the inverses of `n` diagonal bloks; A: the arena the triangle is read from
+void launch_solve_inv(hipStream_t s, const double* A, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
+                      double* inv, int which, int unit) {
+  if (n <= 0) return;
+  const int bytes = (128 * 129 + 128) * (int)sizeof(double);
+  if (!dyn_lds_attr_once((const void*)k_solve_inv, bytes)) return;
+  hipLaunchKernelGGL(k_solve_inv, dim3((unsigned)n), dim3(128), bytes, s, A, tasks, thin_tasks, inv, which, unit);
+}
+void launch_solve_thin(hipStream_t s, bool fwd, const double* P, const SolveChunk* chunks, int64_t nchunk,
+                       const int32_t* ridx, const double* inv, int* ticket, double* x) {
+  if (nchunk <= 0) return;
+  if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, P, chunks, ridx, inv, ticket, x);
+  else hipLaunchKernelGGL(k_solve_thin_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, P, chunks, ridx, inv, ticket, x);
 }
 
 }  // namespace pastix_amd

@@ -530,6 +530,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   constexpr bool quad_on = true;
   const double quad_fill = P.opts.quadrant_fill_pct > 0 ? 0.01 * P.opts.quadrant_fill_pct : 0.25;
   const int64_t quad_min = P.opts.quadrant_min > 0 ? P.opts.quadrant_min : 1024;
+  const int quad_maxpiece = P.opts.quadrant_fill_pct > 100 ? 128 : 64;   // (tests force every partial task with fill > 100 %)
   // The tiles are independent: the sorted piece list is cut at tile boundaries into one range per host thread, every
   // thread groups its tiles into its own lists, which are concatenated in range order (= the serial result).
   struct GOut {
@@ -632,10 +633,19 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       O.slot_flops[slot] += 2.0 * work;
       O.slot_maxwork[slot] = std::max(O.slot_maxwork[slot], work);
       // candidate for quadrant tasks (split after the grouping, once the number of candidates per slot is known)
+      // -- tasks of SMALL pieces only: every piece at most 64 x 64 (the chains inside the leaf domains: 10-40 rows and
+      // columns).  Larger pieces would be cut at the quadrant borders into up to four clipped copies for a kernel that
+      // is built for latency, not for flops: on blend's layouts (cblks of 60-120 columns, bloks of at most 120 rows:
+      // hardly any whole-tile piece, so that the fill rule alone diverted most of the work) the quadrant kernel took
+      // 44 % of the time of an 80^3 factorization driven by the real PaStiX.
       if (quad_on && !raw[q].shared && tk.nfull == 0) {
         double iters = 0;
-        for (size_t z = q; z < e; z++) iters += double((P.pieces[z].k + 15) / 16);
-        if (work < quad_fill * iters * 16.0 * double(TM) * double(TN)) tk.flags |= 64u;
+        int maxmn = 0;
+        for (size_t z = q; z < e; z++) {
+          iters += double((P.pieces[z].k + 15) / 16);
+          maxmn = std::max<int>(maxmn, std::max<int>(P.pieces[z].m, P.pieces[z].n));
+        }
+        if (maxmn <= quad_maxpiece && work < quad_fill * iters * 16.0 * double(TM) * double(TN)) tk.flags |= 64u;
       }
       O.tasks.push_back(tk);
       O.work.push_back(work + 4096.0 * double(e - q));

@@ -66,13 +66,16 @@ struct SolveTask {
   int32_t stride, width;
   int32_t fcol;                // first column = first row of the diagonal blok
   int32_t fblok, lblok;        // blok range [fblok, lblok) in the device blok table (fblok = diagonal)
+  int32_t thin;                // index among the cblks of the thin levels (explicit inverses, fused sweeps), else -1
 };
 struct DevBlok { int32_t frow, lrow, coefind; };
-struct SolveChunk {            // 256 off-diagonal panel rows of one cblk
+struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal panel rows of one cblk
   int64_t off;
   int32_t stride, width, fcol, fblok, lblok;
   int32_t row0, nrows;
   int64_t roff;                // first entry of the cblk in the panel-row -> global-row table
+  int32_t thin;                // thin levels: the cblk's index among the thin cblks (SolveTask::thin), else -1
+  int32_t nwg;                 // thin levels: workgroups of the cblk in this list (its chunks + one with nrows = 0)
 };
 
 
