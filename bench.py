@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F64_PEAK = 78.6e12   # dense fp64 matrix peak of MI355X (vendor); tools/probe_mfma_f64 measures 77.5e12
+MFMA_F32_PEAK = 157.3e12  # dense fp32 (f32-input) matrix peak (MI355X_MICROARCH: 157.3 spec, 155 measured)
 
 
 def cpu_baseline(sample_grid, threads):
@@ -117,7 +118,7 @@ def self_launch(a, argv):
     raise SystemExit(subprocess.call(cmd))
 
 
-def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, local):
+def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, local, f32=False):
     """One configuration on one GPU: analysis, plan, device fill, `warmup` untimed and `steps` timed steps (a step =
     device re-fill + factorization, inputs resident in HBM), then the end-to-end check ||Ax - b|| / ||b|| with the device
     solve on the last factors.  Returns the raw figures the JSON line is made of."""
@@ -142,7 +143,7 @@ def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, 
         facto = {"llt": 0, "ldlt": 1, "lu": 2}[facto_name]
         n, cp, r, v = sy.laplacian_3d(N, full=(facto == 2))
         perm, _ = sy.order_grid(N, N, N)
-        ftype = 1
+        ftype = 0 if f32 else 1                    # IPARM_FLOAT: API_REALSINGLE / API_REALDOUBLE
     s = sy.symbolic(n, cp, r, perm, max_blocksize=blocksize)
     c4, b4 = s["cblk4"], s["blok4"]
     flops = fact_flops(c4, b4, facto, ftype)
@@ -251,6 +252,9 @@ def main():
                          "complex double LDLt on the 3-dof elasticity pattern of a grid^3 node mesh (n = 3 grid^3)")
     ap.add_argument("--cpu-sample-grid", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32: the single-precision engine (the reference's S_ build; kernels_f32.hip), reported against the "
+                         "fp32 matrix peak; one GPU, laplacian workload")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip BASELINE.json configs[1], [2], [4] after the headline (they run by default with the "
                          "default workload on one GPU)")
@@ -308,10 +312,13 @@ def main():
         from pastix_amd import dist as pdist
         res = pdist.bench_distributed(a, rank, world, local)
     else:
-        res = single_gpu_job(a.grid, a.workload, a.facto, a.steps, a.warmup, a.blocksize, a.chunk, local)
+        if a.dtype == "f32" and a.workload != "laplacian":
+            raise SystemExit("bench.py: --dtype f32 is the real single-precision engine (laplacian workload)")
+        res = single_gpu_job(a.grid, a.workload, a.facto, a.steps, a.warmup, a.blocksize, a.chunk, local, f32=a.dtype == "f32")
         a.facto = res["facto"]
 
     if rank == 0:
+        PEAK = MFMA_F32_PEAK if (world == 1 and a.dtype == "f32") else MFMA_F64_PEAK
         K = a.steps
         value = res["flops"] * K / res["wall"] * 1e-9
         # HBM bytes of the bulk kernel from separate --pmc passes (tools/profile_round.sh); only a measurement taken
@@ -329,25 +336,27 @@ def main():
         busy_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
         out = {
             "metric": ("factorization GFLOP/s (complex flops), 3-dof elasticity pattern %d^3 nodes zLDLt" % a.grid) if a.workload == "elasticity"
-                      else "factorization GFLOP/s, 3D 7-point Laplacian %d^3 d%s" % (a.grid, {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
+                      else "factorization GFLOP/s, 3D 7-point Laplacian %d^3 %s%s" % (a.grid, "s" if PEAK == MFMA_F32_PEAK else "d",
+                                                                                      {"llt": "LLt", "ldlt": "LDLt", "lu": "LU"}[a.facto]),
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": round(res["wall"] / K * 1e3, 2), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "c128 (f64 MFMA on split re/im planes)" if a.workload == "elasticity" else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "c128 (f64 MFMA on split re/im planes)" if a.workload == "elasticity" else ("f32" if PEAK == MFMA_F32_PEAK else "f64"), "data": "synthetic",
             "config": {"workload": ("3-dof elasticity pattern on %d^3 nodes (n=%d), complex double symmetric %s, geometric ND, max blocksize %d"
                                     if a.workload == "elasticity" else
-                                    "3-D 7-point Laplacian %d^3 (n=%d), double %s, geometric ND, max blocksize %d")
+                                    "3-D 7-point Laplacian %d^3 (n=%d), " + ("single" if PEAK == MFMA_F32_PEAK else "double")
+                                    + " %s, geometric ND, max blocksize %d")
                                    % (a.grid, res["n"], a.facto, a.blocksize),
                        "cblknbr": res["cblk"], "bloknbr": res["blok"], "nnzL": res["nnzl"],
                        "fact_flops": res["flops"], "parallelism": res["parallelism"],
-                       "pct_of_mfma_f64_peak": round(value * 1e9 / (MFMA_F64_PEAK * world) * 100, 2),
+                       ("pct_of_mfma_f32_peak" if PEAK == MFMA_F32_PEAK else "pct_of_mfma_f64_peak"): round(value * 1e9 / (PEAK * world) * 100, 2),
                        "fact_time_s_per_step": round(res["fact_time"] / K, 4),
                        "residual": res["resid"], "solve_s": round(res["solve_s"], 4) if "solve_s" in res else None, "logdet_rel_err": res.get("logdet_rel_err"),
                        "static_pivots": res["nbpivot"],
                        "analysis_s": {"symbolic": round(res["t_sym"], 2), "plan": round(res["t_plan"], 2),
                                       "fill_prepare": round(res["t_fill"], 2)}},
-            "roofline": {"bound": "mfma", "kernel": "k_update", "achieved": round(upd_rate * 1e-12, 3),
-                         "peak": MFMA_F64_PEAK * 1e-12, "unit": "TFLOP/s",
-                         "frac": round(upd_rate / MFMA_F64_PEAK, 4),
+            "roofline": {"bound": "mfma", "kernel": "k_update_s" if PEAK == MFMA_F32_PEAK else "k_update", "achieved": round(upd_rate * 1e-12, 3),
+                         "peak": PEAK * 1e-12, "unit": "TFLOP/s",
+                         "frac": round(upd_rate / PEAK, 4),
                          "traffic": None if traffic is None else traffic / max(res["nlaunch"], 1),
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) * (bulk_flops / max(res["update_flops"], 1.0)) / max(res["nlaunch"], 1),
@@ -362,13 +371,13 @@ def main():
         if res.get("solve_dev_s"):
             # the next row of the path: forward + backward sweep, HBM-bound -- every panel entry is read
             # once per sweep (LU: L forward, U backward)
-            sb = 2.0 * (16.0 if a.workload == "elasticity" else 8.0) * res["nnzl"]
+            sb = 2.0 * (16.0 if a.workload == "elasticity" else 4.0 if PEAK == MFMA_F32_PEAK else 8.0) * res["nnzl"]
             out["solve"] = {"bound": "hbm", "achieved": round(sb / res["solve_dev_s"] * 1e-9, 1), "peak": 8000.0,
                             "unit": "GB/s", "frac": round(sb / res["solve_dev_s"] / 8e12, 4),
                             "device_s": round(res["solve_dev_s"], 4), "host_to_host_s": round(res["solve_s"], 4),
                             "panel_bytes_per_solve": sb, "nrhs": 1}
         if (world == 1 and not a.no_other_configs and a.grid == 200 and a.workload == "laplacian" and a.facto == "llt"
-                and a.chunk == 0):
+                and a.chunk == 0 and a.dtype == "f64"):
             out["other_configs"] = other_configs(a.blocksize, local)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample_grid, min(os.cpu_count() or 1, 64))

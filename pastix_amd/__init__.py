@@ -3,5 +3,5 @@
 Only the hot path named by BASELINE.json is here: the C-ABI library (csrc/, HIP for gfx950) and
 the thin host-side mirror of the reference interface around it.
 """
-from .solver import (COMPLEXDOUBLE, FACT_LDLT, FACT_LLT, FACT_LU, REALDOUBLE, Plan, fact_flops,  # noqa: F401
+from .solver import (COMPLEXDOUBLE, FACT_LDLT, FACT_LLT, FACT_LU, REALDOUBLE, REALSINGLE, Plan, fact_flops,  # noqa: F401
                      sopalin_tabs)

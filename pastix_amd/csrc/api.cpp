@@ -139,10 +139,10 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     SplitMap& M = p->split;
     try {
       M.upper.resize((size_t)M.ocblknbr);
-      const int es = floattype == PASTIX_AMD_COMPLEXDOUBLE ? 2 : 1;
+      const size_t eb = floattype == PASTIX_AMD_COMPLEXDOUBLE ? 16 : floattype == PASTIX_AMD_REALSINGLE ? 4 : 8;
       for (int64_t k = 0; k < M.ocblknbr; k++)
         if (M.first[k + 1] - M.first[k] > 1 && p->host.role[(size_t)M.first[k]] == 1)
-          M.upper[(size_t)k].assign((size_t)(M.owidth[k] * M.owidth[k] * es), 0.0);
+          M.upper[(size_t)k].assign((size_t)(M.owidth[k] * M.owidth[k]) * eb, 0);
     } catch (const std::bad_alloc&) { delete p; return PASTIX_AMD_ERR_ALLOC; }
   }
   Plan& H = p->host;
@@ -165,9 +165,12 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     p->distributed = owner != nullptr;
     p->own_arena = !(opts && opts->external_arena);
     p->cplx = H.floattype == PASTIX_AMD_COMPLEXDOUBLE;
+    p->f32 = H.floattype == PASTIX_AMD_REALSINGLE;
+    p->esz = p->f32 ? sizeof(float) : sizeof(double);
+    if (p->f32 && !p->own_arena) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (p->cplx && !p->own_arena) return PASTIX_AMD_ERR_UNSUPPORTED;
     if (p->own_arena) {
-      const size_t bytes = std::max<int64_t>(H.coefnbr, 1) * sizeof(double);
+      const size_t bytes = std::max<int64_t>(H.coefnbr, 1) * p->esz;
       // 256 B of slack on both sides: the update kernel's 16-byte DMA lanes may touch the element just
       // before / after a panel when a contribution starts or ends on an odd row (kernels.hip, k_update)
       auto alloc = [&](double** out) -> int {
@@ -325,7 +328,7 @@ int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const
   if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !src || !rows || cblk < 0 || cblk >= p->host.cblknbr || nrows < 0) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
-  if (H.role[cblk] != 1 || p->cplx || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
+  if (H.role[cblk] != 1 || p->cplx || p->f32 || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const int64_t w = H.cblk[cblk].lcolnum - H.cblk[cblk].fcolnum + 1;
   launch_fanin_add(p->stream, p->dL + H.poff[cblk], H.cblk[cblk].stride, (const double*)src, rows, nrows, w);
@@ -454,15 +457,15 @@ static int z_transfer(pastix_amd_plan_t* p, bool to_device, void* host, double* 
 // initial fill there, nothing reads it.
 static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, void* hostU) {
   const Plan& H = p->host;
-  const SplitMap& M = p->split;
-  const int es = p->cplx ? 2 : 1;
+  SplitMap& M = p->split;
+  const size_t eb = p->cplx ? 16 : p->esz;       // bytes per entry of the caller's panels (double complex: interleaved)
   const int64_t s0 = M.first[k], ns = M.first[k + 1] - s0, os = M.ostride[k], ow = M.owidth[k];
   auto xfer = [&](int arena, int64_t off, int64_t cnt, void* host) -> int {
     double* re = arena ? p->dU : p->dL;
     double* im = arena ? p->dUi : p->dLi;
     if (p->cplx) return z_transfer(p, up, host, re, im, off, cnt);
-    if (up) HIPCHK(hipMemcpy(re + off, host, cnt * sizeof(double), hipMemcpyHostToDevice));
-    else HIPCHK(hipMemcpy(host, re + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    if (up) HIPCHK(hipMemcpy(p->at(re, off), host, cnt * eb, hipMemcpyHostToDevice));
+    else HIPCHK(hipMemcpy(host, p->at(re, off), cnt * eb, hipMemcpyDeviceToHost));
     return 0;
   };
   const bool haveU = p->dU && hostU;
@@ -472,43 +475,42 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
     return r;
   }
   const int64_t fcol = H.cblk[s0].fcolnum;
-  std::vector<double>* keep = (!M.upper.empty() && !M.upper[(size_t)k].empty()) ? const_cast<std::vector<double>*>(&M.upper[(size_t)k]) : nullptr;
+  std::vector<unsigned char>* keep = (!M.upper.empty() && !M.upper[(size_t)k].empty()) ? &M.upper[(size_t)k] : nullptr;
   if (up && keep) {                               // the diagonal blok's blocks above the column groups (see SplitMap::upper)
-    const double* host = (const double*)hostL;
+    const unsigned char* host = (const unsigned char*)hostL;
     for (int64_t j = 1; j < ns; j++) {
       const int64_t offj = H.cblk[s0 + j].fcolnum - fcol, wj = H.cblk[s0 + j].lcolnum - H.cblk[s0 + j].fcolnum + 1;
       for (int64_t c = 0; c < wj; c++)
-        memcpy(keep->data() + (offj + c) * ow * es, host + (offj + c) * os * es, (size_t)(offj * es) * sizeof(double));
+        memcpy(keep->data() + (offj + c) * ow * eb, host + (offj + c) * os * eb, (size_t)offj * eb);
     }
   }
-  std::vector<std::vector<double>> tmp[2];
+  std::vector<std::vector<unsigned char>> tmp[2];
   for (int a = 0; a < 2; a++) tmp[a].resize((size_t)ns);
   for (int a = 0; a < (haveU ? 2 : 1); a++) {
-    double* host = (double*)(a ? hostU : hostL);
+    unsigned char* host = (unsigned char*)(a ? hostU : hostL);
     for (int64_t j = 0; j < ns; j++) {
       const int64_t s = s0 + j, off = H.cblk[s].fcolnum - fcol, wj = H.cblk[s].lcolnum - H.cblk[s].fcolnum + 1;
       const int64_t nr = H.cblk[s].stride;                      // == os - off
-      std::vector<double>& t = tmp[a][(size_t)j];
-      t.resize((size_t)(nr * wj * es));
+      std::vector<unsigned char>& t = tmp[a][(size_t)j];
+      t.resize((size_t)(nr * wj) * eb);
       if (up) {
         for (int64_t c = 0; c < wj; c++)
-          memcpy(t.data() + c * nr * es, host + ((off + c) * os + off) * es, (size_t)(nr * es) * sizeof(double));
+          memcpy(t.data() + c * nr * eb, host + ((off + c) * os + off) * eb, (size_t)nr * eb);
         if (a == 1 && H.factotype == PASTIX_AMD_FACT_LU) {
           // LU: the reference keeps the whole square A_kk in coeftab's diagonal blok and zeros in ucoeftab's
           // (csc_intern_solve.c:65-132); the U^T blocks facing the later column groups are the transposes of
           // coeftab's blocks right of this group's diagonal
-          const double* hl = (const double*)hostL;
+          const unsigned char* hl = (const unsigned char*)hostL;
           for (int64_t c = 0; c < wj; c++)
             for (int64_t pr = off + wj; pr < ow; pr++)             // original diagonal-blok row/col index of the later groups
-              for (int e = 0; e < es; e++)
-                t[(size_t)(((pr - off) + c * nr) * es + e)] = hl[(size_t)(((off + c) + pr * os) * es + e)];
+              memcpy(t.data() + ((pr - off) + c * nr) * eb, hl + ((off + c) + pr * os) * eb, eb);
         }
       }
       int r = xfer(a, H.poff[s], nr * wj, t.data());
       if (r) return r;
       if (!up) {
         for (int64_t c = 0; c < wj; c++)
-          memcpy(host + ((off + c) * os + off) * es, t.data() + c * nr * es, (size_t)(nr * es) * sizeof(double));
+          memcpy(host + ((off + c) * os + off) * eb, t.data() + c * nr * eb, (size_t)nr * eb);
       }
     }
   }
@@ -518,22 +520,22 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
     // of each other at fill time, csc_intern_solve.c:65-132)
     const bool lu = H.factotype == PASTIX_AMD_FACT_LU && haveU;
     if (lu && !p->factored)                       // before a factorization ucoeftab's diagonal blok is all zeros
-      for (int64_t c = 0; c < ow; c++) memset((double*)hostU + c * os * es, 0, (size_t)(ow * es) * sizeof(double));
+      for (int64_t c = 0; c < ow; c++) memset((unsigned char*)hostU + c * os * eb, 0, (size_t)ow * eb);
     for (int64_t j = 1; j < ns; j++) {
       const int64_t offj = H.cblk[s0 + j].fcolnum - fcol, wj = H.cblk[s0 + j].lcolnum - H.cblk[s0 + j].fcolnum + 1;
       for (int64_t c = 0; c < wj; c++) {
-        double* col[2] = {(double*)hostL + (offj + c) * os * es, haveU ? (double*)hostU + (offj + c) * os * es : nullptr};
+        unsigned char* col[2] = {(unsigned char*)hostL + (offj + c) * os * eb,
+                                 haveU ? (unsigned char*)hostU + (offj + c) * os * eb : nullptr};
         for (int a = 0; a < (haveU ? 2 : 1); a++) {
-          memset(col[a], 0, (size_t)(offj * es) * sizeof(double));
-          if (a == 0 && keep) memcpy(col[0], keep->data() + (offj + c) * ow * es, (size_t)(offj * es) * sizeof(double));
+          memset(col[a], 0, (size_t)offj * eb);
+          if (a == 0 && keep) memcpy(col[0], keep->data() + (offj + c) * ow * eb, (size_t)offj * eb);
           if (!lu || (a == 1 && !p->factored)) continue;
           for (int64_t i = 0; i < j; i++) {                      // rows of the earlier group i, from the OTHER arena's panel of i
             const int64_t offi = H.cblk[s0 + i].fcolnum - fcol, wi = H.cblk[s0 + i].lcolnum - H.cblk[s0 + i].fcolnum + 1;
             const int64_t ldi = H.cblk[s0 + i].stride;
-            const std::vector<double>& ot = tmp[1 - a][(size_t)i];
+            const std::vector<unsigned char>& ot = tmp[1 - a][(size_t)i];
             for (int64_t q = 0; q < wi; q++)
-              for (int e = 0; e < es; e++)
-                col[a][(offi + q) * es + e] = ot[(size_t)(((offj + c - offi) + q * ldi) * es + e)];
+              memcpy(col[a] + (offi + q) * eb, ot.data() + ((offj + c - offi) + q * ldi) * eb, eb);
           }
         }
       }
@@ -546,10 +548,10 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
 static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab, void* packedL,
                     void* packedU) {
   const SplitMap& M = p->split;
-  const int es = p->cplx ? 2 : 1;
+  const size_t eb = p->cplx ? 16 : p->esz;
   for (int64_t k = 0; k < M.ocblknbr; k++) {
-    void* hl = coeftab ? coeftab[k] : (void*)((double*)packedL + M.ooff[k] * es);
-    void* hu = coeftab ? (ucoeftab ? ucoeftab[k] : nullptr) : (packedU ? (void*)((double*)packedU + M.ooff[k] * es) : nullptr);
+    void* hl = coeftab ? coeftab[k] : (void*)((char*)packedL + M.ooff[k] * eb);
+    void* hu = coeftab ? (ucoeftab ? ucoeftab[k] : nullptr) : (packedU ? (void*)((char*)packedU + M.ooff[k] * eb) : nullptr);
     if (p->host.role[(size_t)M.first[k]] != 1) continue;          // (distributed plans: only owned panels travel)
     if (!hl) return PASTIX_AMD_ERR_BADPARAMETER;
     int r = split_cblk_io(p, k, up, hl, hu);
@@ -575,8 +577,8 @@ int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U)
       if (U) { if ((r = z_transfer(p, true, (void*)U, p->dU, p->dUi, 0, p->host.coefnbr))) return r; }
     }
   } else {
-    HIPCHK(hipMemcpy(p->dL, L, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
-    if (p->dU && U) HIPCHK(hipMemcpy(p->dU, U, p->host.coefnbr * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dL, L, p->host.coefnbr * p->esz, hipMemcpyHostToDevice));
+    if (p->dU && U) HIPCHK(hipMemcpy(p->dU, U, p->host.coefnbr * p->esz, hipMemcpyHostToDevice));
   }
   p->stats.h2d_time = now_s() - t0;
   return PASTIX_AMD_OK;
@@ -597,8 +599,8 @@ int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
     if (r) return r;
     if (p->dU && U && (r = z_transfer(p, false, U, p->dU, p->dUi, 0, p->host.coefnbr))) return r;
   } else {
-    HIPCHK(hipMemcpy(L, p->dL, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
-    if (p->dU && U) HIPCHK(hipMemcpy(U, p->dU, p->host.coefnbr * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(L, p->dL, p->host.coefnbr * p->esz, hipMemcpyDeviceToHost));
+    if (p->dU && U) HIPCHK(hipMemcpy(U, p->dU, p->host.coefnbr * p->esz, hipMemcpyDeviceToHost));
   }
   p->stats.d2h_time = now_s() - t0;
   return PASTIX_AMD_OK;
@@ -616,7 +618,7 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
     return r;
   }
   for (int64_t k = 0; k < H.cblknbr; k++) {
-    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * p->esz;
     if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
     if (p->cplx) {
@@ -627,9 +629,9 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
         return r;
       continue;
     }
-    HIPCHK(hipMemcpyAsync(p->dL + H.poff[k], coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
+    HIPCHK(hipMemcpyAsync(p->at(p->dL, H.poff[k]), coeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
-      HIPCHK(hipMemcpyAsync(p->dU + H.poff[k], ucoeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
+      HIPCHK(hipMemcpyAsync(p->at(p->dU, H.poff[k]), ucoeftab[k], bytes, hipMemcpyHostToDevice, p->stream));
   }
   HIPCHK(hipStreamSynchronize(p->stream));
   p->stats.h2d_time = now_s() - t0;
@@ -648,7 +650,7 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
     return r;
   }
   for (int64_t k = 0; k < H.cblknbr; k++) {
-    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * sizeof(double);
+    size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * p->esz;
     if (H.role[k] != 1) continue;
     if (!coeftab[k]) return PASTIX_AMD_ERR_BADPARAMETER;
     if (p->cplx) {
@@ -659,9 +661,9 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
         return r;
       continue;
     }
-    HIPCHK(hipMemcpyAsync(coeftab[k], p->dL + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipMemcpyAsync(coeftab[k], p->at(p->dL, H.poff[k]), bytes, hipMemcpyDeviceToHost, p->stream));
     if (p->dU && ucoeftab && ucoeftab[k])
-      HIPCHK(hipMemcpyAsync(ucoeftab[k], p->dU + H.poff[k], bytes, hipMemcpyDeviceToHost, p->stream));
+      HIPCHK(hipMemcpyAsync(ucoeftab[k], p->at(p->dU, H.poff[k]), bytes, hipMemcpyDeviceToHost, p->stream));
   }
   HIPCHK(hipStreamSynchronize(p->stream));
   p->stats.d2h_time = now_s() - t0;
@@ -686,8 +688,8 @@ int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, 
     if (U && p->dU && (r = z_transfer(p, false, U, p->dU, p->dUi, off, cnt))) return r;
     return PASTIX_AMD_OK;
   }
-  HIPCHK(hipMemcpy(L, p->dL + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
-  if (U && p->dU) HIPCHK(hipMemcpy(U, p->dU + off, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(L, p->at(p->dL, off), cnt * p->esz, hipMemcpyDeviceToHost));
+  if (U && p->dU) HIPCHK(hipMemcpy(U, p->at(p->dU, off), cnt * p->esz, hipMemcpyDeviceToHost));
   return PASTIX_AMD_OK;
 }
 
@@ -701,8 +703,9 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
   if (!p || !colptr || !rows || !vals_ || !perm) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
-  const double* vals = (const double*)vals_;   // complex: interleaved (re,im)
+  const double* vals = (const double*)vals_;   // complex: interleaved (re,im); single-precision plans: float values
   const int vs = p->cplx ? 2 : 1;
+  auto val_at = [&](int64_t q) -> double { return p->f32 ? (double)((const float*)vals_)[q] : vals[vs * q]; };
   std::vector<double> valLi, valUi;
   HIPCHK(hipSetDevice(p->device));
   std::vector<int32_t> col2cblk((size_t)n);
@@ -732,7 +735,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
     sub2orig.resize((size_t)H.cblknbr);
     for (int64_t k = 0; k < p->split.ocblknbr; k++) {
       for (int64_t q = p->split.first[k]; q < p->split.first[k + 1]; q++) sub2orig[(size_t)q] = k;
-      std::fill(p->split.upper[(size_t)k].begin(), p->split.upper[(size_t)k].end(), 0.0);
+      std::fill(p->split.upper[(size_t)k].begin(), p->split.upper[(size_t)k].end(), (unsigned char)0);
     }
   }
   for (int64_t j = 0; j < n; j++)
@@ -745,24 +748,29 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
         int64_t d = locate(pr, pc, false);
         if (d >= 0) {
           idxL.push_back(d);
-          valL.push_back(vals[vs * q]);
+          valL.push_back(val_at(q));
           // Hermitian input: the mirrored entry is the conjugate (CscOrdistrib type 'H', pastix.c:3309)
           if (p->cplx) valLi.push_back((pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1]);
         } else if (keep_upper) {
           // a re-cut cblk: entries of its diagonal blok above the column group of their column stay on the host
           // (SplitMap::upper) -- the reference's coeftab carries them, unread, from the fill to the caller
           const int64_t ko = sub2orig[(size_t)col2cblk[pc]];
-          std::vector<double>& up = p->split.upper[(size_t)ko];
+          std::vector<unsigned char>& up = p->split.upper[(size_t)ko];
           const int64_t of = H.cblk[(size_t)p->split.first[ko]].fcolnum, ow = p->split.owidth[ko];
           if (!up.empty() && pr >= of && pr < H.cblk[col2cblk[pc]].fcolnum) {
-            const size_t e = (size_t)(((pc - of) * ow + (pr - of)) * vs);
-            up[e] = vals[vs * q];
-            if (p->cplx) up[e + 1] = (pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1];
+            const size_t e = (size_t)((pc - of) * ow + (pr - of));
+            if (p->f32) {
+              ((float*)up.data())[e] = (float)val_at(q);
+            } else {
+              double* ud = (double*)up.data();
+              ud[e * vs] = vals[vs * q];
+              if (p->cplx) ud[e * vs + 1] = (pass && H.factotype == PASTIX_AMD_FACT_LDLH) ? -vals[2 * q + 1] : vals[2 * q + 1];
+            }
           }
         }
         if (lu) {
           d = locate(pc, pr, true);
-          if (d >= 0) { idxU.push_back(d); valU.push_back(vals[vs * q]); if (p->cplx) valUi.push_back(vals[2 * q + 1]); }
+          if (d >= 0) { idxU.push_back(d); valU.push_back(val_at(q)); if (p->cplx) valUi.push_back(vals[2 * q + 1]); }
         }
       }
     }
@@ -804,8 +812,10 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
 int pastix_amd_fill_fake(pastix_amd_plan_t* p, pastix_amd_int_t gnodenbr) {
   if (!p || gnodenbr < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_UNSUPPORTED;
-  for (auto& up : p->split.upper)                  // (re-cut cblks, LLt / LDLt: every coeftab entry is 1, also above the groups)
-    for (size_t e = 0; e < up.size(); e++) up[e] = (p->cplx && (e & 1)) ? 0.0 : 1.0;
+  for (auto& up : p->split.upper) {                // (re-cut cblks, LLt / LDLt: every coeftab entry is 1, also above the groups)
+    if (p->f32) { for (size_t e = 0; e < up.size() / 4; e++) ((float*)up.data())[e] = 1.0f; }
+    else { for (size_t e = 0; e < up.size() / 8; e++) ((double*)up.data())[e] = (p->cplx && (e & 1)) ? 0.0 : 1.0; }
+  }
   const Plan& H = p->host;
   HIPCHK(hipSetDevice(p->device));
   const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
@@ -841,6 +851,17 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   const Plan& H = p->host;
   p->factored = false;
   HIPCHK(hipSetDevice(p->device));
+  if (p->f32) {
+    float *fL = (float*)p->dL, *fU = (float*)p->dU;
+    if (p->fillBaseL != 0.0) launch_fill_const_s(p->stream, fL, H.coefnbr, (float)p->fillBaseL);
+    else HIPCHK(hipMemsetAsync(fL, 0, H.coefnbr * sizeof(float), p->stream));
+    if (fU && p->fillBaseU != 0.0) launch_fill_const_s(p->stream, fU, H.coefnbr, (float)p->fillBaseU);
+    else if (fU) HIPCHK(hipMemsetAsync(fU, 0, H.coefnbr * sizeof(float), p->stream));
+    launch_scatter_s(p->stream, fL, p->dFillIdxL, p->dFillValL, p->nFillL);
+    if (fU && p->nFillU) launch_scatter_s(p->stream, fU, p->dFillIdxU, p->dFillValU, p->nFillU);
+    HIPCHK(hipStreamSynchronize(p->stream));
+    return PASTIX_AMD_OK;
+  }
   if (p->fillBaseL != 0.0) launch_fill_const(p->stream, p->dL, H.coefnbr, p->fillBaseL);
   else HIPCHK(hipMemsetAsync(p->dL, 0, H.coefnbr * sizeof(double), p->stream));
   if (p->dU && p->fillBaseU != 0.0) launch_fill_const(p->stream, p->dU, H.coefnbr, p->fillBaseU);
@@ -859,6 +880,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
 // range go to k_update_small, the rest to k_update
 static void launch_update_range(pastix_amd_plan_t* p, hipStream_t s, int slot, int64_t b, int64_t e, bool urgent) {
   const Plan& H = p->host;
+  if (p->f32) { launch_update_s(s, p->arenas(), p->dTasks + b, p->dPieces, e - b, urgent); return; }
   // the slot's ranges: [t0, us) urgent, [us, tu) urgent quadrants, [tu, sb) bulk, [sb, t1) bulk quadrants
   const int64_t cut[5] = {H.slot_task_ptr[(size_t)slot], H.slot_usmall_begin[(size_t)slot], H.slot_urgent_end[(size_t)slot],
                           H.slot_small_begin[(size_t)slot], H.slot_task_ptr[(size_t)slot + 1]};
@@ -943,6 +965,12 @@ static int launch_panels(pastix_amd_plan_t* p, int l) {
   const int64_t npt = H.lvl_panel_ptr[l + 1] - H.lvl_panel_ptr[l];
   const TrsmTask* tt = p->dTrsm + H.lvl_trsm_ptr[l];
   const int64_t ntt = H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l];
+  if (p->f32) {
+    const int lw = npt > 0 ? (int)H.panel_tasks[(size_t)H.lvl_panel_ptr[l]].width : 1;    // (sorted widest first)
+    launch_diag_s(s, H.factotype, (float*)p->dL, (float*)p->dU, pt, npt, p->crit_run, p->dNbpivot, p->dErr, lw);
+    launch_trsm_s(s, H.factotype, (float*)p->dL, (float*)p->dU, tt, ntt, lw);
+    return PASTIX_AMD_OK;
+  }
   if (p->cplx) {
     if (H.factotype == PASTIX_AMD_FACT_LU) {
       launch_diag_zlu(s, p->arenas(), pt, npt, p->dDinv, p->crit_run, p->dNbpivot, p->maxw);
@@ -1252,9 +1280,9 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
   if (p->nthin > 0 && p->inv_gen != p->fact_gen) {
     // the inverses of the thin cblks' diagonal bloks, once per factorization (k_solve_inv)
     const int unit = H.factotype != PASTIX_AMD_FACT_LLT;
-    launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvF, 0, unit);
-    if (H.factotype == PASTIX_AMD_FACT_LU) launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 2, 0);
-    else launch_solve_inv(p->stream, p->dL, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 1, unit);
+    launch_solve_inv(p->stream, p->dL, p->f32, p->dSolve, p->dThinTasks, p->nthin, p->dInvF, 0, unit);
+    if (H.factotype == PASTIX_AMD_FACT_LU) launch_solve_inv(p->stream, p->dL, p->f32, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 2, 0);
+    else launch_solve_inv(p->stream, p->dL, p->f32, p->dSolve, p->dThinTasks, p->nthin, p->dInvB, 1, unit);
     HIPCHK(hipGetLastError());
     p->inv_gen = p->fact_gen;
   }
@@ -1267,8 +1295,18 @@ void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) 
   if (nr == 1 && p->nthin > 0 && p->lvl_thin[(size_t)l]) {
     const std::vector<int64_t>& ptr = fwd ? p->lvl_thinF_ptr : p->lvl_thinB_ptr;
     const double* P = fwd ? p->dL : (H.factotype == PASTIX_AMD_FACT_LU ? p->dU : p->dL);
-    launch_solve_thin(p->stream, fwd, P, (fwd ? p->dThinF : p->dThinB) + ptr[(size_t)l], ptr[(size_t)l + 1] - ptr[(size_t)l],
+    launch_solve_thin(p->stream, fwd, P, p->f32, (fwd ? p->dThinF : p->dThinB) + ptr[(size_t)l], ptr[(size_t)l + 1] - ptr[(size_t)l],
                       p->dRidx, fwd ? p->dInvF : p->dInvB, p->dTicket + (fwd ? 0 : p->nthin), dx);
+    return;
+  }
+  if (p->f32) {
+    // (single-precision factors: float panels under double vectors, one right-hand side per pass)
+    for (int k = 0; k < nr; k++)
+      launch_solve_level_s(p->stream, fwd, H.factotype, (const float*)p->dL, (const float*)p->dU, p->dSolve + H.lvl_cblk_ptr[l],
+                           H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                           (fwd ? p->dChunk + p->lvl_chunk_ptr[l] : p->dChunkB + p->lvl_chunkB_ptr[l]),
+                           fwd ? p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l] : p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l],
+                           p->dRidx, dx + (int64_t)k * H.ncol, p->lvl_maxw[l]);
     return;
   }
   if (fwd)
@@ -1282,6 +1320,10 @@ void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) 
 }
 void pai_solve_dscale(pastix_amd_plan_t* p, double* dx, int nr) {     // LDLt: x <- D^-1 x on the cblks factorized here
   const Plan& H = p->host;
+  if (p->f32) {
+    for (int k = 0; k < nr; k++) launch_solve_dscale_s(p->stream, (const float*)p->dL, p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx + k * H.ncol);
+    return;
+  }
   for (int k = 0; k < nr; k++) launch_solve_dscale(p->stream, p->dL, p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx + k * H.ncol);
 }
 
@@ -1422,6 +1464,11 @@ static int one_shot_single(int factotype, const pastix_amd_layout_t* layout, voi
                            void* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                            pastix_amd_stats_t* stats, bool cplx) {
   if (!layout || !coeftab || !layout->cblktab) return PASTIX_AMD_ERR_BADPARAMETER;
+  // real single precision: the fp32 engine on the caller's float panels, nothing is widened (kernels_f32.hip);
+  // complex single precision is still widened on the host and factorized by the fp64 engine
+  if (!cplx)
+    return one_shot(factotype, layout, (double* const*)coeftab, (double* const*)ucoeftab, critere, opts, stats,
+                    PASTIX_AMD_REALSINGLE);
   const int64_t nc = layout->cblknbr;
   const int es = cplx ? 2 : 1;
   std::vector<std::vector<double>> L((size_t)nc), U;

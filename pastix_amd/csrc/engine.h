@@ -48,10 +48,20 @@ void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, 
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
-void launch_solve_inv(hipStream_t s, const double* A, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
+// kernels_f32.hip: the single-precision engine (arenas of floats; Arenas::p reinterpreted)
+void launch_update_s(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks, bool urgent);
+void launch_diag_s(hipStream_t s, int factotype, float* L, float* U, const PanelTask* tasks, int64_t n, double critere,
+                   long long* nbpivot, int* errflag, int maxw);
+void launch_trsm_s(hipStream_t s, int factotype, float* L, float* U, const TrsmTask* tasks, int64_t n, int maxw);
+void launch_fill_const_s(hipStream_t s, float* dst, int64_t n, float v);
+void launch_scatter_s(hipStream_t s, float* dst, const int64_t* idx, const double* val, int64_t n);
+void launch_solve_inv(hipStream_t s, const void* A, bool f32, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
                       double* inv, int which, int unit);
-void launch_solve_thin(hipStream_t s, bool fwd, const double* P, const SolveChunk* chunks, int64_t nchunk,
+void launch_solve_thin(hipStream_t s, bool fwd, const void* P, bool f32, const SolveChunk* chunks, int64_t nchunk,
                        const int32_t* ridx, const double* inv, int* ticket, double* x);
+void launch_solve_level_s(hipStream_t s, bool fwd, int factotype, const float* L, const float* U, const SolveTask* tasks,
+                          int64_t ntask, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x, int lvlw);
+void launch_solve_dscale_s(hipStream_t s, const float* L, const SolveTask* tasks, int64_t ntask, double* x);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -74,7 +84,7 @@ struct SplitMap {
   // touches the strict upper triangle), so they are kept here: per re-cut cblk the diagonal blok as a dense ow x ow
   // array (ld ow; complex: interleaved), of which only those blocks are used -- recorded by the fills / uploads, written
   // back by the downloads.
-  std::vector<std::vector<double>> upper;        // [ocblknbr], empty for cblks that are not re-cut
+  std::vector<std::vector<unsigned char>> upper; // [ocblknbr] (entries of the plan's type), empty for cblks not re-cut
 };
 
 struct pastix_amd_dist_s;            // dist.cpp: fan-in schedule, channels, transport
@@ -103,6 +113,10 @@ struct pastix_amd_plan_s {
   double* dLi = nullptr;     // imaginary planes (complex double only)
   double* dUi = nullptr;
   bool cplx = false;
+  bool f32 = false;          // single precision (PASTIX_AMD_REALSINGLE): dL / dU are arenas of FLOATS (kernels_f32.hip)
+  size_t esz = sizeof(double);   // bytes per arena entry
+  // arena + element offset, whatever the entry size (the pointers are typed double* for the fp64 kernels)
+  double* at(double* arena, int64_t off) const { return (double*)((char*)arena + (size_t)off * esz); }
   Arenas arenas() const { return Arenas{{dL, dU, dLi, dUi}}; }
   double* dDinv = nullptr;
   Task* dTasks = nullptr;

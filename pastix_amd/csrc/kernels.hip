@@ -639,13 +639,13 @@ __global__ __launch_bounds__(256) void k_solve_diag_q(const double* __restrict__
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_solve_diag_q1(const double* __restrict__ L,
+template <int MODE, class T>
+__global__ __launch_bounds__(256) void k_solve_diag_q1(const T* __restrict__ L,
                                                       const SolveTask* __restrict__ tasks,
                                                       double* __restrict__ x, int unit) {
   __shared__ double xs[128];
   const SolveTask tk = tasks[blockIdx.x];
-  const double* A = L + tk.off;
+  const T* A = L + tk.off;
   const int64_t ld = tk.stride;
   const int w = tk.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t rcl[2];
@@ -745,15 +745,15 @@ void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, c
 // forward, step 2 / backward, step 1 on chunks of panel rows, NR right-hand sides per pass over the panel (x is
 // n x NR, leading dimension ldx): lane = row, the four waves split the columns in groups (independent coalesced
 // loads in flight, > 2 workgroups per CU on the tall top panels).
-template <int NR>
-__global__ __launch_bounds__(256) void k_solve_off_fwd64(const double* __restrict__ L,
+template <int NR, class T>
+__global__ __launch_bounds__(256) void k_solve_off_fwd64(const T* __restrict__ L,
                                                          const SolveChunk* __restrict__ chunks,
                                                          const int32_t* __restrict__ ridx, double* __restrict__ x,
                                                          int64_t ldx) {
   __shared__ double xs[NR][MAXW];
   __shared__ double part[4][NR][64];
   const SolveChunk ck = chunks[blockIdx.x];
-  const double* A = L + ck.off;
+  const T* A = L + ck.off;
   const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NR * MAXW; i += 256) {
     const int q = i / MAXW, c = i - q * MAXW;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) void k_solve_off_fwd64(const double* __restric
   }
   __syncthreads();
   const int p = ck.row0 + lane;
-  const double* Ap = A + min(p, ld - 1);
+  const T* Ap = A + min(p, ld - 1);
   double sacc[NR];
 #pragma unroll
   for (int k = 0; k < NR; k++) sacc[k] = 0.0;
@@ -790,15 +790,15 @@ __global__ __launch_bounds__(256) void k_solve_off_fwd64(const double* __restric
 // backward: the sum over the 64 rows of a wave for G = 32/NR columns at a time is a *transposed butterfly*: at every
 // step a lane hands half of its partial sums to its partner and keeps the other half (G-1 shuffles for G columns
 // instead of 6G), then the 64/G lanes that hold the same column finish with plain steps.
-template <int NR>
-__global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restrict__ L,
+template <int NR, class T>
+__global__ __launch_bounds__(256) void k_solve_off_bwd64(const T* __restrict__ L,
                                                          const SolveChunk* __restrict__ chunks,
                                                          const int32_t* __restrict__ ridx, double* __restrict__ x,
                                                          int64_t ldx) {
   constexpr int G = 32 / NR;                 // columns per group
   constexpr int LPC = 64 / G;                // lanes that end with the same column
   const SolveChunk ck = chunks[blockIdx.x];
-  const double* A = L + ck.off;
+  const T* A = L + ck.off;
   const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave * G >= w) return;
   const int p = ck.row0 + lane;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restric
       double xr[NR];
 #pragma unroll
       for (int k = 0; k < NR; k++) xr[k] = rv ? x[k * ldx + gr] : 0.0;
-      const double* Ap = A + pp;
+      const T* Ap = A + pp;
       double a[G];
 #pragma unroll
       for (int i = 0; i < G; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
@@ -849,10 +849,11 @@ __global__ __launch_bounds__(256) void k_solve_off_bwd64(const double* __restric
 }
 
 // LDLt: x_k := D_k^-1 x_k between the forward and the backward sweep
-__global__ __launch_bounds__(256) void k_solve_dscale(const double* __restrict__ L,
+template <class T>
+__global__ __launch_bounds__(256) void k_solve_dscale(const T* __restrict__ L,
                                                       const SolveTask* __restrict__ tasks, double* __restrict__ x) {
   const SolveTask tk = tasks[blockIdx.x];
-  const double* A = L + tk.off;
+  const T* A = L + tk.off;
   for (int c = threadIdx.x; c < tk.width; c += 256) x[tk.fcol + c] /= A[c + (int64_t)c * tk.stride];
 }
 
@@ -878,12 +879,13 @@ constexpr int INVLD = 128;          // leading dimension of a stored inverse
 //   which 1: the same T,                                                                        out = M^T    [c + r ld]
 //   which 2: T = U^T, U the upper triangle of the blok (LU: non-unit),                          out = M^T = U^-1 stored
 //            as [c + r ld] of M, i.e. x = U^-1 b is the row-wise product the backward kernel does
-__global__ __launch_bounds__(128) void k_solve_inv(const double* __restrict__ A, const SolveTask* __restrict__ tasks,
+template <class TE>
+__global__ __launch_bounds__(128) void k_solve_inv(const TE* __restrict__ A, const SolveTask* __restrict__ tasks,
                                                    const int32_t* __restrict__ thin_tasks, double* __restrict__ inv,
                                                    int which, int unit) {
   extern __shared__ double S[];                     // M: [i + j * ldl], then the row buffer
   const SolveTask tk = tasks[thin_tasks[blockIdx.x]];
-  const double* T = A + tk.off;
+  const TE* T = A + tk.off;
   const int64_t ld = tk.stride;
   const int w = tk.width, j = threadIdx.x, ldl = w | 1;
   double* row = S + (size_t)ldl * w;
@@ -926,7 +928,8 @@ __device__ __forceinline__ void inv_apply(const double* __restrict__ M, const do
 }
 
 // forward, thin levels: 256 panel rows per workgroup (one per thread); see above
-__global__ __launch_bounds__(256) void k_solve_thin_fwd(const double* __restrict__ L, const SolveChunk* __restrict__ chunks,
+template <class T>
+__global__ __launch_bounds__(256) void k_solve_thin_fwd(const T* __restrict__ L, const SolveChunk* __restrict__ chunks,
                                                         const int32_t* __restrict__ ridx, const double* __restrict__ inv,
                                                         int* __restrict__ ticket, double* __restrict__ x) {
   __shared__ double xs[128], ys[128], tmp[256];
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(256) void k_solve_thin_fwd(const double* __restrict
   const int ld = ck.stride;
   const bool rowv = tid < ck.nrows;
   const int p = ck.row0 + min(tid, max(ck.nrows - 1, 0));
-  const double* Ap = L + ck.off + p;
+  const T* Ap = L + ck.off + p;
   double a0[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) a0[i] = rowv ? Ap[(int64_t)min(i, w - 1) * ld] : 0.0;
@@ -962,7 +965,8 @@ __global__ __launch_bounds__(256) void k_solve_thin_fwd(const double* __restrict
   unsafeAtomicAdd(&x[gr], -sacc);
 }
 
-__global__ __launch_bounds__(256) void k_solve_thin_bwd(const double* __restrict__ B, const SolveChunk* __restrict__ chunks,
+template <class T>
+__global__ __launch_bounds__(256) void k_solve_thin_bwd(const T* __restrict__ B, const SolveChunk* __restrict__ chunks,
                                                         const int32_t* __restrict__ ridx, const double* __restrict__ invT,
                                                         int* __restrict__ ticket, double* __restrict__ x) {
   __shared__ double xs[128], ys[128], tmp[256];
@@ -970,7 +974,7 @@ __global__ __launch_bounds__(256) void k_solve_thin_bwd(const double* __restrict
   const SolveChunk ck = chunks[blockIdx.x];
   const int w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (ck.nrows > 0) {
-    const double* A = B + ck.off;
+    const T* A = B + ck.off;
     const int ld = ck.stride;
     const int p = ck.row0 + lane;
     // x of the chunk's (at most 256) rows, gathered up front: two dependent loads that would otherwise sit in front of
@@ -991,7 +995,7 @@ __global__ __launch_bounds__(256) void k_solve_thin_bwd(const double* __restrict
         if (rb >= ck.nrows) break;
         const int pp = min(p + rb, ld - 1);
         const double xr = xrow[q];
-        const double* Ap = A + pp;
+        const T* Ap = A + pp;
         double a[32];
 #pragma unroll
         for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
@@ -1087,37 +1091,39 @@ static bool dyn_lds_attr_once(const void* fn, int bytes) {
 
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
 // (cblks are at most 128 columns wide: wider ones are re-cut before planning, api.cpp build_split)
-template <int MODE, int NR>
-static void launch_solve_diag(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x,
+// T: the panels' element type -- double, or float for the factors of the single-precision engine (the vectors stay double)
+template <int MODE, int NR, class T>
+static void launch_solve_diag(hipStream_t s, const T* L, const SolveTask* tasks, int64_t ntask, double* x,
                               int64_t ldx, int unit, int lvlw) {
   // MODE 1 turns the blok through dynamic LDS sized for the widest cblk of the level
   const size_t smem = MODE == 1 ? (size_t)lvlw * (lvlw | 1) * sizeof(double) : 0;
-  if (NR == 1) {                                       // one right-hand side: the copy without the systolic loop
-    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE>, 128 * 129 * 8)) return;
-    hipLaunchKernelGGL((k_solve_diag_q1<MODE>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, unit);
-    return;
+  if constexpr (NR == 1 || !std::is_same<T, double>::value) {        // one right-hand side: the copy without the systolic loop
+    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE, T>, 128 * 129 * 8)) return;
+    for (int k = 0; k < NR; k++)
+      hipLaunchKernelGGL((k_solve_diag_q1<MODE, T>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x + k * ldx, unit);
+  } else {
+    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
+    hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
   }
-  if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
-  hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
 }
 // one level of the forward (fwd) or backward sweep for NR right-hand sides (x: n x NR, leading dimension ldx).
 // chunks: the 64-row list forward, the 256-row list backward.
-template <int NR>
-static void solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
+template <int NR, class T>
+static void solve_level(hipStream_t s, bool fwd, int factotype, const T* L, const T* U,
                         const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
                         const int32_t* ridx, double* x, int64_t ldx, int lvlw) {
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
   const dim3 gc((unsigned)nchunk);
   if (fwd) {
-    if (ntask > 0) launch_solve_diag<0, NR>(s, L, tasks, ntask, x, ldx, unit, lvlw);
-    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_fwd64<NR>, gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
+    if (ntask > 0) launch_solve_diag<0, NR, T>(s, L, tasks, ntask, x, ldx, unit, lvlw);
+    if (nchunk > 0) hipLaunchKernelGGL((k_solve_off_fwd64<NR, T>), gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
   } else {
-    const double* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
+    const T* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
     const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
-    if (nchunk > 0) hipLaunchKernelGGL(k_solve_off_bwd64<NR>, gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
+    if (nchunk > 0) hipLaunchKernelGGL((k_solve_off_bwd64<NR, T>), gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
     if (ntask > 0) {
-      if (mode == 2) launch_solve_diag<2, NR>(s, L, tasks, ntask, x, ldx, 0, lvlw);
-      else launch_solve_diag<1, NR>(s, L, tasks, ntask, x, ldx, mode == 1, lvlw);
+      if (mode == 2) launch_solve_diag<2, NR, T>(s, L, tasks, ntask, x, ldx, 0, lvlw);
+      else launch_solve_diag<1, NR, T>(s, L, tasks, ntask, x, ldx, mode == 1, lvlw);
     }
   }
 }
@@ -1126,13 +1132,18 @@ void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw) {
   (void)bl;
   (void)maxw;
-  if (nr == 4) solve_level<4>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
-  else if (nr == 2) solve_level<2>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
-  else solve_level<1>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  if (nr == 4) solve_level<4, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  else if (nr == 2) solve_level<2, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  else solve_level<1, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+}
+// the factors of the single-precision engine: float panels, double vectors, one right-hand side per call
+void launch_solve_level_s(hipStream_t s, bool fwd, int factotype, const float* L, const float* U, const SolveTask* tasks,
+                          int64_t ntask, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x, int lvlw) {
+  solve_level<1, float>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, 0, lvlw);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {
-  if (ntask > 0) hipLaunchKernelGGL(k_solve_dscale, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
+  if (ntask > 0) hipLaunchKernelGGL(k_solve_dscale<double>, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
 }
 
 __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
@@ -1150,19 +1161,33 @@ void launch_scatter(hipStream_t s, double* dst, const int64_t* idx, const double
   hipLaunchKernelGGL(k_scatter, dim3((unsigned)blocks), dim3(256), 0, s, dst, idx, val, n);
 }
 
-// thin levels (see k_solve_inv): the inverses of `n` diagonal bloks; A: the arena the triangle is read from
-void launch_solve_inv(hipStream_t s, const double* A, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
+// thin levels (see k_solve_inv): the inverses of `n` diagonal bloks; A: the arena the triangle is read from (f32: floats)
+void launch_solve_inv(hipStream_t s, const void* A, bool f32, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
                       double* inv, int which, int unit) {
   if (n <= 0) return;
   const int bytes = (128 * 129 + 128) * (int)sizeof(double);
-  if (!dyn_lds_attr_once((const void*)k_solve_inv, bytes)) return;
-  hipLaunchKernelGGL(k_solve_inv, dim3((unsigned)n), dim3(128), bytes, s, A, tasks, thin_tasks, inv, which, unit);
+  if (f32) {
+    if (!dyn_lds_attr_once((const void*)k_solve_inv<float>, bytes)) return;
+    hipLaunchKernelGGL(k_solve_inv<float>, dim3((unsigned)n), dim3(128), bytes, s, (const float*)A, tasks, thin_tasks, inv, which, unit);
+  } else {
+    if (!dyn_lds_attr_once((const void*)k_solve_inv<double>, bytes)) return;
+    hipLaunchKernelGGL(k_solve_inv<double>, dim3((unsigned)n), dim3(128), bytes, s, (const double*)A, tasks, thin_tasks, inv, which, unit);
+  }
 }
-void launch_solve_thin(hipStream_t s, bool fwd, const double* P, const SolveChunk* chunks, int64_t nchunk,
+void launch_solve_thin(hipStream_t s, bool fwd, const void* P, bool f32, const SolveChunk* chunks, int64_t nchunk,
                        const int32_t* ridx, const double* inv, int* ticket, double* x) {
   if (nchunk <= 0) return;
-  if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd, dim3((unsigned)nchunk), dim3(256), 0, s, P, chunks, ridx, inv, ticket, x);
-  else hipLaunchKernelGGL(k_solve_thin_bwd, dim3((unsigned)nchunk), dim3(256), 0, s, P, chunks, ridx, inv, ticket, x);
+  const dim3 g((unsigned)nchunk), b(256);
+  if (f32) {
+    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, x);
+    else hipLaunchKernelGGL(k_solve_thin_bwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, x);
+  } else {
+    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, x);
+    else hipLaunchKernelGGL(k_solve_thin_bwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, x);
+  }
+}
+void launch_solve_dscale_s(hipStream_t s, const float* L, const SolveTask* tasks, int64_t ntask, double* x) {
+  if (ntask > 0) hipLaunchKernelGGL(k_solve_dscale<float>, dim3((unsigned)ntask), dim3(256), 0, s, L, tasks, x);
 }
 
 }  // namespace pastix_amd

@@ -180,7 +180,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   int rc = check_layout(L);
   if (rc) return rc;
   const bool cplx = floattype == PASTIX_AMD_COMPLEXDOUBLE;
-  if (floattype != PASTIX_AMD_REALDOUBLE && !cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
+  // real single precision shares the plan with real double (the arenas hold floats, the kernels are kernels_f32.hip)
+  if (floattype != PASTIX_AMD_REALDOUBLE && floattype != PASTIX_AMD_REALSINGLE && !cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
+  if (floattype == PASTIX_AMD_REALSINGLE && owner) return PASTIX_AMD_ERR_UNSUPPORTED;   // (one GPU)
   if (factotype == PASTIX_AMD_FACT_LDLH && !cplx) factotype = PASTIX_AMD_FACT_LDLT;   // real `he` is `sy`
   if (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT && factotype != PASTIX_AMD_FACT_LU &&
       factotype != PASTIX_AMD_FACT_LDLH)
@@ -529,7 +531,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // k_update would run for them, and a slot gets them when it has at least quad_min candidates
   constexpr bool quad_on = true;
   const double quad_fill = P.opts.quadrant_fill_pct > 0 ? 0.01 * P.opts.quadrant_fill_pct : 0.25;
-  const int64_t quad_min = P.opts.quadrant_min > 0 ? P.opts.quadrant_min : 1024;
+  // (single precision: no quadrant tasks, k_update_s takes every task)
+  const int64_t quad_min = floattype == PASTIX_AMD_REALSINGLE ? (int64_t)1 << 60 : P.opts.quadrant_min > 0 ? P.opts.quadrant_min : 1024;
   const int quad_maxpiece = P.opts.quadrant_fill_pct > 100 ? 128 : 64;   // (tests force every partial task with fill > 100 %)
   // The tiles are independent: the sorted piece list is cut at tile boundaries into one range per host thread, every
   // thread groups its tiles into its own lists, which are concatenated in range order (= the serial result).

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import LayoutArrays, Options, Stats, check
 
 FACT_LLT, FACT_LDLT, FACT_LU, FACT_LDLH = 0, 1, 2, 3
-REALDOUBLE, COMPLEXDOUBLE = 1, 3
+REALSINGLE, REALDOUBLE, COMPLEXDOUBLE = 0, 1, 3        # IPARM_FLOAT values (api.h:522-525)
 
 
 def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
@@ -25,7 +25,9 @@ class Plan:
                  schur=False, quadrant_min=0, quadrant_fill_pct=0):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
-        self.dtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float64
+        # panels / CSC values of the plan's arithmetic; the vectors of a solve stay double for single-precision plans
+        self.dtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float32 if floattype == REALSINGLE else np.float64
+        self.vdtype = np.complex128 if floattype == COMPLEXDOUBLE else np.float64
         self._h = ctypes.c_void_p()
         opts = Options()
         opts.device = device
@@ -102,7 +104,7 @@ class Plan:
     def solve(self, x):
         """x (permuted numbering; n or n x nrhs) -> solution.  A contiguous 1-D array of the plan's dtype is solved in
         place, like the reference's b; anything else is copied."""
-        x = np.ascontiguousarray(x, dtype=self.dtype)      # complex plans: interleaved complex128, like the reference
+        x = np.ascontiguousarray(x, dtype=self.vdtype)     # complex plans: interleaved complex128, like the reference
         nrhs = 1 if x.ndim == 1 else x.shape[1]
         xf = np.asfortranarray(x.reshape(len(x), nrhs))
         check(_lib.lib().pastix_amd_solve(self._h, _lib.ptr(xf), ctypes.c_int64(nrhs)), "pastix_amd_solve")

@@ -307,3 +307,33 @@ def test_fake_fill_matches_reference(name, golden):
     if g["facto"] == 2:
         assert np.abs(U1 - g["U1"]).max() <= TOL * np.abs(g["U1"]).max()
     assert st["nbpivot"] == g["nbpivot"] == 0
+
+
+SINGLE = (golden_names("llt") + golden_names("ldlt") + golden_names("lu"))
+
+
+@pytest.mark.parametrize("name", [n for n in SINGLE if not n.startswith("fake_")])
+def test_native_single_precision_matches_reference_golden(name, golden):
+    """The fp32 engine (kernels_f32.hip: k_update_s on v_mfma_f32_32x32x2_f32, k_diag_s, k_trsm_s) through the staged API
+    with floattype REALSINGLE: float panels in (the reference's input rounded to float), float factors out, against the
+    reference's double factors of the same input at 1e-4 * max|L| (SURVEY 8d's single-precision tolerance); static-pivot
+    counts equal; the device fill from the CSC is the float rounding of the reference's fill, bit for bit."""
+    from pastix_amd import REALSINGLE
+    g = golden(name)
+    c4 = g["cblk4"]
+    lu = g["facto"] == 2
+    with Plan(c4, g["blok4"], g["facto"], floattype=REALSINGLE) as p:
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        L0, U0 = p.download()
+        assert L0.dtype == np.float32 and np.array_equal(L0, g["L0"].astype(np.float32))
+        if lu:
+            assert np.array_equal(U0, g["U0"].astype(np.float32))
+        p.upload(g["L0"], g["U0"] if lu else None)
+        st = p.factorize(g["critere"])
+        L1, U1 = p.download()
+    m = _lower_mask(c4) if g["facto"] == 1 else recut_mask(c4) if g["facto"] == 0 else np.ones(L1.size, bool)
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1.astype(np.float64) - g["L1"])[m].max() <= 1e-4 * scale
+    if lu:
+        assert np.abs(U1.astype(np.float64) - g["U1"]).max() <= 1e-4 * max(scale, np.abs(g["U1"]).max())
+    assert st["nbpivot"] == g["nbpivot"]

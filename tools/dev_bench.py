@@ -19,6 +19,7 @@ ap.add_argument("--look", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--verbose", type=int, default=0)
+ap.add_argument("--f32", action="store_true", help="single precision engine (kernels_f32.hip)")
 a = ap.parse_args()
 N = a.n
 t = time.time()
@@ -29,7 +30,7 @@ c4, b4 = s["cblk4"], s["blok4"]
 fl = fact_flops(c4, b4, 0)
 print("N=%d cblk=%d blok=%d nnzl=%.3e flops=%.4e  symbolic %.1fs" % (N, len(c4) - 1, len(b4), s["nnzl"], fl, time.time() - t), flush=True)
 t = time.time()
-p = Plan(c4, b4, 0, lookahead=a.look, verbose=a.verbose)
+p = Plan(c4, b4, 0, lookahead=a.look, verbose=a.verbose, floattype=0 if a.f32 else 1)
 st = p.stats()
 print("plan %.1fs: levels=%d tasks=%d pieces=%d update_flops=%.4e (%.3f of total), in full pieces %.3f" % (
     time.time() - t, st["nlevels"], st["ntasks"], st["npieces"], st["update_flops"], st["update_flops"] / fl,
@@ -49,4 +50,4 @@ if a.check:
     L1, _ = p.download()
     L0, _ = oracle_lib.fill(0, 1, n, cp, r, v, s["perm"], c4, b4)
     Lo, _, nb = oracle_lib.sopalin(0, c4, b4, L0, None, crit)
-    print("max|L_gpu - L_oracle| / max|L| = %.3e" % (np.abs(L1 - Lo).max() / np.abs(Lo).max()))
+    print("max|L_gpu - L_oracle| / max|L| = %.3e" % (np.abs(L1.astype(np.float64) - Lo).max() / np.abs(Lo).max()))
