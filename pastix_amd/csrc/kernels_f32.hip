@@ -26,9 +26,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // a 16-byte load from a 4-byte aligned address
 
 namespace {
-constexpr int SKC = 16;            // k-lines per chunk
-constexpr int SLDF = 160;          // LDS line: 128 rows + 32 pad floats: the two k-lines a 64-lane read touches sit on
-                                   // different halves of the 64 banks
+constexpr int SKC = 32;            // k-lines per chunk
+constexpr int SLDF = 144;          // LDS line: 128 rows + 16 pad floats (two buffers of 2 x 32 lines = 73.7 KB: two
+                                   // workgroups per CU; the two k-lines a 64-lane read touches overlap in 16 banks)
 __device__ __forceinline__ float* arena_f(const Arenas& ar, int a) { return reinterpret_cast<float*>(ar.p[a]); }
 }  // namespace
 
@@ -39,15 +39,15 @@ __device__ __forceinline__ float* arena_f(const Arenas& ar, int a) { return rein
 template <int KIND>
 __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task* __restrict__ tasks,
                                                     const Piece* __restrict__ pieces) {
-  __shared__ float sh[2][2][SKC * SLDF];         // [buffer][A|B][k][row]   40,960 bytes
+  __shared__ float sh[2][2][SKC * SLDF];         // [buffer][A|B][k][row]   73,728 bytes
   if (KIND == 1) PANEL_PRIO();
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  // loader: thread -> operand (A | B), four consecutive tile rows / columns 4 lq .. 4 lq + 3, k-lines lk and lk + 8:
-  // two 16-byte loads per thread and chunk (one wave-instruction moves 1 KiB)
+  // loader: thread -> operand (A | B), four consecutive tile rows / columns 4 lq .. 4 lq + 3, k-lines lk + 8 h, h < 4:
+  // four 16-byte loads per thread and chunk (one wave-instruction moves 1 KiB)
   const int lo = tid >> 8, lq = tid & 31, lk = (tid >> 5) & 7;
   f16 acc[2];
 #pragma unroll
@@ -56,12 +56,16 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
     for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
   const int pend = tk.p0 + tk.pn;                // (scalar: the Task came through a scalar load)
   int pi = tk.p0, kdone = 0;                     // piece / k-lines of it already fetched: wave-uniform
-  f4 st[2];
-  int actn = 0;                                  // tiles of this wave the staged chunk's piece touches (bit t)
+  // 32-deep chunks: a 16-deep fp32 chunk is ~1.7 us of matrix work per workgroup pair, about one memory round trip --
+  // the fp64 kernel's one chunk of lead would leave it exposed, and a barrier per 16 k-lines costs twice what it costs
+  // there.
+  constexpr int NH = SKC / 8;
+  f4 stA[NH];
+  int actn = 0;                                  // tiles of this wave the chunk just fetched touches (bit t)
   // next chunk of the piece list -> registers.  Every load is unconditional, from an address clamped to the piece (a
   // quad that straddles a piece boundary brings up to three neighbouring panel entries along -- inside the arena or
   // its padding --; rows and k-lines outside the piece become zero by a select): no exec-masked branch per load.
-  auto fetch = [&]() -> bool {
+  auto fetch = [&](f4 (&st)[NH]) -> bool {
     if (pi >= pend) return false;
     const Piece pc = pieces[__builtin_amdgcn_readfirstlane(pi)];
     const int K = (int)pc.k;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
     const float* src = base + min(max(r0, -3), len - 1);
     const int sh0 = r0 - min(max(r0, -3), len - 1);                          // (0 unless the quad lies wholly outside)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < NH; h++) {
       const int k = kdone + lk + 8 * h;
       const f4u v = *(const f4u*)(src + (int64_t)min(k, K - 1) * pc.lda);
       const bool kv = k < K && sh0 == 0;
@@ -92,19 +96,11 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
     if (kdone >= K) { kdone = 0; pi++; }
     return true;
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const f4 (&st)[NH]) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) *(f4*)(sh[buf][lo] + (lk + 8 * h) * SLDF + 4 * lq) = st[h];
+    for (int h = 0; h < NH; h++) *(f4*)(sh[buf][lo] + (lk + 8 * h) * SLDF + 4 * lq) = st[h];
   };
-  bool more = fetch();
-  int actc = actn;
-  if (more) stash(0);
-  __syncthreads();
-  int buf = 0;
-  while (more) {
-    const int act = __builtin_amdgcn_readfirstlane(actc);
-    more = fetch();                              // global loads of the next chunk fly under this chunk's MFMAs
-    const int nact = actn;
+  auto compute = [&](int buf, int act) {
     const float* sA = sh[buf][0] + lh * SLDF + 32 * wr + l31;
     const float* sB = sh[buf][1] + lh * SLDF + 64 * wc + l31;
     if (act == 3) {
@@ -123,7 +119,18 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
       for (int s = 0; s < SKC / 2; s++)
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[2 * s * SLDF + 32], sA[2 * s * SLDF], acc[1], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
+  };
+  bool more = fetch(stA);
+  int actc = actn;
+  if (more) stash(0, stA);
+  __syncthreads();
+  int buf = 0;
+  while (more) {
+    const int act = __builtin_amdgcn_readfirstlane(actc);
+    more = fetch(stA);                           // global loads of the next chunk fly under this chunk's MFMAs
+    const int nact = actn;
+    compute(buf, act);
+    if (more) stash(buf ^ 1, stA);
     actc = nact;
     __syncthreads();
     buf ^= 1;
