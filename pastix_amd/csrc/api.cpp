@@ -111,6 +111,9 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   if (!p) return PASTIX_AMD_ERR_ALLOC;
   int rc;
   double oflops = 0;
+  const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+  double tph = now_s();
+  auto phase = [&](const char* name) { if (ptime) { const double t = now_s(); fprintf(stderr, "[create] %-28s %.2f s\n", name, t - tph); tph = t; } };
   try {
     if (!layout || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1) { delete p; return PASTIX_AMD_ERR_BADPARAMETER; }
     rc = build_split(layout, opts && opts->schur, p->split);
@@ -134,6 +137,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     rc = PASTIX_AMD_ERR_ALLOC;
   }
   if (rc) { delete p; return rc; }
+  phase("re-cut + host plan");
   if (p->split.active) p->host.fact_flops = p->host.local_flops = oflops;   // DPARM_FACT_FLOPS is the caller's layout's
   if (p->split.active && p->host.factotype != PASTIX_AMD_FACT_LU) {
     SplitMap& M = p->split;
@@ -189,10 +193,12 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = alloc(&p->dUi))) return ra;
       }
     }
+    phase("streams + arenas");
     HIPCHK(hipMalloc((void**)&p->dDinv, std::max<int64_t>(H.dinv_ws, 256) * sizeof(double)));
     int r;
     if ((r = to_device(&p->dTasks, H.tasks))) return r;
     if ((r = to_device(&p->dPieces, H.pieces))) return r;
+    phase("task + piece tables -> device");
     if ((r = to_device(&p->dPanel, H.panel_tasks))) return r;
     if ((r = to_device(&p->dTrsm, H.trsm_tasks))) return r;
     HIPCHK(hipMalloc((void**)&p->dNbpivot, 2 * sizeof(long long)));   // [static pivots, positive D entries]
@@ -211,6 +217,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   };
   CHK(body());
 #undef CHK
+  phase("panel tables, events");
   for (int64_t k = 0; k < H.cblknbr - (H.opts.schur ? 1 : 0); k++)     // (the Schur cblk is never factorized)
     p->maxw = std::max<int>(p->maxw, (int)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1));
   pastix_amd_stats_t& S = p->stats;
@@ -268,6 +275,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   // the piece/task tables now live on the device; keep only what the host driver reads
   decltype(H.pieces)().swap(H.pieces);
   std::vector<Task>().swap(H.tasks);
+  phase("statistics, host tables freed");
   *out = p;
   return PASTIX_AMD_OK;
 }

@@ -300,11 +300,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   const bool ldlt = factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH;
   const bool herm = factotype == PASTIX_AMD_FACT_LDLH;
   // Source cblks are independent: piece generation runs on `nthr` host threads (PASTIX_AMD_PLAN_THREADS, default
-  // min(16, cores)), every thread into its own list; the lists are then bucketed by target tile and sorted in
+  // min(32, cores)), every thread into its own list; the lists are then bucketed by target tile and sorted in
   // parallel.  The sort key is a total order, so the result does not depend on the number of threads.
   const int nthr = [] {
     const char* e = getenv("PASTIX_AMD_PLAN_THREADS");
-    int n = e ? atoi(e) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int n = e ? atoi(e) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
     return std::max(1, std::min(n, 64));
   }();
   std::vector<std::vector<RawPiece>> traw((size_t)nthr);

@@ -426,7 +426,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       // No per-merge refresh of all the children of the merged node (that was quadratic in the fan-out).
       struct Ent { double cost; idx c; };
       auto cmp = [](const Ent& a, const Ent& b) { return a.cost > b.cost || (a.cost == b.cost && a.c < b.c); };   // (ties: the node nearer the root first)
-      std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp);
+      std::vector<Ent> heap0;                                  // (built in one make_heap: O(n) instead of n pushes)
       auto cost_of = [&](idx c, idx p) {
         return (double)sw[c] * ((double)sw[p] + (double)sbelow[p] - (double)sbelow[c]);
       };
@@ -440,8 +440,10 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
         rep[s] = p;
         sw[p] += sw[s];
       }
+      heap0.reserve((size_t)ns0);
       for (idx s = 0; s < ns0; s++)
-        if (rep[s] == s && sparent[s] != -1) pq.push(Ent{cost_of(s, find(sparent[s])), s});
+        if (rep[s] == s && sparent[s] != -1) heap0.push_back(Ent{cost_of(s, find(sparent[s])), s});
+      std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp, std::move(heap0));
       const double budget = ratio * nnz0;
       double spent = 0;
       const int64_t maxw_merge = o.max_merge_width > 0 ? o.max_merge_width : (int64_t)1 << 40;
