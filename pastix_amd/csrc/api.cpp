@@ -405,7 +405,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   (void)hipFree(p->dPieces); (void)hipFree(p->dPanel); (void)hipFree(p->dTrsm);
   (void)hipFree(p->dNbpivot); (void)hipFree(p->dErr);
   (void)hipFree(p->dFillIdxL); (void)hipFree(p->dFillValL); (void)hipFree(p->dFillValLi); (void)hipFree(p->dFillValUi); (void)hipFree(p->dFillIdxU); (void)hipFree(p->dFillValU);
-  (void)hipFree(p->dThinF); (void)hipFree(p->dThinB); (void)hipFree(p->dThinTasks); (void)hipFree(p->dInvF); (void)hipFree(p->dInvB);
+  (void)hipFree(p->dThinF); (void)hipFree(p->dThinB); (void)hipFree(p->dThinTasks); (void)hipFree(p->dThinTgt); (void)hipFree(p->dThinExpect); (void)hipFree(p->dInvF); (void)hipFree(p->dInvB);
   (void)hipFree(p->dTicket);
   (void)hipFree(p->dSolve); (void)hipFree(p->dBlok); (void)hipFree(p->dChunk); (void)hipFree(p->dChunkB); (void)hipFree(p->dRidx); (void)hipFree(p->dXws);
   for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
@@ -1191,13 +1191,12 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     std::vector<SolveChunk> thF, thB;
     std::vector<int32_t> thin_tasks;
     p->lvl_thin.assign((size_t)H.nlevels, 0);
-    p->lvl_thinF_ptr.assign((size_t)H.nlevels + 1, 0);
-    p->lvl_thinB_ptr.assign((size_t)H.nlevels + 1, 0);
+    std::vector<int64_t> thF_ptr((size_t)H.nlevels + 1, 0), thB_ptr((size_t)H.nlevels + 1, 0);
     for (int l = 0; l < H.nlevels; l++) {
       p->lvl_chunk_ptr[l] = (int64_t)ch.size();
       p->lvl_chunkB_ptr[l] = (int64_t)chB.size();
-      p->lvl_thinF_ptr[l] = (int64_t)thF.size();
-      p->lvl_thinB_ptr[l] = (int64_t)thB.size();
+      thF_ptr[l] = (int64_t)thF.size();
+      thB_ptr[l] = (int64_t)thB.size();
       const int64_t ncl = H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l];
       const bool thin = !p->cplx && !p->distributed && ncl > 0 && ncl <= THIN;
       p->lvl_thin[l] = thin ? 1 : 0;
@@ -1215,52 +1214,113 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
           const int32_t nf = (sd - w + CHB - 1) / CHB + 1, nb = nf;
           for (int32_t r = w; r < sd; r += CHB)
             thF.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nf});
+                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nf, 0, 0, 0, 0});
           thF.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nf});
+                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nf, 0, 0, 0, 0});
           for (int32_t r = w; r < sd; r += CHB)
             thB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nb});
+                                     (int32_t)H.cblk[k + 1].bloknum, r, std::min(CHB, sd - r), roff[q], tix, nb, 0, 0, 0, 0});
           thB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum, (int32_t)H.cblk[k].bloknum,
-                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nb});
+                                   (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nb, 0, 0, 0, 0});
         }
         p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
         for (int32_t r = w; r < sd; r += CH) {
           const int32_t n = std::min(CH, sd - r);
           ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
-              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0});
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0, 0, 0, 0, 0});
         }
         for (int32_t r = w; r < sd; r += CHB) {
           const int32_t n = std::min(CHB, sd - r);
           chB.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
-              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0});
+              (int32_t)H.cblk[k].bloknum, (int32_t)H.cblk[k + 1].bloknum, r, n, roff[q], -1, 0, 0, 0, 0, 0});
         }
       }
     }
     p->lvl_chunk_ptr[H.nlevels] = (int64_t)ch.size();
     p->lvl_chunkB_ptr[H.nlevels] = (int64_t)chB.size();
-    p->lvl_thinF_ptr[H.nlevels] = (int64_t)thF.size();
-    p->lvl_thinB_ptr[H.nlevels] = (int64_t)thB.size();
+    thF_ptr[H.nlevels] = (int64_t)thF.size();
+    thB_ptr[H.nlevels] = (int64_t)thB.size();
+    // runs of consecutive thin levels: one launch per run and sweep (k_solve_thin_*), its workgroups in sweep order (the
+    // backward list is re-ordered by descending level).  Inside a run the cblks synchronise one by one: a chunk knows
+    // the thin cblks of its run that face its rows (forward: it contributes to them; backward: it reads their solution)
+    p->runF_n.assign((size_t)H.nlevels, 0); p->runF_at.assign((size_t)H.nlevels, 0);
+    p->runB_n.assign((size_t)H.nlevels, 0); p->runB_at.assign((size_t)H.nlevels, 0);
+    std::vector<int32_t> tixc((size_t)H.cblknbr, -1), runc((size_t)H.cblknbr, -1);   // thin index / run (first level) of a cblk
+    for (int l = 0; l < H.nlevels;) {
+      if (!p->lvl_thin[l]) { l++; continue; }
+      int e = l;
+      while (e < H.nlevels && p->lvl_thin[e]) e++;
+      for (int m = l; m < e; m++)
+        for (int64_t q = H.lvl_cblk_ptr[m]; q < H.lvl_cblk_ptr[m + 1]; q++) {
+          tixc[(size_t)H.lvl_cblk[q]] = st[q].thin;
+          runc[(size_t)H.lvl_cblk[q]] = l;
+        }
+      p->runF_n[l] = thF_ptr[e] - thF_ptr[l];
+      p->runF_at[l] = thF_ptr[l];
+      l = e;
+    }
+    {
+      std::vector<SolveChunk> rev;
+      rev.reserve(thB.size());
+      for (int l = H.nlevels - 1; l >= 0;) {
+        if (!p->lvl_thin[l]) { l--; continue; }
+        int e = l;
+        while (e >= 0 && p->lvl_thin[e]) e--;
+        const int64_t at = (int64_t)rev.size();
+        for (int m = l; m > e; m--)
+          for (int64_t i = thB_ptr[m]; i < thB_ptr[m + 1]; i++) rev.push_back(thB[(size_t)i]);
+        p->runB_n[l] = (int64_t)rev.size() - at;
+        p->runB_at[l] = at;
+        l = e;
+      }
+      thB.swap(rev);
+    }
+    std::vector<int32_t> thin_tgt, thin_expect(thin_tasks.size(), 0);
+    auto targets = [&](SolveChunk& c, bool count) {
+      c.tptr = (int32_t)thin_tgt.size();
+      const int32_t k = (int32_t)H.blok[c.fblok].cblknum;      // (the diagonal blok faces its own cblk)
+      if (c.nrows > 0)
+        for (int32_t b = c.fblok + 1; b < c.lblok; b++) {
+          const int64_t r0 = H.blok[b].coefind, r1 = r0 + (H.blok[b].lrownum - H.blok[b].frownum + 1);
+          if (r1 <= c.row0 || r0 >= c.row0 + c.nrows) continue;
+          const int32_t f = (int32_t)H.blok[b].cblknum, t = tixc[(size_t)f];
+          if (t < 0 || runc[(size_t)f] != runc[(size_t)k]) continue;
+          if ((int32_t)thin_tgt.size() > c.tptr && thin_tgt.back() == t) continue;
+          thin_tgt.push_back(t);
+          if (count) thin_expect[(size_t)t]++;
+        }
+      c.tn = (int32_t)thin_tgt.size() - c.tptr;
+    };
+    for (auto& c : thF) targets(c, true);
+    for (auto& c : thF) c.wait = thin_expect[(size_t)c.thin] > 0;
+    for (auto& c : thB) targets(c, false);
+    if (thin_tgt.empty()) thin_tgt.push_back(0);
     std::vector<DevBlok> bl((size_t)H.bloknbr);
     for (int64_t b = 0; b < H.bloknbr; b++)
       bl[b] = DevBlok{(int32_t)H.blok[b].frownum, (int32_t)H.blok[b].lrownum, (int32_t)H.blok[b].coefind};
     // built into locals and published only when complete: a failed build leaves the plan without solve tables
     SolveTask* dS = nullptr; DevBlok* dB = nullptr; SolveChunk *dC = nullptr, *dCB = nullptr; int32_t* dR = nullptr;
     SolveChunk *dTF = nullptr, *dTB = nullptr; int32_t* dTT = nullptr; double *dIF = nullptr, *dIB = nullptr; int* dTk = nullptr;
+    int32_t *dTg = nullptr, *dEx = nullptr;
     int64_t* droff = nullptr;
+    size_t nTk = 0;
     const int64_t nthin = (int64_t)thin_tasks.size();
     auto build = [&]() -> int {
       int r;
       if ((r = to_device(&dTF, thF))) return r;
       if ((r = to_device(&dTB, thB))) return r;
       if ((r = to_device(&dTT, thin_tasks))) return r;
+      if ((r = to_device(&dTg, thin_tgt))) return r;
+      if ((r = to_device(&dEx, thin_expect))) return r;
       if (nthin > 0) {
         const size_t ib = (size_t)nthin * 128 * 128 * sizeof(double);
         HIPCHK(hipMalloc((void**)&dIF, ib));
         HIPCHK(hipMalloc((void**)&dIB, ib));
         HIPCHK(hipMemset(dIF, 0, ib));
         HIPCHK(hipMemset(dIB, 0, ib));
-        HIPCHK(hipMalloc((void**)&dTk, (size_t)nthin * 2 * sizeof(int)));
+        // 2 x nthin tickets, nthin forward counters, the "stuck" flag, then per sweep nthin x 8 padded flags (kernels.hip)
+        nTk = (size_t)nthin * 3 + 64 + 2 * (size_t)nthin * 64 * 8;
+        HIPCHK(hipMalloc((void**)&dTk, nTk * sizeof(int)));
       }
       if ((r = to_device(&dS, st))) return r;
       if ((r = to_device(&dB, bl))) return r;
@@ -1278,11 +1338,14 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     if (rb) {
       (void)hipFree(dS); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dCB); (void)hipFree(dR);
       (void)hipFree(dTF); (void)hipFree(dTB); (void)hipFree(dTT); (void)hipFree(dIF); (void)hipFree(dIB); (void)hipFree(dTk);
+      (void)hipFree(dTg); (void)hipFree(dEx);
       return rb;
     }
     p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
     p->dThinF = dTF; p->dThinB = dTB; p->dThinTasks = dTT; p->dInvF = dIF; p->dInvB = dIB; p->dTicket = dTk;
     p->nthin = nthin;
+    p->nTicket = nTk;
+    p->dThinTgt = dTg; p->dThinExpect = dEx;
     p->inv_gen = -1;
   }
   if (p->nthin > 0 && p->inv_gen != p->fact_gen) {
@@ -1301,10 +1364,15 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
 void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) {
   const Plan& H = p->host;
   if (nr == 1 && p->nthin > 0 && p->lvl_thin[(size_t)l]) {
-    const std::vector<int64_t>& ptr = fwd ? p->lvl_thinF_ptr : p->lvl_thinB_ptr;
+    // the whole run of thin levels that starts here goes in one launch; its other levels have nothing left to do
+    const int64_t n = (fwd ? p->runF_n : p->runB_n)[(size_t)l], at = (fwd ? p->runF_at : p->runB_at)[(size_t)l];
+    if (n == 0) return;
     const double* P = fwd ? p->dL : (H.factotype == PASTIX_AMD_FACT_LU ? p->dU : p->dL);
-    launch_solve_thin(p->stream, fwd, P, p->f32, (fwd ? p->dThinF : p->dThinB) + ptr[(size_t)l], ptr[(size_t)l + 1] - ptr[(size_t)l],
-                      p->dRidx, fwd ? p->dInvF : p->dInvB, p->dTicket + (fwd ? 0 : p->nthin), dx);
+    int* cnt = p->dTicket + 2 * p->nthin;
+    int* stuck = cnt + p->nthin;
+    int* flag = stuck + 64 + (fwd ? 0 : (size_t)p->nthin * 64 * 8);
+    launch_solve_thin(p->stream, fwd, P, p->f32, (fwd ? p->dThinF : p->dThinB) + at, n, p->dRidx, fwd ? p->dInvF : p->dInvB,
+                      p->dTicket + (fwd ? 0 : p->nthin), p->dThinTgt, p->dThinExpect, cnt, flag, stuck, dx);
     return;
   }
   if (p->f32) {
@@ -1399,13 +1467,20 @@ static int solve_impl(pastix_amd_plan_t* p, void* x_, pastix_amd_int_t nrhs, boo
     double* dx = mode == 2 ? x + j * H.ncol : p->dXws;
     if (mode == 1) HIPCHK(hipMemcpyAsync(dx, x + j * H.ncol, H.ncol * nr * sizeof(double), hipMemcpyHostToDevice, p->stream));
     HIPCHK(hipEventRecord(p->ev0, p->stream));
-    if (nr == 1 && p->nthin > 0) HIPCHK(hipMemsetAsync(p->dTicket, 0, (size_t)p->nthin * 2 * sizeof(int), p->stream));
+    if (nr == 1 && p->nthin > 0) HIPCHK(hipMemsetAsync(p->dTicket, 0, p->nTicket * sizeof(int), p->stream));
     for (int l = 0; l < H.nlevels; l++) pai_solve_level(p, true, l, dx, nr);
     if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, nr);
     for (int l = H.nlevels - 1; l >= 0; l--) pai_solve_level(p, false, l, dx, nr);
     HIPCHK(hipEventRecord(p->ev1, p->stream));
     if (mode == 1) HIPCHK(hipMemcpyAsync(x + j * H.ncol, dx, H.ncol * nr * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    int stuck = 0;
+    if (nr == 1 && p->nthin > 0)
+      HIPCHK(hipMemcpyAsync(&stuck, p->dTicket + 3 * p->nthin, sizeof(int), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
+    if (stuck) {
+      fprintf(stderr, "pastix_amd: solve: a workgroup of a thin-level run waited for its predecessors beyond the poll limit\n");
+      return PASTIX_AMD_ERR_DEVICE;
+    }
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     p->stats.solve_time += 1e-3 * ms;

@@ -58,7 +58,8 @@ void launch_scatter_s(hipStream_t s, float* dst, const int64_t* idx, const doubl
 void launch_solve_inv(hipStream_t s, const void* A, bool f32, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,
                       double* inv, int which, int unit);
 void launch_solve_thin(hipStream_t s, bool fwd, const void* P, bool f32, const SolveChunk* chunks, int64_t nchunk,
-                       const int32_t* ridx, const double* inv, int* ticket, double* x);
+                       const int32_t* ridx, const double* inv, int* ticket, const int32_t* tgt, const int32_t* expect, int* cnt,
+                       int* flag, int* stuck, double* x);
 void launch_solve_level_s(hipStream_t s, bool fwd, int factotype, const float* L, const float* U, const SolveTask* tasks,
                           int64_t ntask, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x, int lvlw);
 void launch_solve_dscale_s(hipStream_t s, const float* L, const SolveTask* tasks, int64_t ntask, double* x);
@@ -139,12 +140,16 @@ struct pastix_amd_plan_s {
   std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
   // thin levels (kernels.hip, k_solve_inv): explicit inverses of their diagonal bloks, one launch per level and sweep
   std::vector<uint8_t> lvl_thin;        // [nlevels]
-  std::vector<int64_t> lvl_thinF_ptr, lvl_thinB_ptr;    // [nlevels+1] into dThinF / dThinB (empty ranges for other levels)
+  // a run = consecutive thin levels, one launch per sweep: [nlevels] workgroups of the run that STARTS at this level in
+  // the sweep's direction (0: not a start), and where its list begins in dThinF / dThinB (dThinB: levels descending)
+  std::vector<int64_t> runF_n, runF_at, runB_n, runB_at;
   SolveChunk *dThinF = nullptr, *dThinB = nullptr;      // the thin levels' workgroup lists (chunks + one per cblk)
   int32_t* dThinTasks = nullptr;        // SolveTask index of every thin cblk
+  int32_t *dThinTgt = nullptr, *dThinExpect = nullptr;   // the chunks' target lists; forward contributors of every thin cblk
   int64_t nthin = 0;
   double *dInvF = nullptr, *dInvB = nullptr;            // nthin x 128 x 128: L^-1, and (L^-1)^T / U^-1 for the backward sweep
-  int* dTicket = nullptr;               // 2 x nthin
+  int* dTicket = nullptr;               // 2 x nthin tickets, nthin counters, 1 "stuck" flag, the cblks' flags of both sweeps
+  size_t nTicket = 0;                   // (ints; zeroed per solve)
   long long inv_gen = -1, fact_gen = 0; // the inverses belong to factorization number inv_gen
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   std::vector<hipEvent_t> ev;      // event pairs around update launches

@@ -927,20 +927,55 @@ __device__ __forceinline__ void inv_apply(const double* __restrict__ M, const do
   __syncthreads();
 }
 
-// forward, thin levels: 256 panel rows per workgroup (one per thread); see above
+// ---- runs of consecutive thin levels in ONE launch ------------------------------------------------------------------
+// The workgroups of a run are listed level after level in sweep order and synchronise cblk by cblk.  Forward: the
+// workgroups of cblk k start on b_k when the last chunk that contributes to it inside the run has counted itself
+// (cnt[k] reaching expect[k] raises k's flag); a chunk counts itself at every thin cblk its rows face once its
+// contributions are acknowledged.  Backward: a chunk waits for the flags of the cblks its rows face, raised by the
+// workgroup that solved their diagonal blok.  A workgroup only ever waits for workgroups of earlier levels -- smaller
+// block indices, which the dispatcher has started before it (a 1-D grid is dispatched in index order on every XCD) --
+// so the lowest unfinished workgroup always runs: no deadlock.
+// What it gains over a launch per level: no drain / launch / ramp per level (753 levels at 200^3); the waiting
+// workgroups hold the first part of their panel rows and of the inverse in registers; and the far rows of a tall panel
+// no longer stand between two consecutive diagonal solves -- only the chunk that faces the next cblk does.
+// Visibility without fences (MI355X_MICROARCH, inter-workgroup visibility): contributions are agent-scope atomics,
+// performed at the memory side; a workgroup waits for its own to be acknowledged (vmcnt(0)) before it counts itself;
+// flags and right-hand sides are read with agent-scope (sc1) loads that pass L1 and the XCD's L2, solutions are written
+// through with agent-scope stores.  Polled words are never the counted ones (increments do not queue behind polls), a
+// flag has FLAG_REP copies 256 B apart and a workgroup polls copy blockIdx % FLAG_REP.  The poll is bounded: after
+// SPIN_LIMIT polls (seconds) the workgroup raises *stuck and goes on, the host returns PASTIX_AMD_ERR_DEVICE -- a wrong
+// assumption fails the solve, it cannot hang the device.
+constexpr int SPIN_LIMIT = 1 << 22;
+constexpr int FLAG_PAD = 64;       // ints between two polled words
+constexpr int FLAG_REP = 8;
+__device__ __forceinline__ void thin_poll(const int* flag, const int t, int* stuck) {
+  const int* f = flag + ((int64_t)t * FLAG_REP + blockIdx.x % FLAG_REP) * FLAG_PAD;
+  int it = 0;
+  while (!__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (++it > SPIN_LIMIT) { *stuck = 1; break; }
+    if (it < 64) __builtin_amdgcn_s_sleep(8);                  // (~0.2 us, later ~1.3 us between polls)
+    else __builtin_amdgcn_s_sleep(48);
+  }
+}
+__device__ __forceinline__ void thin_raise(int* flag, const int t) {
+#pragma unroll
+  for (int r = 0; r < FLAG_REP; r++)
+    __hip_atomic_store(flag + ((int64_t)t * FLAG_REP + r) * FLAG_PAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// forward: 256 panel rows per workgroup (one per thread); every workgroup applies the inverse for itself
 template <class T>
 __global__ __launch_bounds__(256) void k_solve_thin_fwd(const T* __restrict__ L, const SolveChunk* __restrict__ chunks,
                                                         const int32_t* __restrict__ ridx, const double* __restrict__ inv,
-                                                        int* __restrict__ ticket, double* __restrict__ x) {
+                                                        int* __restrict__ ticket, const int32_t* __restrict__ tgt,
+                                                        const int32_t* __restrict__ expect, int* __restrict__ cnt,
+                                                        int* __restrict__ flag, int* __restrict__ stuck,
+                                                        double* __restrict__ x) {
   __shared__ double xs[128], ys[128], tmp[256];
   __shared__ int last;
   const SolveChunk ck = chunks[blockIdx.x];
   const int w = ck.width, tid = threadIdx.x;
-  if (tid < 128) xs[tid] = tid < w ? x[ck.fcol + tid] : 0.0;
-  __syncthreads();
-  // (every read of b_k by this workgroup is complete: the ticket may be drawn)
-  if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
-  // the thread's panel row, first 32 columns: in flight under the inverse's matrix-vector product
+  // the thread's panel row, first 32 columns: in flight while the levels in front finish
   const int ld = ck.stride;
   const bool rowv = tid < ck.nrows;
   const int p = ck.row0 + min(tid, max(ck.nrows - 1, 0));
@@ -949,90 +984,138 @@ __global__ __launch_bounds__(256) void k_solve_thin_fwd(const T* __restrict__ L,
 #pragma unroll
   for (int i = 0; i < 32; i++) a0[i] = rowv ? Ap[(int64_t)min(i, w - 1) * ld] : 0.0;
   const int32_t gr = rowv ? ridx[ck.roff + p] : 0;
-  inv_apply(inv + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
-  if (last && tid < w) x[ck.fcol + tid] = ys[tid];
-  if (!rowv) return;
-  double sacc = 0.0;
+  // ... and the first half of the thread's part of the inverse
+  const double* Mr = inv + (int64_t)ck.thin * INVLD * INVLD + (tid & 127) + (int64_t)(64 * (tid >> 7)) * INVLD;
+  double m0[32];
 #pragma unroll
-  for (int i = 0; i < 32; i++) sacc = __builtin_fma((i < w) ? a0[i] : 0.0, ys[i], sacc);
-  for (int c0 = 32; c0 < w; c0 += 32) {
-    double a[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
-#pragma unroll
-    for (int i = 0; i < 32; i++) sacc = __builtin_fma((c0 + i < w) ? a[i] : 0.0, ys[min(c0 + i, 127)], sacc);
+  for (int i = 0; i < 32; i++) m0[i] = Mr[(int64_t)i * INVLD];
+  if (ck.wait) {
+    if (tid == 0) thin_poll(flag, ck.thin, stuck);
+    __syncthreads();
   }
-  unsafeAtomicAdd(&x[gr], -sacc);
+  if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+  __syncthreads();
+  // (every read of b_k by this workgroup is complete: the ticket may be drawn)
+  if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
+  {
+    const int h = tid >> 7;
+    double m1[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) m1[i] = Mr[(int64_t)(32 + i) * INVLD];
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc = __builtin_fma(m0[i], xs[64 * h + i], acc);
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc = __builtin_fma(m1[i], xs[64 * h + 32 + i], acc);
+    tmp[tid] = acc;
+    __syncthreads();
+    if (tid < 128) ys[tid] = tmp[tid] + tmp[tid + 128];
+    __syncthreads();
+  }
+  // (read again by the backward sweep only, another launch; written through so that no line of x is ever dirty in an L2)
+  if (last && tid < w) __hip_atomic_store(&x[ck.fcol + tid], ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (rowv) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) sacc = __builtin_fma((i < w) ? a0[i] : 0.0, ys[i], sacc);
+    for (int c0 = 32; c0 < w; c0 += 32) {
+      double a[32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+      for (int i = 0; i < 32; i++) sacc = __builtin_fma((c0 + i < w) ? a[i] : 0.0, ys[min(c0 + i, 127)], sacc);
+    }
+    unsafeAtomicAdd(&x[gr], -sacc);
+  }
+  if (ck.tn > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = tid; i < ck.tn; i += 256) {
+      const int t = tgt[ck.tptr + i];
+      if (atomicAdd(&cnt[t], 1) == expect[t] - 1) thin_raise(flag, t);
+    }
+  }
 }
 
 template <class T>
 __global__ __launch_bounds__(256) void k_solve_thin_bwd(const T* __restrict__ B, const SolveChunk* __restrict__ chunks,
                                                         const int32_t* __restrict__ ridx, const double* __restrict__ invT,
-                                                        int* __restrict__ ticket, double* __restrict__ x) {
+                                                        int* __restrict__ ticket, const int32_t* __restrict__ tgt,
+                                                        int* __restrict__ flag, int* __restrict__ stuck,
+                                                        double* __restrict__ x) {
   __shared__ double xs[128], ys[128], tmp[256];
   __shared__ int last;
   const SolveChunk ck = chunks[blockIdx.x];
   const int w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (ck.nrows > 0) {
-    const T* A = B + ck.off;
-    const int ld = ck.stride;
-    const int p = ck.row0 + lane;
-    // x of the chunk's (at most 256) rows, gathered up front: two dependent loads that would otherwise sit in front of
-    // every 64-row step
+  const T* A = B + ck.off;
+  const int ld = ck.stride;
+  const int p = ck.row0 + lane;
+  const int c0 = wave * 32;                                // the wave's 32 columns (w <= 128)
+  const bool work = ck.nrows > 0 && c0 < w;
+  // the first 64 rows of the wave's columns and the chunk's row indices: in flight while the levels in front finish
+  double a[32];
+  int32_t gr[4];
+  if (work) {
+    const T* Ap = A + min(p, ld - 1);
+#pragma unroll
+    for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+#pragma unroll
+    for (int q = 0; q < 4; q++) gr[q] = ridx[ck.roff + min(p + 64 * q, ld - 1)];
+  }
+  if (ck.tn > 0) {
+    for (int i = tid; i < ck.tn; i += 256) thin_poll(flag, tgt[ck.tptr + i], stuck);
+    __syncthreads();
+  }
+  if (work) {
     double xrow[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const bool rv = lane + 64 * q < ck.nrows;
-      xrow[q] = rv ? x[ridx[ck.roff + min(p + 64 * q, ld - 1)]] : 0.0;
+      const double xv = __hip_atomic_load(&x[gr[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xrow[q] = lane + 64 * q < ck.nrows ? xv : 0.0;
     }
-    for (int c0 = wave * 32; c0 < w; c0 += 128) {
-      double acc[32];
+    double acc[32];
 #pragma unroll
-      for (int i = 0; i < 32; i++) acc[i] = 0.0;
+    for (int i = 0; i < 32; i++) acc[i] = a[i] * xrow[0];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {                        // the chunk's rows, 64 at a time
-        const int rb = 64 * q;
-        if (rb >= ck.nrows) break;
-        const int pp = min(p + rb, ld - 1);
-        const double xr = xrow[q];
-        const T* Ap = A + pp;
-        double a[32];
+    for (int q = 1; q < 4; q++) {                          // the chunk's other rows, 64 at a time
+      if (64 * q >= ck.nrows) break;
+      const T* Ap = A + min(p + 64 * q, ld - 1);
 #pragma unroll
-        for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
+      for (int i = 0; i < 32; i++) a[i] = Ap[(int64_t)min(c0 + i, w - 1) * ld];
 #pragma unroll
-        for (int i = 0; i < 32; i++) acc[i] = __builtin_fma(a[i], xr, acc[i]);
-      }
-      // transposed butterfly: 32 column sums over the 64 lanes (as k_solve_off_bwd64)
-#pragma unroll
-      for (int n = 32, d = 32; n > 1; n >>= 1, d >>= 1) {
-        const int half = n >> 1;
-        const bool up = (lane & d) != 0;
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-          const double send = up ? acc[i] : acc[i + half];
-          const double keep = up ? acc[i + half] : acc[i];
-          acc[i] = keep + __shfl_xor(send, d);
-        }
-      }
-      acc[0] += __shfl_xor(acc[0], 1);
-      const int c = c0 + ((lane >> 1) & 31);
-      if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
+      for (int i = 0; i < 32; i++) acc[i] = __builtin_fma(a[i], xrow[q], acc[i]);
     }
+    // transposed butterfly: 32 column sums over the 64 lanes (as k_solve_off_bwd64)
+#pragma unroll
+    for (int n = 32, d = 32; n > 1; n >>= 1, d >>= 1) {
+      const int half = n >> 1;
+      const bool up = (lane & d) != 0;
+#pragma unroll
+      for (int i = 0; i < half; i++) {
+        const double send = up ? acc[i] : acc[i + half];
+        const double keep = up ? acc[i + half] : acc[i];
+        acc[i] = keep + __shfl_xor(send, d);
+      }
+    }
+    acc[0] += __shfl_xor(acc[0], 1);
+    const int c = c0 + ((lane >> 1) & 31);
+    if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
   }
-  // Hand-off without fences (MI355X_MICROARCH, inter-workgroup visibility): the contributions are agent-scope atomics --
-  // performed at the memory side, not parked in this XCD's L2 --, so what the ticket needs is that every wave's atomics
-  // have been acknowledged (vmcnt(0)) before one lane draws it behind a workgroup barrier; a __threadfence here (L2
-  // write-back + invalidate by all 256 threads of every workgroup) cost ~100 us per level.
+  // the cblk's ticket: the last of its workgroups solves the diagonal blok (every contribution has been acknowledged)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
   __syncthreads();
-  if (!last) return;
-  // every contribution to b_k has been performed: read it with agent-scope (sc1) loads, past L1 and this XCD's L2
-  if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-  __syncthreads();
-  inv_apply(invT + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
-  if (tid < w) x[ck.fcol + tid] = ys[tid];
+  if (last) {
+    if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    inv_apply(invT + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
+    // (written through to memory: the next levels' workgroups, on any XCD, read it in this launch)
+    if (tid < w) __hip_atomic_store(&x[ck.fcol + tid], ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) thin_raise(flag, ck.thin);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1174,16 +1257,18 @@ void launch_solve_inv(hipStream_t s, const void* A, bool f32, const SolveTask* t
     hipLaunchKernelGGL(k_solve_inv<double>, dim3((unsigned)n), dim3(128), bytes, s, (const double*)A, tasks, thin_tasks, inv, which, unit);
   }
 }
+// one run of thin levels (chunks: its workgroups in sweep order); ticket / cnt / flag zero before the launch
 void launch_solve_thin(hipStream_t s, bool fwd, const void* P, bool f32, const SolveChunk* chunks, int64_t nchunk,
-                       const int32_t* ridx, const double* inv, int* ticket, double* x) {
+                       const int32_t* ridx, const double* inv, int* ticket, const int32_t* tgt, const int32_t* expect, int* cnt,
+                       int* flag, int* stuck, double* x) {
   if (nchunk <= 0) return;
   const dim3 g((unsigned)nchunk), b(256);
   if (f32) {
-    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, x);
-    else hipLaunchKernelGGL(k_solve_thin_bwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, x);
+    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, tgt, expect, cnt, flag, stuck, x);
+    else hipLaunchKernelGGL(k_solve_thin_bwd<float>, g, b, 0, s, (const float*)P, chunks, ridx, inv, ticket, tgt, flag, stuck, x);
   } else {
-    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, x);
-    else hipLaunchKernelGGL(k_solve_thin_bwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, x);
+    if (fwd) hipLaunchKernelGGL(k_solve_thin_fwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, tgt, expect, cnt, flag, stuck, x);
+    else hipLaunchKernelGGL(k_solve_thin_bwd<double>, g, b, 0, s, (const double*)P, chunks, ridx, inv, ticket, tgt, flag, stuck, x);
   }
 }
 void launch_solve_dscale_s(hipStream_t s, const float* L, const SolveTask* tasks, int64_t ntask, double* x) {

@@ -76,6 +76,9 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
   int64_t roff;                // first entry of the cblk in the panel-row -> global-row table
   int32_t thin;                // thin levels: the cblk's index among the thin cblks (SolveTask::thin), else -1
   int32_t nwg;                 // thin levels: workgroups of the cblk in this list (its chunks + one with nrows = 0)
+  // thin levels, runs in one launch: the thin cblks of the same run that face the chunk's rows (dThinTgt[tptr .. +tn));
+  // forward: wait = the cblk receives contributions inside the run (its flag is raised by the last of them)
+  int32_t tptr, tn, wait, pad_;
 };
 
 
