@@ -1186,8 +1186,8 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     // one set of atomics per 256 rows)
     const int32_t CH = 64;
     const int32_t CHB = 256;
-    // thin levels: at most THIN cblks (real arithmetic, one GPU): explicit inverses + one launch per level and sweep
-    constexpr int64_t THIN = 16;
+    // thin levels: at most THIN cblks (real arithmetic, one GPU): explicit inverses; their runs go in one launch per sweep
+    constexpr int64_t THIN = 64;
     std::vector<SolveChunk> thF, thB;
     std::vector<int32_t> thin_tasks;
     p->lvl_thin.assign((size_t)H.nlevels, 0);

@@ -22,7 +22,9 @@
 #include <functional>
 #include <new>
 #include <numeric>
+#include <atomic>
 #include <queue>
+#include <thread>
 #include <vector>
 
 #include "../../include/pastix_amd.h"
@@ -440,13 +442,116 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
         rep[s] = p;
         sw[p] += sw[s];
       }
-      heap0.reserve((size_t)ns0);
-      for (idx s = 0; s < ns0; s++)
-        if (rep[s] == s && sparent[s] != -1) heap0.push_back(Ent{cost_of(s, find(sparent[s])), s});
-      std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp, std::move(heap0));
       const double budget = ratio * nnz0;
       double spent = 0;
       const int64_t maxw_merge = o.max_merge_width > 0 ? o.max_merge_width : (int64_t)1 << 40;
+      auto schur_cross = [&](idx c, idx p) {
+        return o.schur_n > 0 && (sfirst[c] >= n - o.schur_n) != (sfirst[p] >= n - o.schur_n);
+      };
+      // ---- rounds: the same greedy sequence, the cheap merges of a round found subtree by subtree on host threads ----
+      // The costs the heap pops never decrease (above), so all merges of cost <= C happen before any dearer one; and an
+      // edge (c, parent) whose cost exceeds C now exceeds it for good.  Cutting those edges leaves components that cannot
+      // influence each other while only merges of cost <= C are made: a cost reads the widths of c and of its parent
+      // only, and a component's root does not merge upward in this round.  Every component runs the heap loop on its own
+      // -- the global sequence restricted to it -- and the union is what the single heap would have produced, provided the
+      // budget cannot run out inside the round: C = (budget - spent) / (nodes left) guarantees that.  The rounds stop
+      // when few nodes are left or a round achieves little; the single heap finishes (it must find the merge at which
+      // the budget ends).
+      std::vector<idx> alive;
+      alive.reserve((size_t)ns0);
+      for (idx s = 0; s < ns0; s++) if (rep[s] == s && sparent[s] != -1) alive.push_back(s);
+      const int nthr = [] {
+        const char* e = getenv("PASTIX_AMD_PLAN_THREADS");
+        const int nn = e ? atoi(e) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(nn, 64));
+      }();
+      {
+        std::vector<idx> croot((size_t)ns0), cstart((size_t)ns0 + 1, 0), members, comps;
+        std::iota(croot.begin(), croot.end(), 0);
+        for (int round = 0; round < 16 && alive.size() > 50000; round++) {
+          const double C = std::floor((budget - spent) / (double)alive.size());
+          if (C < 1) break;
+          // exact parents and component roots, parents before children (a parent has the larger index)
+          size_t nmem = 0;
+          for (size_t i = alive.size(); i-- > 0;) {
+            const idx c = alive[i], p = find(sparent[c]);
+            sparent[c] = p;
+            const bool cut = cost_of(c, p) > C || schur_cross(c, p);
+            croot[c] = cut ? c : croot[p];
+            if (!cut) { cstart[(size_t)croot[c] + 1]++; nmem++; }
+          }
+          if (nmem == 0) break;
+          // the components with members, in ascending root order (a root is alive or a tree root: scan the counters)
+          comps.clear();
+          for (idx r = 0; r < ns0; r++) if (cstart[(size_t)r + 1] > 0) comps.push_back(r);
+          members.resize(nmem);
+          std::vector<int64_t> cofs(comps.size() + 1, 0);
+          for (size_t q = 0; q < comps.size(); q++) cofs[q + 1] = cofs[q] + cstart[(size_t)comps[q] + 1];
+          for (size_t q = 0; q < comps.size(); q++) cstart[(size_t)comps[q] + 1] = (idx)q;      // root -> component number
+          {
+            std::vector<int64_t> pos(cofs.begin(), cofs.end() - 1);
+            for (size_t i = 0; i < alive.size(); i++) {
+              const idx c = alive[i], r = croot[c];
+              if (r != c) members[(size_t)pos[(size_t)cstart[(size_t)r + 1]]++] = c;
+            }
+          }
+          for (size_t q = 0; q < comps.size(); q++) cstart[(size_t)comps[q] + 1] = 0;            // (clean for the next round)
+          std::vector<double> tspent((size_t)nthr, 0.0);
+          std::vector<int> tbad((size_t)nthr, 0);
+          std::atomic<size_t> next{0};
+          auto work = [&](int t) {
+            try {
+              std::vector<Ent> heap;
+              double ls = 0;
+              for (;;) {
+                const size_t q0 = next.fetch_add(64);
+                if (q0 >= comps.size()) break;
+                for (size_t q = q0; q < std::min(comps.size(), q0 + 64); q++) {
+                  heap.clear();
+                  for (int64_t i = cofs[q]; i < cofs[q + 1]; i++) {
+                    const idx c = members[(size_t)i];
+                    heap.push_back(Ent{cost_of(c, sparent[c]), c});
+                  }
+                  std::make_heap(heap.begin(), heap.end(), cmp);
+                  while (!heap.empty()) {
+                    std::pop_heap(heap.begin(), heap.end(), cmp);
+                    const Ent e = heap.back();
+                    heap.pop_back();
+                    if (e.cost > C) break;
+                    const idx c = e.c;
+                    idx p = sparent[c];
+                    while (rep[p] != p) { rep[p] = rep[rep[p]]; p = rep[p]; }
+                    sparent[c] = p;
+                    const double cost = cost_of(c, p);
+                    if (cost > e.cost) { heap.push_back(Ent{cost, c}); std::push_heap(heap.begin(), heap.end(), cmp); continue; }
+                    if (cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
+                    ls += std::max(0.0, cost);
+                    rep[c] = p;
+                    sw[p] += sw[c];
+                  }
+                }
+              }
+              tspent[(size_t)t] = ls;
+            } catch (const std::bad_alloc&) { tbad[(size_t)t] = 1; }
+          };
+          {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthr; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto& x : th) x.join();
+          }
+          for (int t = 0; t < nthr; t++) if (tbad[(size_t)t]) throw std::bad_alloc();
+          for (int t = 0; t < nthr; t++) spent += tspent[(size_t)t];      // (integer-valued doubles: exact in any order)
+          const size_t before = alive.size();
+          size_t k2 = 0;
+          for (size_t i = 0; i < alive.size(); i++) if (rep[alive[i]] == alive[i]) alive[k2++] = alive[i];
+          alive.resize(k2);
+          if (before - k2 < before / 50) break;
+        }
+      }
+      heap0.reserve(alive.size());
+      for (const idx s : alive) heap0.push_back(Ent{cost_of(s, find(sparent[s])), s});
+      std::priority_queue<Ent, std::vector<Ent>, decltype(cmp)> pq(cmp, std::move(heap0));
       while (!pq.empty()) {
         const Ent e = pq.top();
         pq.pop();
@@ -456,7 +561,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
         sparent[c] = p;
         const double cost = cost_of(c, p);
         if (cost > e.cost) { pq.push(Ent{cost, c}); continue; }                     // stale: a lower bound, see above
-        if (o.schur_n > 0 && (sfirst[c] >= n - o.schur_n) != (sfirst[p] >= n - o.schur_n)) continue;   // never across the Schur boundary
+        if (schur_cross(c, p)) continue;                       // never across the Schur boundary
         if (cost > 0 && spent + cost > budget) break;          // cheapest remaining does not fit
         if (cost > 0 && sw[c] + sw[p] > maxw_merge) continue;
         spent += std::max(0.0, cost);
