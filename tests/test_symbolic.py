@@ -186,3 +186,24 @@ def test_producer_close_to_blend_on_the_same_ordering(golden):
         assert abs((len(s["cblk4"]) - 1) / (len(c4) - 1) - 1) <= 0.15
         fl = fact_flops(s["cblk4"], s["blok4"], 0)
         assert -0.07 <= fl / g["flops"] - 1 <= 0.0
+
+
+def _layout_hash(s):
+    import hashlib
+    m = hashlib.sha256()
+    for k in ("cblk4", "blok4", "perm"):
+        m.update(np.ascontiguousarray(s[k]).tobytes())
+    return m.hexdigest()[:16]
+
+
+@pytest.mark.parametrize("pct,mw,want", [(5, 0, "2c7f09b27d21bd9d"), (20, 64, "9c42e732e5df1406"), (1, 64, "f1195b34094cd831")])
+def test_amalgamation_rounds_reproduce_single_heap_layout(pct, mw, want, monkeypatch):
+    """The amalgamation finds the cheap merges of a round component by component on host threads (symbolic.cpp); the
+    layout must be the one the single global heap produced (hashes recorded from that implementation on the 60^3
+    Laplacian, 140 k fundamental supernodes: the rounds are active), whatever the number of threads."""
+    n, cp, r, v = sy.laplacian_3d(60)
+    perm, _ = sy.order_grid(60, 60, 60)
+    for thr in ("1", "3", "8"):
+        monkeypatch.setenv("PASTIX_AMD_PLAN_THREADS", thr)
+        s = sy.symbolic(n, cp, r, perm, amalgamation_pct=pct, max_merge_width=mw)
+        assert _layout_hash(s) == want, (thr, len(s["cblk4"]))
