@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -114,6 +116,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
   double tph = now_s();
   auto phase = [&](const char* name) { if (ptime) { const double t = now_s(); fprintf(stderr, "[create] %-28s %.2f s\n", name, t - tph); tph = t; } };
+  struct { std::thread th; int rc = 0, n = 0, device = 0; size_t bytes = 0; char* raw[4] = {nullptr, nullptr, nullptr, nullptr}; } pre;
   try {
     if (!layout || !layout->cblktab || !layout->bloktab || layout->cblknbr < 1) { delete p; return PASTIX_AMD_ERR_BADPARAMETER; }
     rc = build_split(layout, opts && opts->schur, p->split);
@@ -132,11 +135,40 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       sl.bloktab = p->split.blok.data();
       oflops = fact_flops(layout, factotype, floattype);
     }
+    if (!rc && !owner && !(opts && opts->external_arena)) {
+      // one GPU, library-owned panels: their size is known from the layout alone, so the device allocation (0.6 s for the
+      // 150 GB of 200^3, more on a box that has just released memory) runs on a thread of its own beside the host plan
+      const pastix_amd_layout_t* L = p->split.active ? &sl : layout;
+      int64_t coef = 0;
+      for (int64_t k = 0; k < L->cblknbr; k++)
+        coef += L->cblktab[k].stride * (L->cblktab[k].lcolnum - L->cblktab[k].fcolnum + 1);
+      const size_t esz = floattype == PASTIX_AMD_REALSINGLE ? sizeof(float) : sizeof(double);
+      pre.bytes = (size_t)std::max<int64_t>(coef, 1) * esz;
+      pre.n = (factotype != PASTIX_AMD_FACT_LLT ? 2 : 1) * (floattype == PASTIX_AMD_COMPLEXDOUBLE ? 2 : 1);
+      pre.device = opts ? opts->device : 0;
+      pre.th = std::thread([&pre] {
+        if (hipSetDevice(pre.device) != hipSuccess) { pre.rc = PASTIX_AMD_ERR_DEVICE; return; }
+        for (int i = 0; i < pre.n; i++) {
+          if (hipMalloc((void**)&pre.raw[i], pre.bytes + 2 * ARENA_PAD) != hipSuccess) { pre.raw[i] = nullptr; pre.rc = PASTIX_AMD_ERR_ALLOC; return; }
+          if (hipMemset(pre.raw[i], 0, ARENA_PAD) != hipSuccess || hipMemset(pre.raw[i] + ARENA_PAD + pre.bytes, 0, ARENA_PAD) != hipSuccess) {
+            pre.rc = PASTIX_AMD_ERR_DEVICE;
+            return;
+          }
+        }
+      });
+    }
     if (!rc) rc = build_plan(p->split.active ? &sl : layout, factotype, floattype, opts, owner, myrank, p->host);
   } catch (const std::bad_alloc&) {
     rc = PASTIX_AMD_ERR_ALLOC;
+  } catch (const std::system_error&) {
+    rc = PASTIX_AMD_ERR_ALLOC;
   }
-  if (rc) { delete p; return rc; }
+  if (pre.th.joinable()) pre.th.join();
+  auto pre_free = [&] {
+    for (int i = 0; i < 4; i++) { if (pre.raw[i]) (void)hipFree(pre.raw[i]); pre.raw[i] = nullptr; }
+    (void)hipGetLastError();
+  };
+  if (rc) { pre_free(); delete p; return rc; }
   phase("re-cut + host plan");
   if (p->split.active) p->host.fact_flops = p->host.local_flops = oflops;   // DPARM_FACT_FLOPS is the caller's layout's
   if (p->split.active && p->host.factotype != PASTIX_AMD_FACT_LU) {
@@ -147,17 +179,18 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       for (int64_t k = 0; k < M.ocblknbr; k++)
         if (M.first[k + 1] - M.first[k] > 1 && p->host.role[(size_t)M.first[k]] == 1)
           M.upper[(size_t)k].assign((size_t)(M.owidth[k] * M.owidth[k]) * eb, 0);
-    } catch (const std::bad_alloc&) { delete p; return PASTIX_AMD_ERR_ALLOC; }
+    } catch (const std::bad_alloc&) { pre_free(); delete p; return PASTIX_AMD_ERR_ALLOC; }
   }
   Plan& H = p->host;
   p->device = H.opts.device;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= p->device) {
     fprintf(stderr, "pastix_amd: no HIP device %d (the product path has no CPU fallback)\n", p->device);
+    pre_free();
     delete p;
     return PASTIX_AMD_ERR_DEVICE;
   }
-#define CHK(x) do { int r_ = (x); if (r_) { pastix_amd_plan_destroy(p); return r_; } } while (0)
+#define CHK(x) do { int r_ = (x); if (r_) { pre_free(); pastix_amd_plan_destroy(p); return r_; } } while (0)
   auto body = [&]() -> int {
     HIPCHK(hipSetDevice(p->device));
     {
@@ -185,12 +218,22 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         *out = (double*)(raw + ARENA_PAD);
         return 0;
       };
+      // (the arenas allocated beside the host plan, when they are what is needed; else they are released and made here)
+      int npre = 0;
+      const bool use_pre = pre.rc == 0 && pre.n > 0 && pre.bytes == bytes && p->device == pre.device;
+      if (!use_pre) pre_free();
+      auto take = [&](double** out) -> int {
+        if (!use_pre) return alloc(out);
+        *out = (double*)(pre.raw[npre] + ARENA_PAD);
+        pre.raw[npre++] = nullptr;
+        return 0;
+      };
       int ra;
-      if ((ra = alloc(&p->dL))) return ra;
-      if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = alloc(&p->dU))) return ra;
+      if ((ra = take(&p->dL))) return ra;
+      if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = take(&p->dU))) return ra;
       if (p->cplx) {
-        if ((ra = alloc(&p->dLi))) return ra;
-        if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = alloc(&p->dUi))) return ra;
+        if ((ra = take(&p->dLi))) return ra;
+        if (H.factotype != PASTIX_AMD_FACT_LLT && (ra = take(&p->dUi))) return ra;
       }
     }
     phase("streams + arenas");
@@ -272,9 +315,20 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         }
       }
   }
-  // the piece/task tables now live on the device; keep only what the host driver reads
-  decltype(H.pieces)().swap(H.pieces);
-  std::vector<Task>().swap(H.tasks);
+  // the piece/task tables now live on the device; keep only what the host driver reads.  (Returning several GB to the
+  // system takes 0.4 s at 200^3: a thread of its own does it.)
+  {
+    struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks; };
+    Junk* junk = new (std::nothrow) Junk();
+    if (junk) {
+      junk->pieces.swap(H.pieces);
+      junk->tasks.swap(H.tasks);
+      try { std::thread([junk] { delete junk; }).detach(); } catch (const std::system_error&) { delete junk; }
+    } else {
+      decltype(H.pieces)().swap(H.pieces);
+      std::vector<Task>().swap(H.tasks);
+    }
+  }
   phase("statistics, host tables freed");
   *out = p;
   return PASTIX_AMD_OK;

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <sys/mman.h>
 #include <memory>
 #include <numeric>
 #include <thread>
@@ -60,6 +61,45 @@ struct RawPiece {
   uint8_t carena; // arena (plane) of the target: 0 L, 1 U, 2/3 their imaginary planes
   uint8_t shared; // target receives contributions from several ranks (windowed schedule)
   Piece p;
+};
+
+// Big, write-once host buffers of the plan (several GB at 200^3): 2-MB aligned and advised for transparent huge pages --
+// a 4-KB first-touch fault per 85 pieces was a third of the planning time.
+inline void advise_huge(void* p, size_t bytes) {
+  const uintptr_t H = (uintptr_t)2 << 20;
+  const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
+  if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+}
+template <class T>
+T* huge_alloc(size_t n) {
+  const size_t H = (size_t)2 << 20, bytes = (std::max<size_t>(n, 1) * sizeof(T) + H - 1) / H * H;
+  void* p = aligned_alloc(H, bytes);
+  if (!p) throw std::bad_alloc();
+  advise_huge(p, bytes);
+  return (T*)p;
+}
+struct FreeDeleter { void operator()(void* p) const { free(p); } };
+// append-only list in blocks of 2^20 elements: no reallocation copies, no estimate of the final size
+template <class T>
+struct BlockList {
+  static constexpr size_t BL = (size_t)1 << 20;
+  std::vector<std::unique_ptr<T, FreeDeleter>> blk;
+  size_t n = 0;
+  void push_back(const T& v) {
+    if ((n & (BL - 1)) == 0) blk.emplace_back(huge_alloc<T>(BL));
+    blk.back().get()[n & (BL - 1)] = v;
+    n++;
+  }
+  size_t size() const { return n; }
+  const T& operator[](size_t i) const { return blk[i >> 20].get()[i & (BL - 1)]; }
+  template <class F> void for_each(F&& f) const {
+    for (size_t b = 0; b < blk.size(); b++) {
+      const T* q = blk[b].get();
+      const size_t m = std::min(BL, n - b * BL);
+      for (size_t i = 0; i < m; i++) f(q[i]);
+    }
+  }
+  void release() { blk.clear(); blk.shrink_to_fit(); n = 0; }
 };
 }  // namespace
 
@@ -307,12 +347,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     int n = e ? atoi(e) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
     return std::max(1, std::min(n, 64));
   }();
-  std::vector<std::vector<RawPiece>> traw((size_t)nthr);
+  std::vector<BlockList<RawPiece>> traw((size_t)nthr);
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
+  std::atomic<int64_t> gen_next{0};
   auto gen_body = [&](int tid) {
-    std::vector<RawPiece>& raw = traw[(size_t)tid];
-    raw.reserve((size_t)P.bloknbr * 8 / (size_t)nthr + 16);
+    BlockList<RawPiece>& raw = traw[(size_t)tid];
     double uflops = 0, ubytes = 0;
 
     auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
@@ -370,7 +410,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       }
     };
 
-    for (int64_t k = tid; k < nc; k += nthr) {
+    // (source cblks are handed out from the top of the tree down, a few at a time: the cblks of the top separators have
+    // hundreds of bloks -- O(bloks^2) pieces each -- and would otherwise decide which thread finishes last)
+    for (;;) {
+      const int64_t kc = gen_next.fetch_add(8);
+      if (kc >= nc) break;
+      for (int64_t k = nc - 1 - kc; k >= std::max<int64_t>(0, nc - 8 - kc); k--) {
       if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
       const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
       for (int64_t i = fb + 1; i < lb; i++) {
@@ -422,6 +467,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         }
         flush();
       }
+      }
     }
     tuf[(size_t)tid] = uflops;
     tub[(size_t)tid] = ubytes;
@@ -457,18 +503,33 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     return a.p.dc < b.p.dc;
   };
   struct RawArr {                      // (uninitialised storage: a vector would zero ~10 GB on one thread first)
-    std::unique_ptr<RawPiece[]> p;
+    std::unique_ptr<RawPiece, FreeDeleter> p;
     size_t n = 0;
     size_t size() const { return n; }
-    RawPiece& operator[](size_t i) { return p[i]; }
-    const RawPiece& operator[](size_t i) const { return p[i]; }
+    RawPiece& operator[](size_t i) { return p.get()[i]; }
+    const RawPiece& operator[](size_t i) const { return p.get()[i]; }
     RawPiece* begin() { return p.get(); }
   } raw;
   {
-    // counting sort into coarse tile bins (placement by thread order), then every bin sorted on its own
+    // counting sort into tile bins (placement by thread order), then every bin sorted on its own.  The bins hold about
+    // the same number of pieces each -- their boundaries are quantiles of a sample of the tile numbers; bins of equal
+    // tile ranges left the tiles of the top separators, thousands of pieces each, to a few threads.  Which bins there are
+    // does not matter for the result: the sort key is a total order with the tile first.
     constexpr int64_t NB = 8192;
-    const int64_t tspan = std::max<int64_t>(ntile * 4, 1);
-    auto bin_of = [&](int64_t tile) { return (int64_t)((__int128)tile * NB / tspan); };
+    std::vector<int64_t> splitter;                 // first tile of bins 1 .. : ascending, distinct
+    {
+      std::vector<int64_t> sample;
+      for (int t = 0; t < nthr; t++)
+        for (size_t i = 0; i < traw[(size_t)t].size(); i += 61) sample.push_back(traw[(size_t)t][i].tile);
+      std::sort(sample.begin(), sample.end());
+      for (int64_t b2 = 1; b2 < NB && !sample.empty(); b2++) {
+        const int64_t v = sample[(size_t)((__int128)sample.size() * b2 / NB)];
+        if (splitter.empty() || splitter.back() < v) splitter.push_back(v);
+      }
+    }
+    auto bin_of = [&](int64_t tile) {
+      return (int64_t)(std::upper_bound(splitter.begin(), splitter.end(), tile) - splitter.begin());
+    };
     std::vector<std::vector<int64_t>> cnt((size_t)nthr, std::vector<int64_t>((size_t)NB + 1, 0));
     auto par = [&](auto&& fn) {
       auto guarded = [&](int t) {
@@ -479,7 +540,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       guarded(0);
       for (auto& x : th) x.join();
     };
-    par([&](int t) { for (const RawPiece& r : traw[(size_t)t]) cnt[(size_t)t][(size_t)bin_of(r.tile)]++; });
+    par([&](int t) { traw[(size_t)t].for_each([&](const RawPiece& r) { cnt[(size_t)t][(size_t)bin_of(r.tile)]++; }); });
     std::vector<int64_t> binoff((size_t)NB + 1, 0);
     for (int64_t b2 = 0; b2 < NB; b2++) {
       int64_t c = 0;
@@ -487,11 +548,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       binoff[(size_t)b2 + 1] = binoff[(size_t)b2] + c;
     }
     raw.n = (size_t)binoff[(size_t)NB];
-    raw.p.reset(new RawPiece[raw.n + 1]);
+    raw.p.reset(huge_alloc<RawPiece>(raw.n + 1));
     par([&](int t) {
       std::vector<int64_t>& pos = cnt[(size_t)t];
-      for (const RawPiece& r : traw[(size_t)t]) raw[(size_t)pos[(size_t)bin_of(r.tile)]++] = r;
-      std::vector<RawPiece>().swap(traw[(size_t)t]);
+      traw[(size_t)t].for_each([&](const RawPiece& r) { raw[(size_t)pos[(size_t)bin_of(r.tile)]++] = r; });
+      traw[(size_t)t].release();
     });
     std::atomic<int64_t> next{0};
     par([&](int) {
@@ -506,6 +567,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   phase("piece sort");
   // (room for the clipped copies the quadrant tasks below append, without touching the memory now)
   P.pieces.reserve(raw.size() + raw.size() / 3 + 1024);
+  advise_huge(P.pieces.data(), P.pieces.capacity() * sizeof(Piece));
   P.pieces.resize(raw.size());
   {
     std::vector<std::thread> th;
@@ -870,6 +932,17 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.tasks.swap(sorted);
   }
   phase("task ordering");
+  if (ptime) {
+    // (a fingerprint of the schedule: equal for equal inputs whatever the number of host threads)
+    auto mix = [](uint64_t h, const void* data, size_t bytes) {
+      const uint64_t* w = (const uint64_t*)data;
+      for (size_t i = 0; i < bytes / 8; i++) { h ^= w[i]; h *= 0x100000001b3ULL; h ^= h >> 29; }
+      return h;
+    };
+    uint64_t h = mix(0xcbf29ce484222325ULL, P.tasks.data(), P.tasks.size() * sizeof(Task));
+    h = mix(h, P.pieces.data(), P.pieces.size() * sizeof(Piece));
+    fprintf(stderr, "[plan] tasks %zu pieces %zu fingerprint %016llx\n", P.tasks.size(), P.pieces.size(), (unsigned long long)h);
+  }
   return PASTIX_AMD_OK;
 }
 
