@@ -60,6 +60,17 @@ for tag in sys.argv[2:]:
     if l2 and l2.get("TCC_REQ_sum"):
         out["l2"] = {"TCC_HIT_sum": l2.get("TCC_HIT_sum"), "TCC_MISS_sum": l2.get("TCC_MISS_sum"), "TCC_REQ_sum": l2.get("TCC_REQ_sum"),
                      "hit_rate": l2.get("TCC_HIT_sum", 0.0) / max(l2.get("TCC_HIT_sum", 0.0) + l2.get("TCC_MISS_sum", 0.0), 1.0)}
+    # derived: the counters are sums over the chip's 8 XCDs x 32 CUs x 4 SIMDs and over the launches; GRBM_GUI_ACTIVE counts
+    # per XCD, so GRBM / 8 = the GPU cycles the kernels were running
+    if bz and wv and wv.get("GRBM_GUI_ACTIVE"):
+        cyc = wv["GRBM_GUI_ACTIVE"] / 8.0
+        out["derived"] = {"gpu_cycles_while_kernels_run": cyc,
+                          "clock_GHz": cyc / kt * 1e-9 if kt else None,
+                          "mfma_pipe_busy_frac": bz["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
+                          "cu_busy_frac": bz["SQ_BUSY_CU_CYCLES"] / (cyc * 256.0),
+                          "mfma_pipe_busy_frac_inside_busy_cus": bz["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * bz["SQ_BUSY_CU_CYCLES"]),
+                          # (SQ_WAVE_CYCLES counts in units of 4 cycles)
+                          "waves_per_simd_avg": 4.0 * wv["SQ_WAVE_CYCLES"] / (cyc * 1024.0) if wv.get("SQ_WAVE_CYCLES") else None}
     json.dump(out, open(os.path.join(pdir, "pmc_%s.json" % tag), "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    print(json.dumps(out.get("derived"), indent=1))
 json.dump(d, open(tpath, "w"), indent=1)
