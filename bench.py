@@ -336,6 +336,8 @@ def main():
         bulk_flops = res["update_flops"] - res.get("urgent_flops", 0.0)
         upd_rate = bulk_flops * K / max(ut_sum, 1e-12)
         busy_rate = res["update_flops"] * K / max(res["update_time"], 1e-12)
+        esz = 16.0 if a.workload == "elasticity" else 4.0 if PEAK == MFMA_F32_PEAK else 8.0
+        compulsory = 2.0 * esz * res["coefnbr"] * (2 if a.facto in ("ldlt", "lu") or a.workload == "elasticity" else 1)
         out = {
             "metric": ("factorization GFLOP/s (complex flops), 3-dof elasticity pattern %d^3 nodes zLDLt" % a.grid) if a.workload == "elasticity"
                       else "factorization GFLOP/s, 3D 7-point Laplacian %d^3 %s%s" % (a.grid, "s" if PEAK == MFMA_F32_PEAK else "d",
@@ -362,6 +364,12 @@ def main():
                          "traffic": None if traffic is None else traffic / max(res["nlaunch"], 1),
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": res.get("update_bytes", 0.0) * (bulk_flops / max(res["update_flops"], 1.0)) / max(res["nlaunch"], 1),
+                         # the other definition of the path's bytes: every panel entry read once and written once
+                         # per factorization, 2 * sizeof(element) * coefnbr (the arenas of the variant counted)
+                         "compulsory_bytes_per_step": compulsory,
+                         "traffic_over_compulsory": None if traffic is None else round(traffic / max(compulsory, 1.0), 2),
+                         "traffic_over_algorithmic": None if traffic is None else round(
+                             traffic / max(res.get("update_bytes", 0.0) * (bulk_flops / max(res["update_flops"], 1.0)), 1.0), 3),
                          "launches_per_step": res["nlaunch"],
                          "avg_launch_ms": round(ut_sum / K / max(res["nlaunch"], 1) * 1e3, 4),
                          "achieved_while_in_flight": round(busy_rate * 1e-12, 3),
