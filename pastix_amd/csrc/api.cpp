@@ -1029,8 +1029,8 @@ static int launch_panels(pastix_amd_plan_t* p, int l) {
   const int64_t ntt = H.lvl_trsm_ptr[l + 1] - H.lvl_trsm_ptr[l];
   if (p->f32) {
     const int lw = npt > 0 ? (int)H.panel_tasks[(size_t)H.lvl_panel_ptr[l]].width : 1;    // (sorted widest first)
-    launch_diag_s(s, H.factotype, (float*)p->dL, (float*)p->dU, pt, npt, p->crit_run, p->dNbpivot, p->dErr, lw);
-    launch_trsm_s(s, H.factotype, (float*)p->dL, (float*)p->dU, tt, ntt, lw);
+    launch_diag_s(s, H.factotype, (float*)p->dL, (float*)p->dU, pt, npt, (float*)p->dDinv, p->crit_run, p->dNbpivot, p->dErr, lw);
+    launch_trsm_s(s, H.factotype, (float*)p->dL, (float*)p->dU, tt, ntt, (const float*)p->dDinv, lw);
     return PASTIX_AMD_OK;
   }
   if (p->cplx) {

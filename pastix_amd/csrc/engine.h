@@ -50,9 +50,10 @@ void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
 // kernels_f32.hip: the single-precision engine (arenas of floats; Arenas::p reinterpreted)
 void launch_update_s(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks, bool urgent);
-void launch_diag_s(hipStream_t s, int factotype, float* L, float* U, const PanelTask* tasks, int64_t n, double critere,
-                   long long* nbpivot, int* errflag, int maxw);
-void launch_trsm_s(hipStream_t s, int factotype, float* L, float* U, const TrsmTask* tasks, int64_t n, int maxw);
+void launch_diag_s(hipStream_t s, int factotype, float* L, float* U, const PanelTask* tasks, int64_t n, float* dinv,
+                   double critere, long long* nbpivot, int* errflag, int maxw);
+void launch_trsm_s(hipStream_t s, int factotype, float* L, float* U, const TrsmTask* tasks, int64_t n, const float* dinv,
+                   int maxw);
 void launch_fill_const_s(hipStream_t s, float* dst, int64_t n, float v);
 void launch_scatter_s(hipStream_t s, float* dst, const int64_t* idx, const double* val, int64_t n);
 void launch_solve_inv(hipStream_t s, const void* A, bool f32, const SolveTask* tasks, const int32_t* thin_tasks, int64_t n,

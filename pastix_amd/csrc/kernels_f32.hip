@@ -9,9 +9,9 @@
 //                the driver and the schedule are shared with the fp64 engine; only the arenas hold floats.
 //   k_diag_s   : factor_diag (compute_diag.c:538-605) for LLt / LDLt / LU with the static-pivot clamp and count
 //                (:133-137, :439-468), the diagonal blok resident in LDS;
-//   k_trsm_s   : factor_trsm1d / kernel_trsm (compute_trsm.c:58-171), one panel row per thread against the diagonal
-//                blok in LDS, 16-column blocks in registers.
-// The panel kernels are plain (no MFMA): < 3 % of the flops; the update kernel stages its operands through registers
+//   k_trsm_s   : factor_trsm1d / kernel_trsm (compute_trsm.c:58-171): X^T in fp32 MFMA accumulators, 16 x 16 tile inverses
+//                from k_diag_s (the fp64 kernels' organisation).
+// k_diag_s is plain (no MFMA; < 1 % of the flops); the update kernel stages its operands through registers
 // (coalesced 4-byte loads, masks for partial pieces: any alignment, any rectangle) instead of the LDS-DMA of the fp64
 // kernel -- a 16-byte DMA lane would carry four floats across a piece boundary.
 #include <hip/hip_runtime.h>
@@ -172,10 +172,35 @@ void launch_update_s(hipStream_t s, const Arenas& ar, const Task* tasks, const P
 //   (B) one thread per row below the tile solves it against the tile (LU: and one thread per column right of it);
 //   (C) all threads update the trailing square in 4 x 4 register tiles (LLt / LDLt: its lower part).
 // ------------------------------------------------------------------------------------------------
+// column j of the inverse of the lower-triangular 16 x 16 tile at (kb, kb) of the blok S (TRANS: of the transposed upper
+// tile; UNIT: unit diagonal; rows / columns beyond nb: identity), forward substitution in registers; dst[i + 16 j]
+template <bool UNIT, bool TRANS>
+__device__ __forceinline__ void tile_inverse_col(const float* S, const int ldl, const int kb, const int nb, const int j,
+                                                 float* __restrict__ dst) {
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    float sum = (i == j) ? 1.f : 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+      if (p < i) {
+        const int ii = min(kb + i, kb + nb - 1), pp = min(kb + p, kb + nb - 1);
+        const float t = TRANS ? S[pp + ii * ldl] : S[ii + pp * ldl];
+        sum -= ((i < nb && p < nb) ? t : 0.f) * x[p];
+      }
+    }
+    const float d = (UNIT || i >= nb) ? 1.f : S[(kb + i) + (kb + i) * ldl];
+    x[i] = sum / d;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) dst[i + 16 * j] = x[i];
+}
+
 template <int FACTO>
 __global__ __launch_bounds__(256) void k_diag_s(float* __restrict__ L, float* __restrict__ U,
-                                                const PanelTask* __restrict__ tasks, float critere,
-                                                long long* __restrict__ nbpivot, int* __restrict__ errflag) {
+                                                const PanelTask* __restrict__ tasks, float* __restrict__ dinv_ws,
+                                                float critere, long long* __restrict__ nbpivot,
+                                                int* __restrict__ errflag) {
   PANEL_PRIO();
   extern __shared__ float S[];                   // the blok [r + c * ldl]; LDLt: then Y[16][ldy] = (L D) of the block step
   const PanelTask tk = tasks[blockIdx.x];
@@ -226,6 +251,16 @@ __global__ __launch_bounds__(256) void k_diag_s(float* __restrict__ L, float* __
       }
     }
     __syncthreads();
+    // ---- the tile's inverse for the panel solve (k_trsm_s), beside (B) on lanes (B) never uses: lane j = column j.
+    // LLt: L_t^-1; LDLt: the unit L_t^-1; LU: (U_t^T)^-1 for the L side, then the unit L_t^-1 for the U side
+    if (tid >= 240) {
+      float* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+      if (FACTO == 0) tile_inverse_col<false, false>(S, ldl, kb, nb, tid - 240, dst);
+      else if (FACTO == 1) tile_inverse_col<true, false>(S, ldl, kb, nb, tid - 240, dst);
+      else tile_inverse_col<false, true>(S, ldl, kb, nb, tid - 240, dst);
+    }
+    if (FACTO == 2 && tid >= 112 && tid < 128)
+      tile_inverse_col<true, false>(S, ldl, kb, nb, tid - 112, dinv_ws + tk.dinv_off + (int64_t)(((w + 15) >> 4) + (kb >> 4)) * 256);
     // ---- (B) rows below the tile (threads 0..rem-1); LU: columns right of it (threads 128..128+rem-1)
     if (tid < rem) {
       const int r = kb + nb + tid;
@@ -322,95 +357,91 @@ __global__ __launch_bounds__(256) void k_diag_s(float* __restrict__ L, float* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_trsm_s<MODE>: x_j = (a_j - sum_{p<j} x_p M[j,p]) s_j for the (at most 64) panel rows of a task, one WAVE per task
-// (64 threads, 16 KB of LDS: fits any hole a bulk workgroup leaves).  32-column block steps: the lane keeps the 32
-// columns of its row in registers; the strip M[jb .. jb+31][0 .. jb+31] of the diagonal blok is staged in LDS once per
-// step (one memory round trip) and read back as broadcasts; the earlier blocks of the row are re-read from the panel.
-//   0 LLt        M = L_d (lower), s = 1 / diag            panel in L                 (R,L,T,N compute_trsm.c:67-70)
-//   1 LDLt       M = L_d unit;  L*D = x -> U arena, L = x / d_j -> L arena           (:92-113)
-//   2 LU, L side M[j,p] = U_d[p,j], s = 1 / U_d[j,j]      panel in L                 (R,U,N,N :62-63)
-//   3 LU, U side M = L_d unit                             panel in U                 (R,U,N,U on dU :64-66)
+// k_trsm_s<MODE>: the panel solve X = A T^-T for 64 panel rows per workgroup, one wave per 16 rows, X^T in MFMA
+// accumulators -- the organisation of k_trsm_llt / k_trsm_var (kernels.hip, kernels_var.hip) on v_mfma_f32_16x16x4_f32:
+//   X^T[ct] = Tinv[ct] (A^T[ct] - sum_{p<ct} T[ct,p] X^T[p]),   Tinv[ct] = the 16 x 16 diagonal-tile inverses of k_diag_s.
+// An accumulator tile of the fp32 instruction has ROW 4 g + q in register q of lane group g (the fp64 one: g + 4 q), and a
+// k-step takes k = g from lane group g.  For accumulator register q of tile p to BE the B operand of k-step q without any
+// lane movement, the instruction's row index m stands for the logical column pi(m) = (m >> 2) + 4 (m & 3) of the tile:
+// register q of lane group g is then logical column g + 4 q, exactly the fp64 kernel's picture, and the A operand -- which
+// decides what row m means -- supplies the coefficients of logical row pi(l15).
+//   0 LLt        T = L_d (lower)                          panel in L                 (R,L,T,N compute_trsm.c:67-70)
+//   1 LDLt       T = L_d unit;  L*D = x -> U arena, L = x / d_j -> L arena           (:92-113)
+//   2 LU, L side T[j,p] = U_d[p,j]                        panel in L                 (R,U,N,N :62-63)
+//   3 LU, U side T = L_d unit                             panel in U                 (R,U,N,U on dU :64-66)
+// The first version (a wave per 64 rows, the strip of the blok in LDS, scalar FMAs) took 267 us per level at 100^3 and
+// was half of that factorization's time.
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(64) void k_trsm_s(float* __restrict__ L, float* __restrict__ U,
-                                               const TrsmTask* __restrict__ tasks) {
+__global__ __launch_bounds__(256, 4) void k_trsm_s(float* __restrict__ L, float* __restrict__ U,
+                                                   const TrsmTask* __restrict__ tasks,
+                                                   const float* __restrict__ dinv_ws) {
   PANEL_PRIO();
-  extern __shared__ float Ms[];                  // Ms[p * 32 + j] = M[jb + j][p], p < the widest cblk of the launch
+  constexpr int NT = 8;
   const TrsmTask tk = tasks[blockIdx.x];
-  const int64_t ld = tk.stride;
-  const int w = tk.width, tid = threadIdx.x;
-  const float* Ad = L + tk.off;                  // the factored diagonal blok is in the L arena for every mode
-  const int row = tk.row0 + min(tid, tk.nrows - 1);
-  const bool rv = tid < tk.nrows;
-  float* P = (MODE == 3 ? U : L) + tk.off + row;           // the row being solved (in place)
-  float* Y = MODE == 1 ? U + tk.off + row : P;             // where the recurrence's x_p are re-read from
-  for (int jb = 0; jb < w; jb += 32) {
-    const int np = min(jb + 32, w);              // columns 0 .. np-1 of the strip are needed
-    // (16 loads in flight per lane and batch: a plain loop would pay one memory round trip per element)
-    for (int b0 = 0; b0 < 32 * np; b0 += 64 * 16) {
-      float v[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int l15p = (l15 >> 2) + 4 * (l15 & 3);
+  const int ld = tk.stride, w = tk.width;
+  const int nbk = (w + 15) >> 4;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  float* X = (MODE == 3 ? U : L) + tk.off + tk.row0;
+  float* Xp = X + rloc;
+  const float* Xpc = X + min(rloc, tk.nrows - 1);
+  const float* Td = L + tk.off;                        // the factored diagonal blok (always in the L arena)
+  const float* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)nbk * 256 : 0);
+
+  f4 acc[NT];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int idx = min(b0 + 64 * i + tid, 32 * np - 1);
-        int j, p;
-        if (MODE == 2) { j = idx / np; p = idx - j * np; }                     // U_d[p][jb + j]: contiguous in p
-        else { j = idx & 31; p = idx >> 5; }                                   // L_d[jb + j][p]: contiguous in j
-        const int jj = min(jb + j, w - 1);
-        v[i] = MODE == 2 ? Ad[p + (int64_t)jj * ld] : Ad[jj + (int64_t)p * ld];
-      }
+  for (int ct = 0; ct < NT; ct++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int idx = b0 + 64 * i + tid;
-        if (idx < 32 * np) {
-          int j, p;
-          if (MODE == 2) { j = idx / np; p = idx - j * np; }
-          else { j = idx & 31; p = idx >> 5; }
-          Ms[p * 32 + j] = jb + j < w ? v[i] : 0.f;
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const float v = Xpc[(int64_t)min(col, w - 1) * ld];
+      acc[ct][q] = (rvalid && col < w) ? v : 0.f;
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ct++) {
+    if (ct < nbk) {
+      const int li = ct * 16 + l15p;
+      const int lic = min(li, w - 1);
+#pragma unroll
+      for (int p = 0; p < ct; p++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int lc = p * 16 + g + 4 * q;
+          const float tv = (MODE == 2) ? Td[lc + (int64_t)lic * ld] : Td[lic + (int64_t)lc * ld];
+          const float a = (li < w) ? -tv : 0.f;
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[p][q], acc[ct], 0, 0, 0);
         }
       }
+      f4 t = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float a = Ti[ct * 256 + l15p + 16 * (g + 4 * q)];
+        t = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[ct][q], t, 0, 0, 0);
+      }
+      acc[ct] = t;
     }
-    float x[32];
+  }
 #pragma unroll
-    for (int j = 0; j < 32; j++) x[j] = P[(int64_t)min(jb + j, w - 1) * ld];
-    __builtin_amdgcn_wave_barrier();             // (one wave: its LDS writes are ordered in front of its reads)
-    for (int pb = 0; pb < jb; pb += 32) {
-      float xp[32];
+  for (int ct = 0; ct < NT; ct++) {
 #pragma unroll
-      for (int p = 0; p < 32; p++) xp[p] = Y[(int64_t)(pb + p) * ld];
-#pragma unroll
-      for (int p = 0; p < 32; p++) {
-        const f4* Mp = (const f4*)(Ms + (pb + p) * 32);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const f4 m = Mp[q];
-          x[4 * q + 0] -= xp[p] * m[0];
-          x[4 * q + 1] -= xp[p] * m[1];
-          x[4 * q + 2] -= xp[p] * m[2];
-          x[4 * q + 3] -= xp[p] * m[3];
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      if (MODE == 1) {
+        const float dv = Td[min(col, w - 1) * (int64_t)(ld + 1)];
+        if (rvalid && col < w) {
+          (U + tk.off + tk.row0 + rloc)[(int64_t)col * ld] = acc[ct][q];           // L*D (compute_trsm.c:108-109)
+          Xp[(int64_t)col * ld] = acc[ct][q] / dv;                                // L   (:110)
         }
+      } else {
+        if (rvalid && col < w) Xp[(int64_t)col * ld] = acc[ct][q];
       }
     }
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-#pragma unroll
-      for (int p = 0; p < 32; p++)
-        if (p < j) x[j] -= x[p] * Ms[(jb + p) * 32 + j];
-      if (MODE == 0 || MODE == 2) x[j] /= Ms[min(jb + j, w - 1) * 32 + min(j, w - 1 - jb)];
-    }
-    if (rv) {
-#pragma unroll
-      for (int j = 0; j < 32; j++) {
-        if (jb + j < w) {
-          if (MODE == 1) {
-            Y[(int64_t)(jb + j) * ld] = x[j];                                          // L*D  (compute_trsm.c:108-109)
-            P[(int64_t)(jb + j) * ld] = x[j] / Ms[(jb + j) * 32 + j];                  // L    (:110)
-          } else {
-            P[(int64_t)(jb + j) * ld] = x[j];
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();             // (the strip is rewritten by the next step)
   }
 }
 
@@ -421,34 +452,35 @@ static bool lds_attr(const void* fn, int bytes) {
 }
 
 // maxw: the widest cblk of the launch (LDS is sized for it: the narrow cblks of the leaf levels then fit many per CU)
-void launch_diag_s(hipStream_t s, int factotype, float* L, float* U, const PanelTask* tasks, int64_t n, double critere,
-                   long long* nbpivot, int* errflag, int maxw) {
+void launch_diag_s(hipStream_t s, int factotype, float* L, float* U, const PanelTask* tasks, int64_t n, float* dinv,
+                   double critere, long long* nbpivot, int* errflag, int maxw) {
   if (n <= 0) return;
   const int bytes = (maxw * (maxw | 1) + 16 * (maxw | 1)) * (int)sizeof(float);
   const dim3 g((unsigned)n), b(256);
   if (factotype == PASTIX_AMD_FACT_LLT) {
     if (!lds_attr((const void*)k_diag_s<0>, bytes)) return;
-    hipLaunchKernelGGL(k_diag_s<0>, g, b, bytes, s, L, U, tasks, (float)critere, nbpivot, errflag);
+    hipLaunchKernelGGL(k_diag_s<0>, g, b, bytes, s, L, U, tasks, dinv, (float)critere, nbpivot, errflag);
   } else if (factotype == PASTIX_AMD_FACT_LU) {
     if (!lds_attr((const void*)k_diag_s<2>, bytes)) return;
-    hipLaunchKernelGGL(k_diag_s<2>, g, b, bytes, s, L, U, tasks, (float)critere, nbpivot, errflag);
+    hipLaunchKernelGGL(k_diag_s<2>, g, b, bytes, s, L, U, tasks, dinv, (float)critere, nbpivot, errflag);
   } else {
     if (!lds_attr((const void*)k_diag_s<1>, bytes)) return;
-    hipLaunchKernelGGL(k_diag_s<1>, g, b, bytes, s, L, U, tasks, (float)critere, nbpivot, errflag);
+    hipLaunchKernelGGL(k_diag_s<1>, g, b, bytes, s, L, U, tasks, dinv, (float)critere, nbpivot, errflag);
   }
 }
 
-void launch_trsm_s(hipStream_t s, int factotype, float* L, float* U, const TrsmTask* tasks, int64_t n, int maxw) {
+void launch_trsm_s(hipStream_t s, int factotype, float* L, float* U, const TrsmTask* tasks, int64_t n, const float* dinv,
+                   int maxw) {
+  (void)maxw;
   if (n <= 0) return;
-  const dim3 g((unsigned)n), b(64);
-  const int bytes = 32 * ((maxw + 31) & ~31) * (int)sizeof(float);      // <= 16 KB: the narrow cblks of the leaf levels fit many per CU
+  const dim3 g((unsigned)n), b(256);
   if (factotype == PASTIX_AMD_FACT_LLT) {
-    hipLaunchKernelGGL(k_trsm_s<0>, g, b, bytes, s, L, U, tasks);
+    hipLaunchKernelGGL(k_trsm_s<0>, g, b, 0, s, L, U, tasks, dinv);
   } else if (factotype == PASTIX_AMD_FACT_LU) {
-    hipLaunchKernelGGL(k_trsm_s<2>, g, b, bytes, s, L, U, tasks);
-    hipLaunchKernelGGL(k_trsm_s<3>, g, b, bytes, s, L, U, tasks);
+    hipLaunchKernelGGL(k_trsm_s<2>, g, b, 0, s, L, U, tasks, dinv);
+    hipLaunchKernelGGL(k_trsm_s<3>, g, b, 0, s, L, U, tasks, dinv);
   } else {
-    hipLaunchKernelGGL(k_trsm_s<1>, g, b, bytes, s, L, U, tasks);
+    hipLaunchKernelGGL(k_trsm_s<1>, g, b, 0, s, L, U, tasks, dinv);
   }
 }
 
