@@ -932,6 +932,29 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.tasks.swap(sorted);
   }
   phase("task ordering");
+  if (P.opts.verbose >= 3) {
+    // developer aid: the pieces of the tasks that run the masked loop (any partial piece), by extent in 16-row / 16-column
+    // bands: share of those tasks' chunk iterations and of their flops
+    double it[9][9] = {}, fl[9][9] = {}, tit = 0, tfl = 0, allfl = 0;
+    for (const Task& t : P.tasks) {
+      const bool masked = (int)t.nfull != t.pn && !(t.flags & 32u);
+      for (int i = 0; i < t.pn; i++) {
+        const Piece& pc = P.pieces[(size_t)t.p0 + i];
+        const double f = 2.0 * pc.m * (double)pc.n * pc.k;
+        allfl += f;
+        if (!masked) continue;
+        const int mb = (pc.m + 15) / 16, nb = (pc.n + 15) / 16;
+        const double c = (pc.k + 15) / 16;
+        it[mb][nb] += c; fl[mb][nb] += f; tit += c; tfl += f;
+      }
+    }
+    fprintf(stderr, "[plan] masked-loop tasks: %.2f %% of the update flops; rows: m in 16-row bands, columns: n; %% of their chunk iterations / %% of their flops\n", 100.0 * tfl / std::max(allfl, 1.0));
+    for (int a = 1; a <= 8; a++) {
+      fprintf(stderr, "[plan]  m<=%3d:", 16 * a);
+      for (int b = 1; b <= 8; b++) fprintf(stderr, " %5.1f/%-5.1f", 100.0 * it[a][b] / std::max(tit, 1.0), 100.0 * fl[a][b] / std::max(tfl, 1.0));
+      fprintf(stderr, "\n");
+    }
+  }
   if (ptime) {
     // (a fingerprint of the schedule: equal for equal inputs whatever the number of host threads)
     auto mix = [](uint64_t h, const void* data, size_t bytes) {
