@@ -932,7 +932,7 @@ __device__ __forceinline__ void inv_apply(const double* __restrict__ M, const do
 // workgroups of cblk k start on b_k when the last chunk that contributes to it inside the run has counted itself
 // (cnt[k] reaching expect[k] raises k's flag); a chunk counts itself at every thin cblk its rows face once its
 // contributions are acknowledged.  Backward: a chunk waits for the flags of the cblks its rows face, raised by the
-// workgroup that solved their diagonal blok.  A workgroup only ever waits for workgroups of earlier levels -- smaller
+// cblk's solver -- its workgroup without rows, which waits for the cblk's chunks on a ticket.  A workgroup only ever waits for workgroups of earlier levels -- smaller
 // block indices, which the dispatcher has started before it (a 1-D grid is dispatched in index order on every XCD) --
 // so the lowest unfinished workgroup always runs: no deadlock.
 // What it gains over a launch per level: no drain / launch / ramp per level (753 levels at 200^3); the waiting
@@ -984,11 +984,13 @@ __global__ __launch_bounds__(256) void k_solve_thin_fwd(const T* __restrict__ L,
 #pragma unroll
   for (int i = 0; i < 32; i++) a0[i] = rowv ? Ap[(int64_t)min(i, w - 1) * ld] : 0.0;
   const int32_t gr = rowv ? ridx[ck.roff + p] : 0;
-  // ... and the first half of the thread's part of the inverse
+  // ... and the thread's part of the inverse
   const double* Mr = inv + (int64_t)ck.thin * INVLD * INVLD + (tid & 127) + (int64_t)(64 * (tid >> 7)) * INVLD;
-  double m0[32];
+  double m0[32], m1[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) m0[i] = Mr[(int64_t)i * INVLD];
+#pragma unroll
+  for (int i = 0; i < 32; i++) m1[i] = Mr[(int64_t)(32 + i) * INVLD];
   if (ck.wait) {
     if (tid == 0) thin_poll(flag, ck.thin, stuck);
     __syncthreads();
@@ -999,9 +1001,6 @@ __global__ __launch_bounds__(256) void k_solve_thin_fwd(const T* __restrict__ L,
   if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
   {
     const int h = tid >> 7;
-    double m1[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) m1[i] = Mr[(int64_t)(32 + i) * INVLD];
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 32; i++) acc = __builtin_fma(m0[i], xs[64 * h + i], acc);
@@ -1043,10 +1042,42 @@ __global__ __launch_bounds__(256) void k_solve_thin_bwd(const T* __restrict__ B,
                                                         int* __restrict__ ticket, const int32_t* __restrict__ tgt,
                                                         int* __restrict__ flag, int* __restrict__ stuck,
                                                         double* __restrict__ x) {
-  __shared__ double xs[128], ys[128], tmp[256];
-  __shared__ int last;
+  __shared__ double xs[128], tmp[256];
   const SolveChunk ck = chunks[blockIdx.x];
   const int w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (ck.nrows == 0) {
+    // The cblk's SOLVER: its workgroup without panel rows (listed behind the cblk's chunks).  It takes its part of the
+    // inverse into registers at once, waits until every chunk of the cblk has counted itself on the ticket (their
+    // contributions to b_k are acknowledged by then), and applies the inverse: no load stands between the last
+    // contribution and the solution but the right-hand side itself.
+    const int h = tid >> 7;
+    const double* Mr = invT + (int64_t)ck.thin * INVLD * INVLD + (tid & 127) + (int64_t)(64 * h) * INVLD;
+    double m[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) m[i] = Mr[(int64_t)i * INVLD];
+    if (tid == 0 && ck.nwg > 1) {
+      int it = 0;
+      while (__hip_atomic_load(&ticket[ck.thin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ck.nwg - 1) {
+        if (++it > SPIN_LIMIT) { *stuck = 1; break; }
+        if (it < 64) __builtin_amdgcn_s_sleep(8);
+        else __builtin_amdgcn_s_sleep(48);
+      }
+    }
+    __syncthreads();
+    if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) acc = __builtin_fma(m[i], xs[64 * h + i], acc);
+    tmp[tid] = acc;
+    __syncthreads();
+    // (written through to memory: the next levels' workgroups, on any XCD, read it in this launch)
+    if (tid < w) __hip_atomic_store(&x[ck.fcol + tid], tmp[tid] + tmp[tid + 128], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) thin_raise(flag, ck.thin);
+    return;
+  }
   const T* A = B + ck.off;
   const int ld = ck.stride;
   const int p = ck.row0 + lane;
@@ -1101,21 +1132,10 @@ __global__ __launch_bounds__(256) void k_solve_thin_bwd(const T* __restrict__ B,
     const int c = c0 + ((lane >> 1) & 31);
     if (!(lane & 1) && c < w) unsafeAtomicAdd(&x[ck.fcol + c], -acc[0]);
   }
-  // the cblk's ticket: the last of its workgroups solves the diagonal blok (every contribution has been acknowledged)
+  // the cblk's ticket: every contribution of this chunk has been acknowledged
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) last = atomicAdd(&ticket[ck.thin], 1) == ck.nwg - 1;
-  __syncthreads();
-  if (last) {
-    if (tid < 128) xs[tid] = tid < w ? __hip_atomic_load(&x[ck.fcol + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    __syncthreads();
-    inv_apply(invT + (int64_t)ck.thin * INVLD * INVLD, xs, ys, tmp, tid);
-    // (written through to memory: the next levels' workgroups, on any XCD, read it in this launch)
-    if (tid < w) __hip_atomic_store(&x[ck.fcol + tid], ys[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) thin_raise(flag, ck.thin);
-  }
+  if (tid == 0) atomicAdd(&ticket[ck.thin], 1);
 }
 
 // ------------------------------------------------------------------------------------------------
