@@ -32,10 +32,26 @@ constexpr int SLDF = 144;          // LDS line: 128 rows + 16 pad floats (two bu
 __device__ __forceinline__ float* arena_f(const Arenas& ar, int a) { return reinterpret_cast<float*>(ar.p[a]); }
 }  // namespace
 
+// 512 B of zeros: the DMA source of k-lines beyond a piece's K and of tile rows / columns outside a partial piece
+__device__ float g_zero_line_s[128];
+
+// LDS-DMA, 4 bytes per lane: one wave-instruction copies 64 consecutive floats of a k-line straight into LDS (no staging
+// registers, no ds_write).  Four-byte granularity: any alignment, any piece boundary -- the 16-byte form of the fp64 kernel
+// would carry four floats across it.
+#define PASTIX_AMD_GLDS4(gptr, lptr)                                                             \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
+                                   (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0)
+
 // MFMA f32 32x32x2 lane maps: A operand: lane l holds A[i = l & 31][k = l >> 5]; B operand: B[k = l >> 5][j = l & 31];
 // D: lane l, register q holds D[i = 8 (q >> 2) + 4 (l >> 5) + (q & 3)][j = l & 31].  As in the fp64 kernel the target
 // COLUMN is fed as "i" and the target ROW as "j": every accumulator register is 32 consecutive rows of one column.
 // Workgroup: 512 threads = 8 waves, wave (wr, wc) owns rows [32 wr, +32) x columns [64 wc, +64) = two 32 x 32 tiles.
+// Staging (round 3, second version): the fp64 kernel's loop -- the operands of chunk i+1 travel by LDS-DMA while chunk i
+// is multiplied, one barrier per chunk -- with 32-deep chunks and 4-byte DMA lanes; wave w copies the k-lines w, w+8, w+16,
+// w+24 of both operands, two instructions per line (rows 0-63, 64-127).  Per piece a lane keeps, for each of the four
+// (operand, half) pairs, a source pointer and a line stride: inside the piece the panel entry and lda, outside it the
+// zero line and 0 -- one loop for whole and partial pieces.  The first version staged through registers (16-byte loads,
+// selects, ds_write) and kept the matrix pipe busy 65 % of the time on the big launches of 200^3 (PMC), the fp64 kernel 86 %.
 template <int KIND>
 __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task* __restrict__ tasks,
                                                     const Piece* __restrict__ pieces) {
@@ -46,45 +62,31 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  // loader: thread -> operand (A | B), four consecutive tile rows / columns 4 lq .. 4 lq + 3, k-lines lk + 8 h, h < 4:
-  // four 16-byte loads per thread and chunk (one wave-instruction moves 1 KiB)
-  const int lo = tid >> 8, lq = tid & 31, lk = (tid >> 5) & 7;
   f16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; t++)
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
   const int pend = tk.p0 + tk.pn;                // (scalar: the Task came through a scalar load)
-  int pi = tk.p0, kdone = 0;                     // piece / k-lines of it already fetched: wave-uniform
-  // 32-deep chunks: a 16-deep fp32 chunk is ~1.7 us of matrix work per workgroup pair, about one memory round trip --
-  // the fp64 kernel's one chunk of lead would leave it exposed, and a barrier per 16 k-lines costs twice what it costs
-  // there.
-  constexpr int NH = SKC / 8;
-  f4 stA[NH];
-  int actn = 0;                                  // tiles of this wave the chunk just fetched touches (bit t)
-  // next chunk of the piece list -> registers.  Every load is unconditional, from an address clamped to the piece (a
-  // quad that straddles a piece boundary brings up to three neighbouring panel entries along -- inside the arena or
-  // its padding --; rows and k-lines outside the piece become zero by a select): no exec-masked branch per load.
-  auto fetch = [&](f4 (&st)[NH]) -> bool {
-    if (pi >= pend) return false;
+  int pi = tk.p0, kdone = 0;                     // piece / k-lines of it already issued: wave-uniform
+  const float* zl = g_zero_line_s + lane;
+  // the lane's sources for the current piece: [operand][half]
+  const float* src[2][2];
+  int str[2][2];
+  int K = 0, actn = 0;
+  auto setup = [&]() {
     const Piece pc = pieces[__builtin_amdgcn_readfirstlane(pi)];
-    const int K = (int)pc.k;
+    K = (int)pc.k;
     const float* pa = arena_f(ar, pc.flags & 3) + pc.a_off;                  // (scalar address arithmetic)
     const float* pb = arena_f(ar, (pc.flags >> 2) & 3) + pc.b_off;
-    const float* base = lo ? pb : pa;
-    const int d0 = lo ? (int)pc.dc : (int)pc.dr, len = lo ? (int)pc.n : (int)pc.m;
-    const int r0 = 4 * lq - d0;                                              // piece row of the quad's first element
-    const float* src = base + min(max(r0, -3), len - 1);
-    const int sh0 = r0 - min(max(r0, -3), len - 1);                          // (0 unless the quad lies wholly outside)
 #pragma unroll
-    for (int h = 0; h < NH; h++) {
-      const int k = kdone + lk + 8 * h;
-      const f4u v = *(const f4u*)(src + (int64_t)min(k, K - 1) * pc.lda);
-      const bool kv = k < K && sh0 == 0;
-      st[h][0] = (kv && r0 >= 0 && r0 < len) ? v.x : 0.f;
-      st[h][1] = (kv && r0 + 1 >= 0 && r0 + 1 < len) ? v.y : 0.f;
-      st[h][2] = (kv && r0 + 2 >= 0 && r0 + 2 < len) ? v.z : 0.f;
-      st[h][3] = (kv && r0 + 3 >= 0 && r0 + 3 < len) ? v.w : 0.f;
+    for (int h = 0; h < 2; h++) {
+      const int ra = 64 * h + lane - (int)pc.dr, rb = 64 * h + lane - (int)pc.dc;
+      const bool va = ra >= 0 && ra < (int)pc.m, vb = rb >= 0 && rb < (int)pc.n;
+      src[0][h] = va ? pa + ra : zl;
+      str[0][h] = va ? pc.lda : 0;
+      src[1][h] = vb ? pb + rb : zl;
+      str[1][h] = vb ? pc.lda : 0;
     }
     const int re = (int)pc.dr + (int)pc.m, ce = (int)pc.dc + (int)pc.n;
     actn = 0;
@@ -92,18 +94,38 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
       if (64 * wc < ce && 64 * wc + 32 > (int)pc.dc) actn |= 1;
       if (64 * wc + 32 < ce && 64 * wc + 64 > (int)pc.dc) actn |= 2;
     }
+  };
+  // the next chunk of the piece list -> LDS buffer b (DMA); returns the tiles of this wave it touches
+  auto issue = [&](int b) -> int {
+    if (kdone == 0) setup();
+#pragma unroll
+    for (int q = 0; q < SKC / 8; q++) {
+      const int line = wave + 8 * q, k = kdone + line;
+      float* dA = sh[b][0] + line * SLDF;
+      float* dB = sh[b][1] + line * SLDF;
+      if (k < K) {                               // (wave-uniform: a scalar branch)
+        PASTIX_AMD_GLDS4(src[0][0] + (int64_t)k * str[0][0], dA);
+        PASTIX_AMD_GLDS4(src[0][1] + (int64_t)k * str[0][1], dA + 64);
+        PASTIX_AMD_GLDS4(src[1][0] + (int64_t)k * str[1][0], dB);
+        PASTIX_AMD_GLDS4(src[1][1] + (int64_t)k * str[1][1], dB + 64);
+      } else {
+        PASTIX_AMD_GLDS4(zl, dA);
+        PASTIX_AMD_GLDS4(zl, dA + 64);
+        PASTIX_AMD_GLDS4(zl, dB);
+        PASTIX_AMD_GLDS4(zl, dB + 64);
+      }
+    }
+    const int a = actn;
     kdone += SKC;
     if (kdone >= K) { kdone = 0; pi++; }
-    return true;
-  };
-  auto stash = [&](int buf, const f4 (&st)[NH]) {
-#pragma unroll
-    for (int h = 0; h < NH; h++) *(f4*)(sh[buf][lo] + (lk + 8 * h) * SLDF + 4 * lq) = st[h];
+    return a;
   };
   auto compute = [&](int buf, int act) {
     const float* sA = sh[buf][0] + lh * SLDF + 32 * wr + l31;
     const float* sB = sh[buf][1] + lh * SLDF + 64 * wc + l31;
     if (act == 3) {
+      // (the compiler's own schedule -- the next k-pair's reads issued behind this pair's MFMAs -- measured faster than
+      // operands pinned a quarter of the chunk ahead: 97.8 against 93.7 TFLOP/s at 200^3)
 #pragma unroll
       for (int s = 0; s < SKC / 2; s++) {
         const float bm = sA[2 * s * SLDF];
@@ -120,20 +142,20 @@ __global__ __launch_bounds__(512, 4) void k_update_s(const Arenas ar, const Task
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sB[2 * s * SLDF + 32], sA[2 * s * SLDF], acc[1], 0, 0, 0);
     }
   };
-  bool more = fetch(stA);
-  int actc = actn;
-  if (more) stash(0, stA);
-  __syncthreads();
-  int buf = 0;
-  while (more) {
-    const int act = __builtin_amdgcn_readfirstlane(actc);
-    more = fetch(stA);                           // global loads of the next chunk fly under this chunk's MFMAs
-    const int nact = actn;
-    compute(buf, act);
-    if (more) stash(buf ^ 1, stA);
-    actc = nact;
-    __syncthreads();
-    buf ^= 1;
+  if (pi < pend) {
+    int actc = issue(0);
+    __syncthreads();                             // (vmcnt(0): chunk 0 has landed)
+    int buf = 0;
+    while (true) {
+      const bool more = pi < pend;
+      int nact = 0;
+      if (more) nact = issue(buf ^ 1);           // the next chunk's DMA flies under this chunk's MFMAs
+      compute(buf, __builtin_amdgcn_readfirstlane(actc));
+      __syncthreads();                           // the next chunk has landed, this buffer is fully read
+      if (!more) break;
+      actc = nact;
+      buf ^= 1;
+    }
   }
   // C -= acc: the 32 loads of a lane first (clamped addresses), then the stores
   float* C = arena_f(ar, tk.flags & 3) + tk.c_off;
