@@ -72,34 +72,46 @@ inline void advise_huge(void* p, size_t bytes) {
 }
 template <class T>
 T* huge_alloc(size_t n) {
-  const size_t H = (size_t)2 << 20, bytes = (std::max<size_t>(n, 1) * sizeof(T) + H - 1) / H * H;
+  const size_t H = (size_t)2 << 20, raw = std::max<size_t>(n, 1) * sizeof(T);
+  if (raw < H) {                                   // (small: an ordinary allocation)
+    void* p = malloc(raw);
+    if (!p) throw std::bad_alloc();
+    return (T*)p;
+  }
+  const size_t bytes = (raw + H - 1) / H * H;
   void* p = aligned_alloc(H, bytes);
   if (!p) throw std::bad_alloc();
   advise_huge(p, bytes);
   return (T*)p;
 }
 struct FreeDeleter { void operator()(void* p) const { free(p); } };
-// append-only list in blocks of 2^20 elements: no reallocation copies, no estimate of the final size
+// append-only list in blocks (4096 elements first, doubling up to 2^20): no reallocation copies, no estimate of the final
+// size, and a plan of a few hundred pieces does not map megabytes per host thread
 template <class T>
 struct BlockList {
-  static constexpr size_t BL = (size_t)1 << 20;
+  static constexpr size_t BMAX = (size_t)1 << 20;
   std::vector<std::unique_ptr<T, FreeDeleter>> blk;
-  size_t n = 0;
+  std::vector<size_t> cap;
+  size_t n = 0, used = 0;                          // elements in all / in the last block
   void push_back(const T& v) {
-    if ((n & (BL - 1)) == 0) blk.emplace_back(huge_alloc<T>(BL));
-    blk.back().get()[n & (BL - 1)] = v;
+    if (blk.empty() || used == cap.back()) {
+      const size_t c = blk.empty() ? 4096 : std::min(BMAX, cap.back() * 2);
+      blk.emplace_back(huge_alloc<T>(c));
+      cap.push_back(c);
+      used = 0;
+    }
+    blk.back().get()[used++] = v;
     n++;
   }
   size_t size() const { return n; }
-  const T& operator[](size_t i) const { return blk[i >> 20].get()[i & (BL - 1)]; }
   template <class F> void for_each(F&& f) const {
     for (size_t b = 0; b < blk.size(); b++) {
       const T* q = blk[b].get();
-      const size_t m = std::min(BL, n - b * BL);
+      const size_t m = b + 1 < blk.size() ? cap[b] : used;
       for (size_t i = 0; i < m; i++) f(q[i]);
     }
   }
-  void release() { blk.clear(); blk.shrink_to_fit(); n = 0; }
+  void release() { blk.clear(); blk.shrink_to_fit(); cap.clear(); n = used = 0; }
 };
 }  // namespace
 
@@ -519,8 +531,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     std::vector<int64_t> splitter;                 // first tile of bins 1 .. : ascending, distinct
     {
       std::vector<int64_t> sample;
-      for (int t = 0; t < nthr; t++)
-        for (size_t i = 0; i < traw[(size_t)t].size(); i += 61) sample.push_back(traw[(size_t)t][i].tile);
+      for (int t = 0; t < nthr; t++) {
+        size_t i = 0;
+        traw[(size_t)t].for_each([&](const RawPiece& r) { if (i++ % 61 == 0) sample.push_back(r.tile); });
+      }
       std::sort(sample.begin(), sample.end());
       for (int64_t b2 = 1; b2 < NB && !sample.empty(); b2++) {
         const int64_t v = sample[(size_t)((__int128)sample.size() * b2 / NB)];
