@@ -62,3 +62,39 @@ def test_config5_elasticity_40_zldlt():
     n, cp, r, v, _ = sy.elasticity_3d(N)
     perm, _ = sy.order_grid_dof(N, 3)
     _run(n, cp, r, v, perm, 1, COMPLEXDOUBLE, 1e-12, False)
+
+
+@pytest.mark.parametrize("facto", [0, 1, 2])
+def test_fused_thin_level_solve_agrees_with_level_kernels_and_repeats(facto):
+    """One right-hand side takes the runs of thin levels in one launch per sweep (cblks synchronised by flags in memory,
+    kernels.hip k_solve_thin_*); several right-hand sides take a launch per level with the triangular kernels.  Both must
+    give the same solution at a size with more than a hundred levels (56^3), the flags and tickets must come back clean for
+    every further solve, and a refactorization must give the solve new inverses."""
+    N = 56
+    full = facto == 2
+    n, cp, r, v = sy.laplacian_3d(N, full=full)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    if not full:
+        A = A + sp.tril(A, -1).T
+    rng = np.random.default_rng(11)
+    b = rng.random(n)
+    bp = np.empty(n)
+    bp[s["perm"]] = b
+    with Plan(s["cblk4"], s["blok4"], facto) as p:
+        p.fill_csc(0 if full else 1, n, cp, r, v, s["perm"])
+        p.factorize(1e-14)
+        x1 = p.solve(bp.copy())
+        X2 = p.solve(np.stack([bp, 2.0 * bp], axis=1))
+        scale = np.abs(x1).max()
+        assert np.abs(X2[:, 0] - x1).max() <= 1e-12 * scale
+        assert np.abs(X2[:, 1] - 2.0 * x1).max() <= 2e-12 * scale
+        for _ in range(6):
+            assert np.abs(p.solve(bp.copy()) - x1).max() <= 1e-12 * scale
+        assert np.linalg.norm(A @ x1[s["perm"]] - b) / np.linalg.norm(b) <= 1e-10
+        # other values on the same structure: the inverses of the diagonal bloks belong to a factorization
+        p.fill_csc(0 if full else 1, n, cp, r, 3.0 * v, s["perm"])
+        p.factorize(1e-14)
+        x3 = p.solve(bp.copy())
+        assert np.abs(3.0 * x3 - x1).max() <= 1e-12 * scale
