@@ -1276,6 +1276,7 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     p->lvl_chunk_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_chunkB_ptr.assign((size_t)H.nlevels + 1, 0);
     p->lvl_maxw.assign((size_t)H.nlevels, 1);
+    p->lvl_nwide.assign((size_t)H.nlevels, 0);
     std::vector<int64_t> roff((size_t)nown + 1, 0);          // in level order, like st
     for (int64_t q = 0; q < nown; q++) roff[q + 1] = roff[q] + H.cblk[H.lvl_cblk[q]].stride;
     // panel rows per chunk: 64 forward (many workgroups on the tall top panels), 256 backward (one butterfly and
@@ -1320,6 +1321,8 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
                                    (int32_t)H.cblk[k + 1].bloknum, w, 0, roff[q], tix, nb, 0, 0, 0, 0});
         }
         p->lvl_maxw[l] = std::max(p->lvl_maxw[l], (int)w);
+        // (the level's cblks are listed widest first, plan.cpp: a prefix)
+        if (w > 64 && q == H.lvl_cblk_ptr[l] + p->lvl_nwide[l]) p->lvl_nwide[l]++;
         for (int32_t r = w; r < sd; r += CH) {
           const int32_t n = std::min(CH, sd - r);
           ch.push_back(SolveChunk{H.poff[k], sd, w, (int32_t)H.cblk[k].fcolnum,
@@ -1475,7 +1478,7 @@ void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) 
     // (single-precision factors: float panels under double vectors, one right-hand side per pass)
     for (int k = 0; k < nr; k++)
       launch_solve_level_s(p->stream, fwd, H.factotype, (const float*)p->dL, (const float*)p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                           H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                           H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->lvl_nwide[(size_t)l],
                            (fwd ? p->dChunk + p->lvl_chunk_ptr[l] : p->dChunkB + p->lvl_chunkB_ptr[l]),
                            fwd ? p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l] : p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l],
                            p->dRidx, dx + (int64_t)k * H.ncol, p->lvl_maxw[l]);
@@ -1483,11 +1486,11 @@ void pai_solve_level(pastix_amd_plan_t* p, bool fwd, int l, double* dx, int nr) 
   }
   if (fwd)
     launch_solve_level(p->stream, true, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunk + p->lvl_chunk_ptr[l],
+                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->lvl_nwide[(size_t)l], p->dChunk + p->lvl_chunk_ptr[l],
                        p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
   else
     launch_solve_level(p->stream, false, H.factotype, p->dL, p->dU, p->dSolve + H.lvl_cblk_ptr[l],
-                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->dChunkB + p->lvl_chunkB_ptr[l],
+                       H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l], p->lvl_nwide[(size_t)l], p->dChunkB + p->lvl_chunkB_ptr[l],
                        p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok, p->dRidx, dx, H.ncol, nr, p->maxw, p->lvl_maxw[l]);
 }
 void pai_solve_dscale(pastix_amd_plan_t* p, double* dx, int nr) {     // LDLt: x <- D^-1 x on the cblks factorized here

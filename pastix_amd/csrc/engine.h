@@ -46,7 +46,7 @@ void launch_trsm_ldlt(hipStream_t s, double* L, double* U, const TrsmTask* tasks
 void launch_trsm_lu(hipStream_t s, double* L, double* U, const TrsmTask* tasks, int64_t n, const double* dinv,
                     int maxw);
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
-                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const SolveTask* tasks, int64_t ntask, int64_t nwide, const SolveChunk* chunks, int64_t nchunk,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw);
 // kernels_f32.hip: the single-precision engine (arenas of floats; Arenas::p reinterpreted)
 void launch_update_s(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks, bool urgent);
@@ -62,7 +62,8 @@ void launch_solve_thin(hipStream_t s, bool fwd, const void* P, bool f32, const S
                        const int32_t* ridx, const double* inv, int* ticket, const int32_t* tgt, const int32_t* expect, int* cnt,
                        int* flag, int* stuck, double* x);
 void launch_solve_level_s(hipStream_t s, bool fwd, int factotype, const float* L, const float* U, const SolveTask* tasks,
-                          int64_t ntask, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x, int lvlw);
+                          int64_t ntask, int64_t nwide, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x,
+                          int lvlw);
 void launch_solve_dscale_s(hipStream_t s, const float* L, const SolveTask* tasks, int64_t ntask, double* x);
 void launch_solve_rowidx(hipStream_t s, const SolveTask* tasks, int64_t ntask, const int64_t* roff,
                          const DevBlok* bl, int32_t* ridx);
@@ -141,6 +142,7 @@ struct pastix_amd_plan_s {
   std::vector<int> lvl_maxw;            // widest cblk of every level (LDS size of the solve's L^T diagonal kernel)
   // thin levels (kernels.hip, k_solve_inv): explicit inverses of their diagonal bloks, one launch per level and sweep
   std::vector<uint8_t> lvl_thin;        // [nlevels]
+  std::vector<int64_t> lvl_nwide;       // [nlevels] cblks of the level wider than 64 columns (listed first)
   // a run = consecutive thin levels, one launch per sweep: [nlevels] workgroups of the run that STARTS at this level in
   // the sweep's direction (0: not a start), and where its list begins in dThinF / dThinB (dThinB: levels descending)
   std::vector<int64_t> runF_n, runF_at, runB_n, runB_at;

@@ -927,6 +927,85 @@ __device__ __forceinline__ void inv_apply(const double* __restrict__ M, const do
   __syncthreads();
 }
 
+// The diagonal-blok solve of the levels below the thin ones (tens of thousands of cblks per level), one WAVE per cblk, four
+// per workgroup: lane = row, the row's entries in registers (coalesced column reads),
+// x on the lanes, the pivot travels by v_readlane.  MODE 0: forward, lower (unit: unit diagonal).  MODE 2: backward,
+// upper (LU).  MODE 1: backward with L^T (LLt / LDLt) -- the lane that holds row j holds L[j][c] for every c < j, so
+// x_c = (b_c - sum_{j > c} L[j][c] x_j) / d_c is a sum over the lanes: a wave reduction per column instead of a
+// transposed copy of the blok.  k_solve_diag_q1 (four waves and an LDS hand-over per cblk) took 0.75 / 1.75 ms per
+// sweep for the 42 k leaf cblks of 200^3, whose diagonal bloks are 0.76 GB.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+// RP = rows per lane: 1 for cblks of at most 64 columns, 2 up to 128 (rows lane and lane + 64).
+template <int MODE, int RP, class T>
+__global__ __launch_bounds__(256) void k_solve_diag_n64(const T* __restrict__ L, const SolveTask* __restrict__ tasks,
+                                                       int64_t ntask, double* __restrict__ x, int unit) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ti = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ti >= ntask) return;
+  const SolveTask tk = tasks[ti];
+  const T* A = L + tk.off;
+  const int64_t ld = tk.stride;
+  const int w = tk.width;
+  int64_t rc[RP];
+  double rinv[RP], xr[RP];
+#pragma unroll
+  for (int j = 0; j < RP; j++) {
+    rc[j] = min(lane + 64 * j, w - 1);
+    rinv[j] = unit ? 1.0 : 1.0 / (double)A[rc[j] + rc[j] * ld];
+    xr[j] = lane + 64 * j < w ? x[tk.fcol + lane + 64 * j] : 0.0;
+  }
+  // (32 columns at a time: 64 registers per row instead of 128 -- the waves of a SIMD hide the later round trips)
+#pragma unroll
+  for (int h = 0; h < 2 * RP; h++) {
+    if (32 * h < w) {                                // (wave-uniform)
+      double a[RP][32];
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        const int g = 32 * h + i;
+        const int64_t c = min(max(MODE == 0 ? g : w - 1 - g, 0), w - 1);
+#pragma unroll
+        for (int j = 0; j < RP; j++) a[j][i] = A[rc[j] + c * ld];
+      }
+#pragma unroll
+      for (int i = 0; i < 32; i++) {
+        const int g = 32 * h + i;
+        if (g < w) {                                 // (wave-uniform)
+          const int c = MODE == 0 ? g : w - 1 - g;
+          const int slot = c >> 6, src = c & 63;
+          if (MODE == 1) {
+            double pr = 0.0;
+#pragma unroll
+            for (int j = 0; j < RP; j++) {
+              const int r = lane + 64 * j;
+              pr += (r > c && r < w) ? a[j][i] * xr[j] : 0.0;
+            }
+            const double sm = wave_sum_f64(pr);
+#pragma unroll
+            for (int j = 0; j < RP; j++)
+              if (lane + 64 * j == c) xr[j] = (xr[j] - sm) * rinv[j];
+          } else {
+            const double v = (RP == 2 && slot) ? xr[RP - 1] * rinv[RP - 1] : xr[0] * rinv[0];
+            const double xc = readlane_f64(v, src);
+#pragma unroll
+            for (int j = 0; j < RP; j++) {
+              const int r = lane + 64 * j;
+              const bool upd = MODE == 0 ? (r > c && r < w) : (r < c);
+              xr[j] = r == c ? xc : upd ? __builtin_fma(-a[j][i], xc, xr[j]) : xr[j];
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < RP; j++)
+    if (lane + 64 * j < w) x[tk.fcol + lane + 64 * j] = xr[j];
+}
+
 // ---- runs of consecutive thin levels in ONE launch ------------------------------------------------------------------
 // The workgroups of a run are listed level after level in sweep order and synchronise cblk by cblk.  Forward: the
 // workgroups of cblk k start on b_k when the last chunk that contributes to it inside the run has counted itself
@@ -1195,16 +1274,30 @@ static bool dyn_lds_attr_once(const void* fn, int bytes) {
 // fwd: L (unit for LDLt/LU).  bwd: LLt/LDLt gather through the L arena, LU through the U arena (U^T panels).
 // (cblks are at most 128 columns wide: wider ones are re-cut before planning, api.cpp build_split)
 // T: the panels' element type -- double, or float for the factors of the single-precision engine (the vectors stay double)
+// nwide: the first nwide tasks of the level are wider than 64 columns (the level's cblks are listed widest first)
 template <int MODE, int NR, class T>
-static void launch_solve_diag(hipStream_t s, const T* L, const SolveTask* tasks, int64_t ntask, double* x,
+static void launch_solve_diag(hipStream_t s, const T* L, const SolveTask* tasks, int64_t ntask, int64_t nwide, double* x,
                               int64_t ldx, int unit, int lvlw) {
   // MODE 1 turns the blok through dynamic LDS sized for the widest cblk of the level
   const size_t smem = MODE == 1 ? (size_t)lvlw * (lvlw | 1) * sizeof(double) : 0;
   if constexpr (NR == 1 || !std::is_same<T, double>::value) {        // one right-hand side: the copy without the systolic loop
-    if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE, T>, 128 * 129 * 8)) return;
-    for (int k = 0; k < NR; k++)
-      hipLaunchKernelGGL((k_solve_diag_q1<MODE, T>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x + k * ldx, unit);
+    nwide = std::max<int64_t>(0, std::min(nwide, ntask));
+    // cblks wider than 64 columns: a wave per cblk where the level has enough of them to fill the chip that way (the leaf
+    // levels: 11 k at 200^3), else four waves per cblk (a 128-step chain on one wave is the slower one when it is exposed)
+    const bool wide_by_wave = nwide >= 2048;
+    if (MODE == 1 && nwide > 0 && !wide_by_wave && !dyn_lds_attr_once((const void*)k_solve_diag_q1<MODE, T>, 128 * 129 * 8)) return;
+    for (int k = 0; k < NR; k++) {
+      if (nwide > 0 && wide_by_wave)
+        hipLaunchKernelGGL((k_solve_diag_n64<MODE, 2, T>), dim3((unsigned)((nwide + 3) / 4)), dim3(256), 0, s, L, tasks, nwide,
+                           x + k * ldx, unit);
+      else if (nwide > 0)
+        hipLaunchKernelGGL((k_solve_diag_q1<MODE, T>), dim3((unsigned)nwide), dim3(256), smem, s, L, tasks, x + k * ldx, unit);
+      if (ntask > nwide)
+        hipLaunchKernelGGL((k_solve_diag_n64<MODE, 1, T>), dim3((unsigned)((ntask - nwide + 3) / 4)), dim3(256), 0, s, L,
+                           tasks + nwide, ntask - nwide, x + k * ldx, unit);
+    }
   } else {
+    (void)nwide;
     if (MODE == 1 && !dyn_lds_attr_once((const void*)k_solve_diag_q<MODE, NR>, 128 * 129 * 8)) return;
     hipLaunchKernelGGL((k_solve_diag_q<MODE, NR>), dim3((unsigned)ntask), dim3(256), smem, s, L, tasks, x, ldx, unit);
   }
@@ -1213,36 +1306,37 @@ static void launch_solve_diag(hipStream_t s, const T* L, const SolveTask* tasks,
 // chunks: the 64-row list forward, the 256-row list backward.
 template <int NR, class T>
 static void solve_level(hipStream_t s, bool fwd, int factotype, const T* L, const T* U,
-                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const SolveTask* tasks, int64_t ntask, int64_t nwide, const SolveChunk* chunks, int64_t nchunk,
                         const int32_t* ridx, double* x, int64_t ldx, int lvlw) {
   const int unit = factotype != PASTIX_AMD_FACT_LLT;
   const dim3 gc((unsigned)nchunk);
   if (fwd) {
-    if (ntask > 0) launch_solve_diag<0, NR, T>(s, L, tasks, ntask, x, ldx, unit, lvlw);
+    if (ntask > 0) launch_solve_diag<0, NR, T>(s, L, tasks, ntask, nwide, x, ldx, unit, lvlw);
     if (nchunk > 0) hipLaunchKernelGGL((k_solve_off_fwd64<NR, T>), gc, dim3(256), 0, s, L, chunks, ridx, x, ldx);
   } else {
     const T* B = factotype == PASTIX_AMD_FACT_LU ? U : L;
     const int mode = factotype == PASTIX_AMD_FACT_LLT ? 0 : factotype == PASTIX_AMD_FACT_LDLT ? 1 : 2;
     if (nchunk > 0) hipLaunchKernelGGL((k_solve_off_bwd64<NR, T>), gc, dim3(256), 0, s, B, chunks, ridx, x, ldx);
     if (ntask > 0) {
-      if (mode == 2) launch_solve_diag<2, NR, T>(s, L, tasks, ntask, x, ldx, 0, lvlw);
-      else launch_solve_diag<1, NR, T>(s, L, tasks, ntask, x, ldx, mode == 1, lvlw);
+      if (mode == 2) launch_solve_diag<2, NR, T>(s, L, tasks, ntask, nwide, x, ldx, 0, lvlw);
+      else launch_solve_diag<1, NR, T>(s, L, tasks, ntask, nwide, x, ldx, mode == 1, lvlw);
     }
   }
 }
 void launch_solve_level(hipStream_t s, bool fwd, int factotype, const double* L, const double* U,
-                        const SolveTask* tasks, int64_t ntask, const SolveChunk* chunks, int64_t nchunk,
+                        const SolveTask* tasks, int64_t ntask, int64_t nwide, const SolveChunk* chunks, int64_t nchunk,
                         const DevBlok* bl, const int32_t* ridx, double* x, int64_t ldx, int nr, int maxw, int lvlw) {
   (void)bl;
   (void)maxw;
-  if (nr == 4) solve_level<4, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
-  else if (nr == 2) solve_level<2, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
-  else solve_level<1, double>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, ldx, lvlw);
+  if (nr == 4) solve_level<4, double>(s, fwd, factotype, L, U, tasks, ntask, nwide, chunks, nchunk, ridx, x, ldx, lvlw);
+  else if (nr == 2) solve_level<2, double>(s, fwd, factotype, L, U, tasks, ntask, nwide, chunks, nchunk, ridx, x, ldx, lvlw);
+  else solve_level<1, double>(s, fwd, factotype, L, U, tasks, ntask, nwide, chunks, nchunk, ridx, x, ldx, lvlw);
 }
 // the factors of the single-precision engine: float panels, double vectors, one right-hand side per call
 void launch_solve_level_s(hipStream_t s, bool fwd, int factotype, const float* L, const float* U, const SolveTask* tasks,
-                          int64_t ntask, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x, int lvlw) {
-  solve_level<1, float>(s, fwd, factotype, L, U, tasks, ntask, chunks, nchunk, ridx, x, 0, lvlw);
+                          int64_t ntask, int64_t nwide, const SolveChunk* chunks, int64_t nchunk, const int32_t* ridx, double* x,
+                          int lvlw) {
+  solve_level<1, float>(s, fwd, factotype, L, U, tasks, ntask, nwide, chunks, nchunk, ridx, x, 0, lvlw);
 }
 
 void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks, int64_t ntask, double* x) {
