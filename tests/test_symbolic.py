@@ -196,14 +196,19 @@ def _layout_hash(s):
     return m.hexdigest()[:16]
 
 
-@pytest.mark.parametrize("pct,mw,want", [(5, 0, "2c7f09b27d21bd9d"), (20, 64, "9c42e732e5df1406"), (1, 64, "f1195b34094cd831")])
-def test_amalgamation_rounds_reproduce_single_heap_layout(pct, mw, want, monkeypatch):
+@pytest.mark.parametrize("pct,mw,schur,want", [(5, 0, 0, "2c7f09b27d21bd9d"), (20, 64, 0, "9c42e732e5df1406"),
+                                               (1, 64, 0, "f1195b34094cd831"), (12, 0, 0, "e5a361a50d5575b2"),
+                                               (5, 96, 0, "b6cbc6a6277720d4"), (5, 0, 3600, "ae135905ac8a2557"),
+                                               (2, 0, 3600, "d1134bcf7bb7e2bc")])
+def test_amalgamation_rounds_reproduce_single_heap_layout(pct, mw, schur, want, monkeypatch):
     """The amalgamation finds the cheap merges of a round component by component on host threads (symbolic.cpp); the
     layout must be the one the single global heap produced (hashes recorded from that implementation on the 60^3
-    Laplacian, 140 k fundamental supernodes: the rounds are active), whatever the number of threads."""
+    Laplacian, 140 k fundamental supernodes: the rounds are active; fill budgets, a merge-width bound, a Schur block),
+    whatever the number of threads.  (Both implementations also agreed on 80^3, the elasticity pattern, block sizes 64 /
+    blend's rule and the graph ordering when they were compared side by side.)"""
     n, cp, r, v = sy.laplacian_3d(60)
     perm, _ = sy.order_grid(60, 60, 60)
     for thr in ("1", "3", "8"):
         monkeypatch.setenv("PASTIX_AMD_PLAN_THREADS", thr)
-        s = sy.symbolic(n, cp, r, perm, amalgamation_pct=pct, max_merge_width=mw)
+        s = sy.symbolic(n, cp, r, perm, amalgamation_pct=pct, max_merge_width=mw, schur_n=schur)
         assert _layout_hash(s) == want, (thr, len(s["cblk4"]))
