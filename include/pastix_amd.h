@@ -81,7 +81,13 @@ typedef struct pastix_amd_options_s {
                             into 64x64 quadrant tasks for k_update_small (plan.cpp); <= 0 = default (1024) */
   int quadrant_fill_pct; /* ... a task qualifies when its pieces fill less than this many percent of the 128x128x16
                             chunks k_update would run for them; <= 0 = default (25) */
-  int reserved[9];
+  int run_schedule;      /* the thin levels at the top of the elimination tree (at most run_max_cblks cblks each) as ONE
+                            dependency-driven launch -- tasks gated by tile counters, the way the reference's tasks wait
+                            for TASK_CTRBCNT (sopalin3d.c:790-1025) -- instead of launches per level: 0 = default (on
+                            where it is built: real double, one GPU), 1 = on, -1 = off (the level-by-level schedule) */
+  int run_max_cblks;     /* <= 0 = default (32) */
+  int run_t_workers;     /* resident workgroups of the run's panel kernel that solve panel rows; <= 0 = default (48) */
+  int reserved[6];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */
@@ -221,6 +227,12 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, co
                             const int32_t *owner, int32_t myrank, pastix_amd_int_t maxlevels, double *slot_flops,
                             double *slot_maxwork, pastix_amd_int_t *slot_tasks, double *level_panel_flops,
                             pastix_amd_int_t *nlevels, double *slot_urgent_flops /* may be NULL */);
+/* host-only: the run schedule of a layout (opts.run_schedule; the thin levels at the top of the tree in one dependency-driven
+ * launch) and its replay check.  info[0..7] = first level of the run (-1: none), levels, update tasks in the run, source-tile
+ * waits, resident workgroups for diagonal bloks, panel-solve tasks, update flops inside the run, result of the replay (0 =
+ * every task can run when the tickets are served one at a time in order: the schedule cannot deadlock) */
+int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
+                             pastix_amd_int_t *info);
 /* ---- multi-GPU driver: asynchronous fan-in over RCCL point-to-point (csrc/dist.cpp) ------------------------------
  * One process per GPU.  Every rank: plan_create_dist (own arena), fill_csc, then ONCE pastix_amd_dist_attach_rccl,
  * then pastix_amd_factorize_dist as often as needed (pastix_amd_refill in between).  The reference's counterpart is the

@@ -32,7 +32,8 @@ class Layout(ctypes.Structure):
 class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
                 ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("quadrant_min", ctypes.c_int),
-                ("quadrant_fill_pct", ctypes.c_int), ("reserved", ctypes.c_int * 9)]
+                ("quadrant_fill_pct", ctypes.c_int), ("run_schedule", ctypes.c_int), ("run_max_cblks", ctypes.c_int),
+                ("run_t_workers", ctypes.c_int), ("reserved", ctypes.c_int * 6)]
 
 
 class Stats(ctypes.Structure):
@@ -74,7 +75,7 @@ EXPORTS = [
     "pastix_amd_device_arenas", "pastix_amd_fact_flops", "pastix_amd_version",
     "pastix_amd_plan_create_dist", "pastix_amd_plan_layout_info", "pastix_amd_plan_set_arena", "pastix_amd_plan_arena_info", "pastix_amd_fill_fake",
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
-    "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add", "pastix_amd_download_cblk",
+    "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_plan_run_info", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add", "pastix_amd_download_cblk",
     "pastix_amd_dist_unique_id", "pastix_amd_dist_selftest_rccl", "pastix_amd_dist_attach_rccl", "pastix_amd_dist_attach_local", "pastix_amd_dist_info",
     "pastix_amd_factorize_dist", "pastix_amd_factorize_dist_local", "pastix_amd_solve_dist", "pastix_amd_solve_dist_local", "pastix_amd_dist_schedule",
 ]

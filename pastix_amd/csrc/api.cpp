@@ -257,6 +257,36 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     p->evB.resize((size_t)H.nlevels);
     for (auto& e : p->evP) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : p->evB) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (H.run_L0 >= 0 && !H.run_tasks.empty()) {
+      // the run schedule: its tables, its flags, two more streams for the resident panel kernels
+      if ((r = to_device(&p->dRunTasks, H.run_tasks))) return r;
+      if ((r = to_device(&p->dRunInfo, H.run_info))) return r;
+      if ((r = to_device(&p->dRunWaits, H.run_waits))) return r;
+      if ((r = to_device(&p->dRunD, H.run_d))) return r;
+      if ((r = to_device(&p->dRunDptr, H.run_dptr))) return r;
+      if ((r = to_device(&p->dRunT, H.run_t))) return r;
+      const size_t nseq = (size_t)H.ntile * (size_t)H.nplanes, nfin = (size_t)H.ntile, ndf = (size_t)std::max<int64_t>(H.run_ndflag, 1);
+      p->nRunFlags = nseq + nfin + ndf + RUN_MISC_INTS + 64;
+      HIPCHK(hipMalloc((void**)&p->dRunFlags, p->nRunFlags * sizeof(int32_t)));
+      p->runctl.tile_seq = p->dRunFlags;
+      p->runctl.tile_fin = p->dRunFlags + nseq;
+      p->runctl.dflag = p->runctl.tile_fin + nfin;
+      p->runctl.misc = p->dRunFlags + ((nseq + nfin + ndf + 63) / 64) * 64;
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIPCHK(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi));
+      HIPCHK(hipStreamCreateWithPriority(&p->stream4, hipStreamNonBlocking, hi));
+      HIPCHK(hipHostMalloc((void**)&p->hResident, 64, hipHostMallocCoherent | hipHostMallocMapped));
+      *p->hResident = 0;
+      HIPCHK(hipEventCreateWithFlags(&p->evZ, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&p->evRun1, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&p->evS3, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&p->evS4, hipEventDisableTiming));
+      const int64_t nt = (int64_t)H.run_t.size();
+      const int gtw = H.opts.run_t_workers > 0 ? H.opts.run_t_workers : 48;
+      p->run_gt = (int)std::min<int64_t>(nt, gtw);
+      p->run_ready = true;
+    }
     return 0;
   };
   CHK(body());
@@ -319,11 +349,14 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   // the piece/task tables now live on the device; keep only what the host driver reads.  (Returning several GB to the
   // system takes 0.4 s at 200^3: a thread of its own does it.)
   {
-    struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks; };
+    struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks, rtasks; std::vector<RunInfo> rinfo; std::vector<int32_t> rwaits; };
     Junk* junk = new (std::nothrow) Junk();
     if (junk) {
       junk->pieces.swap(H.pieces);
       junk->tasks.swap(H.tasks);
+      junk->rtasks.swap(H.run_tasks);
+      junk->rinfo.swap(H.run_info);
+      junk->rwaits.swap(H.run_waits);
       try { std::thread([junk] { delete junk; }).detach(); } catch (const std::system_error&) { delete junk; }
     } else {
       decltype(H.pieces)().swap(H.pieces);
@@ -377,6 +410,31 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
       }
       level_panel_flops[l] = f;
     }
+  }
+  return PASTIX_AMD_OK;
+}
+
+// Host-only (tests, capacity planning): the run schedule of a layout (plan.h RunInfo) and its replay check.
+// info[0..7] = first level of the run (-1: none), levels, update tasks in the run, source-tile waits, diagonal workers,
+// panel-solve tasks, update flops inside the run (rounded), result of run_verify (0 = every ticket can run).
+int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, const pastix_amd_options_t* opts,
+                             pastix_amd_int_t* info) {
+  if (!layout || !info) return PASTIX_AMD_ERR_BADPARAMETER;
+  Plan P;
+  int rc;
+  try {
+    rc = build_plan(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, nullptr, 0, P);
+    if (rc) return rc;
+    info[0] = P.run_L0;
+    info[1] = P.nlevels;
+    info[2] = (pastix_amd_int_t)P.run_tasks.size();
+    info[3] = (pastix_amd_int_t)P.run_waits.size();
+    info[4] = P.run_gd;
+    info[5] = (pastix_amd_int_t)P.run_t.size();
+    info[6] = (pastix_amd_int_t)P.run_flops;
+    info[7] = run_verify(P, P.opts.run_t_workers > 0 ? P.opts.run_t_workers : 48);
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
   }
   return PASTIX_AMD_OK;
 }
@@ -468,6 +526,11 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
+  for (hipStream_t st : {p->stream3, p->stream4}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (hipEvent_t e : {p->evZ, p->evRun1, p->evS3, p->evS4}) if (e) (void)hipEventDestroy(e);
+  (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunWaits); (void)hipFree(p->dRunD);
+  (void)hipFree(p->dRunDptr); (void)hipFree(p->dRunT); (void)hipFree(p->dRunFlags);
+  if (p->hResident) (void)hipHostFree(p->hResident);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
   if (p->stream && p->own_stream) (void)hipStreamDestroy(p->stream);
@@ -1004,6 +1067,7 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
   p->nupd_run = 0;
+  p->run_used = false;
   p->launch_events = true;
   p->nupdB_run = 0;
   p->crit_run = critere;
@@ -1133,7 +1197,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   }
   if (p->nupdB_run > 0 && H.opts.verbose >= 2 && p->overlap_mode == 1 && !H.slot_mode_flops.empty()) {
     int i = 0;
-    for (int l = 0; l < H.nlevels && i < p->nupdB_run; l++) {
+    for (int l = 0; l < (p->run_used ? H.run_L0 : H.nlevels) && i < p->nupdB_run; l++) {
       const int64_t tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
       if (t1 <= tu) continue;
       float m2 = 0;
@@ -1186,8 +1250,30 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   p->stats.nupdate_launches = two_kernels ? p->nupdB_run : p->nupd_run + p->nupdB_run;
   p->stats.nurgent_launches = two_kernels ? p->nupd_run : 0;
   p->stats.urgent_flops = two_kernels ? p->host.urgent_flops : 0.0;
+  if (p->run_used) {
+    // the run's update launch carries the urgent tasks of its levels too: update_time_sum = the bulk launches below the
+    // run + the run launch, carrying update_flops - urgent_flops with urgent_flops = those of the levels below the run
+    double uf = 0;
+    for (int l = 0; l < H.run_L0; l++) uf += H.slot_urgent_flops[(size_t)l];
+    p->stats.urgent_flops = uf;
+    if (H.opts.verbose >= 2 && p->nupdB_run > 0) {
+      float m2 = 0;
+      HIPCHK(hipEventElapsedTime(&m2, p->evT[2 * (p->nupdB_run - 1)], p->evT[2 * (p->nupdB_run - 1) + 1]));
+      fprintf(stderr, "run  levels %d..%d: tasks %lld flops %.4e  %9.1f us  %8.1f GF/s\n", H.run_L0, H.nlevels - 1,
+              (long long)(H.slot_task_ptr[H.nlevels] - H.slot_task_ptr[H.run_L0]), H.run_flops, m2 * 1e3, H.run_flops / (m2 * 1e-3) * 1e-9);
+    }
+  }
   long long nb[2] = {0, 0};
   int err = 0;
+  if (p->run_used) {
+    int stuck = 0;
+    HIPCHK(hipMemcpy(&stuck, p->runctl.misc + RUN_STUCK, sizeof(int), hipMemcpyDeviceToHost));
+    if (stuck) {
+      fprintf(stderr, "pastix_amd: a wait inside the run launch expired (PASTIX_AMD_RUN_TIMEOUT): the factorization failed\n");
+      p->factored = false;
+      return PASTIX_AMD_ERR_DEVICE;
+    }
+  }
   HIPCHK(hipMemcpy(nb, p->dNbpivot, sizeof(nb), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&err, p->dErr, sizeof(err), hipMemcpyDeviceToHost));
   p->stats.nbpivot = nb[0];
@@ -1232,7 +1318,34 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   const bool tev = p->launch_events;
   int lastN = -1;
   bool s2_used = false;
-  for (int l = 0; l < H.nlevels; l++) {
+  // The run schedule (plan.h RunInfo): levels [L0, nlevels) are not launched level by level -- their panel tasks go to
+  // resident workgroups started NOW (streams 3 and 4: the chip is idle or about to be, they are placed at once and stay),
+  // their update tasks to one launch behind the last level below L0.  PASTIX_AMD_RUN=0 keeps the level-by-level
+  // schedule on the same plan (both give bitwise the same factors).
+  const char* run_env = getenv("PASTIX_AMD_RUN");          // (read per call: tests switch it between factorizations)
+  const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0);
+  const int L0 = use_run ? H.run_L0 : H.nlevels;
+  const long long run_limit = [] {             // bound of a single wait inside the run, in ticks of the 100 MHz clock
+    const char* e = getenv("PASTIX_AMD_RUN_TIMEOUT");
+    const double sec = e ? atof(e) : 20.0;
+    return (long long)(std::max(sec, 0.001) * 1e8);
+  }();
+  p->run_used = use_run;
+  const int run_nwk = use_run ? H.run_gd + p->run_gt : 0;
+  if (use_run) {
+    HIPCHK(hipMemsetAsync(p->dRunFlags, 0, p->nRunFlags * sizeof(int32_t), s1));
+    *(volatile int*)p->hResident = 0;
+    HIPCHK(hipEventRecord(p->evZ, s1));
+    HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));
+    HIPCHK(hipStreamWaitEvent(p->stream4, p->evZ, 0));
+    HIPCHK(hipStreamWaitEvent(s2, p->evZ, 0));
+    launch_run_panel(p->stream3, p->stream4, H.factotype, p->arenas(), p->dRunD, p->dRunDptr, H.nlevels - L0, H.run_gd,
+                     p->dRunT, (int64_t)H.run_t.size(), p->run_gt, p->dDinv, critere, p->dNbpivot, p->dErr, p->runctl,
+                     p->hResident, run_limit);
+    HIPCHK(hipEventRecord(p->evS3, p->stream3));
+    HIPCHK(hipEventRecord(p->evS4, p->stream4));
+  }
+  for (int l = 0; l < L0; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
     if (lastN >= 0) { HIPCHK(hipStreamWaitEvent(s1, p->evB[lastN], 0)); lastN = -1; }
     if (tu > t0) {
@@ -1255,6 +1368,33 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       p->nupdB_run++;
       s2_used = true;
     }
+  }
+  if (use_run) {
+    // the update launch of the run: behind the panels of level L0 - 1 (stream 1) and the bulk launch of slot L0 - 1 (this
+    // stream's order).  The panel kernels must be RESIDENT before it starts: its workgroups wait for them while they hold
+    // their slots.  The workgroups counted themselves in host memory long ago (they were launched first); checked here.
+    if (L0 > 0) HIPCHK(hipStreamWaitEvent(s2, p->evP[L0 - 1], 0));
+    const double tw0 = now_s();
+    while (*(volatile int*)p->hResident < run_nwk) {
+      if (now_s() - tw0 > 10.0) {
+        fprintf(stderr, "pastix_amd: the run's panel workgroups did not start (%d of %d)\n", *(volatile int*)p->hResident, run_nwk);
+        int one = 1;                                     // (lets the ones that did start leave their loops)
+        (void)hipMemcpyAsync(p->runctl.misc + RUN_STUCK, &one, sizeof(int), hipMemcpyHostToDevice, s2);
+        (void)hipStreamSynchronize(s2);
+        (void)hipStreamSynchronize(p->stream3);
+        (void)hipStreamSynchronize(p->stream4);
+        (void)hipStreamSynchronize(s1);
+        return PASTIX_AMD_ERR_DEVICE;
+      }
+    }
+    if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
+    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunWaits, p->runctl,
+                      H.slot_task_ptr[H.nlevels] - H.slot_task_ptr[L0], run_limit);
+    if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
+    p->nupdB_run++;
+    s2_used = true;
+    HIPCHK(hipStreamWaitEvent(s1, p->evS3, 0));
+    HIPCHK(hipStreamWaitEvent(s1, p->evS4, 0));
   }
   if (s2_used) {
     HIPCHK(hipEventRecord(p->evB[0], s2));

@@ -17,6 +17,13 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
 // the quadrant tasks of a slot (Task flag 32, kernels_small.hip)
 void launch_update_small(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
                          bool urgent);
+// the run schedule (plan.h RunInfo): the update tasks of the thin levels in one launch, their panel tasks on resident
+// workgroups of two kernels on streams of their own
+void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
+                       const int32_t* waits, const RunCtl& rc, int64_t ntasks, long long limit);
+void launch_run_panel(hipStream_t sd, hipStream_t st, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr,
+                      int nlev, int gd, const RunT* rt, int64_t nt, int gt, double* dinv, double critere, long long* nbpivot,
+                      int* errflag, const RunCtl& rc, int* resident, long long limit);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
@@ -155,6 +162,16 @@ struct pastix_amd_plan_s {
   size_t nTicket = 0;                   // (ints; zeroed per solve)
   long long inv_gen = -1, fact_gen = 0; // the inverses belong to factorization number inv_gen
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
+  // the run schedule: device tables, the synchronisation words (zeroed per factorization), the panel kernels' streams
+  bool run_ready = false, run_used = false;
+  Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunWaits = nullptr;
+  RunD* dRunD = nullptr; int64_t* dRunDptr = nullptr; RunT* dRunT = nullptr;
+  int32_t* dRunFlags = nullptr; size_t nRunFlags = 0;
+  RunCtl runctl{};
+  hipStream_t stream3 = nullptr, stream4 = nullptr;
+  int* hResident = nullptr;            // host memory the panel kernels' workgroups count themselves in
+  int run_gt = 0;
+  hipEvent_t evZ = nullptr, evRun1 = nullptr, evS3 = nullptr, evS4 = nullptr;
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};

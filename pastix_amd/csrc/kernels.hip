@@ -30,6 +30,7 @@
 
 #include "plan.h"
 #include "devmath.h"
+#include "run_sync.h"
 
 namespace pastix_amd {
 
@@ -53,21 +54,20 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
-                                                    double* __restrict__ dinv_ws, double critere,
-                                                    long long* __restrict__ nbpivot, int* __restrict__ errflag) {
-  // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
-  // only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
-  // size fits beside one k_update workgroup.  Entries outside the w x w part are zero.
-  __shared__ double D[128 * 129 / 2];
+// D: lower triangle of the blok, packed by columns (66 KB of LDS): with the 132 KB of a full square the workgroup could
+// only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
+// size fits beside one k_update workgroup.  Entries outside the w x w part are zero.  Ri: reciprocals of the tile's
+// diagonal (two tiles: wave 1 inverts the previous tile while wave 0 factorizes the next one).
+// COH: the results are stored write-through (the run launch, run_sync.h).
+constexpr int DIAG_LDS_DOUBLES = 128 * 129 / 2;
+template <bool COH>
+__device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double (*__restrict__ Ri)[16], double* __restrict__ L,
+                                              const PanelTask& tk, double* __restrict__ dinv_ws, const double critere,
+                                              long long* __restrict__ nbpivot, int* __restrict__ errflag, const int tid) {
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
-  __shared__ double Ri[2][16];         // reciprocals of the tile's diagonal (two tiles: wave 1 inverts the previous tile
-                                       // while wave 0 factorizes the next one)
-  PANEL_PRIO();
-  const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   {
     // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
     if (lane < 16) {
       double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
 #pragma unroll
-      for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+      for (int i = 0; i < 16; i++) pst<COH>(&dst[i + 16 * l15], x[i]);
     }
   };
   for (int kb = 0; kb < w; kb += 16) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
-      if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
+      if (r < w && r >= c) pst<COH>(&A[r + (int64_t)c * ld], DP(c, r));
   }
   STAMP(5)
 #ifdef DIAG_PROFILE
@@ -256,6 +256,17 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
     if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
     if (bad) atomicOr(errflag, 1);
   }
+#undef DP
+}
+
+__global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                    double* __restrict__ dinv_ws, double critere,
+                                                    long long* __restrict__ nbpivot, int* __restrict__ errflag) {
+  __shared__ double D[DIAG_LDS_DOUBLES];
+  __shared__ double Ri[2][16];
+  PANEL_PRIO();
+  const PanelTask tk = tasks[blockIdx.x];
+  diag_llt_body<false>(D, Ri, L, tk, dinv_ws, critere, nbpivot, errflag, threadIdx.x);
 }
 
 // k_diag_ldlt_w : the same organisation for the LDLt diagonal blok (PASTIX_sytrf_block, compute_diag.c:262-307), w <= 128:
@@ -458,11 +469,10 @@ void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_
 // tile p (register q = rows g+4q of X^T[p]) is used directly as the B operand of k-step q; the A
 // operand supplies the matching column g+4q of L[ct,p], so no lane shuffles or LDS are needed.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
-                                                  const double* __restrict__ dinv_ws) {
-  PANEL_PRIO();
-  const TrsmTask tk = tasks[blockIdx.x];
+// (a wave solves 16 panel rows: 4 waves = the 64 rows of a TrsmTask, 8 waves = the 128 rows of a run task; COH: the
+// solved rows are stored write-through, run_sync.h)
+template <int NT, bool COH>
+__device__ __forceinline__ void trsm_llt_body(double* __restrict__ L, const TrsmTask& tk, const double* __restrict__ dinv_ws) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int ld = tk.stride, w = tk.width;
@@ -514,8 +524,78 @@ __global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __res
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int col = ct * 16 + g + 4 * q;
-      if (rvalid && col < w) Ap[(int64_t)col * ld] = acc[ct][q];
+      if (rvalid && col < w) pst<COH>(&Ap[(int64_t)col * ld], acc[ct][q]);
     }
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __restrict__ L, const TrsmTask* __restrict__ tasks,
+                                                  const double* __restrict__ dinv_ws) {
+  PANEL_PRIO();
+  const TrsmTask tk = tasks[blockIdx.x];
+  trsm_llt_body<NT, false>(L, tk, dinv_ws);
+}
+
+// ---- the run's panel kernel (real LLt) -------------------------------------------------------------------------------
+// The diagonal-blok and panel-solve tasks of the run's levels (plan.h RunD / RunT) on a few RESIDENT workgroups, started
+// before the run's update launch and alive until the last task: the workgroups of k_run_diag_llt factorize diagonal bloks
+// -- workgroup d the d-th cblk of every level that has one --, those of k_run_trsm_llt solve panel tiles, task i on
+// workgroup i % gt (two kernels: in one, the compiler's register allocation for either role spills); each walks its list in level order and waits per task for the tile counters of k_run_update (the diagonal
+// blok: its tile's run updates are all in; a panel tile: that, and the cblk's diagonal flag).  Being resident they never
+// wait for a slot behind the update workgroups that wait for them; the host checks `resident` (a counter in host
+// memory) before it launches k_run_update.
+__global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L, const RunD* __restrict__ rd,
+                                                         const int64_t* __restrict__ dptr, const int nlev,
+                                                         double* __restrict__ dinv_ws, const double critere,
+                                                         long long* __restrict__ nbpivot, int* __restrict__ errflag,
+                                                         const RunCtl rc, int* __restrict__ resident, const long long limit) {
+  __shared__ double D[DIAG_LDS_DOUBLES];
+  __shared__ double Ri[2][16];
+  PANEL_PRIO();
+  const int tid = threadIdx.x, wk = blockIdx.x;
+  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int32_t* stuck = rc.misc + RUN_STUCK;
+  for (int l = 0; l < nlev; l++) {
+    const int64_t b = dptr[l];
+    if (wk >= dptr[l + 1] - b) continue;
+    const RunD d = rd[b + wk];
+    if (tid == 0) {
+      run_poll(rc.tile_seq + d.tile0, d.need0, stuck, limit);
+      run_acquire();
+    }
+    __syncthreads();
+    // (the thread index is laundered per task: otherwise everything the body derives from it is hoisted out of this loop
+    // and kept in registers across it -- 59 spilled VGPRs instead of the 17 of the same body in k_diag_llt_w)
+    int ltid = threadIdx.x;
+    asm volatile("" : "+v"(ltid));
+    diag_llt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, errflag, ltid);
+    run_drain();
+    __syncthreads();
+    if (tid == 0) {
+      run_st(rc.dflag + d.dflag, 1);
+      if (d.fin) run_st(rc.tile_fin + d.tile0, 1);
+    }
+  }
+}
+__global__ __launch_bounds__(512, 4) void k_run_trsm_llt(double* __restrict__ L, const RunT* __restrict__ rt, const int64_t nt,
+                                                         const double* __restrict__ dinv_ws, const RunCtl rc,
+                                                         int* __restrict__ resident, const long long limit) {
+  PANEL_PRIO();
+  const int tid = threadIdx.x;
+  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  int32_t* stuck = rc.misc + RUN_STUCK;
+  for (int64_t i = blockIdx.x; i < nt; i += gridDim.x) {
+    const RunT t = rt[i];
+    if (tid == 0) {
+      run_poll(rc.dflag + t.dflag, 1, stuck, limit);
+      run_poll(rc.tile_seq + t.tile, t.need, stuck, limit);
+      run_acquire();
+    }
+    __syncthreads();
+    trsm_llt_body<8, true>(L, t.tt, dinv_ws);
+    run_drain();
+    __syncthreads();
+    if (tid == 0) run_st(rc.tile_fin + t.tile, 1);
   }
 }
 
@@ -1346,6 +1426,17 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
 __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
+void launch_run_panel(hipStream_t sd, hipStream_t st, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr,
+                      int nlev, int gd, const RunT* rt, int64_t nt, int gt, double* dinv, double critere, long long* nbpivot,
+                      int* errflag, const RunCtl& rc, int* resident, long long limit) {
+  (void)factotype;
+  if (gd > 0)
+    hipLaunchKernelGGL(k_run_diag_llt, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, dptr, nlev, dinv, critere, nbpivot,
+                       errflag, rc, resident, limit);
+  if (gt > 0 && nt > 0)
+    hipLaunchKernelGGL(k_run_trsm_llt, dim3((unsigned)gt), dim3(512), 0, st, ar.p[0], rt, nt, dinv, rc, resident, limit);
+}
+
 void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_fill_const, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, s, dst, n, v);

@@ -33,6 +33,7 @@
 
 #include "plan.h"
 #include "devmath.h"
+#include "run_sync.h"
 
 namespace pastix_amd {
 
@@ -116,7 +117,8 @@ __device__ __forceinline__ void mfma_pat(const int pat, const double (&an)[NI], 
 // C -= acc for the row band MIX of the wave: loads of one 16-row band are issued together from clamped addresses (one
 // latency per band, not per element); ATOMIC: tiles that several workgroups update in the same launch (split piece
 // lists of the multi-GPU fan-in schedule) combine with f64 atomics instead of an exclusive read-modify-write.
-template <int MIX, bool ATOMIC>
+// COH: the stores are write-through (the run launch: the tile is handed to another workgroup of the same launch).
+template <int MIX, bool ATOMIC, bool COH = false>
 __device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsigned touched, const int row0, const int col0,
                                               const int l15, const int g, const int tm1, const int tn1, const int ldc) {
   if (!((touched >> MIX) & 1u)) return;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsi
     if (r <= tm1 && c <= tn1) {
       const double a = acc_read<4 * MIX + ni, q>();
       if (ATOMIC) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -a);
-      else C[r + (int64_t)c * ldc] = cv[ni][q] - a;
+      else pst<COH>(&C[r + (int64_t)c * ldc], cv[ni][q] - a);
     }
   };
 #define PA_PUT4(ni)                                                              \
@@ -385,6 +387,73 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   }
   epilogue_band<0, false>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
   epilogue_band<1, false>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+}
+
+// ---- the run launch ------------------------------------------------------------------------------
+// The update tasks of the thin levels at the top of the tree, all in ONE launch (plan.h RunInfo; the reference's tasks
+// wait for TASK_CTRBCNT == 0 the same way, sopalin3d.c:790-1025 / contrib.c:45-88).  A workgroup draws a ticket (the
+// tasks are listed in a topological order of the task graph, so whatever a ticket waits for is a smaller ticket -- held
+// by a workgroup that runs -- or a resident workgroup of k_run_panel: no deadlock, and no assumption about the order in
+// which the hardware starts the workgroups of a grid), waits for the tile's previous writer (counter == seq) and for the
+// source tiles its pieces read (final flags), runs the task exactly as k_update does -- same pieces, same order, same
+// arithmetic: the factors are bitwise those of the level-by-level schedule -- and publishes the tile.
+__global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
+                                                               const Piece* __restrict__ pieces,
+                                                               const RunInfo* __restrict__ info,
+                                                               const int32_t* __restrict__ waits, const RunCtl rc,
+                                                               const long long limit) {
+  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* tick = (int*)&sh[0][0][0];
+  if (tid == 0) *tick = atomicAdd(rc.misc + RUN_HEAD, 1);
+  __syncthreads();
+  const int t = __builtin_amdgcn_readfirstlane(*tick);
+  const Task tk = tasks[t];
+  const RunInfo ri = info[t];
+  if (wave == 0) {
+    // lane 0 of the first pass: the tile's previous writer; the other lanes: one source tile each
+    for (int base = -1; base < ri.wn; base += 64) {
+      const int i = base + lane;
+      if (i < 0) {
+        if (ri.seq > 0) run_poll(rc.tile_seq + ri.tile, ri.seq, rc.misc + RUN_STUCK, limit);
+      } else if (i < ri.wn) {
+        run_poll(rc.tile_fin + waits[ri.wptr + i], 1, rc.misc + RUN_STUCK, limit);
+      }
+    }
+    run_acquire();
+  }
+  __syncthreads();                               // (also: the ticket word in LDS is dead from here on)
+  const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
+  const int l15 = lane & 15, g = lane >> 4;
+  acc_zero();
+  unsigned touched;
+  const bool neg = (tk.flags & 8u) != 0;
+  if ((int)tk.nfull == tk.pn) {
+    if (tk.tm == TM && tk.tn == TN) {
+      if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    } else {
+      if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    }
+  } else {
+    if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+  }
+  acc_settle();
+  double* C = ar.p[tk.flags & 3] + tk.c_off;
+  const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
+  epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+  epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+  run_drain();
+  __syncthreads();
+  if (tid == 0) run_st(rc.tile_seq + ri.tile, ri.seq + 1);
+}
+
+void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
+                       const int32_t* waits, const RunCtl& rc, int64_t ntasks, long long limit) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(k_run_update, dim3((unsigned)ntasks), dim3(64 * UW), 0, s, ar, tasks, pieces, info, waits, rc, limit);
 }
 
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,

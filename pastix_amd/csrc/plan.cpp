@@ -307,13 +307,37 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     for (int64_t k = 0; k < nc; k++) if (factored(k)) P.lvl_cblk[pos[P.level[k]]++] = (int32_t)k;
   }
 
+  // ---- the run: the longest suffix of levels with at most run_max_cblks cblks each (plan.h, RunInfo) -----------------
+  // Built for one GPU, real double LLt (v1).  The plan carries BOTH schedules: the level-by-level launches work on
+  // the same tables, which of the two runs is decided per factorization (api.cpp).
+  P.run_L0 = -1;
+  {
+    const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE && factotype == PASTIX_AMD_FACT_LLT;
+    if (built && P.opts.run_schedule >= 0) {
+      const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
+      int L0 = NL;
+      auto narrow = [&](int l) {       // (the run's panel kernel takes cblks of at most 128 columns, like k_diag_llt_w)
+        for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
+          const int32_t k = P.lvl_cblk[(size_t)q];
+          if (P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1 > TN) return false;
+        }
+        return true;
+      };
+      while (L0 > 0 && P.lvl_cblk_ptr[L0] - P.lvl_cblk_ptr[L0 - 1] <= maxc && narrow(L0 - 1)) L0--;
+      if (NL - L0 >= 2) P.run_L0 = L0;
+    }
+  }
+  const int RL0 = P.run_L0 >= 0 ? P.run_L0 : NL + 1;
+
   // ---- panel / trsm tasks per level ------------------------------------------------------------
   P.lvl_panel_ptr.assign(NL + 1, 0);
   P.lvl_trsm_ptr.assign(NL + 1, 0);
   P.panel_tasks.resize(nowned);
   P.dinv_ws = 0;
+  int64_t ws_run = 0;                    // (levels of the run overlap in time: their tile inverses do not share space)
   for (int l = 0; l < NL; l++) {
-    int64_t ws = 0;
+    if (l == RL0) ws_run = P.dinv_ws;
+    int64_t ws = l >= RL0 ? ws_run : 0;
     P.lvl_panel_ptr[l] = P.lvl_cblk_ptr[l];
     P.lvl_trsm_ptr[l] = (int64_t)P.trsm_tasks.size();
     // widest / tallest first: better tail behaviour inside a launch
@@ -334,6 +358,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       }
       ws += (int64_t)((w + 15) / 16) * 256 * (factotype == PASTIX_AMD_FACT_LU ? 2 : 1) * (cplx ? 2 : 1);
     }
+    if (l >= RL0) ws_run = ws;
     P.dinv_ws = std::max(P.dinv_ws, ws);
   }
   P.lvl_panel_ptr[NL] = nowned;
@@ -598,6 +623,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<double> task_work;
   std::vector<int32_t> task_slot;
   std::vector<uint8_t> task_urgent;
+  std::vector<int64_t> task_tile;
   P.slot_flops.assign(NL, 0.0);
   P.slot_urgent_flops.assign(NL, 0.0);
   P.slot_pieces.assign(NL, 0);
@@ -617,6 +643,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     std::vector<double> work;
     std::vector<int32_t> slot;
     std::vector<uint8_t> urgent;
+    std::vector<int64_t> tile;
     std::vector<double> slot_flops, slot_urgent_flops, slot_maxwork;
     std::vector<int64_t> slot_pieces, slot_cnt;
     std::vector<int32_t> slot_maxpn;
@@ -717,7 +744,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       // is built for latency, not for flops: on blend's layouts (cblks of 60-120 columns, bloks of at most 120 rows:
       // hardly any whole-tile piece, so that the fill rule alone diverted most of the work) the quadrant kernel took
       // 44 % of the time of an 80^3 factorization driven by the real PaStiX.
-      if (quad_on && !raw[q].shared && tk.nfull == 0) {
+      if (quad_on && !raw[q].shared && tk.nfull == 0 && slot < RL0) {     // (the run takes whole tiles only)
         double iters = 0;
         int maxmn = 0;
         for (size_t z = q; z < e; z++) {
@@ -730,6 +757,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       O.work.push_back(work + 4096.0 * double(e - q));
       O.slot.push_back(slot);
       O.urgent.push_back(urg);
+      O.tile.push_back(raw[q].tile);
       O.slot_cnt[slot]++;
       O.ubytes += 16.0 * double(tk.tm) * double(tk.tn);
       O.slot_pieces[slot] += (int64_t)(e - q);
@@ -754,11 +782,13 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     task_work.reserve(ntr);
     task_slot.reserve(ntr);
     task_urgent.reserve(ntr);
+    task_tile.reserve(ntr);
     for (GOut& O : gout) {
       P.tasks.insert(P.tasks.end(), O.tasks.begin(), O.tasks.end());
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
       task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
       task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
+      task_tile.insert(task_tile.end(), O.tile.begin(), O.tile.end());
       P.urgent_flops += O.urgent_flops;
       P.full_flops += O.full_flops;
       ubytes += O.ubytes;
@@ -878,6 +908,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       task_work.insert(task_work.end(), O.work.begin(), O.work.end());
       task_slot.insert(task_slot.end(), O.slot.begin(), O.slot.end());
       task_urgent.insert(task_urgent.end(), O.urgent.begin(), O.urgent.end());
+      task_tile.insert(task_tile.end(), O.tasks.size(), (int64_t)-1);
       for (auto& d : O.dcnt) P.slot_task_ptr[(size_t)d.first + 1] += d.second;
       ubytes += O.dbytes;
       QOut().pieces.swap(O.pieces);
@@ -944,6 +975,131 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (auto& x : th) x.join();
     }
     P.tasks.swap(sorted);
+    // ---- the run schedule -----------------------------------------------------------------------------------------
+    // Ticket order (any topological order of the task graph is deadlock-free: a workgroup only waits for smaller
+    // tickets and for the resident panel workgroups): A(L0), then per slot s >= L0: B(s).next | A(s+1) | B(s).rest,
+    // where A(s) are the urgent tasks of slot s (targets of level s, sources of level s-1), B(s).next the bulk tasks
+    // whose targets are of level s+1 and B(s).rest the others -- the tasks the next level's panels wait for are drawn
+    // before the bulk of their slot.  Tasks of one tile keep their slot order (their ranges are visited in slot order).
+    P.ntile = ntile;
+    P.nplanes = (lu ? 2 : 1) * (cplx ? 2 : 1);
+    if (P.run_L0 >= 0) {
+      const int L0 = P.run_L0;
+      std::vector<int64_t> order;
+      order.reserve((size_t)(P.slot_task_ptr[NL] - P.slot_task_ptr[L0]));
+      auto app = [&](int64_t b, int64_t e) { for (int64_t q = b; q < e; q++) order.push_back(q); };
+      app(P.slot_task_ptr[L0], P.slot_urgent_end[L0]);
+      for (int sl = L0; sl < NL; sl++) {
+        app(P.slot_urgent_end[sl], P.slot_next_end[sl]);
+        if (sl + 1 < NL) app(P.slot_task_ptr[sl + 1], P.slot_urgent_end[sl + 1]);
+        app(P.slot_next_end[sl], P.slot_task_ptr[sl + 1]);
+      }
+      const size_t nr = order.size();
+      P.run_tasks.resize(nr);
+      P.run_info.resize(nr);
+      std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // run tasks per tile counter
+      bool bad = false;
+      for (size_t i = 0; i < nr; i++) {
+        const int64_t q = order[i];
+        P.run_tasks[i] = P.tasks[(size_t)q];
+        const int64_t tl = task_tile[(size_t)idx[(size_t)q]];
+        if (tl < 0 || (P.tasks[(size_t)q].flags & (4u | 32u))) { bad = true; break; }   // (quadrant / shared tasks: not in a run)
+        P.run_info[i].tile = (int32_t)tl;
+        P.run_info[i].seq = tcount[(size_t)tl]++;
+      }
+      if (bad || (int64_t)ntile * P.nplanes > 0x7fffffffLL) {
+        P.run_L0 = -1;
+        P.run_tasks.clear();
+        P.run_info.clear();
+      } else {
+        // source tiles a task waits for: the 128-row tiles of the source panels its pieces read (A rows, B rows),
+        // sources of the run's levels only -- older panels are final when the run starts
+        std::vector<std::vector<int32_t>> tw((size_t)nthr);
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> tpw((size_t)nthr);   // per task of the range: (first, count) in tw
+        std::vector<double> trf((size_t)nthr, 0.0);
+        const size_t per = (nr + (size_t)nthr - 1) / (size_t)nthr;
+        auto wbody = [&](int t) {
+          std::vector<int32_t>& W = tw[(size_t)t];
+          std::vector<int32_t> tmp;
+          double fl = 0;
+          for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
+            const Task& tk = P.run_tasks[i];
+            tmp.clear();
+            for (int z = 0; z < tk.pn; z++) {
+              const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+              fl += 2.0 * pc.m * (double)pc.n * pc.k;
+              const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), pc.a_off) - P.poff.begin() - 1;
+              if (P.level[(size_t)k] < L0) continue;
+              const int64_t a0 = pc.a_off - P.poff[(size_t)k], b0 = pc.b_off - P.poff[(size_t)k];   // rows (column 0 of the panel)
+              for (int64_t rt = a0 / TM; rt <= (a0 + pc.m - 1) / TM; rt++) tmp.push_back((int32_t)(tile_base[(size_t)k] + rt));
+              for (int64_t rt = b0 / TM; rt <= (b0 + pc.n - 1) / TM; rt++) tmp.push_back((int32_t)(tile_base[(size_t)k] + rt));
+            }
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            tpw[(size_t)t].emplace_back((int32_t)W.size(), (int32_t)tmp.size());
+            W.insert(W.end(), tmp.begin(), tmp.end());
+          }
+          trf[(size_t)t] = fl;
+        };
+        {
+          std::vector<std::thread> th;
+          for (int t = 1; t < nthr; t++) th.emplace_back(wbody, t);
+          wbody(0);
+          for (auto& x : th) x.join();
+        }
+        size_t tot = 0;
+        for (int t = 0; t < nthr; t++) tot += tw[(size_t)t].size();
+        if (tot > 0x7fffffffULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+        P.run_waits.resize(tot);
+        size_t base = 0;
+        P.run_flops = 0;
+        for (int t = 0; t < nthr; t++) {
+          std::copy(tw[(size_t)t].begin(), tw[(size_t)t].end(), P.run_waits.begin() + base);
+          for (size_t j = 0; j < tpw[(size_t)t].size(); j++) {
+            RunInfo& ri = P.run_info[(size_t)t * per + j];
+            ri.wptr = (int32_t)(base + (size_t)tpw[(size_t)t][j].first);
+            ri.wn = tpw[(size_t)t][j].second;
+          }
+          base += tw[(size_t)t].size();
+          P.run_flops += trf[(size_t)t];
+        }
+        // the panel side: per level the diagonal tasks (one per cblk, the level's order) and the panel-solve tasks,
+        // one per 128-row tile of the panel that holds off-diagonal rows
+        P.run_dptr.assign((size_t)(NL - L0) + 1, 0);
+        P.run_gd = 0;
+        int32_t ndf = 0;
+        for (int l = L0; l < NL; l++) {
+          P.run_dptr[(size_t)(l - L0)] = (int64_t)P.run_d.size();
+          P.run_gd = std::max<int32_t>(P.run_gd, (int32_t)(P.lvl_cblk_ptr[l + 1] - P.lvl_cblk_ptr[l]));
+          for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
+            const int32_t k = P.lvl_cblk[(size_t)q];
+            const PanelTask& pt = P.panel_tasks[(size_t)q];
+            const int32_t w = pt.width, st = pt.stride;
+            RunD d{};
+            d.pt = pt;
+            d.tile0 = (int32_t)tile_base[(size_t)k];
+            d.need0 = tcount[(size_t)d.tile0];
+            d.tile0u = -1; d.need0u = 0;
+            d.dflag = ndf++;
+            d.fin = !(w < TM && st > w);
+            P.run_d.push_back(d);
+            for (int32_t rt = w / TM; (int64_t)rt * TM < st; rt++) {
+              const int32_t r0 = std::max<int32_t>(w, rt * TM), r1 = std::min<int32_t>(st, (rt + 1) * TM);
+              if (r1 <= r0) continue;
+              RunT tt{};
+              tt.tt = TrsmTask{pt.off, st, w, r0, r1 - r0, pt.dinv_off};
+              tt.tile = (int32_t)(tile_base[(size_t)k] + rt);
+              tt.need = tcount[(size_t)tt.tile];
+              tt.tileu = -1; tt.needu = 0;
+              tt.dflag = d.dflag;
+              P.run_t.push_back(tt);
+            }
+          }
+        }
+        P.run_dptr[(size_t)(NL - L0)] = (int64_t)P.run_d.size();
+        P.run_ndflag = ndf;
+      }
+    }
   }
   phase("task ordering");
   if (P.opts.verbose >= 3) {
@@ -981,6 +1137,75 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     fprintf(stderr, "[plan] tasks %zu pieces %zu fingerprint %016llx\n", P.tasks.size(), P.pieces.size(), (unsigned long long)h);
   }
   return PASTIX_AMD_OK;
+}
+
+// Host-only check of a run schedule (tests): replays the tickets ONE AT A TIME in ticket order -- the weakest progress the
+// device guarantees, since a ticket is only ever held by a workgroup that runs -- with the panel workers advancing whenever
+// their next task's counters allow, `gt` solve workers walking the task list with stride gt.  Returns 0 when every ticket's
+// waits are met by smaller tickets and panel tasks (no deadlock, every counter ends where the waiters expect it), else the
+// 1-based index of the first ticket that could not run, or -1 for an inconsistent table.
+int64_t run_verify(const Plan& P, int gt) {
+  if (P.run_L0 < 0) return 0;
+  const size_t nr = P.run_tasks.size();
+  if (P.run_info.size() != nr) return -1;
+  std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl((size_t)std::max<int64_t>(P.run_ndflag, 1), 0);
+  const int nlev = P.nlevels - P.run_L0;
+  gt = (int)std::max<int64_t>(1, std::min<int64_t>(gt, (int64_t)P.run_t.size()));
+  std::vector<int> dpos((size_t)std::max(P.run_gd, 1), 0);      // next level of every diagonal worker
+  std::vector<int64_t> tpos((size_t)gt);
+  for (int w = 0; w < gt; w++) tpos[(size_t)w] = w;
+  auto advance = [&]() {
+    bool any = false;
+    for (int w = 0; w < P.run_gd; w++) {
+      for (;;) {
+        int& l = dpos[(size_t)w];
+        while (l < nlev && w >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) l++;
+        if (l >= nlev) break;
+        const RunD& d = P.run_d[(size_t)(P.run_dptr[(size_t)l] + w)];
+        if (seq[(size_t)d.tile0] < d.need0) break;
+        if (d.tile0u >= 0 && seq[(size_t)d.tile0u] < d.need0u) break;
+        dfl[(size_t)d.dflag] = 1;
+        if (d.fin) fin[(size_t)d.tile0] = 1;
+        l++;
+        any = true;
+      }
+    }
+    for (int w = 0; w < gt; w++) {
+      while (tpos[(size_t)w] < (int64_t)P.run_t.size()) {
+        const RunT& t = P.run_t[(size_t)tpos[(size_t)w]];
+        if (!dfl[(size_t)t.dflag] || seq[(size_t)t.tile] < t.need) break;
+        if (t.tileu >= 0 && seq[(size_t)t.tileu] < t.needu) break;
+        fin[(size_t)t.tile] = 1;
+        tpos[(size_t)w] += gt;
+        any = true;
+      }
+    }
+    return any;
+  };
+  for (size_t i = 0; i < nr; i++) {
+    const RunInfo& ri = P.run_info[i];
+    if (ri.tile < 0 || (size_t)ri.tile >= seq.size() || ri.wptr < 0 || (size_t)ri.wptr + (size_t)ri.wn > P.run_waits.size()) return -1;
+    for (;;) {
+      bool ok = seq[(size_t)ri.tile] == ri.seq;
+      if (seq[(size_t)ri.tile] > ri.seq) return -1;
+      for (int q = 0; ok && q < ri.wn; q++) {
+        const int32_t f = P.run_waits[(size_t)ri.wptr + (size_t)q];
+        if (f < 0 || (size_t)f >= fin.size()) return -1;
+        ok = fin[(size_t)f] != 0;
+      }
+      if (ok) break;
+      if (!advance()) return (int64_t)i + 1;
+    }
+    seq[(size_t)ri.tile] = ri.seq + 1;
+  }
+  while (advance()) {}
+  for (int w = 0; w < P.run_gd; w++) {
+    int l = dpos[(size_t)w];
+    while (l < nlev && w >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) l++;
+    if (l < nlev) return (int64_t)nr + 1;
+  }
+  for (int w = 0; w < gt; w++) if (tpos[(size_t)w] < (int64_t)P.run_t.size()) return (int64_t)nr + 1;
+  return 0;
 }
 
 }  // namespace pastix_amd

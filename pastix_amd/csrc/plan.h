@@ -82,6 +82,41 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
 };
 
 
+// ---- the run schedule (round 4): the thin levels at the top of the tree in ONE dependency-driven launch ---------------
+// The reference's engine is counter-driven, not level-synchronous: a task runs when TASK_CTRBCNT reaches zero
+// (sopalin3d.c:790-1025, wait_contrib_comp_1d contrib.c:45-88).  Here: every update task of the levels >= run_L0 is a
+// workgroup of one launch (k_run_update) that takes a ticket, waits for its tile's previous writer and for the panel
+// tiles its pieces read, and publishes its tile; the diagonal and panel-solve tasks of those levels run on a few
+// resident workgroups of a second kernel (k_run_panel) that wait for the tiles' counters the same way.
+struct RunInfo {             // per update task of the run, in ticket order
+  int32_t tile;              // index of the target tile's sequence counter (tile id + plane * ntile)
+  int32_t seq;               // number of earlier tasks of the run on this tile: the task waits for counter == seq
+  int32_t wptr, wn;          // run_waits[wptr .. +wn): source tiles (L-arena tile ids) that must be final
+};
+struct RunD {                // a diagonal-blok task of the run
+  PanelTask pt;
+  int32_t tile0, need0;      // the diagonal tile's counter and the number of run tasks that update it
+  int32_t tile0u, need0u;    // LU: the same in the U arena (-1: none)
+  int32_t dflag;             // index of the cblk's "diagonal blok factorized" flag
+  int32_t fin;               // 1: nobody solves rows in tile 0 (no off-diagonal rows there): the task raises its final flag
+  int32_t cntlvl, pad_;      // (reserved)
+};
+struct RunT {                // a panel-solve task of the run: the off-diagonal rows of one 128-row tile
+  TrsmTask tt;
+  int32_t tile, need;        // the tile's counter (L arena), run tasks that update it
+  int32_t tileu, needu;      // LU: U arena (-1: none)
+  int32_t dflag, pad_;
+};
+
+// device-side synchronisation state of a run (ints, zeroed at the start of every factorization)
+struct RunCtl {
+  int32_t* tile_seq;         // [ntile * nplanes] update tasks of the run that have written the tile so far
+  int32_t* tile_fin;         // [ntile] 1: the tile's off-diagonal rows are solved (final: readable as a source)
+  int32_t* dflag;            // [run cblks] 1: the diagonal blok is factorized
+  int32_t* misc;             // RUN_HEAD: ticket counter; RUN_STUCK: a bounded wait expired (the run failed)
+};
+constexpr int RUN_HEAD = 0, RUN_STUCK = 64, RUN_MISC_INTS = 128;
+
 // std::allocator whose value-less construct() default-initialises (leaves trivially constructible T untouched)
 template <class T>
 struct NoInitAlloc : std::allocator<T> {
@@ -145,6 +180,20 @@ struct Plan {
   std::vector<double> slot_maxwork;      // [nlevels] largest task (multiply-adds)
   double fact_flops = 0;
 
+  // run schedule (see RunInfo): levels [run_L0, nlevels); -1: none
+  int32_t run_L0 = -1;
+  int64_t ntile = 0;                     // target tiles per plane
+  int32_t nplanes = 1;                   // planes that are update targets (1 LLt/LDLt, 2 LU, x2 complex)
+  std::vector<Task> run_tasks;           // the update tasks of slots >= run_L0 in ticket order
+  std::vector<RunInfo> run_info;         // [run_tasks.size()]
+  std::vector<int32_t> run_waits;
+  std::vector<RunD> run_d;               // level-major; run_dptr[l - run_L0] = first task of level l
+  std::vector<int64_t> run_dptr;
+  std::vector<RunT> run_t;               // level-major (cblk, row tile)
+  int32_t run_gd = 0;                    // resident workgroups for the diagonal tasks (max cblks of a run level)
+  int64_t run_ndflag = 0;
+  double run_flops = 0;                  // update flops inside the run
+
   // solve schedule: cblks grouped by level (same levels as the factorization)
   std::vector<int64_t> lvl_cblk_ptr;     // [nlevels+1]
   std::vector<int32_t> lvl_cblk;
@@ -154,6 +203,7 @@ struct Plan {
 int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
+int64_t run_verify(const Plan& plan, int gt);
 int owner_view(const pastix_amd_layout_t* layout, const int32_t* owner, int32_t myrank, Plan& plan);
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
 int fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask);
