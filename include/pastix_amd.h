@@ -87,7 +87,8 @@ typedef struct pastix_amd_options_s {
                             where it is built: real double, one GPU), 1 = on, -1 = off (the level-by-level schedule) */
   int run_max_cblks;     /* <= 0 = default (32) */
   int run_t_workers;     /* resident workgroups of the run's panel kernel that solve panel rows; <= 0 = default (48) */
-  int reserved[6];
+  int run_d_workers;     /* ... that factorize diagonal bloks (a level's cblks are dealt round-robin); <= 0 = default (8) */
+  int reserved[5];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */

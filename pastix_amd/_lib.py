@@ -33,7 +33,7 @@ class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
                 ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("quadrant_min", ctypes.c_int),
                 ("quadrant_fill_pct", ctypes.c_int), ("run_schedule", ctypes.c_int), ("run_max_cblks", ctypes.c_int),
-                ("run_t_workers", ctypes.c_int), ("reserved", ctypes.c_int * 6)]
+                ("run_t_workers", ctypes.c_int), ("run_d_workers", ctypes.c_int), ("reserved", ctypes.c_int * 5)]
 
 
 class Stats(ctypes.Structure):

@@ -264,7 +264,6 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       if ((r = to_device(&p->dRunWaits, H.run_waits))) return r;
       if ((r = to_device(&p->dRunD, H.run_d))) return r;
       if ((r = to_device(&p->dRunDptr, H.run_dptr))) return r;
-      if ((r = to_device(&p->dRunT, H.run_t))) return r;
       const size_t nseq = (size_t)H.ntile * (size_t)H.nplanes, nfin = (size_t)H.ntile, ndf = (size_t)std::max<int64_t>(H.run_ndflag, 1);
       p->nRunFlags = nseq + nfin + ndf + RUN_MISC_INTS + 64;
       HIPCHK(hipMalloc((void**)&p->dRunFlags, p->nRunFlags * sizeof(int32_t)));
@@ -275,16 +274,17 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       HIPCHK(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi));
-      HIPCHK(hipStreamCreateWithPriority(&p->stream4, hipStreamNonBlocking, hi));
       HIPCHK(hipHostMalloc((void**)&p->hResident, 64, hipHostMallocCoherent | hipHostMallocMapped));
       *p->hResident = 0;
       HIPCHK(hipEventCreateWithFlags(&p->evZ, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&p->evRun1, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&p->evS3, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&p->evS4, hipEventDisableTiming));
-      const int64_t nt = (int64_t)H.run_t.size();
-      const int gtw = H.opts.run_t_workers > 0 ? H.opts.run_t_workers : 48;
-      p->run_gt = (int)std::min<int64_t>(nt, gtw);
+      p->run_nticket = (int64_t)H.run_tasks.size();
+      if (getenv("PASTIX_AMD_RUN_PROF")) {
+        p->nRunProf = 4 * (H.run_tasks.size() + H.run_d.size());
+        HIPCHK(hipMalloc((void**)&p->dRunProf, p->nRunProf * sizeof(long long)));
+        HIPCHK(hipMemset(p->dRunProf, 0, p->nRunProf * sizeof(long long)));
+      }
+      p->runctl.prof = p->dRunProf;
       p->run_ready = true;
     }
     return 0;
@@ -430,9 +430,9 @@ int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, c
     info[2] = (pastix_amd_int_t)P.run_tasks.size();
     info[3] = (pastix_amd_int_t)P.run_waits.size();
     info[4] = P.run_gd;
-    info[5] = (pastix_amd_int_t)P.run_t.size();
+    info[5] = 0; for (const RunInfo& ri : P.run_info) info[5] += ri.wn < 0;
     info[6] = (pastix_amd_int_t)P.run_flops;
-    info[7] = run_verify(P, P.opts.run_t_workers > 0 ? P.opts.run_t_workers : 48);
+    info[7] = run_verify(P);
   } catch (const std::bad_alloc&) {
     return PASTIX_AMD_ERR_ALLOC;
   }
@@ -526,10 +526,10 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->evP) if (e) (void)hipEventDestroy(e);
   for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
-  for (hipStream_t st : {p->stream3, p->stream4}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-  for (hipEvent_t e : {p->evZ, p->evRun1, p->evS3, p->evS4}) if (e) (void)hipEventDestroy(e);
+  if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
+  for (hipEvent_t e : {p->evZ, p->evS3}) if (e) (void)hipEventDestroy(e);
   (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunWaits); (void)hipFree(p->dRunD);
-  (void)hipFree(p->dRunDptr); (void)hipFree(p->dRunT); (void)hipFree(p->dRunFlags);
+  (void)hipFree(p->dRunDptr); (void)hipFree(p->dRunFlags); (void)hipFree(p->dRunProf);
   if (p->hResident) (void)hipHostFree(p->hResident);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1259,12 +1259,29 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
     if (H.opts.verbose >= 2 && p->nupdB_run > 0) {
       float m2 = 0;
       HIPCHK(hipEventElapsedTime(&m2, p->evT[2 * (p->nupdB_run - 1)], p->evT[2 * (p->nupdB_run - 1) + 1]));
-      fprintf(stderr, "run  levels %d..%d: tasks %lld flops %.4e  %9.1f us  %8.1f GF/s\n", H.run_L0, H.nlevels - 1,
-              (long long)(H.slot_task_ptr[H.nlevels] - H.slot_task_ptr[H.run_L0]), H.run_flops, m2 * 1e3, H.run_flops / (m2 * 1e-3) * 1e-9);
+      fprintf(stderr, "run  levels %d..%d: tickets %lld flops %.4e  %9.1f us  %8.1f GF/s\n", H.run_L0, H.nlevels - 1,
+              (long long)p->run_nticket, H.run_flops, m2 * 1e3, H.run_flops / (m2 * 1e-3) * 1e-9);
     }
   }
   long long nb[2] = {0, 0};
   int err = 0;
+  if (p->run_used && p->dRunProf) {
+    // developer aid: [n update tickets, n diagonal tasks, n panel-solve tasks] then 4 stamps each (drawn, ready, done, 0),
+    // 100 MHz ticks; tools/run_prof.py reads it
+    if (const char* fn = getenv("PASTIX_AMD_RUN_PROF")) {
+      std::vector<long long> h(p->nRunProf);
+      HIPCHK(hipMemcpy(h.data(), p->dRunProf, p->nRunProf * sizeof(long long), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(fn, "wb")) {
+        const long long hdr[4] = {(long long)p->run_nticket, (long long)H.run_d.size(), 0, H.run_L0};
+        fwrite(hdr, sizeof(hdr), 1, f);
+        fwrite(h.data(), sizeof(long long), h.size(), f);
+        std::vector<long long> cl(H.run_cat.size());
+        for (size_t i = 0; i < cl.size(); i++) cl[i] = (long long)H.run_cat[i] | ((long long)H.run_lvl[i] << 8);
+        fwrite(cl.data(), sizeof(long long), cl.size(), f);
+        fclose(f);
+      }
+    }
+  }
   if (p->run_used) {
     int stuck = 0;
     HIPCHK(hipMemcpy(&stuck, p->runctl.misc + RUN_STUCK, sizeof(int), hipMemcpyDeviceToHost));
@@ -1331,19 +1348,16 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
     return (long long)(std::max(sec, 0.001) * 1e8);
   }();
   p->run_used = use_run;
-  const int run_nwk = use_run ? H.run_gd + p->run_gt : 0;
+  const int run_nwk = use_run ? H.run_gd : 0;
   if (use_run) {
     HIPCHK(hipMemsetAsync(p->dRunFlags, 0, p->nRunFlags * sizeof(int32_t), s1));
     *(volatile int*)p->hResident = 0;
     HIPCHK(hipEventRecord(p->evZ, s1));
     HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));
-    HIPCHK(hipStreamWaitEvent(p->stream4, p->evZ, 0));
     HIPCHK(hipStreamWaitEvent(s2, p->evZ, 0));
-    launch_run_panel(p->stream3, p->stream4, H.factotype, p->arenas(), p->dRunD, p->dRunDptr, H.nlevels - L0, H.run_gd,
-                     p->dRunT, (int64_t)H.run_t.size(), p->run_gt, p->dDinv, critere, p->dNbpivot, p->dErr, p->runctl,
-                     p->hResident, run_limit);
+    launch_run_panel(p->stream3, H.factotype, p->arenas(), p->dRunD, p->dRunDptr, H.nlevels - L0, H.run_gd, p->dDinv, critere,
+                     p->dNbpivot, p->dErr, p->runctl, p->hResident, run_limit, p->run_nticket);
     HIPCHK(hipEventRecord(p->evS3, p->stream3));
-    HIPCHK(hipEventRecord(p->evS4, p->stream4));
   }
   for (int l = 0; l < L0; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
@@ -1382,19 +1396,17 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
         (void)hipMemcpyAsync(p->runctl.misc + RUN_STUCK, &one, sizeof(int), hipMemcpyHostToDevice, s2);
         (void)hipStreamSynchronize(s2);
         (void)hipStreamSynchronize(p->stream3);
-        (void)hipStreamSynchronize(p->stream4);
         (void)hipStreamSynchronize(s1);
         return PASTIX_AMD_ERR_DEVICE;
       }
     }
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunWaits, p->runctl,
-                      H.slot_task_ptr[H.nlevels] - H.slot_task_ptr[L0], run_limit);
+    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunWaits, p->runctl, p->dDinv,
+                      p->run_nticket, run_limit);
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
     p->nupdB_run++;
     s2_used = true;
     HIPCHK(hipStreamWaitEvent(s1, p->evS3, 0));
-    HIPCHK(hipStreamWaitEvent(s1, p->evS4, 0));
   }
   if (s2_used) {
     HIPCHK(hipEventRecord(p->evB[0], s2));

@@ -20,10 +20,10 @@ void launch_update_small(hipStream_t s, const Arenas& ar, const Task* tasks, con
 // the run schedule (plan.h RunInfo): the update tasks of the thin levels in one launch, their panel tasks on resident
 // workgroups of two kernels on streams of their own
 void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* waits, const RunCtl& rc, int64_t ntasks, long long limit);
-void launch_run_panel(hipStream_t sd, hipStream_t st, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr,
-                      int nlev, int gd, const RunT* rt, int64_t nt, int gt, double* dinv, double critere, long long* nbpivot,
-                      int* errflag, const RunCtl& rc, int* resident, long long limit);
+                       const int32_t* waits, const RunCtl& rc, const double* dinv, int64_t ntasks, long long limit);
+void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr, int nlev, int gd,
+                      double* dinv, double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident,
+                      long long limit, int64_t nticket);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
@@ -165,13 +165,15 @@ struct pastix_amd_plan_s {
   // the run schedule: device tables, the synchronisation words (zeroed per factorization), the panel kernels' streams
   bool run_ready = false, run_used = false;
   Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunWaits = nullptr;
-  RunD* dRunD = nullptr; int64_t* dRunDptr = nullptr; RunT* dRunT = nullptr;
+  RunD* dRunD = nullptr; int64_t* dRunDptr = nullptr;
   int32_t* dRunFlags = nullptr; size_t nRunFlags = 0;
   RunCtl runctl{};
-  hipStream_t stream3 = nullptr, stream4 = nullptr;
+  hipStream_t stream3 = nullptr;
+  int64_t run_nticket = 0;
   int* hResident = nullptr;            // host memory the panel kernels' workgroups count themselves in
-  int run_gt = 0;
-  hipEvent_t evZ = nullptr, evRun1 = nullptr, evS3 = nullptr, evS4 = nullptr;
+  long long* dRunProf = nullptr;       // PASTIX_AMD_RUN_PROF: clock stamps of the run's tasks (developer aid)
+  size_t nRunProf = 0;
+  hipEvent_t evZ = nullptr, evS3 = nullptr;
   std::vector<hipEvent_t> ev;      // event pairs around update launches
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};

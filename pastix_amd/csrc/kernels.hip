@@ -536,19 +536,19 @@ __global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __res
   trsm_llt_body<NT, false>(L, tk, dinv_ws);
 }
 
-// ---- the run's panel kernel (real LLt) -------------------------------------------------------------------------------
-// The diagonal-blok and panel-solve tasks of the run's levels (plan.h RunD / RunT) on a few RESIDENT workgroups, started
-// before the run's update launch and alive until the last task: the workgroups of k_run_diag_llt factorize diagonal bloks
-// -- workgroup d the d-th cblk of every level that has one --, those of k_run_trsm_llt solve panel tiles, task i on
-// workgroup i % gt (two kernels: in one, the compiler's register allocation for either role spills); each walks its list in level order and waits per task for the tile counters of k_run_update (the diagonal
-// blok: its tile's run updates are all in; a panel tile: that, and the cblk's diagonal flag).  Being resident they never
-// wait for a slot behind the update workgroups that wait for them; the host checks `resident` (a counter in host
-// memory) before it launches k_run_update.
+// ---- the run's diagonal kernel (real LLt) ---------------------------------------------------------------------------
+// The diagonal-blok tasks of the run's levels (plan.h RunD) on a few RESIDENT workgroups, started before the run's
+// launch and alive until the last task: workgroup d factorizes the cblks d, d + gd, ... of every level, walking its
+// list in level order, and waits per task for the counter of the diagonal tile (its run updates are all in).  Being
+// resident the workgroups never wait for a slot behind the tickets that wait for them; the host checks `resident` (a
+// counter in host memory) before it launches k_run_update.  (The panel solves are tickets of that launch,
+// kernels_update.hip trsm_llt_parked: resident workgroups for them cost slots all the time -- 48 of 512 measured -4 %.)
 __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L, const RunD* __restrict__ rd,
                                                          const int64_t* __restrict__ dptr, const int nlev,
                                                          double* __restrict__ dinv_ws, const double critere,
                                                          long long* __restrict__ nbpivot, int* __restrict__ errflag,
-                                                         const RunCtl rc, int* __restrict__ resident, const long long limit) {
+                                                         const RunCtl rc, int* __restrict__ resident, const long long limit,
+                                                         const int64_t pbase) {
   __shared__ double D[DIAG_LDS_DOUBLES];
   __shared__ double Ri[2][16];
   PANEL_PRIO();
@@ -556,14 +556,16 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L,
   if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   int32_t* stuck = rc.misc + RUN_STUCK;
   for (int l = 0; l < nlev; l++) {
-    const int64_t b = dptr[l];
-    if (wk >= dptr[l + 1] - b) continue;
-    const RunD d = rd[b + wk];
+   const int64_t b = dptr[l], nd = dptr[l + 1] - b;
+   for (int64_t di = wk; di < nd; di += gridDim.x) {
+    const RunD d = rd[b + di];
+    if (rc.prof && tid == 0) rc.prof[4 * (pbase + b + di)] = wall_clock64();
     if (tid == 0) {
       run_poll(rc.tile_seq + d.tile0, d.need0, stuck, limit);
       run_acquire();
     }
     __syncthreads();
+    if (rc.prof && tid == 0) rc.prof[4 * (pbase + b + di) + 1] = wall_clock64();
     // (the thread index is laundered per task: otherwise everything the body derives from it is hoisted out of this loop
     // and kept in registers across it -- 59 spilled VGPRs instead of the 17 of the same body in k_diag_llt_w)
     int ltid = threadIdx.x;
@@ -574,31 +576,11 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L,
     if (tid == 0) {
       run_st(rc.dflag + d.dflag, 1);
       if (d.fin) run_st(rc.tile_fin + d.tile0, 1);
+      if (rc.prof) rc.prof[4 * (pbase + b + di) + 2] = wall_clock64();
     }
+   }
   }
 }
-__global__ __launch_bounds__(512, 4) void k_run_trsm_llt(double* __restrict__ L, const RunT* __restrict__ rt, const int64_t nt,
-                                                         const double* __restrict__ dinv_ws, const RunCtl rc,
-                                                         int* __restrict__ resident, const long long limit) {
-  PANEL_PRIO();
-  const int tid = threadIdx.x;
-  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int32_t* stuck = rc.misc + RUN_STUCK;
-  for (int64_t i = blockIdx.x; i < nt; i += gridDim.x) {
-    const RunT t = rt[i];
-    if (tid == 0) {
-      run_poll(rc.dflag + t.dflag, 1, stuck, limit);
-      run_poll(rc.tile_seq + t.tile, t.need, stuck, limit);
-      run_acquire();
-    }
-    __syncthreads();
-    trsm_llt_body<8, true>(L, t.tt, dinv_ws);
-    run_drain();
-    __syncthreads();
-    if (tid == 0) run_st(rc.tile_fin + t.tile, 1);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // coefficient fill: scatter (destination, value) pairs  (Csc2solv_cblk, csc_intern_solve.c:65-132)
 // ------------------------------------------------------------------------------------------------
@@ -1426,15 +1408,13 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
 __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
-void launch_run_panel(hipStream_t sd, hipStream_t st, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr,
-                      int nlev, int gd, const RunT* rt, int64_t nt, int gt, double* dinv, double critere, long long* nbpivot,
-                      int* errflag, const RunCtl& rc, int* resident, long long limit) {
+void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr, int nlev, int gd,
+                      double* dinv, double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident,
+                      long long limit, int64_t nticket) {
   (void)factotype;
   if (gd > 0)
     hipLaunchKernelGGL(k_run_diag_llt, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, dptr, nlev, dinv, critere, nbpivot,
-                       errflag, rc, resident, limit);
-  if (gt > 0 && nt > 0)
-    hipLaunchKernelGGL(k_run_trsm_llt, dim3((unsigned)gt), dim3(512), 0, st, ar.p[0], rt, nt, dinv, rc, resident, limit);
+                       errflag, rc, resident, limit, nticket);
 }
 
 void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v) {

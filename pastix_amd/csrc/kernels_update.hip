@@ -389,6 +389,136 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   epilogue_band<1, false>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
 }
 
+// ---- the panel solve as a task of the run launch ---------------------------------------------------
+// k_trsm_llt's algorithm (kernels.hip: X^T in 16 x 16 column tiles, X^T[ct] = Tinv[ct] (A^T[ct] - sum_p L[ct,p] X^T[p]), a
+// wave per 16 panel rows) inside the register budget of the update kernel: the eight column tiles of a wave REST in the
+// accumulation registers a[0:63] -- which the update tasks of the same kernel own anyway -- and only the tile being
+// computed lives in VGPRs: finished tiles are read back one operand pair at a time where a later tile multiplies them.
+// (With compiler-allocated tiles the routine needs 109 VGPRs beside the update path's 64 AGPRs: it spilled.)  The MFMAs
+// here work on VGPRs only, so the AGPR traffic is plain VALU moves without MFMA hazards.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// Wait states are ours on both sides of an asm statement (cdna_hip_programming.md 5.7 item 2): FRESH = the value was just
+// produced by an MFMA of the compiler's (its D must have retired before a VALU move reads it: the nops lead the string);
+// acc_read_m = the value feeds an MFMA of the compiler's next (VALU write -> MFMA operand: the nops end the string).
+template <int T, int Q, bool FRESH = false>
+__device__ __forceinline__ void acc_write(const double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (FRESH)
+    asm volatile("s_nop 15\n\ts_nop 7\n\tv_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(lo), "v"(hi),
+                 "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
+                 : PA_ACC_CLOBBER);
+  else
+    asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(lo), "v"(hi), "n"(8 * T + 2 * Q),
+                 "n"(8 * T + 2 * Q + 1)
+                 : PA_ACC_CLOBBER);
+}
+template <int T, int Q>
+__device__ __forceinline__ double acc_read_m() {
+  int lo, hi;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]\n\ts_nop 3"
+               : "=v"(lo), "=v"(hi)
+               : "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
+               : PA_ACC_CLOBBER);
+  return __hiloint2double(hi, lo);
+}
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+template <bool COH>
+__device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const TrsmTask& tk, const double* __restrict__ dinv_ws) {
+  constexpr int NT = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int rloc = wave * 16 + l15;
+  if (wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  double* Ap = L + tk.off + tk.row0 + rloc;          // panel row of this lane
+  const double* Apc = L + tk.off + tk.row0 + min(rloc, tk.nrows - 1);   // clamped: always readable
+  const double* Ld = L + tk.off;                     // diagonal blok (factored)
+  const double* Ti = dinv_ws + tk.dinv_off;
+  static_for<NT>([&](auto CT) {
+    constexpr int ct = decltype(CT)::value;
+    double v[4];
+    int lds = ld;
+    asm volatile("" : "+s"(lds));
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = Apc[(int64_t)min(ct * 16 + g + 4 * q, w - 1) * lds];
+    acc_write<ct, 0>((rvalid && ct * 16 + g + 0 < w) ? v[0] : 0.0);
+    acc_write<ct, 1>((rvalid && ct * 16 + g + 4 < w) ? v[1] : 0.0);
+    acc_write<ct, 2>((rvalid && ct * 16 + g + 8 < w) ? v[2] : 0.0);
+    acc_write<ct, 3>((rvalid && ct * 16 + g + 12 < w) ? v[3] : 0.0);
+    if (ct & 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' loads in flight at a time: the registers are few)
+  });
+  // 36 steps in order: for ct = 0..7 the products with the finished tiles p < ct, then the tile's own step with Tinv[ct].
+  // Every step multiplies four operand entries per lane read from memory (L[ct, p] or Tinv[ct]): the loads of step i + 1
+  // are issued in front of the MFMAs of step i (two operand sets live; the scheduling barrier per step keeps the compiler
+  // from hoisting more and spilling).
+  constexpr int NSTEP = NT * (NT + 1) / 2;
+  auto step_ct = [](int i) constexpr { int ct = 0; while (i > ct) { i -= ct + 1; ct++; } return ct; };
+  auto step_p = [](int i) constexpr { int ct = 0; while (i > ct) { i -= ct + 1; ct++; } return i; };   // p == ct: the tile's own step
+  auto load_step = [&](auto II, double (&o)[4]) {
+    constexpr int i = decltype(II)::value;
+    constexpr int ct = step_ct(i), p = step_p(i);
+    // (the leading dimension is laundered per step: the address arithmetic of all 36 steps would otherwise be done up
+    // front and kept in registers -- 67 spilled VGPRs)
+    int lds = ld, ws = w;
+    asm volatile("" : "+s"(lds), "+s"(ws));
+    if constexpr (p < ct) {
+      const int li = ct * 16 + l15, lic = min(li, ws - 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double lv = Ld[lic + (int64_t)min(p * 16 + g + 4 * q, ws - 1) * lds];
+        o[q] = (li < ws) ? -lv : 0.0;
+      }
+    } else {
+      const int nb1 = ((ws + 15) >> 4) - 1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) o[q] = Ti[min(ct, nb1) * 256 + l15 + 16 * (g + 4 * q)];
+    }
+  };
+  double cu[4], nx[4];
+  d4_t c;
+  load_step(std::integral_constant<int, 0>{}, cu);
+  static_for<NSTEP>([&](auto II) {
+    constexpr int i = decltype(II)::value;
+    constexpr int ct = step_ct(i), p = step_p(i);
+    if constexpr (i + 1 < NSTEP) load_step(std::integral_constant<int, i + 1>{}, nx);
+    // (tiles beyond the cblk's width hold zeros and stay zero: no branch on the width, which would cost registers)
+    if constexpr (p == 0 || ct == 0) { c[0] = acc_read_m<ct, 0>(); c[1] = acc_read_m<ct, 1>(); c[2] = acc_read_m<ct, 2>(); c[3] = acc_read_m<ct, 3>(); }
+    if constexpr (p < ct) {
+      const double b0 = acc_read_m<p, 0>(), b1 = acc_read_m<p, 1>(), b2 = acc_read_m<p, 2>(), b3 = acc_read_m<p, 3>();
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[0], b0, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[1], b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[2], b2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[3], b3, c, 0, 0, 0);
+    } else {
+      d4_t t = d4_t{0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) t = __builtin_amdgcn_mfma_f64_16x16x4f64(cu[q], c[q], t, 0, 0, 0);
+      // (the four writes read the D of the last MFMA: the first one waits for it, asm statements keep their order)
+      acc_write<ct, 0, true>(t[0]); acc_write<ct, 1>(t[1]); acc_write<ct, 2>(t[2]); acc_write<ct, 3>(t[3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) cu[q] = nx[q];
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  static_for<NT>([&](auto CT) {
+    constexpr int ct = decltype(CT)::value;
+    int lds = ld, gs = (int)(threadIdx.x & 63u) >> 4;
+    asm volatile("" : "+s"(lds), "+v"(gs));
+    if (rvalid && ct * 16 + gs + 0 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 0) * lds], acc_read<ct, 0>());
+    if (rvalid && ct * 16 + gs + 4 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 4) * lds], acc_read<ct, 1>());
+    if (rvalid && ct * 16 + gs + 8 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 8) * lds], acc_read<ct, 2>());
+    if (rvalid && ct * 16 + gs + 12 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 12) * lds], acc_read<ct, 3>());
+  });
+}
+
 // ---- the run launch ------------------------------------------------------------------------------
 // The update tasks of the thin levels at the top of the tree, all in ONE launch (plan.h RunInfo; the reference's tasks
 // wait for TASK_CTRBCNT == 0 the same way, sopalin3d.c:790-1025 / contrib.c:45-88).  A workgroup draws a ticket (the
@@ -401,7 +531,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
                                                                const Piece* __restrict__ pieces,
                                                                const RunInfo* __restrict__ info,
                                                                const int32_t* __restrict__ waits, const RunCtl rc,
-                                                               const long long limit) {
+                                                               const double* __restrict__ dinv, const long long limit) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* tick = (int*)&sh[0][0][0];
@@ -410,6 +540,28 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   const int t = __builtin_amdgcn_readfirstlane(*tick);
   const Task tk = tasks[t];
   const RunInfo ri = info[t];
+  if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t] = wall_clock64();
+  if (ri.wn < 0) {
+    // a panel-solve ticket (RunInfo: tile / seq = the tile's counter and the run updates it must have seen, wptr = the
+    // cblk's diagonal flag; the Task record holds a TrsmTask): 128 panel rows, a wave per 16
+    if (tid == 0) {
+      run_poll(rc.dflag + ri.wptr, 1, rc.misc + RUN_STUCK, limit);
+      if (ri.seq > 0) run_poll(rc.tile_seq + ri.tile, ri.seq, rc.misc + RUN_STUCK, limit);
+      run_acquire();
+    }
+    __syncthreads();
+    if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t + 1] = wall_clock64();
+    TrsmTask tt;
+    __builtin_memcpy(&tt, &tk, sizeof(tt));
+    trsm_llt_parked<true>(ar.p[0], tt, dinv);
+    run_drain();
+    __syncthreads();
+    if (tid == 0) {
+      run_st(rc.tile_fin + ri.tile, 1);
+      if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
+    }
+    return;
+  }
   if (wave == 0) {
     // lane 0 of the first pass: the tile's previous writer; the other lanes: one source tile each
     for (int base = -1; base < ri.wn; base += 64) {
@@ -423,6 +575,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     run_acquire();
   }
   __syncthreads();                               // (also: the ticket word in LDS is dead from here on)
+  if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t + 1] = wall_clock64();
   const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
   const int l15 = lane & 15, g = lane >> 4;
   acc_zero();
@@ -447,13 +600,16 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
   run_drain();
   __syncthreads();
-  if (tid == 0) run_st(rc.tile_seq + ri.tile, ri.seq + 1);
+  if (tid == 0) {
+    run_st(rc.tile_seq + ri.tile, ri.seq + 1);
+    if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
+  }
 }
 
 void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* waits, const RunCtl& rc, int64_t ntasks, long long limit) {
+                       const int32_t* waits, const RunCtl& rc, const double* dinv, int64_t ntasks, long long limit) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(k_run_update, dim3((unsigned)ntasks), dim3(64 * UW), 0, s, ar, tasks, pieces, info, waits, rc, limit);
+  hipLaunchKernelGGL(k_run_update, dim3((unsigned)ntasks), dim3(64 * UW), 0, s, ar, tasks, pieces, info, waits, rc, dinv, limit);
 }
 
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,

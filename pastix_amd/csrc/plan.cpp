@@ -976,46 +976,160 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
     P.tasks.swap(sorted);
     // ---- the run schedule -----------------------------------------------------------------------------------------
-    // Ticket order (any topological order of the task graph is deadlock-free: a workgroup only waits for smaller
-    // tickets and for the resident panel workgroups): A(L0), then per slot s >= L0: B(s).next | A(s+1) | B(s).rest,
-    // where A(s) are the urgent tasks of slot s (targets of level s, sources of level s-1), B(s).next the bulk tasks
-    // whose targets are of level s+1 and B(s).rest the others -- the tasks the next level's panels wait for are drawn
-    // before the bulk of their slot.  Tasks of one tile keep their slot order (their ranges are visited in slot order).
+    // Tickets = the update tasks of slots >= L0 and the panel-solve tasks T(s) of levels >= L0 (one per 128-row tile with
+    // off-diagonal rows); the diagonal tasks D(s) run on resident workgroups.  Any topological order of the task graph is
+    // deadlock-free (a ticket only waits for smaller tickets and for the resident workgroups).  The order is a merge of
+    //   the chain      A(L0) T(L0) A(L0+1) T(L0+1) ...     A(s): urgent tasks of slot s (targets of level s, sources of
+    //                                                       level s-1); T(s) needs D(s), which needs A(s);
+    //   the bulk       B(L0).next B(L0).rest B(L0+1).next ...   B(s): sources <= s-1, .next = targets of level s+1;
+    // under:  A(s) behind B(s-1).next (same tiles, older sources);  B(s) behind T(s-1) (it reads level s-1).
+    // A ticket that is drawn before its inputs exist holds a slot of the chip while it waits, so a chain item is not
+    // emitted the moment it may be but after `delay` worth of bulk work since the previous one -- about the time the
+    // previous link takes (D before T, T before A) -- unless the bulk has nothing it may emit: then the chain is what the
+    // chip waits for and its tickets go out at once.
     P.ntile = ntile;
     P.nplanes = (lu ? 2 : 1) * (cplx ? 2 : 1);
+    if (P.run_L0 >= 0 && (int64_t)ntile * P.nplanes > 0x7fffffffLL) P.run_L0 = -1;
     if (P.run_L0 >= 0) {
       const int L0 = P.run_L0;
+      auto envd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
+      const double mac_per_us = 3.4e7;                          // multiply-adds the chip does per microsecond (68 TFLOP/s)
+      const double delayT = envd("PASTIX_AMD_RUN_DELAY_D", 120.0) * mac_per_us;   // in front of T(s): A(s) + D(s)
+      const double delayA = envd("PASTIX_AMD_RUN_DELAY_T", 40.0) * mac_per_us;    // in front of A(s+1): T(s)
+      // the panel side: diagonal tasks per level, panel-solve tasks per level
+      std::vector<int64_t> tptr((size_t)(NL - L0) + 1, 0);
+      std::vector<RunT> rt;
+      P.run_d.clear();
+      P.run_dptr.assign((size_t)(NL - L0) + 1, 0);
+      P.run_gd = 0;
+      int32_t ndf = 0;
+      for (int l = L0; l < NL; l++) {
+        P.run_dptr[(size_t)(l - L0)] = (int64_t)P.run_d.size();
+        tptr[(size_t)(l - L0)] = (int64_t)rt.size();
+        P.run_gd = std::max<int32_t>(P.run_gd, (int32_t)(P.lvl_cblk_ptr[l + 1] - P.lvl_cblk_ptr[l]));
+        for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
+          const int32_t k = P.lvl_cblk[(size_t)q];
+          const PanelTask& pt = P.panel_tasks[(size_t)q];
+          const int32_t w = pt.width, st = pt.stride;
+          RunD d{};
+          d.pt = pt;
+          d.tile0 = (int32_t)tile_base[(size_t)k];
+          d.tile0u = -1;
+          d.dflag = ndf++;
+          d.fin = !(w < TM && st > w);
+          P.run_d.push_back(d);
+          for (int32_t r = w / TM; (int64_t)r * TM < st; r++) {
+            const int32_t r0 = std::max<int32_t>(w, r * TM), r1 = std::min<int32_t>(st, (r + 1) * TM);
+            if (r1 <= r0) continue;
+            RunT tt{};
+            tt.tt = TrsmTask{pt.off, st, w, r0, r1 - r0, pt.dinv_off};
+            tt.tile = (int32_t)(tile_base[(size_t)k] + r);
+            tt.tileu = -1;
+            tt.dflag = d.dflag;
+            rt.push_back(tt);
+          }
+        }
+      }
+      P.run_dptr[(size_t)(NL - L0)] = (int64_t)P.run_d.size();
+      tptr[(size_t)(NL - L0)] = (int64_t)rt.size();
+      P.run_ndflag = ndf;
+      P.run_gd = std::min<int32_t>(P.run_gd, P.opts.run_d_workers > 0 ? P.opts.run_d_workers : 8);
+      // the merge.  order[]: >= 0 an update task (index into the slot-ordered task list), < 0 panel-solve task -1 - i
       std::vector<int64_t> order;
-      order.reserve((size_t)(P.slot_task_ptr[NL] - P.slot_task_ptr[L0]));
-      auto app = [&](int64_t b, int64_t e) { for (int64_t q = b; q < e; q++) order.push_back(q); };
-      app(P.slot_task_ptr[L0], P.slot_urgent_end[L0]);
-      for (int sl = L0; sl < NL; sl++) {
-        app(P.slot_urgent_end[sl], P.slot_next_end[sl]);
-        if (sl + 1 < NL) app(P.slot_task_ptr[sl + 1], P.slot_urgent_end[sl + 1]);
-        app(P.slot_next_end[sl], P.slot_task_ptr[sl + 1]);
+      order.reserve((size_t)(P.slot_task_ptr[NL] - P.slot_task_ptr[L0]) + rt.size());
+      {
+        int cs = L0, ck = 0;                   // chain head: A(cs) (ck = 0) or T(cs) (ck = 1); cs == NL: exhausted
+        int bs = L0;                           // bulk head: task bq of slot bs
+        int64_t bq = P.slot_urgent_end[L0];
+        auto bulk_skip = [&]() { while (bs < NL && bq >= P.slot_task_ptr[bs + 1]) { bs++; if (bs < NL) bq = P.slot_urgent_end[bs]; } };
+        bulk_skip();
+        double acc = 0;
+        for (;;) {
+          const bool chain_left = cs < NL;
+          // A(cs) may go once B(cs-1).next is out: the bulk head is past it
+          const bool chain_ok = chain_left && (ck == 1 || cs == L0 || bs > cs - 1 || (bs == cs - 1 && bq >= P.slot_next_end[cs - 1]));
+          // a bulk task of slot bs may go once T(bs-1) is out: the chain head is past it
+          const bool bulk_ok = bs < NL && (bs == L0 || cs > bs - 1);
+          if (!chain_left && bs >= NL) break;
+          if (chain_ok && (!bulk_ok || acc >= (ck == 1 ? delayT : delayA))) {
+            if (ck == 0) {
+              for (int64_t q = P.slot_task_ptr[cs]; q < P.slot_urgent_end[cs]; q++) order.push_back(q);
+              ck = 1;
+            } else {
+              for (int64_t i2 = tptr[(size_t)(cs - L0)]; i2 < tptr[(size_t)(cs - L0) + 1]; i2++) order.push_back(-1 - i2);
+              ck = 0;
+              cs++;
+            }
+            acc = 0;
+          } else if (bulk_ok) {
+            order.push_back(bq);
+            const Task& tk = P.tasks[(size_t)bq];
+            for (int z = 0; z < tk.pn; z++) {
+              const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+              acc += double(pc.m) * pc.n * pc.k;
+            }
+            bq++;
+            bulk_skip();
+          } else {
+            return PASTIX_AMD_ERR_LAYOUT;       // (cannot happen: one of the two heads is always free to go)
+          }
+        }
       }
       const size_t nr = order.size();
+      if (getenv("PASTIX_AMD_RUN_PROF")) {
+        // developer aid (tools/run_prof.py): category (0 A, 1 B.next, 2 B.rest, 3 T) and slot / level of every ticket
+        P.run_cat.resize(nr);
+        P.run_lvl.resize(nr);
+        for (size_t i = 0; i < nr; i++) {
+          const int64_t q = order[i];
+          if (q < 0) {
+            const int lv = (int)(std::upper_bound(tptr.begin(), tptr.end(), -1 - q) - tptr.begin() - 1) + L0;
+            P.run_cat[i] = 3; P.run_lvl[i] = lv;
+          } else {
+            const int sl = (int)(std::upper_bound(P.slot_task_ptr.begin(), P.slot_task_ptr.end(), q) - P.slot_task_ptr.begin() - 1);
+            P.run_cat[i] = q < P.slot_urgent_end[sl] ? 0 : q < P.slot_next_end[sl] ? 1 : 2;
+            P.run_lvl[i] = sl;
+          }
+        }
+      }
       P.run_tasks.resize(nr);
       P.run_info.resize(nr);
-      std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // run tasks per tile counter
+      std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // update tasks of the run per tile counter
       bool bad = false;
-      for (size_t i = 0; i < nr; i++) {
+      for (size_t i = 0; i < nr && !bad; i++) {
         const int64_t q = order[i];
-        P.run_tasks[i] = P.tasks[(size_t)q];
-        const int64_t tl = task_tile[(size_t)idx[(size_t)q]];
-        if (tl < 0 || (P.tasks[(size_t)q].flags & (4u | 32u))) { bad = true; break; }   // (quadrant / shared tasks: not in a run)
-        P.run_info[i].tile = (int32_t)tl;
-        P.run_info[i].seq = tcount[(size_t)tl]++;
+        RunInfo& ri = P.run_info[i];
+        if (q >= 0) {
+          P.run_tasks[i] = P.tasks[(size_t)q];
+          const int64_t tl = task_tile[(size_t)idx[(size_t)q]];
+          if (tl < 0 || (P.tasks[(size_t)q].flags & (4u | 32u))) { bad = true; break; }   // (quadrant / shared tasks: not in a run)
+          ri.tile = (int32_t)tl;
+          ri.seq = tcount[(size_t)tl]++;
+          ri.wptr = 0;
+          ri.wn = 0;
+        } else {
+          // the panel-solve ticket of tile rt: by now every update task of the run on that tile has its ticket (A(s) is
+          // the last slot that targets level s), so the count is final
+          const RunT& tt = rt[(size_t)(-1 - q)];
+          static_assert(sizeof(Task) == sizeof(TrsmTask), "a panel-solve ticket travels in a Task record");
+          memcpy(&P.run_tasks[i], &tt.tt, sizeof(Task));
+          ri.tile = tt.tile;
+          ri.seq = tcount[(size_t)tt.tile];
+          ri.wptr = tt.dflag;
+          ri.wn = -1;
+        }
       }
-      if (bad || (int64_t)ntile * P.nplanes > 0x7fffffffLL) {
+      if (bad) {
         P.run_L0 = -1;
         P.run_tasks.clear();
         P.run_info.clear();
+        P.run_d.clear();
       } else {
-        // source tiles a task waits for: the 128-row tiles of the source panels its pieces read (A rows, B rows),
-        // sources of the run's levels only -- older panels are final when the run starts
+        for (RunD& d : P.run_d) d.need0 = tcount[(size_t)d.tile0];
+        // source tiles an update ticket waits for: the 128-row tiles of the source panels its pieces read (A rows, B
+        // rows), sources of the run's levels only -- older panels are final when the run starts
         std::vector<std::vector<int32_t>> tw((size_t)nthr);
-        std::vector<std::vector<std::pair<int32_t, int32_t>>> tpw((size_t)nthr);   // per task of the range: (first, count) in tw
+        std::vector<std::vector<std::pair<int32_t, int32_t>>> tpw((size_t)nthr);   // per ticket of the range: (first, count) in tw
         std::vector<double> trf((size_t)nthr, 0.0);
         const size_t per = (nr + (size_t)nthr - 1) / (size_t)nthr;
         auto wbody = [&](int t) {
@@ -1023,19 +1137,21 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           std::vector<int32_t> tmp;
           double fl = 0;
           for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
-            const Task& tk = P.run_tasks[i];
             tmp.clear();
-            for (int z = 0; z < tk.pn; z++) {
-              const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
-              fl += 2.0 * pc.m * (double)pc.n * pc.k;
-              const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), pc.a_off) - P.poff.begin() - 1;
-              if (P.level[(size_t)k] < L0) continue;
-              const int64_t a0 = pc.a_off - P.poff[(size_t)k], b0 = pc.b_off - P.poff[(size_t)k];   // rows (column 0 of the panel)
-              for (int64_t rt = a0 / TM; rt <= (a0 + pc.m - 1) / TM; rt++) tmp.push_back((int32_t)(tile_base[(size_t)k] + rt));
-              for (int64_t rt = b0 / TM; rt <= (b0 + pc.n - 1) / TM; rt++) tmp.push_back((int32_t)(tile_base[(size_t)k] + rt));
+            if (P.run_info[i].wn >= 0) {
+              const Task& tk = P.run_tasks[i];
+              for (int z = 0; z < tk.pn; z++) {
+                const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+                fl += 2.0 * pc.m * (double)pc.n * pc.k;
+                const int64_t k = std::upper_bound(P.poff.begin(), P.poff.end(), pc.a_off) - P.poff.begin() - 1;
+                if (P.level[(size_t)k] < L0) continue;
+                const int64_t a0 = pc.a_off - P.poff[(size_t)k], b0 = pc.b_off - P.poff[(size_t)k];   // rows (column 0 of the panel)
+                for (int64_t r = a0 / TM; r <= (a0 + pc.m - 1) / TM; r++) tmp.push_back((int32_t)(tile_base[(size_t)k] + r));
+                for (int64_t r = b0 / TM; r <= (b0 + pc.n - 1) / TM; r++) tmp.push_back((int32_t)(tile_base[(size_t)k] + r));
+              }
+              std::sort(tmp.begin(), tmp.end());
+              tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
             }
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
             tpw[(size_t)t].emplace_back((int32_t)W.size(), (int32_t)tmp.size());
             W.insert(W.end(), tmp.begin(), tmp.end());
           }
@@ -1055,49 +1171,15 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         P.run_flops = 0;
         for (int t = 0; t < nthr; t++) {
           std::copy(tw[(size_t)t].begin(), tw[(size_t)t].end(), P.run_waits.begin() + base);
-          for (size_t j = 0; j < tpw[(size_t)t].size(); j++) {
-            RunInfo& ri = P.run_info[(size_t)t * per + j];
-            ri.wptr = (int32_t)(base + (size_t)tpw[(size_t)t][j].first);
-            ri.wn = tpw[(size_t)t][j].second;
+          for (size_t j2 = 0; j2 < tpw[(size_t)t].size(); j2++) {
+            RunInfo& ri = P.run_info[(size_t)t * per + j2];
+            if (ri.wn < 0) continue;
+            ri.wptr = (int32_t)(base + (size_t)tpw[(size_t)t][j2].first);
+            ri.wn = tpw[(size_t)t][j2].second;
           }
           base += tw[(size_t)t].size();
           P.run_flops += trf[(size_t)t];
         }
-        // the panel side: per level the diagonal tasks (one per cblk, the level's order) and the panel-solve tasks,
-        // one per 128-row tile of the panel that holds off-diagonal rows
-        P.run_dptr.assign((size_t)(NL - L0) + 1, 0);
-        P.run_gd = 0;
-        int32_t ndf = 0;
-        for (int l = L0; l < NL; l++) {
-          P.run_dptr[(size_t)(l - L0)] = (int64_t)P.run_d.size();
-          P.run_gd = std::max<int32_t>(P.run_gd, (int32_t)(P.lvl_cblk_ptr[l + 1] - P.lvl_cblk_ptr[l]));
-          for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
-            const int32_t k = P.lvl_cblk[(size_t)q];
-            const PanelTask& pt = P.panel_tasks[(size_t)q];
-            const int32_t w = pt.width, st = pt.stride;
-            RunD d{};
-            d.pt = pt;
-            d.tile0 = (int32_t)tile_base[(size_t)k];
-            d.need0 = tcount[(size_t)d.tile0];
-            d.tile0u = -1; d.need0u = 0;
-            d.dflag = ndf++;
-            d.fin = !(w < TM && st > w);
-            P.run_d.push_back(d);
-            for (int32_t rt = w / TM; (int64_t)rt * TM < st; rt++) {
-              const int32_t r0 = std::max<int32_t>(w, rt * TM), r1 = std::min<int32_t>(st, (rt + 1) * TM);
-              if (r1 <= r0) continue;
-              RunT tt{};
-              tt.tt = TrsmTask{pt.off, st, w, r0, r1 - r0, pt.dinv_off};
-              tt.tile = (int32_t)(tile_base[(size_t)k] + rt);
-              tt.need = tcount[(size_t)tt.tile];
-              tt.tileu = -1; tt.needu = 0;
-              tt.dflag = d.dflag;
-              P.run_t.push_back(tt);
-            }
-          }
-        }
-        P.run_dptr[(size_t)(NL - L0)] = (int64_t)P.run_d.size();
-        P.run_ndflag = ndf;
       }
     }
   }
@@ -1140,43 +1222,33 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
 }
 
 // Host-only check of a run schedule (tests): replays the tickets ONE AT A TIME in ticket order -- the weakest progress the
-// device guarantees, since a ticket is only ever held by a workgroup that runs -- with the panel workers advancing whenever
-// their next task's counters allow, `gt` solve workers walking the task list with stride gt.  Returns 0 when every ticket's
-// waits are met by smaller tickets and panel tasks (no deadlock, every counter ends where the waiters expect it), else the
-// 1-based index of the first ticket that could not run, or -1 for an inconsistent table.
-int64_t run_verify(const Plan& P, int gt) {
+// device guarantees, since a ticket is only ever held by a workgroup that runs -- with the resident diagonal workers
+// advancing whenever their next task's counter allows.  Returns 0 when every ticket's waits are met by smaller tickets and
+// diagonal tasks (no deadlock, every counter ends where the waiters expect it), else the 1-based index of the first ticket
+// that could not run, or -1 for an inconsistent table.
+int64_t run_verify(const Plan& P) {
   if (P.run_L0 < 0) return 0;
   const size_t nr = P.run_tasks.size();
   if (P.run_info.size() != nr) return -1;
   std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl((size_t)std::max<int64_t>(P.run_ndflag, 1), 0);
   const int nlev = P.nlevels - P.run_L0;
-  gt = (int)std::max<int64_t>(1, std::min<int64_t>(gt, (int64_t)P.run_t.size()));
-  std::vector<int> dpos((size_t)std::max(P.run_gd, 1), 0);      // next level of every diagonal worker
-  std::vector<int64_t> tpos((size_t)gt);
-  for (int w = 0; w < gt; w++) tpos[(size_t)w] = w;
+  std::vector<int> dpos((size_t)std::max(P.run_gd, 1), 0);      // next (level, cblk of the level) of every diagonal worker
+  std::vector<int64_t> dsub((size_t)std::max(P.run_gd, 1));
+  for (int w = 0; w < P.run_gd; w++) dsub[(size_t)w] = w;
   auto advance = [&]() {
     bool any = false;
     for (int w = 0; w < P.run_gd; w++) {
       for (;;) {
         int& l = dpos[(size_t)w];
-        while (l < nlev && w >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) l++;
+        int64_t& di = dsub[(size_t)w];
+        while (l < nlev && di >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) { l++; di = w; }
         if (l >= nlev) break;
-        const RunD& d = P.run_d[(size_t)(P.run_dptr[(size_t)l] + w)];
+        const RunD& d = P.run_d[(size_t)(P.run_dptr[(size_t)l] + di)];
         if (seq[(size_t)d.tile0] < d.need0) break;
         if (d.tile0u >= 0 && seq[(size_t)d.tile0u] < d.need0u) break;
         dfl[(size_t)d.dflag] = 1;
         if (d.fin) fin[(size_t)d.tile0] = 1;
-        l++;
-        any = true;
-      }
-    }
-    for (int w = 0; w < gt; w++) {
-      while (tpos[(size_t)w] < (int64_t)P.run_t.size()) {
-        const RunT& t = P.run_t[(size_t)tpos[(size_t)w]];
-        if (!dfl[(size_t)t.dflag] || seq[(size_t)t.tile] < t.need) break;
-        if (t.tileu >= 0 && seq[(size_t)t.tileu] < t.needu) break;
-        fin[(size_t)t.tile] = 1;
-        tpos[(size_t)w] += gt;
+        di += P.run_gd;
         any = true;
       }
     }
@@ -1184,27 +1256,34 @@ int64_t run_verify(const Plan& P, int gt) {
   };
   for (size_t i = 0; i < nr; i++) {
     const RunInfo& ri = P.run_info[i];
-    if (ri.tile < 0 || (size_t)ri.tile >= seq.size() || ri.wptr < 0 || (size_t)ri.wptr + (size_t)ri.wn > P.run_waits.size()) return -1;
-    for (;;) {
-      bool ok = seq[(size_t)ri.tile] == ri.seq;
-      if (seq[(size_t)ri.tile] > ri.seq) return -1;
-      for (int q = 0; ok && q < ri.wn; q++) {
-        const int32_t f = P.run_waits[(size_t)ri.wptr + (size_t)q];
-        if (f < 0 || (size_t)f >= fin.size()) return -1;
-        ok = fin[(size_t)f] != 0;
-      }
-      if (ok) break;
-      if (!advance()) return (int64_t)i + 1;
+    if (ri.tile < 0 || (size_t)ri.tile >= seq.size()) return -1;
+    if (ri.wn < 0) {                               // a panel-solve ticket
+      if ((size_t)ri.tile >= fin.size() || ri.wptr < 0 || (size_t)ri.wptr >= dfl.size()) return -1;
+      if (seq[(size_t)ri.tile] != ri.seq) return (int64_t)i + 1;      // (its tile's updates all have smaller tickets)
+      while (!dfl[(size_t)ri.wptr]) if (!advance()) return (int64_t)i + 1;
+      if (fin[(size_t)ri.tile]) return -1;
+      fin[(size_t)ri.tile] = 1;
+      continue;
     }
+    if (ri.wptr < 0 || (size_t)ri.wptr + (size_t)ri.wn > P.run_waits.size()) return -1;
+    if (seq[(size_t)ri.tile] != ri.seq) return seq[(size_t)ri.tile] > ri.seq ? -1 : (int64_t)i + 1;
+    for (int q = 0; q < ri.wn; q++) {
+      const int32_t f = P.run_waits[(size_t)ri.wptr + (size_t)q];
+      if (f < 0 || (size_t)f >= fin.size()) return -1;
+      if (!fin[(size_t)f]) return (int64_t)i + 1;   // (a source tile is final by a smaller panel-solve ticket or a diagonal task
+                                                    //  whose inputs are smaller tickets: nothing to advance for)
+    }
+    if (fin[(size_t)ri.tile < fin.size() ? (size_t)ri.tile : 0] && (size_t)ri.tile < fin.size()) return -1;   // (written after it was final)
     seq[(size_t)ri.tile] = ri.seq + 1;
+    advance();
   }
   while (advance()) {}
   for (int w = 0; w < P.run_gd; w++) {
     int l = dpos[(size_t)w];
-    while (l < nlev && w >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) l++;
+    int64_t di = dsub[(size_t)w];
+    while (l < nlev && di >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) { l++; di = w; }
     if (l < nlev) return (int64_t)nr + 1;
   }
-  for (int w = 0; w < gt; w++) if (tpos[(size_t)w] < (int64_t)P.run_t.size()) return (int64_t)nr + 1;
   return 0;
 }
 

@@ -88,10 +88,11 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
 // workgroup of one launch (k_run_update) that takes a ticket, waits for its tile's previous writer and for the panel
 // tiles its pieces read, and publishes its tile; the diagonal and panel-solve tasks of those levels run on a few
 // resident workgroups of a second kernel (k_run_panel) that wait for the tiles' counters the same way.
-struct RunInfo {             // per update task of the run, in ticket order
+struct RunInfo {             // per ticket of the run
   int32_t tile;              // index of the target tile's sequence counter (tile id + plane * ntile)
-  int32_t seq;               // number of earlier tasks of the run on this tile: the task waits for counter == seq
-  int32_t wptr, wn;          // run_waits[wptr .. +wn): source tiles (L-arena tile ids) that must be final
+  int32_t seq;               // number of earlier update tasks of the run on this tile: the ticket waits for counter == seq
+  int32_t wptr, wn;          // update task: run_waits[wptr .. +wn): source tiles (L-arena tile ids) that must be final
+                             // panel-solve task: wn = -1, wptr = the cblk's diagonal flag; it makes `tile` final
 };
 struct RunD {                // a diagonal-blok task of the run
   PanelTask pt;
@@ -101,7 +102,7 @@ struct RunD {                // a diagonal-blok task of the run
   int32_t fin;               // 1: nobody solves rows in tile 0 (no off-diagonal rows there): the task raises its final flag
   int32_t cntlvl, pad_;      // (reserved)
 };
-struct RunT {                // a panel-solve task of the run: the off-diagonal rows of one 128-row tile
+struct RunT {                // (plan construction) a panel-solve task of the run: the off-diagonal rows of one 128-row tile
   TrsmTask tt;
   int32_t tile, need;        // the tile's counter (L arena), run tasks that update it
   int32_t tileu, needu;      // LU: U arena (-1: none)
@@ -114,6 +115,7 @@ struct RunCtl {
   int32_t* tile_fin;         // [ntile] 1: the tile's off-diagonal rows are solved (final: readable as a source)
   int32_t* dflag;            // [run cblks] 1: the diagonal blok is factorized
   int32_t* misc;             // RUN_HEAD: ticket counter; RUN_STUCK: a bounded wait expired (the run failed)
+  long long* prof;           // developer aid (PASTIX_AMD_RUN_PROF): 4 clock stamps per update ticket, then per panel task; else null
 };
 constexpr int RUN_HEAD = 0, RUN_STUCK = 64, RUN_MISC_INTS = 128;
 
@@ -184,12 +186,14 @@ struct Plan {
   int32_t run_L0 = -1;
   int64_t ntile = 0;                     // target tiles per plane
   int32_t nplanes = 1;                   // planes that are update targets (1 LLt/LDLt, 2 LU, x2 complex)
-  std::vector<Task> run_tasks;           // the update tasks of slots >= run_L0 in ticket order
+  std::vector<Task> run_tasks;           // the tickets: update tasks of slots >= run_L0 and panel-solve tasks (a TrsmTask in
+                                         // the record; RunInfo::wn < 0) of levels >= run_L0
   std::vector<RunInfo> run_info;         // [run_tasks.size()]
   std::vector<int32_t> run_waits;
+  std::vector<uint8_t> run_cat;          // (PASTIX_AMD_RUN_PROF) per ticket: 0 A, 1 B.next, 2 B.rest, 3 panel solve; its slot / level
+  std::vector<int32_t> run_lvl;
   std::vector<RunD> run_d;               // level-major; run_dptr[l - run_L0] = first task of level l
   std::vector<int64_t> run_dptr;
-  std::vector<RunT> run_t;               // level-major (cblk, row tile)
   int32_t run_gd = 0;                    // resident workgroups for the diagonal tasks (max cblks of a run level)
   int64_t run_ndflag = 0;
   double run_flops = 0;                  // update flops inside the run
@@ -203,7 +207,7 @@ struct Plan {
 int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
-int64_t run_verify(const Plan& plan, int gt);
+int64_t run_verify(const Plan& plan);
 int owner_view(const pastix_amd_layout_t* layout, const int32_t* owner, int32_t myrank, Plan& plan);
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
 int fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask);

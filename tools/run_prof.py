@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Reads a PASTIX_AMD_RUN_PROF dump (api.cpp): clock stamps (100 MHz) of every ticket of the run launch and of the
+resident diagonal tasks.  Prints slot-time by category (waiting / running) and a per-level chain timeline."""
+import sys
+import numpy as np
+
+raw = np.fromfile(sys.argv[1], dtype=np.int64)
+nu, nd, _, L0 = [int(x) for x in raw[:4]]
+n = nu + nd
+st = raw[4:4 + 4 * n].reshape(n, 4)
+cl = raw[4 + 4 * n:4 + 4 * n + nu]
+cat = cl & 255
+lvl = cl >> 8
+U = st[:nu]; D = st[nu:]
+t0 = U[:, 0].min(); t1 = max(U[:, 2].max(), D[:, 2].max() if nd else 0)
+wall = (t1 - t0) * 1e-8
+print("run: %d tickets, %d diag tasks; wall %.3f ms; first level %d" % (nu, nd, wall * 1e3, L0))
+names = ["A (urgent, targets of the level)", "B.next (targets of next level)", "B.rest", "T (panel solve, 128 rows)"]
+tot_slot = 0
+for c in range(4):
+    m = cat == c
+    if not m.any(): continue
+    w = (U[m, 1] - U[m, 0]).sum() * 1e-8; r = (U[m, 2] - U[m, 1]).sum() * 1e-8
+    tot_slot += w + r
+    print("  %-34s %8d: waiting %9.3f ms  running %9.3f ms (slot-time; mean wait %.1f us, mean run %.1f us)" % (
+        names[c], m.sum(), w * 1e3, r * 1e3, w / m.sum() * 1e6, r / m.sum() * 1e6))
+print("  ticket slot-time total %.3f ms = %.1f slots busy on average (of 512)" % (tot_slot * 1e3, tot_slot / wall))
+if nd:
+    print("  diag tasks: waiting %.3f ms running %.3f ms (mean run %.1f us; last 20: %.1f us)" % (
+        (D[:, 1] - D[:, 0]).sum() * 1e-5, (D[:, 2] - D[:, 1]).sum() * 1e-5, (D[:, 2] - D[:, 1]).mean() * 1e-2, (D[-20:, 2] - D[-20:, 1]).mean() * 1e-2))
+mt = cat == 3
+if mt.any():
+    top = mt & (lvl >= lvl.max() - 20)
+    print("  T at the top 20 levels: mean run %.1f us, mean wait %.1f us" % ((U[top, 2] - U[top, 1]).mean() * 1e-2, (U[top, 1] - U[top, 0]).mean() * 1e-2))
+print("level: A first drawn / last ready / last done | T last done | period (us)")
+rows = []
+for s in range(L0, int(lvl.max()) + 1):
+    m = (cat == 0) & (lvl == s)
+    if not m.any(): continue
+    t = (cat == 3) & (lvl == s)
+    rows.append((s, (U[m, 0].min() - t0) * 1e-2, (U[m, 1].max() - t0) * 1e-2, (U[m, 2].max() - t0) * 1e-2, int(m.sum()),
+                 (U[t, 2].max() - t0) * 1e-2 if t.any() else 0.0, (U[t, 1] - U[t, 0]).mean() * 1e-2 if t.any() else 0.0))
+step = max(1, len(rows) // 40)
+for i, (s, a0, ar, ad, k, td, tw) in enumerate(rows):
+    if i % step == 0 or i >= len(rows) - 3:
+        per = (ad - rows[i - 1][3]) if i > 0 else 0
+        print("  %4d: n=%4d drawn %10.1f ready %10.1f done %10.1f | T done %10.1f (mean wait %6.1f) | A spin %7.1f period %7.1f" % (
+            s, k, a0, ar, ad, td, tw, ar - a0, per))
