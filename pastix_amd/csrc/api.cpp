@@ -261,16 +261,38 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       // the run schedule: its tables, its flags, two more streams for the resident panel kernels
       if ((r = to_device(&p->dRunTasks, H.run_tasks))) return r;
       if ((r = to_device(&p->dRunInfo, H.run_info))) return r;
-      if ((r = to_device(&p->dRunWaits, H.run_waits))) return r;
+      if ((r = to_device(&p->dRunCons, H.run_cons))) return r;
       if ((r = to_device(&p->dRunD, H.run_d))) return r;
-      if ((r = to_device(&p->dRunDptr, H.run_dptr))) return r;
-      const size_t nseq = (size_t)H.ntile * (size_t)H.nplanes, nfin = (size_t)H.ntile, ndf = (size_t)std::max<int64_t>(H.run_ndflag, 1);
-      p->nRunFlags = nseq + nfin + ndf + RUN_MISC_INTS + 64;
-      HIPCHK(hipMalloc((void**)&p->dRunFlags, p->nRunFlags * sizeof(int32_t)));
-      p->runctl.tile_seq = p->dRunFlags;
-      p->runctl.tile_fin = p->dRunFlags + nseq;
-      p->runctl.dflag = p->runctl.tile_fin + nfin;
-      p->runctl.misc = p->dRunFlags + ((nseq + nfin + ndf + 63) / 64) * 64;
+      // the run's state: [counters of the tickets and diagonal tasks | three ticket rings | diagonal ring | control words],
+      // and its initial image (what is ready when the run starts sits in the rings, their tails behind it)
+      const size_t nr = H.run_tasks.size(), nd = H.run_d.size();
+      auto up64 = [](size_t x) { return (x + 63) / 64 * 64; };
+      const size_t o_cnt = 0, o_q = up64(nr + nd), o_qd = o_q + up64(nr), o_ctl = o_qd + up64(nd);
+      p->nRunState = o_ctl + RUN_CTL_INTS;
+      {
+        std::vector<int32_t> img(p->nRunState, -1);
+        std::copy(H.run_dep.begin(), H.run_dep.end(), img.begin() + (ptrdiff_t)o_cnt);
+        for (size_t c = 0; c < (size_t)RUN_CTL_INTS; c++) img[o_ctl + c] = 0;
+        std::copy(H.run_ready.begin(), H.run_ready.end(), img.begin() + (ptrdiff_t)o_q);
+        img[o_ctl + RUN_TAIL] = (int32_t)H.run_ready.size();
+        std::copy(H.run_dready.begin(), H.run_dready.end(), img.begin() + (ptrdiff_t)o_qd);
+        img[o_ctl + RUN_TAIL + 64] = (int32_t)H.run_dready.size();
+        HIPCHK(hipMalloc((void**)&p->dRunImage, p->nRunState * sizeof(int32_t)));
+        HIPCHK(hipMalloc((void**)&p->dRunState, p->nRunState * sizeof(int32_t)));
+        HIPCHK(hipMemcpy(p->dRunImage, img.data(), p->nRunState * sizeof(int32_t), hipMemcpyHostToDevice));
+      }
+      p->runctl.cnt = p->dRunState + o_cnt;
+      p->runctl.q = p->dRunState + o_q;
+      p->runctl.qd = p->dRunState + o_qd;
+      p->runctl.ctl = p->dRunState + o_ctl;
+      p->runctl.nd = (int32_t)nd;
+      p->runctl.nticket = (int32_t)nr;
+      p->run_nd = (int64_t)nd;
+      {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, p->device));
+        p->run_nwg = 2 * std::max(prop.multiProcessorCount, 1);
+      }
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       HIPCHK(hipStreamCreateWithPriority(&p->stream3, hipStreamNonBlocking, hi));
@@ -349,7 +371,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   // the piece/task tables now live on the device; keep only what the host driver reads.  (Returning several GB to the
   // system takes 0.4 s at 200^3: a thread of its own does it.)
   {
-    struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks, rtasks; std::vector<RunInfo> rinfo; std::vector<int32_t> rwaits; };
+    struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks, rtasks; std::vector<RunInfo> rinfo; std::vector<int32_t> rwaits, rcons, rdep; std::vector<RunCheck> rchk; };
     Junk* junk = new (std::nothrow) Junk();
     if (junk) {
       junk->pieces.swap(H.pieces);
@@ -357,6 +379,9 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       junk->rtasks.swap(H.run_tasks);
       junk->rinfo.swap(H.run_info);
       junk->rwaits.swap(H.run_waits);
+      junk->rcons.swap(H.run_cons);
+      junk->rdep.swap(H.run_dep);
+      junk->rchk.swap(H.run_chk);
       try { std::thread([junk] { delete junk; }).detach(); } catch (const std::system_error&) { delete junk; }
     } else {
       decltype(H.pieces)().swap(H.pieces);
@@ -428,9 +453,9 @@ int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, c
     info[0] = P.run_L0;
     info[1] = P.nlevels;
     info[2] = (pastix_amd_int_t)P.run_tasks.size();
-    info[3] = (pastix_amd_int_t)P.run_waits.size();
+    info[3] = (pastix_amd_int_t)P.run_cons.size();
     info[4] = P.run_gd;
-    info[5] = 0; for (const RunInfo& ri : P.run_info) info[5] += ri.wn < 0;
+    info[5] = 0; for (const RunInfo& ri : P.run_info) info[5] += (ri.kind & 4) != 0;
     info[6] = (pastix_amd_int_t)P.run_flops;
     info[7] = run_verify(P);
   } catch (const std::bad_alloc&) {
@@ -528,8 +553,8 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
   for (hipEvent_t e : {p->evZ, p->evS3}) if (e) (void)hipEventDestroy(e);
-  (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunWaits); (void)hipFree(p->dRunD);
-  (void)hipFree(p->dRunDptr); (void)hipFree(p->dRunFlags); (void)hipFree(p->dRunProf);
+  (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunCons); (void)hipFree(p->dRunD);
+  (void)hipFree(p->dRunState); (void)hipFree(p->dRunImage); (void)hipFree(p->dRunProf);
   if (p->hResident) (void)hipHostFree(p->hResident);
   if (p->ev0) (void)hipEventDestroy(p->ev0);
   if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -1284,7 +1309,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   }
   if (p->run_used) {
     int stuck = 0;
-    HIPCHK(hipMemcpy(&stuck, p->runctl.misc + RUN_STUCK, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&stuck, p->runctl.ctl + RUN_STUCK, sizeof(int), hipMemcpyDeviceToHost));
     if (stuck) {
       fprintf(stderr, "pastix_amd: a wait inside the run launch expired (PASTIX_AMD_RUN_TIMEOUT): the factorization failed\n");
       p->factored = false;
@@ -1350,13 +1375,13 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   p->run_used = use_run;
   const int run_nwk = use_run ? H.run_gd : 0;
   if (use_run) {
-    HIPCHK(hipMemsetAsync(p->dRunFlags, 0, p->nRunFlags * sizeof(int32_t), s1));
+    HIPCHK(hipMemcpyAsync(p->dRunState, p->dRunImage, p->nRunState * sizeof(int32_t), hipMemcpyDeviceToDevice, s1));
     *(volatile int*)p->hResident = 0;
     HIPCHK(hipEventRecord(p->evZ, s1));
     HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));
     HIPCHK(hipStreamWaitEvent(s2, p->evZ, 0));
-    launch_run_panel(p->stream3, H.factotype, p->arenas(), p->dRunD, p->dRunDptr, H.nlevels - L0, H.run_gd, p->dDinv, critere,
-                     p->dNbpivot, p->dErr, p->runctl, p->hResident, run_limit, p->run_nticket);
+    launch_run_panel(p->stream3, H.factotype, p->arenas(), p->dRunD, p->dRunInfo, H.run_gd, p->dDinv, critere, p->dNbpivot,
+                     p->dErr, p->runctl, p->hResident, run_limit);
     HIPCHK(hipEventRecord(p->evS3, p->stream3));
   }
   for (int l = 0; l < L0; l++) {
@@ -1393,7 +1418,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       if (now_s() - tw0 > 10.0) {
         fprintf(stderr, "pastix_amd: the run's panel workgroups did not start (%d of %d)\n", *(volatile int*)p->hResident, run_nwk);
         int one = 1;                                     // (lets the ones that did start leave their loops)
-        (void)hipMemcpyAsync(p->runctl.misc + RUN_STUCK, &one, sizeof(int), hipMemcpyHostToDevice, s2);
+        (void)hipMemcpyAsync(p->runctl.ctl + RUN_STUCK, &one, sizeof(int), hipMemcpyHostToDevice, s2);
         (void)hipStreamSynchronize(s2);
         (void)hipStreamSynchronize(p->stream3);
         (void)hipStreamSynchronize(s1);
@@ -1401,8 +1426,8 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       }
     }
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunWaits, p->runctl, p->dDinv,
-                      p->run_nticket, run_limit);
+    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunCons, p->runctl, p->dDinv,
+                      p->run_nticket, p->run_nwg, run_limit);
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
     p->nupdB_run++;
     s2_used = true;

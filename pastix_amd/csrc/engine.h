@@ -20,10 +20,9 @@ void launch_update_small(hipStream_t s, const Arenas& ar, const Task* tasks, con
 // the run schedule (plan.h RunInfo): the update tasks of the thin levels in one launch, their panel tasks on resident
 // workgroups of two kernels on streams of their own
 void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* waits, const RunCtl& rc, const double* dinv, int64_t ntasks, long long limit);
-void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr, int nlev, int gd,
-                      double* dinv, double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident,
-                      long long limit, int64_t nticket);
+                       const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit);
+void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                      double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,
                      long long* nbpivot, int maxw);
 void launch_zsolve_level(hipStream_t s, bool fwd, int factotype, const Arenas& ar, const SolveTask* tasks, int64_t ntask,
@@ -164,9 +163,12 @@ struct pastix_amd_plan_s {
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   // the run schedule: device tables, the synchronisation words (zeroed per factorization), the panel kernels' streams
   bool run_ready = false, run_used = false;
-  Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunWaits = nullptr;
-  RunD* dRunD = nullptr; int64_t* dRunDptr = nullptr;
-  int32_t* dRunFlags = nullptr; size_t nRunFlags = 0;
+  Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunCons = nullptr;
+  RunD* dRunD = nullptr;
+  int32_t *dRunState = nullptr, *dRunImage = nullptr;   // the counters / rings / control words and their initial image
+  size_t nRunState = 0;
+  int64_t run_nd = 0;
+  int run_nwg = 512;                   // workgroups of the run launch: two per CU
   RunCtl runctl{};
   hipStream_t stream3 = nullptr;
   int64_t run_nticket = 0;

@@ -538,34 +538,37 @@ __global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __res
 
 // ---- the run's diagonal kernel (real LLt) ---------------------------------------------------------------------------
 // The diagonal-blok tasks of the run's levels (plan.h RunD) on a few RESIDENT workgroups, started before the run's
-// launch and alive until the last task: workgroup d factorizes the cblks d, d + gd, ... of every level, walking its
-// list in level order, and waits per task for the counter of the diagonal tile (its run updates are all in).  Being
-// resident the workgroups never wait for a slot behind the tickets that wait for them; the host checks `resident` (a
-// counter in host memory) before it launches k_run_update.  (The panel solves are tickets of that launch,
-// kernels_update.hip trsm_llt_parked: resident workgroups for them cost slots all the time -- 48 of 512 measured -4 %.)
+// launch and alive until the last diagonal task is taken: each pops ready diagonal tasks from their ring (a task is ready
+// when the last update of its diagonal tile has counted down its counter), factorizes the blok exactly as k_diag_llt_w
+// does, stores it write-through and counts down the cblk's panel-solve tickets.  (Diagonal tasks are not tickets of
+// k_run_update because their code needs 128 VGPRs beside that kernel's 64 accumulation registers; a workgroup that is
+// resident never waits for a slot behind tickets that wait for it.  The host checks `resident` before it launches
+// k_run_update.)
 __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L, const RunD* __restrict__ rd,
-                                                         const int64_t* __restrict__ dptr, const int nlev,
-                                                         double* __restrict__ dinv_ws, const double critere,
-                                                         long long* __restrict__ nbpivot, int* __restrict__ errflag,
-                                                         const RunCtl rc, int* __restrict__ resident, const long long limit,
-                                                         const int64_t pbase) {
+                                                         const RunInfo* __restrict__ info, double* __restrict__ dinv_ws,
+                                                         const double critere, long long* __restrict__ nbpivot,
+                                                         int* __restrict__ errflag, const RunCtl rc,
+                                                         int* __restrict__ resident, const long long limit) {
   __shared__ double D[DIAG_LDS_DOUBLES];
   __shared__ double Ri[2][16];
+  __shared__ int s_task;
   PANEL_PRIO();
-  const int tid = threadIdx.x, wk = blockIdx.x;
+  const int tid = threadIdx.x;
   if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  int32_t* stuck = rc.misc + RUN_STUCK;
-  for (int l = 0; l < nlev; l++) {
-   const int64_t b = dptr[l], nd = dptr[l + 1] - b;
-   for (int64_t di = wk; di < nd; di += gridDim.x) {
-    const RunD d = rd[b + di];
-    if (rc.prof && tid == 0) rc.prof[4 * (pbase + b + di)] = wall_clock64();
+  for (;;) {
     if (tid == 0) {
-      run_poll(rc.tile_seq + d.tile0, d.need0, stuck, limit);
-      run_acquire();
+      // (no time limit of its own: a diagonal worker may legitimately find nothing for most of the factorization; the
+      // tickets' limit raises RUN_STUCK if the run stops moving, and then the workers leave too)
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 0);
+      s_task = v;
+      if (v >= 0) run_acquire();
     }
     __syncthreads();
-    if (rc.prof && tid == 0) rc.prof[4 * (pbase + b + di) + 1] = wall_clock64();
+    const int di = s_task;
+    if (di < 0) break;                               // every diagonal task is taken (or the run is stuck)
+    const RunD d = rd[di];
+    long long tp = 0;
+    if (rc.prof && tid == 0) tp = wall_clock64();
     // (the thread index is laundered per task: otherwise everything the body derives from it is hoisted out of this loop
     // and kept in registers across it -- 59 spilled VGPRs instead of the 17 of the same body in k_diag_llt_w)
     int ltid = threadIdx.x;
@@ -573,14 +576,17 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L,
     diag_llt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, errflag, ltid);
     run_drain();
     __syncthreads();
-    if (tid == 0) {
-      run_st(rc.dflag + d.dflag, 1);
-      if (d.fin) run_st(rc.tile_fin + d.tile0, 1);
-      if (rc.prof) rc.prof[4 * (pbase + b + di) + 2] = wall_clock64();
+    if (tid < 64) {
+      for (int i = tid; i < d.tn; i += 64) run_dec_ticket(rc, info, d.t0 + i);
+      if (rc.prof && tid == 0) {
+        long long* pr = rc.prof + 4 * ((int64_t)rc.nticket + di);
+        pr[0] = tp; pr[1] = tp; pr[2] = wall_clock64();
+      }
     }
-   }
+    __syncthreads();
   }
 }
+
 // ------------------------------------------------------------------------------------------------
 // coefficient fill: scatter (destination, value) pairs  (Csc2solv_cblk, csc_intern_solve.c:65-132)
 // ------------------------------------------------------------------------------------------------
@@ -1408,13 +1414,12 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
 __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
-void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const int64_t* dptr, int nlev, int gd,
-                      double* dinv, double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident,
-                      long long limit, int64_t nticket) {
+void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                      double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit) {
   (void)factotype;
   if (gd > 0)
-    hipLaunchKernelGGL(k_run_diag_llt, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, dptr, nlev, dinv, critere, nbpivot,
-                       errflag, rc, resident, limit, nticket);
+    hipLaunchKernelGGL(k_run_diag_llt, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag,
+                       rc, resident, limit);
 }
 
 void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v) {

@@ -28,6 +28,8 @@
 // accumulate chains need none; the zeroing writes and the epilogue's reads are padded.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -430,9 +432,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 template <bool COH>
-__device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const TrsmTask& tk, const double* __restrict__ dinv_ws) {
+__device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const TrsmTask& tk, const double* __restrict__ dinv_ws,
+                                                const int tid) {
   constexpr int NT = 8;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int ld = tk.stride, w = tk.width;
   const int rloc = wave * 16 + l15;
@@ -510,7 +513,7 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
   });
   static_for<NT>([&](auto CT) {
     constexpr int ct = decltype(CT)::value;
-    int lds = ld, gs = (int)(threadIdx.x & 63u) >> 4;
+    int lds = ld, gs = (tid & 63) >> 4;
     asm volatile("" : "+s"(lds), "+v"(gs));
     if (rvalid && ct * 16 + gs + 0 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 0) * lds], acc_read<ct, 0>());
     if (rvalid && ct * 16 + gs + 4 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 4) * lds], acc_read<ct, 1>());
@@ -520,96 +523,97 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
 }
 
 // ---- the run launch ------------------------------------------------------------------------------
-// The update tasks of the thin levels at the top of the tree, all in ONE launch (plan.h RunInfo; the reference's tasks
-// wait for TASK_CTRBCNT == 0 the same way, sopalin3d.c:790-1025 / contrib.c:45-88).  A workgroup draws a ticket (the
-// tasks are listed in a topological order of the task graph, so whatever a ticket waits for is a smaller ticket -- held
-// by a workgroup that runs -- or a resident workgroup of k_run_panel: no deadlock, and no assumption about the order in
-// which the hardware starts the workgroups of a grid), waits for the tile's previous writer (counter == seq) and for the
-// source tiles its pieces read (final flags), runs the task exactly as k_update does -- same pieces, same order, same
-// arithmetic: the factors are bitwise those of the level-by-level schedule -- and publishes the tile.
+// The update and panel-solve tasks of the thin levels at the top of the tree, all in ONE launch (plan.h RunInfo; the
+// reference's tasks wait for TASK_CTRBCNT == 0 and are queued by the last contributor the same way, sopalin3d.c:790-1025 /
+// sopalin_compute.c:958-985).  As many workgroups as the chip holds (two per CU), each looping: pop the next ready ticket
+// (run_sync.h), run it exactly as k_update / k_trsm_llt would -- same pieces, same order, same arithmetic: the factors
+// are bitwise those of the level-by-level schedule --, store the result write-through, tell the consumers.  Only ready
+// tickets are ever held, so the launch needs no assumption about the order in which the hardware starts workgroups and
+// cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
+// the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
                                                                const RunInfo* __restrict__ info,
-                                                               const int32_t* __restrict__ waits, const RunCtl rc,
+                                                               const int32_t* __restrict__ cons, const RunCtl rc,
                                                                const double* __restrict__ dinv, const long long limit) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* tick = (int*)&sh[0][0][0];
-  if (tid == 0) *tick = atomicAdd(rc.misc + RUN_HEAD, 1);
-  __syncthreads();
-  const int t = __builtin_amdgcn_readfirstlane(*tick);
-  const Task tk = tasks[t];
-  const RunInfo ri = info[t];
-  if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t] = wall_clock64();
-  if (ri.wn < 0) {
-    // a panel-solve ticket (RunInfo: tile / seq = the tile's counter and the run updates it must have seen, wptr = the
-    // cblk's diagonal flag; the Task record holds a TrsmTask): 128 panel rows, a wave per 16
+  for (;;) {
+    // (the thread index is laundered per ticket: what is derived from it is recomputed, not kept in registers across the loop)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    long long tdraw = 0;
     if (tid == 0) {
-      run_poll(rc.dflag + ri.wptr, 1, rc.misc + RUN_STUCK, limit);
-      if (ri.seq > 0) run_poll(rc.tile_seq + ri.tile, ri.seq, rc.misc + RUN_STUCK, limit);
+      if (rc.prof) tdraw = wall_clock64();
+      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, rc.nticket, rc.ctl + RUN_STUCK, limit);
       run_acquire();
     }
     __syncthreads();
-    if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t + 1] = wall_clock64();
-    TrsmTask tt;
-    __builtin_memcpy(&tt, &tk, sizeof(tt));
-    trsm_llt_parked<true>(ar.p[0], tt, dinv);
+    const int t = __builtin_amdgcn_readfirstlane(*tick);
+    if (t < 0) return;                           // (every ticket is taken, or the run is stuck)
+    const Task tk = tasks[t];
+    const RunInfo ri = info[t];
+    __syncthreads();                             // (the ticket word in LDS is dead from here on)
+    if (rc.prof && tid == 0) {
+      rc.prof[4 * (int64_t)t] = tdraw;
+      rc.prof[4 * (int64_t)t + 1] = wall_clock64();
+      unsigned hw, xcc;                          // which CU ran the ticket (tools/run_prof.py: idle time per CU)
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+      rc.prof[4 * (int64_t)t + 3] = ((long long)(xcc & 0xf) << 32) | hw;
+    }
+    if (ri.kind & 4) {
+      // a panel-solve ticket (the Task record holds a TrsmTask): 128 panel rows, a wave per 16
+      TrsmTask tt;
+      __builtin_memcpy(&tt, &tk, sizeof(tt));
+      trsm_llt_parked<true>(ar.p[0], tt, dinv, tid);
+      run_drain();
+      __syncthreads();
+      if (wave == 0) {
+        for (int i = lane; i < ri.cn; i += 64) run_dec_ticket(rc, info, cons[ri.cptr + i]);
+        if (rc.prof && lane == 0) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
+      }
+      __syncthreads();
+      continue;
+    }
+    const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
+    const int l15 = lane & 15, g = lane >> 4;
+    acc_zero();
+    unsigned touched;
+    const bool neg = (tk.flags & 8u) != 0;
+    if ((int)tk.nfull == tk.pn) {
+      if (tk.tm == TM && tk.tn == TN) {
+        if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+        else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      } else {
+        if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+        else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      }
+    } else {
+      if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    }
+    acc_settle();
+    double* C = ar.p[tk.flags & 3] + tk.c_off;
+    const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
+    epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
     run_drain();
     __syncthreads();
     if (tid == 0) {
-      run_st(rc.tile_fin + ri.tile, 1);
+      if (ri.succ >= 0) run_dec_ticket(rc, info, ri.succ);
+      else if (ri.succ <= -2) run_dec_diag(rc, -2 - ri.succ);
       if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
     }
-    return;
-  }
-  if (wave == 0) {
-    // lane 0 of the first pass: the tile's previous writer; the other lanes: one source tile each
-    for (int base = -1; base < ri.wn; base += 64) {
-      const int i = base + lane;
-      if (i < 0) {
-        if (ri.seq > 0) run_poll(rc.tile_seq + ri.tile, ri.seq, rc.misc + RUN_STUCK, limit);
-      } else if (i < ri.wn) {
-        run_poll(rc.tile_fin + waits[ri.wptr + i], 1, rc.misc + RUN_STUCK, limit);
-      }
-    }
-    run_acquire();
-  }
-  __syncthreads();                               // (also: the ticket word in LDS is dead from here on)
-  if (rc.prof && tid == 0) rc.prof[4 * (int64_t)t + 1] = wall_clock64();
-  const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
-  const int l15 = lane & 15, g = lane >> 4;
-  acc_zero();
-  unsigned touched;
-  const bool neg = (tk.flags & 8u) != 0;
-  if ((int)tk.nfull == tk.pn) {
-    if (tk.tm == TM && tk.tn == TN) {
-      if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    } else {
-      if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    }
-  } else {
-    if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-  }
-  acc_settle();
-  double* C = ar.p[tk.flags & 3] + tk.c_off;
-  const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
-  epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
-  epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
-  run_drain();
-  __syncthreads();
-  if (tid == 0) {
-    run_st(rc.tile_seq + ri.tile, ri.seq + 1);
-    if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
+    __syncthreads();
   }
 }
 
 void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* waits, const RunCtl& rc, const double* dinv, int64_t ntasks, long long limit) {
+                       const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(k_run_update, dim3((unsigned)ntasks), dim3(64 * UW), 0, s, ar, tasks, pieces, info, waits, rc, dinv, limit);
+  hipLaunchKernelGGL(k_run_update, dim3((unsigned)std::min<int64_t>(ntasks, std::max(nwg, 1))), dim3(64 * UW), 0, s, ar, tasks, pieces,
+                     info, cons, rc, dinv, limit);
 }
 
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,

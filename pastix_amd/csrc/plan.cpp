@@ -975,36 +975,25 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (auto& x : th) x.join();
     }
     P.tasks.swap(sorted);
-    // ---- the run schedule -----------------------------------------------------------------------------------------
+    // ---- the run schedule (plan.h RunInfo) -------------------------------------------------------------------------
     // Tickets = the update tasks of slots >= L0 and the panel-solve tasks T(s) of levels >= L0 (one per 128-row tile with
-    // off-diagonal rows); the diagonal tasks D(s) run on resident workgroups.  Any topological order of the task graph is
-    // deadlock-free (a ticket only waits for smaller tickets and for the resident workgroups).  The order is a merge of
-    //   the chain      A(L0) T(L0) A(L0+1) T(L0+1) ...     A(s): urgent tasks of slot s (targets of level s, sources of
-    //                                                       level s-1); T(s) needs D(s), which needs A(s);
-    //   the bulk       B(L0).next B(L0).rest B(L0+1).next ...   B(s): sources <= s-1, .next = targets of level s+1;
-    // under:  A(s) behind B(s-1).next (same tiles, older sources);  B(s) behind T(s-1) (it reads level s-1).
-    // A ticket that is drawn before its inputs exist holds a slot of the chip while it waits, so a chain item is not
-    // emitted the moment it may be but after `delay` worth of bulk work since the previous one -- about the time the
-    // previous link takes (D before T, T before A) -- unless the bulk has nothing it may emit: then the chain is what the
-    // chip waits for and its tickets go out at once.
+    // off-diagonal rows); the diagonal tasks D(s) are popped by resident workgroups.  The ticket ARRAY is ordered as a merge
+    // of the chain A(L0) T(L0) A(L0+1) T(L0+1) ... (A(s): urgent tasks of slot s -- targets of level s, sources of level
+    // s-1) and the bulk B(L0).next B(L0).rest B(L0+1).next ... (B(s): sources <= s-1; .next = targets of level s+1) with
+    // A(s) behind B(s-1).next (same tiles, older sources) and B(s) behind T(s-1) (it reads level s-1): a topological order,
+    // in which the counters and consumer lists are built; at run time the order of execution is the order of readiness.
     P.ntile = ntile;
     P.nplanes = (lu ? 2 : 1) * (cplx ? 2 : 1);
     if (P.run_L0 >= 0 && (int64_t)ntile * P.nplanes > 0x7fffffffLL) P.run_L0 = -1;
     if (P.run_L0 >= 0) {
       const int L0 = P.run_L0;
-      auto envd = [](const char* n, double d) { const char* e = getenv(n); return e ? atof(e) : d; };
-      const double mac_per_us = 3.4e7;                          // multiply-adds the chip does per microsecond (68 TFLOP/s)
-      const double delayT = envd("PASTIX_AMD_RUN_DELAY_D", 120.0) * mac_per_us;   // in front of T(s): A(s) + D(s)
-      const double delayA = envd("PASTIX_AMD_RUN_DELAY_T", 40.0) * mac_per_us;    // in front of A(s+1): T(s)
-      // the panel side: diagonal tasks per level, panel-solve tasks per level
+      struct RunT { TrsmTask tt; int32_t tile, dtask; };
       std::vector<int64_t> tptr((size_t)(NL - L0) + 1, 0);
       std::vector<RunT> rt;
+      std::vector<int32_t> dtile0;
       P.run_d.clear();
-      P.run_dptr.assign((size_t)(NL - L0) + 1, 0);
       P.run_gd = 0;
-      int32_t ndf = 0;
       for (int l = L0; l < NL; l++) {
-        P.run_dptr[(size_t)(l - L0)] = (int64_t)P.run_d.size();
         tptr[(size_t)(l - L0)] = (int64_t)rt.size();
         P.run_gd = std::max<int32_t>(P.run_gd, (int32_t)(P.lvl_cblk_ptr[l + 1] - P.lvl_cblk_ptr[l]));
         for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
@@ -1013,26 +1002,23 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           const int32_t w = pt.width, st = pt.stride;
           RunD d{};
           d.pt = pt;
-          d.tile0 = (int32_t)tile_base[(size_t)k];
-          d.tile0u = -1;
-          d.dflag = ndf++;
-          d.fin = !(w < TM && st > w);
+          d.t0 = 0;
+          d.tn = 0;
+          const int32_t di = (int32_t)P.run_d.size();
           P.run_d.push_back(d);
+          dtile0.push_back((int32_t)tile_base[(size_t)k]);
           for (int32_t r = w / TM; (int64_t)r * TM < st; r++) {
             const int32_t r0 = std::max<int32_t>(w, r * TM), r1 = std::min<int32_t>(st, (r + 1) * TM);
             if (r1 <= r0) continue;
             RunT tt{};
             tt.tt = TrsmTask{pt.off, st, w, r0, r1 - r0, pt.dinv_off};
             tt.tile = (int32_t)(tile_base[(size_t)k] + r);
-            tt.tileu = -1;
-            tt.dflag = d.dflag;
+            tt.dtask = di;
             rt.push_back(tt);
           }
         }
       }
-      P.run_dptr[(size_t)(NL - L0)] = (int64_t)P.run_d.size();
       tptr[(size_t)(NL - L0)] = (int64_t)rt.size();
-      P.run_ndflag = ndf;
       P.run_gd = std::min<int32_t>(P.run_gd, P.opts.run_d_workers > 0 ? P.opts.run_d_workers : 8);
       // the merge.  order[]: >= 0 an update task (index into the slot-ordered task list), < 0 panel-solve task -1 - i
       std::vector<int64_t> order;
@@ -1043,7 +1029,6 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         int64_t bq = P.slot_urgent_end[L0];
         auto bulk_skip = [&]() { while (bs < NL && bq >= P.slot_task_ptr[bs + 1]) { bs++; if (bs < NL) bq = P.slot_urgent_end[bs]; } };
         bulk_skip();
-        double acc = 0;
         for (;;) {
           const bool chain_left = cs < NL;
           // A(cs) may go once B(cs-1).next is out: the bulk head is past it
@@ -1051,7 +1036,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           // a bulk task of slot bs may go once T(bs-1) is out: the chain head is past it
           const bool bulk_ok = bs < NL && (bs == L0 || cs > bs - 1);
           if (!chain_left && bs >= NL) break;
-          if (chain_ok && (!bulk_ok || acc >= (ck == 1 ? delayT : delayA))) {
+          if (chain_ok) {
             if (ck == 0) {
               for (int64_t q = P.slot_task_ptr[cs]; q < P.slot_urgent_end[cs]; q++) order.push_back(q);
               ck = 1;
@@ -1060,15 +1045,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
               ck = 0;
               cs++;
             }
-            acc = 0;
           } else if (bulk_ok) {
-            order.push_back(bq);
-            const Task& tk = P.tasks[(size_t)bq];
-            for (int z = 0; z < tk.pn; z++) {
-              const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
-              acc += double(pc.m) * pc.n * pc.k;
-            }
-            bq++;
+            order.push_back(bq++);
             bulk_skip();
           } else {
             return PASTIX_AMD_ERR_LAYOUT;       // (cannot happen: one of the two heads is always free to go)
@@ -1076,6 +1054,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         }
       }
       const size_t nr = order.size();
+      const size_t nd = P.run_d.size();
+      if (nr + nd > 0x7ffffff0ULL) return PASTIX_AMD_ERR_UNSUPPORTED;
+      auto slot_of = [&](int64_t q) { return (int)(std::upper_bound(P.slot_task_ptr.begin(), P.slot_task_ptr.end(), q) - P.slot_task_ptr.begin() - 1); };
       if (getenv("PASTIX_AMD_RUN_PROF")) {
         // developer aid (tools/run_prof.py): category (0 A, 1 B.next, 2 B.rest, 3 T) and slot / level of every ticket
         P.run_cat.resize(nr);
@@ -1083,51 +1064,78 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         for (size_t i = 0; i < nr; i++) {
           const int64_t q = order[i];
           if (q < 0) {
-            const int lv = (int)(std::upper_bound(tptr.begin(), tptr.end(), -1 - q) - tptr.begin() - 1) + L0;
-            P.run_cat[i] = 3; P.run_lvl[i] = lv;
+            P.run_cat[i] = 3;
+            P.run_lvl[i] = (int)(std::upper_bound(tptr.begin(), tptr.end(), -1 - q) - tptr.begin() - 1) + L0;
           } else {
-            const int sl = (int)(std::upper_bound(P.slot_task_ptr.begin(), P.slot_task_ptr.end(), q) - P.slot_task_ptr.begin() - 1);
+            const int sl = slot_of(q);
             P.run_cat[i] = q < P.slot_urgent_end[sl] ? 0 : q < P.slot_next_end[sl] ? 1 : 2;
             P.run_lvl[i] = sl;
           }
         }
       }
       P.run_tasks.resize(nr);
-      P.run_info.resize(nr);
-      std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // update tasks of the run per tile counter
+      P.run_info.assign(nr, RunInfo{-1, 0, 0, 0});
+      P.run_chk.assign(nr, RunCheck{0, 0, 0, 0});
+      P.run_dep.assign(nr + nd, 0);
+      std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // update tickets so far per tile counter
+      std::vector<int32_t> last((size_t)ntile * (size_t)P.nplanes, -1);       // ... and the last of them
+      std::vector<int32_t> tile_ticket((size_t)ntile, -1);                    // the panel-solve ticket of a tile
       bool bad = false;
       for (size_t i = 0; i < nr && !bad; i++) {
         const int64_t q = order[i];
         RunInfo& ri = P.run_info[i];
+        RunCheck& ck = P.run_chk[i];
         if (q >= 0) {
           P.run_tasks[i] = P.tasks[(size_t)q];
           const int64_t tl = task_tile[(size_t)idx[(size_t)q]];
           if (tl < 0 || (P.tasks[(size_t)q].flags & (4u | 32u))) { bad = true; break; }   // (quadrant / shared tasks: not in a run)
-          ri.tile = (int32_t)tl;
-          ri.seq = tcount[(size_t)tl]++;
-          ri.wptr = 0;
-          ri.wn = 0;
+          const int sl = slot_of(q);
+          ri.kind = q < P.slot_urgent_end[sl] ? 0 : q < P.slot_next_end[sl] ? 1 : 2;
+          ck.tile = (int32_t)tl;
+          ck.seq = tcount[(size_t)tl]++;
+          if (last[(size_t)tl] >= 0) { P.run_info[(size_t)last[(size_t)tl]].succ = (int32_t)i; P.run_dep[i]++; }
+          last[(size_t)tl] = (int32_t)i;
         } else {
-          // the panel-solve ticket of tile rt: by now every update task of the run on that tile has its ticket (A(s) is
-          // the last slot that targets level s), so the count is final
+          // the panel-solve ticket of a tile: every update ticket of the run on that tile precedes it (A(s) is the last
+          // slot that targets level s).  It waits for the diagonal task and, unless the tile is the diagonal tile
+          // (whose updates the diagonal task has waited for), for the tile's last update
           const RunT& tt = rt[(size_t)(-1 - q)];
           static_assert(sizeof(Task) == sizeof(TrsmTask), "a panel-solve ticket travels in a Task record");
           memcpy(&P.run_tasks[i], &tt.tt, sizeof(Task));
-          ri.tile = tt.tile;
-          ri.seq = tcount[(size_t)tt.tile];
-          ri.wptr = tt.dflag;
-          ri.wn = -1;
+          ri.kind = 0 | 4;
+          ck.tile = tt.tile;
+          ck.seq = tcount[(size_t)tt.tile];
+          ck.wptr = tt.dtask;
+          ck.wn = -1;
+          P.run_dep[i] = 1;
+          RunD& d = P.run_d[(size_t)tt.dtask];
+          if (d.tn == 0) d.t0 = (int32_t)i;
+          if (d.t0 + d.tn != (int32_t)i) { bad = true; break; }       // (the tickets of a cblk are consecutive)
+          d.tn++;
+          if (tt.tile != dtile0[(size_t)tt.dtask] && last[(size_t)tt.tile] >= 0) {
+            P.run_info[(size_t)last[(size_t)tt.tile]].succ = (int32_t)i;
+            P.run_dep[i]++;
+          }
+          tile_ticket[(size_t)tt.tile] = (int32_t)i;
         }
       }
       if (bad) {
         P.run_L0 = -1;
         P.run_tasks.clear();
         P.run_info.clear();
+        P.run_chk.clear();
+        P.run_dep.clear();
         P.run_d.clear();
       } else {
-        for (RunD& d : P.run_d) d.need0 = tcount[(size_t)d.tile0];
-        // source tiles an update ticket waits for: the 128-row tiles of the source panels its pieces read (A rows, B
-        // rows), sources of the run's levels only -- older panels are final when the run starts
+        // a diagonal task waits for the last update of the diagonal tile
+        P.run_dchk.resize(nd);
+        for (size_t d = 0; d < nd; d++) {
+          const int32_t l0 = last[(size_t)dtile0[d]];
+          if (l0 >= 0) { P.run_info[(size_t)l0].succ = -2 - (int32_t)d; P.run_dep[nr + d] = 1; }
+          P.run_dchk[d] = {dtile0[d], tcount[(size_t)dtile0[d]]};
+        }
+        // source tiles an update ticket reads: the 128-row tiles of the source panels of its pieces (A rows, B rows),
+        // sources of the run's levels only -- older panels are final when the run starts
         std::vector<std::vector<int32_t>> tw((size_t)nthr);
         std::vector<std::vector<std::pair<int32_t, int32_t>>> tpw((size_t)nthr);   // per ticket of the range: (first, count) in tw
         std::vector<double> trf((size_t)nthr, 0.0);
@@ -1138,7 +1146,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           double fl = 0;
           for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
             tmp.clear();
-            if (P.run_info[i].wn >= 0) {
+            if (!(P.run_info[i].kind & 4)) {
               const Task& tk = P.run_tasks[i];
               for (int z = 0; z < tk.pn; z++) {
                 const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
@@ -1172,14 +1180,45 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         for (int t = 0; t < nthr; t++) {
           std::copy(tw[(size_t)t].begin(), tw[(size_t)t].end(), P.run_waits.begin() + base);
           for (size_t j2 = 0; j2 < tpw[(size_t)t].size(); j2++) {
-            RunInfo& ri = P.run_info[(size_t)t * per + j2];
-            if (ri.wn < 0) continue;
-            ri.wptr = (int32_t)(base + (size_t)tpw[(size_t)t][j2].first);
-            ri.wn = tpw[(size_t)t][j2].second;
+            RunCheck& ck = P.run_chk[(size_t)t * per + j2];
+            if (ck.wn < 0) continue;
+            ck.wptr = (int32_t)(base + (size_t)tpw[(size_t)t][j2].first);
+            ck.wn = tpw[(size_t)t][j2].second;
           }
           base += tw[(size_t)t].size();
           P.run_flops += trf[(size_t)t];
         }
+        // consumer lists of the panel-solve tickets (CSR by producer) and the counters of the readers
+        for (size_t i = 0; i < nr && !bad; i++) {
+          const RunCheck& ck = P.run_chk[i];
+          if (ck.wn < 0) continue;
+          for (int q = 0; q < ck.wn; q++) {
+            const int32_t pt2 = tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]];
+            if (pt2 < 0 || pt2 >= (int32_t)i) { bad = true; break; }   // (a source tile of the run has its ticket, in front of its readers)
+            P.run_info[(size_t)pt2].cn++;
+          }
+          P.run_dep[i] += ck.wn;
+        }
+        if (bad) return PASTIX_AMD_ERR_LAYOUT;
+        {
+          int64_t off = 0;
+          for (size_t i = 0; i < nr; i++)
+            if (P.run_info[i].kind & 4) { P.run_info[i].cptr = (int32_t)off; off += P.run_info[i].cn; P.run_info[i].cn = 0; }
+          P.run_cons.resize((size_t)off);
+          for (size_t i = 0; i < nr; i++) {
+            const RunCheck& ck = P.run_chk[i];
+            if (ck.wn < 0) continue;
+            for (int q = 0; q < ck.wn; q++) {
+              RunInfo& pi = P.run_info[(size_t)tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]]];
+              P.run_cons[(size_t)pi.cptr + (size_t)pi.cn++] = (int32_t)i;
+            }
+          }
+        }
+        // what is ready when the run starts, in ticket order
+        P.run_ready.clear();
+        P.run_dready.clear();
+        for (size_t i = 0; i < nr; i++) if (P.run_dep[i] == 0) P.run_ready.push_back((int32_t)i);
+        for (size_t d = 0; d < nd; d++) if (P.run_dep[nr + d] == 0) P.run_dready.push_back((int32_t)d);
       }
     }
   }
@@ -1221,70 +1260,64 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   return PASTIX_AMD_OK;
 }
 
-// Host-only check of a run schedule (tests): replays the tickets ONE AT A TIME in ticket order -- the weakest progress the
-// device guarantees, since a ticket is only ever held by a workgroup that runs -- with the resident diagonal workers
-// advancing whenever their next task's counter allows.  Returns 0 when every ticket's waits are met by smaller tickets and
-// diagonal tasks (no deadlock, every counter ends where the waiters expect it), else the 1-based index of the first ticket
-// that could not run, or -1 for an inconsistent table.
+// Host-only check of a run schedule (tests): replays the counter protocol with ONE worker -- pop the next ready ticket,
+// diagonal tasks whenever one is ready, decrement the consumers, push what reaches zero -- and checks at
+// every pop what the task must find (its tile written exactly `seq` times, its source tiles solved, its cblk's diagonal
+// blok factorized).  Returns 0 when every ticket and diagonal task ran and found that; else the 1-based index of the first
+// ticket that found something else, -1 for an inconsistent table, -2 when tasks were left (a cycle or a lost decrement).
 int64_t run_verify(const Plan& P) {
   if (P.run_L0 < 0) return 0;
-  const size_t nr = P.run_tasks.size();
-  if (P.run_info.size() != nr) return -1;
-  std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl((size_t)std::max<int64_t>(P.run_ndflag, 1), 0);
-  const int nlev = P.nlevels - P.run_L0;
-  std::vector<int> dpos((size_t)std::max(P.run_gd, 1), 0);      // next (level, cblk of the level) of every diagonal worker
-  std::vector<int64_t> dsub((size_t)std::max(P.run_gd, 1));
-  for (int w = 0; w < P.run_gd; w++) dsub[(size_t)w] = w;
-  auto advance = [&]() {
-    bool any = false;
-    for (int w = 0; w < P.run_gd; w++) {
-      for (;;) {
-        int& l = dpos[(size_t)w];
-        int64_t& di = dsub[(size_t)w];
-        while (l < nlev && di >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) { l++; di = w; }
-        if (l >= nlev) break;
-        const RunD& d = P.run_d[(size_t)(P.run_dptr[(size_t)l] + di)];
-        if (seq[(size_t)d.tile0] < d.need0) break;
-        if (d.tile0u >= 0 && seq[(size_t)d.tile0u] < d.need0u) break;
-        dfl[(size_t)d.dflag] = 1;
-        if (d.fin) fin[(size_t)d.tile0] = 1;
-        di += P.run_gd;
-        any = true;
+  const size_t nr = P.run_tasks.size(), nd = P.run_d.size();
+  if (P.run_info.size() != nr || P.run_chk.size() != nr || P.run_dep.size() != nr + nd) return -1;
+  std::vector<int32_t> cnt(P.run_dep);
+  std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl(std::max<size_t>(nd, 1), 0);
+  std::vector<int32_t> q(P.run_ready), qd(P.run_dready);
+  size_t head = 0, hd = 0, done = 0, doned = 0;
+  auto dec_ticket = [&](int32_t c) {
+    if (c < 0 || (size_t)c >= nr || cnt[(size_t)c] <= 0) return false;
+    if (--cnt[(size_t)c] == 0) q.push_back(c);
+    return true;
+  };
+  for (;;) {
+    while (hd < qd.size()) {                         // diagonal tasks first (resident workers)
+      const int32_t d = qd[hd++];
+      if (d < 0 || (size_t)d >= nd || dfl[(size_t)d] || P.run_dchk.size() != nd) return -1;
+      if (seq[(size_t)P.run_dchk[(size_t)d].first] != P.run_dchk[(size_t)d].second) return -3 - (int64_t)d;
+      dfl[(size_t)d] = 1;
+      doned++;
+      const RunD& rd = P.run_d[(size_t)d];
+      for (int32_t t = rd.t0; t < rd.t0 + rd.tn; t++) if (!dec_ticket(t)) return -1;
+    }
+    if (head >= q.size()) break;
+    const int32_t i = q[head++];
+    const RunInfo& ri = P.run_info[(size_t)i];
+    const RunCheck& ck = P.run_chk[(size_t)i];
+    done++;
+    if (ri.kind & 4) {
+      if (ck.tile < 0 || (size_t)ck.tile >= fin.size() || ck.wptr < 0 || (size_t)ck.wptr >= nd) return -1;
+      if (!dfl[(size_t)ck.wptr] || seq[(size_t)ck.tile] != ck.seq || fin[(size_t)ck.tile]) return (int64_t)i + 1;
+      fin[(size_t)ck.tile] = 1;
+      if (ri.cptr < 0 || (size_t)ri.cptr + (size_t)ri.cn > P.run_cons.size()) return -1;
+      for (int z = 0; z < ri.cn; z++) if (!dec_ticket(P.run_cons[(size_t)ri.cptr + (size_t)z])) return -1;
+    } else {
+      if (ck.tile < 0 || (size_t)ck.tile >= seq.size() || ck.wptr < 0 || (size_t)ck.wptr + (size_t)ck.wn > P.run_waits.size()) return -1;
+      if (seq[(size_t)ck.tile] != ck.seq) return (int64_t)i + 1;
+      if ((size_t)ck.tile < fin.size() && fin[(size_t)ck.tile]) return (int64_t)i + 1;     // (written after it was solved)
+      for (int z = 0; z < ck.wn; z++) {
+        const int32_t f = P.run_waits[(size_t)ck.wptr + (size_t)z];
+        if (f < 0 || (size_t)f >= fin.size()) return -1;
+        if (!fin[(size_t)f]) return (int64_t)i + 1;
+      }
+      seq[(size_t)ck.tile] = ck.seq + 1;
+      if (ri.succ >= 0) { if (!dec_ticket(ri.succ)) return -1; }
+      else if (ri.succ <= -2) {
+        const size_t d = (size_t)(-2 - ri.succ);
+        if (d >= nd || cnt[nr + d] <= 0) return -1;
+        if (--cnt[nr + d] == 0) qd.push_back((int32_t)d);
       }
     }
-    return any;
-  };
-  for (size_t i = 0; i < nr; i++) {
-    const RunInfo& ri = P.run_info[i];
-    if (ri.tile < 0 || (size_t)ri.tile >= seq.size()) return -1;
-    if (ri.wn < 0) {                               // a panel-solve ticket
-      if ((size_t)ri.tile >= fin.size() || ri.wptr < 0 || (size_t)ri.wptr >= dfl.size()) return -1;
-      if (seq[(size_t)ri.tile] != ri.seq) return (int64_t)i + 1;      // (its tile's updates all have smaller tickets)
-      while (!dfl[(size_t)ri.wptr]) if (!advance()) return (int64_t)i + 1;
-      if (fin[(size_t)ri.tile]) return -1;
-      fin[(size_t)ri.tile] = 1;
-      continue;
-    }
-    if (ri.wptr < 0 || (size_t)ri.wptr + (size_t)ri.wn > P.run_waits.size()) return -1;
-    if (seq[(size_t)ri.tile] != ri.seq) return seq[(size_t)ri.tile] > ri.seq ? -1 : (int64_t)i + 1;
-    for (int q = 0; q < ri.wn; q++) {
-      const int32_t f = P.run_waits[(size_t)ri.wptr + (size_t)q];
-      if (f < 0 || (size_t)f >= fin.size()) return -1;
-      if (!fin[(size_t)f]) return (int64_t)i + 1;   // (a source tile is final by a smaller panel-solve ticket or a diagonal task
-                                                    //  whose inputs are smaller tickets: nothing to advance for)
-    }
-    if (fin[(size_t)ri.tile < fin.size() ? (size_t)ri.tile : 0] && (size_t)ri.tile < fin.size()) return -1;   // (written after it was final)
-    seq[(size_t)ri.tile] = ri.seq + 1;
-    advance();
   }
-  while (advance()) {}
-  for (int w = 0; w < P.run_gd; w++) {
-    int l = dpos[(size_t)w];
-    int64_t di = dsub[(size_t)w];
-    while (l < nlev && di >= P.run_dptr[(size_t)l + 1] - P.run_dptr[(size_t)l]) { l++; di = w; }
-    if (l < nlev) return (int64_t)nr + 1;
-  }
-  return 0;
+  return (done == nr && doned == nd) ? 0 : -2;
 }
 
 }  // namespace pastix_amd

@@ -83,41 +83,43 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
 
 
 // ---- the run schedule (round 4): the thin levels at the top of the tree in ONE dependency-driven launch ---------------
-// The reference's engine is counter-driven, not level-synchronous: a task runs when TASK_CTRBCNT reaches zero
-// (sopalin3d.c:790-1025, wait_contrib_comp_1d contrib.c:45-88).  Here: every update task of the levels >= run_L0 is a
-// workgroup of one launch (k_run_update) that takes a ticket, waits for its tile's previous writer and for the panel
-// tiles its pieces read, and publishes its tile; the diagonal and panel-solve tasks of those levels run on a few
-// resident workgroups of a second kernel (k_run_panel) that wait for the tiles' counters the same way.
+// The reference's engine is counter-driven, not level-synchronous: a task runs when TASK_CTRBCNT reaches zero and the
+// last contributor puts it on a ready queue (sopalin3d.c:790-1025, sopalin_compute.c:958-985, contrib.c:45-88).  The
+// same here for the levels >= run_L0: every task carries a counter of the inputs that do not exist yet; whoever
+// finishes an input decrements the counters of its consumers and pushes the ones that reach zero into a ready queue;
+// the workgroups of ONE launch (k_run_update) each pop one ready ticket -- an update task (a tile of a target panel,
+// its pieces in the plan's order) or a panel-solve task (the off-diagonal rows of one 128-row tile) --, the diagonal
+// tasks are popped by a few resident workgroups of a second kernel (k_run_diag_*).  Nobody waits for a particular
+// task: a slot of the chip is idle only when nothing is ready.  Inputs: an update task waits for the previous update
+// of its tile (tile ownership is a chain of tasks, not a mutex) and for the source tiles its pieces read to be solved;
+// a panel-solve task for its cblk's diagonal blok and the last update of its tile; a diagonal task for the last update
+// of the diagonal tile.
 struct RunInfo {             // per ticket of the run
-  int32_t tile;              // index of the target tile's sequence counter (tile id + plane * ntile)
-  int32_t seq;               // number of earlier update tasks of the run on this tile: the ticket waits for counter == seq
-  int32_t wptr, wn;          // update task: run_waits[wptr .. +wn): source tiles (L-arena tile ids) that must be final
-                             // panel-solve task: wn = -1, wptr = the cblk's diagonal flag; it makes `tile` final
+  int32_t succ;              // update ticket: who waits for this write of the tile: >= 0 a ticket (the tile's next update or
+                             // its panel solve), <= -2 the diagonal task -2 - succ, -1 nobody
+  int32_t cptr, cn;          // panel-solve ticket: run_cons[cptr .. +cn) = the update tickets that read its tile
+  int32_t kind;              // bits 0-1: 0 on the chain (urgent updates, panel solves), 1 updates of the next level's panels,
+                             // 2 the rest (statistics); bit 2: panel-solve ticket (the Task record holds a TrsmTask)
 };
 struct RunD {                // a diagonal-blok task of the run
   PanelTask pt;
-  int32_t tile0, need0;      // the diagonal tile's counter and the number of run tasks that update it
-  int32_t tile0u, need0u;    // LU: the same in the U arena (-1: none)
-  int32_t dflag;             // index of the cblk's "diagonal blok factorized" flag
-  int32_t fin;               // 1: nobody solves rows in tile 0 (no off-diagonal rows there): the task raises its final flag
-  int32_t cntlvl, pad_;      // (reserved)
+  int32_t t0, tn;            // the panel-solve tickets [t0, t0 + tn) of the cblk wait for it
 };
-struct RunT {                // (plan construction) a panel-solve task of the run: the off-diagonal rows of one 128-row tile
-  TrsmTask tt;
-  int32_t tile, need;        // the tile's counter (L arena), run tasks that update it
-  int32_t tileu, needu;      // LU: U arena (-1: none)
-  int32_t dflag, pad_;
+struct RunCheck {            // host only (run_verify): what a ticket must find when it runs
+  int32_t tile, seq;         // update: tile counter index and its value; panel solve: the L-arena tile it makes final
+  int32_t wptr, wn;          // update: run_waits[wptr .. +wn) source tiles that must be final; panel solve: wn = -1, wptr = cblk's diagonal task
 };
 
-// device-side synchronisation state of a run (ints, zeroed at the start of every factorization)
+// device-side state of a run: one block of ints, reset from an image of the same layout before every factorization
 struct RunCtl {
-  int32_t* tile_seq;         // [ntile * nplanes] update tasks of the run that have written the tile so far
-  int32_t* tile_fin;         // [ntile] 1: the tile's off-diagonal rows are solved (final: readable as a source)
-  int32_t* dflag;            // [run cblks] 1: the diagonal blok is factorized
-  int32_t* misc;             // RUN_HEAD: ticket counter; RUN_STUCK: a bounded wait expired (the run failed)
-  long long* prof;           // developer aid (PASTIX_AMD_RUN_PROF): 4 clock stamps per update ticket, then per panel task; else null
+  int32_t* cnt;              // [ntickets + ndiag] inputs a task still waits for
+  int32_t* q;                // ready ring of the tickets (every ticket is pushed once: no wrap); -1 = empty slot
+  int32_t* qd;               // ready ring of the diagonal tasks
+  int32_t* ctl;              // heads, tails, the "stuck" flag: RUN_* below, one 256-byte line each
+  int32_t nd, nticket;       // ring sizes
+  long long* prof;           // developer aid (PASTIX_AMD_RUN_PROF): 4 clock stamps per ticket, then per diagonal task; else null
 };
-constexpr int RUN_HEAD = 0, RUN_STUCK = 64, RUN_MISC_INTS = 128;
+constexpr int RUN_HEAD = 0, RUN_TAIL = 2 * 64, RUN_STUCK = 4 * 64, RUN_CTL_INTS = 6 * 64;   // (+ 64: the diagonal ring's)
 
 // std::allocator whose value-less construct() default-initialises (leaves trivially constructible T untouched)
 template <class T>
@@ -187,16 +189,19 @@ struct Plan {
   int64_t ntile = 0;                     // target tiles per plane
   int32_t nplanes = 1;                   // planes that are update targets (1 LLt/LDLt, 2 LU, x2 complex)
   std::vector<Task> run_tasks;           // the tickets: update tasks of slots >= run_L0 and panel-solve tasks (a TrsmTask in
-                                         // the record; RunInfo::wn < 0) of levels >= run_L0
+                                         // the record) of levels >= run_L0
   std::vector<RunInfo> run_info;         // [run_tasks.size()]
+  std::vector<int32_t> run_cons;         // consumer lists of the panel-solve tickets
+  std::vector<int32_t> run_dep;          // [tickets + diagonal tasks] initial counters
+  std::vector<int32_t> run_ready, run_dready;      // tasks that are ready when the run starts, per ring
+  std::vector<RunD> run_d;               // diagonal tasks, level-major
+  int32_t run_gd = 0;                    // resident workgroups for the diagonal tasks
+  double run_flops = 0;                  // update flops inside the run
+  std::vector<RunCheck> run_chk;         // host only (run_verify)
+  std::vector<std::pair<int32_t, int32_t>> run_dchk;   // ... per diagonal task: its tile counter and the value it must find
   std::vector<int32_t> run_waits;
   std::vector<uint8_t> run_cat;          // (PASTIX_AMD_RUN_PROF) per ticket: 0 A, 1 B.next, 2 B.rest, 3 panel solve; its slot / level
   std::vector<int32_t> run_lvl;
-  std::vector<RunD> run_d;               // level-major; run_dptr[l - run_L0] = first task of level l
-  std::vector<int64_t> run_dptr;
-  int32_t run_gd = 0;                    // resident workgroups for the diagonal tasks (max cblks of a run level)
-  int64_t run_ndflag = 0;
-  double run_flops = 0;                  // update flops inside the run
 
   // solve schedule: cblks grouped by level (same levels as the factorization)
   std::vector<int64_t> lvl_cblk_ptr;     // [nlevels+1]

@@ -1,12 +1,17 @@
-// run_sync.h -- device-only: waiting and publishing inside the run launches (k_run_update, k_run_panel).
+// run_sync.h -- device-only: the ready queues and the hand-off rules of the run launches (k_run_update, k_run_diag_*).
 //
+// Scheduling (plan.h RunInfo): every task has a counter of inputs that do not exist yet; a finished task decrements its
+// consumers' counters and pushes the ones that reach zero into a ready ring (one for the tickets, one for the diagonal
+// tasks; every task is pushed exactly once, so a ring never wraps: push = reserve the next slot with an atomic add on the
+// tail, store the task there; pop = reserve the next slot with an atomic add on the head, wait for its task).  A
+// workgroup never waits for a particular task: it runs the next one to become ready.
 // Visibility (MI355X_MICROARCH, "inter-workgroup visibility", valid forms): a producer stores its bytes write-through
 // (agent-scope stores, `sc1`), every storing wave waits for its stores (`s_waitcnt vmcnt(0)`), the workgroup meets at a
-// barrier, ONE lane stores the flag (`sc1`); a consumer polls the flag with agent-scope loads, runs ONE agent-scope
+// barrier, then its decrements and pushes (agent-scope atomics); a consumer that popped a task runs ONE agent-scope
 // acquire (invalidates its CU's vector L1), waits for it, meets its workgroup at a barrier and then reads with plain
-// loads.  A wait is bounded in TIME: after `limit` ticks of the 100 MHz clock the waiter raises RUN_STUCK and goes on;
-// every other waiter sees the flag within a few hundred polls and goes on too, the host returns PASTIX_AMD_ERR_DEVICE --
-// a wrong assumption fails the factorization, it cannot hang the device.
+// loads.  Waiting is bounded in TIME: a workgroup that finds nothing to pop for `limit` ticks of the 100 MHz clock raises
+// RUN_STUCK and leaves; every other one sees the flag within a few hundred polls and leaves too, the host returns
+// PASTIX_AMD_ERR_DEVICE -- a wrong assumption fails the factorization, it cannot hang the device.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -20,28 +25,51 @@ __device__ __forceinline__ int run_ld(const int32_t* p) {
 __device__ __forceinline__ void run_st(int32_t* p, int v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until *p >= need (one lane per flag; other lanes of the wave may poll other flags)
-__device__ __forceinline__ void run_poll(const int32_t* p, const int need, int32_t* stuck, const long long limit) {
-  if (run_ld(p) >= need) return;
+// take the NEXT slot of a ring of n slots (a wait-free reservation: an atomic add on the head, ~90 per microsecond on one
+// word where a compare-and-swap loop of 500 contenders managed a fraction of one) and wait for the task that is -- or will
+// be -- pushed there: workgroup i of the launch runs the i-th task to become ready.  Every task is pushed exactly once and
+// there are exactly as many workgroups as tickets, so every reservation is served; a slot of the chip is idle only while
+// fewer tasks are ready than workgroups are waiting.  Returns -1 when the ring is used up or the run is stuck.
+// `limit` > 0 bounds the wait (100 MHz ticks; on expiry RUN_STUCK is raised), 0 = no bound of its own.
+__device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit) {
+  const int h = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (h >= n) return -1;
+  int v = run_ld(ring + h);
+  if (v >= 0) return v;
   const long long t0 = wall_clock64();
   int it = 0;
-  while (run_ld(p) < need) {
+  while ((v = run_ld(ring + h)) < 0) {
     ++it;
-    if ((it & 127) == 0) {
-      if (run_ld(stuck)) return;
-      if (wall_clock64() - t0 > limit) { run_st(stuck, 1); return; }
+    if ((it & 63) == 0) {
+      if (run_ld(stuck)) return -1;
+      if (limit > 0 && wall_clock64() - t0 > limit) { run_st(stuck, 1); return -1; }
     }
-    if (it < 32) __builtin_amdgcn_s_sleep(2);
-    else __builtin_amdgcn_s_sleep(20);
+    if (it < 16) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(32);
   }
+  return v;
 }
-// consumer side, after the polls of the workgroup's polling wave: acquire + wait (the caller's barrier follows)
+__device__ __forceinline__ void run_push(int32_t* ring, int32_t* tail, const int task) {
+  const int pos = __hip_atomic_fetch_add(tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  run_st(ring + pos, task);
+}
+// an input of ticket c exists now
+__device__ __forceinline__ void run_dec_ticket(const RunCtl& rc, const RunInfo* __restrict__ info, const int c) {
+  (void)info;
+  if (__hip_atomic_fetch_add(rc.cnt + c, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+    run_push(rc.q, rc.ctl + RUN_TAIL, c);
+}
+__device__ __forceinline__ void run_dec_diag(const RunCtl& rc, const int d) {
+  if (__hip_atomic_fetch_add(rc.cnt + rc.nticket + d, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
+    run_push(rc.qd, rc.ctl + RUN_TAIL + 64, d);
+}
+// consumer side, after the pop: acquire + wait (the caller's barrier follows)
 __device__ __forceinline__ void run_acquire() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-// producer side: every wave calls this after its last store of handed-off bytes, then the workgroup's barrier, then
-// one lane's run_st of the flag
+// producer side: every wave calls this after its last store of handed-off bytes, then the workgroup's barrier, then the
+// decrements
 __device__ __forceinline__ void run_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // write-through store / plain store of a panel entry

@@ -32,6 +32,27 @@ mt = cat == 3
 if mt.any():
     top = mt & (lvl >= lvl.max() - 20)
     print("  T at the top 20 levels: mean run %.1f us, mean wait %.1f us" % ((U[top, 2] - U[top, 1]).mean() * 1e-2, (U[top, 1] - U[top, 0]).mean() * 1e-2))
+# per CU: time covered by tickets (two workgroups fit a CU)
+hw = U[:, 3]
+cu = ((hw >> 32) << 16) | (hw & 0xff00)       # xcc | se, sh, cu bits of HW_ID
+cus = np.unique(cu)
+occ = 0.0
+for c in cus[:64]:
+    m = cu == c
+    occ += (U[m, 2] - U[m, 0]).sum() * 1e-8
+print("  %d distinct CU ids; on the first %d of them tickets cover %.1f %% of 2 slots x wall" % (len(cus), min(64, len(cus)), 100 * occ / (min(64, len(cus)) * 2 * wall)))
+order = np.argsort(U[:, 0])
+gaps = []
+for c in cus[:16]:
+    m = np.where(cu == c)[0]
+    ev = sorted([(U[i, 0], 1) for i in m] + [(U[i, 2], -1) for i in m])
+    lvl2 = 0; last = t0; idle1 = 0; idle2 = 0
+    for tme, d in ev:
+        if lvl2 == 0: idle2 += 2 * (tme - last)
+        elif lvl2 == 1: idle1 += (tme - last)
+        lvl2 += d; last = tme
+    gaps.append((idle1 + idle2) * 1e-8 / (2 * wall))
+print("  idle share of the two slots on 16 CUs: mean %.3f min %.3f max %.3f" % (np.mean(gaps), np.min(gaps), np.max(gaps)))
 print("level: A first drawn / last ready / last done | T last done | period (us)")
 rows = []
 for s in range(L0, int(lvl.max()) + 1):
