@@ -83,10 +83,13 @@ def engine_source_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(grid, facto, blocksize):
-    """PMC-measured HBM bytes of the bulk k_update launches of one factorization of this workload, from the newest
-    profiles/rNN/traffic_k_update.json collected on exactly these engine sources; else None."""
+def measured_traffic(grid, facto, blocksize, dtype="f64", chunk=0, workload="laplacian"):
+    """PMC-measured HBM bytes of the bulk update kernels of one factorization of this workload, from the newest
+    profiles/rNN/traffic_k_update.json collected on exactly these engine sources; else None.  The file holds the fp64
+    engine's default schedule on the Laplacian only: any other arithmetic, chunk size or workload has no measurement."""
     import glob
+    if dtype != "f64" or chunk != 0 or workload != "laplacian":
+        return None, None
     sha = engine_source_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_k_update.json")), reverse=True):
         try:
@@ -327,7 +330,7 @@ def main():
         # on exactly these engine sources counts, anything else is stale -> null
         traffic, traffic_src = (None, None)
         if world == 1:
-            traffic, traffic_src = measured_traffic(a.grid, a.facto, a.blocksize)
+            traffic, traffic_src = measured_traffic(a.grid, a.facto, a.blocksize, a.dtype, a.chunk, a.workload)
         # Dominant kernel: k_update<0>, the bulk contribution launches.  achieved = its flops / the sum of its
         # launches' durations (HIP events around every launch, on the stream it is launched on) = what
         # rocprofv3 --kernel-trace --stats reports for that kernel.  The few urgent tasks of every level run as

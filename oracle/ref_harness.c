@@ -14,8 +14,12 @@
  *          and scalars to a raw binary file (packed to .npz by tests/golden/make_golden.py).
  *   time:  same pipeline without dumping; prints one JSON line with DPARM_FACT_FLOPS /
  *          DPARM_FACT_TIME (bench.py's cpu_baseline kind="reference").
+ *   cmp:   (the *_amd build) ONE analysis, then the numerical factorization twice on the same SolverMatrix: the
+ *          reference's CPU engine, whose factors are kept, and the MI355X engine through integration/sopalin_amd_stub.h;
+ *          prints max |L_gpu - L_ref| / max |L_ref| over the entries that belong to the factor (and the same for U),
+ *          the static-pivot counts and inertias of both -- parity at sizes no fixture file can hold.
  *
- * usage: ref_harness {dump|time|amd} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]
+ * usage: ref_harness {dump|time|amd|cmp} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]
  *        (rlap3d = 3-D 7-point pattern with deterministic pseudo-random values:
  *         SPD for llt/ldlt, unsymmetric diagonally dominant for lu)
  */
@@ -311,9 +315,10 @@ int main(int argc, char **argv)
   int minbs = -1, maxbs = -1;
 
   if (argc < 7) {
-    fprintf(stderr, "usage: %s {dump|time|amd} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]\n", argv[0]);
+    fprintf(stderr, "usage: %s {dump|time|amd|cmp} {lap3d|lap1d|rlap3d|mtx} ARG {llt|ldlt|lu|ldlh} THREADS OUT [minbs maxbs]\n", argv[0]);
     return 2;
   }
+  const int cmp = !strcmp(argv[1], "cmp");
   dump = !strcmp(argv[1], "dump");
   /* mode "amd" (the *_amd build): like "time", with the numerical factorization on the MI355X engine */
   if (!strcmp(argv[1], "amd")) setenv("PASTIX_AMD_ENGINE", "1", 1);
@@ -497,6 +502,57 @@ int main(int argc, char **argv)
   iparm[IPARM_START_TASK] = API_TASK_NUMFACT;
   iparm[IPARM_END_TASK] = API_TASK_NUMFACT;
   pastix(&pd, 0, n, A.colptr, A.rows, A.vals, perm, invp, b, 1, iparm, dparm);
+  if (cmp) {
+    /* keep the CPU engine's factors, factorize again through the stub (the reference re-fills the panels from its
+     * internal CSC at every numerical factorization), compare entry by entry.  Compared: `po` / `sy` / `he` -- the lower
+     * triangle of every diagonal blok and all rows below (the strict upper triangle is not part of the factor and holds
+     * by-products of the rectangular scatter, sopalin_compute.c:427-452); `ge` -- coeftab and ucoeftab in full. */
+    long k, c, r;
+    const long nc = sm->cblknbr;
+    PASTIX_FLOAT **refL = malloc(nc * sizeof(*refL)), **refU = malloc(nc * sizeof(*refU));
+    const double t_ref = dparm[DPARM_FACT_TIME];
+    const long npiv_ref = iparm[IPARM_STATIC_PIVOTING], inertia_ref = iparm[IPARM_INERTIA];
+    double maxL = 0, maxU = 0, dL = 0, dU = 0;
+    long worst_k = -1;
+    for (k = 0; k < nc; k++) {
+      const size_t sz = (size_t)sm->cblktab[k].stride * (sm->cblktab[k].lcolnum - sm->cblktab[k].fcolnum + 1);
+      refL[k] = malloc(sz * sizeof(PASTIX_FLOAT));
+      memcpy(refL[k], sm->cblktab[k].coeftab, sz * sizeof(PASTIX_FLOAT));
+      refU[k] = NULL;
+      if (facto == API_FACT_LU) {
+        refU[k] = malloc(sz * sizeof(PASTIX_FLOAT));
+        memcpy(refU[k], sm->cblktab[k].ucoeftab, sz * sizeof(PASTIX_FLOAT));
+      }
+    }
+    setenv("PASTIX_AMD_ENGINE", "1", 1);
+    pastix(&pd, 0, n, A.colptr, A.rows, A.vals, perm, invp, b, 1, iparm, dparm);
+    sm = &pd->solvmatr;
+    for (k = 0; k < nc; k++) {
+      const long w = sm->cblktab[k].lcolnum - sm->cblktab[k].fcolnum + 1, sd = sm->cblktab[k].stride;
+      const PASTIX_FLOAT *gl = sm->cblktab[k].coeftab, *gu = sm->cblktab[k].ucoeftab;
+      for (c = 0; c < w; c++)
+        for (r = (facto == API_FACT_LU ? 0 : c); r < sd; r++) {
+          const double a = ABS_FLOAT(refL[k][r + c * sd]), d = ABS_FLOAT(gl[r + c * sd] - refL[k][r + c * sd]);
+          if (a > maxL) maxL = a;
+          if (!(d <= dL)) { dL = d; worst_k = k; }               /* (a NaN counts) */
+        }
+      if (facto == API_FACT_LU)
+        for (c = 0; c < w; c++)
+          for (r = 0; r < sd; r++) {
+            const double a = ABS_FLOAT(refU[k][r + c * sd]), d = ABS_FLOAT(gu[r + c * sd] - refU[k][r + c * sd]);
+            if (a > maxU) maxU = a;
+            if (!(d <= dU)) dU = d;
+          }
+      free(refL[k]); free(refU[k]);
+    }
+    free(refL); free(refU);
+    OUT("{\"cmp\": 1, \"maxabs_L\": %.6e, \"maxdiff_L\": %.6e, \"rel_L\": %.3e, \"maxabs_U\": %.6e, \"maxdiff_U\": %.6e, "
+        "\"rel_U\": %.3e, \"worst_cblk\": %ld, \"static_pivots_ref\": %ld, \"static_pivots_gpu\": %ld, \"inertia_ref\": %ld, "
+        "\"inertia_gpu\": %ld, \"time_ref\": %.6f, \"time_gpu\": %.6f, \"gpu_engine_calls\": %d, \"gpu_engine_rc\": %d}\n",
+        maxL, dL, dL / (maxL > 0 ? maxL : 1), maxU, dU, dU / (maxU > 0 ? maxU : 1), worst_k, npiv_ref,
+        (long)iparm[IPARM_STATIC_PIVOTING], inertia_ref, (long)iparm[IPARM_INERTIA], t_ref, dparm[DPARM_FACT_TIME],
+        pastix_amd_hook_calls, pastix_amd_hook_last_rc);
+  }
   {
     double flops = dparm[DPARM_FACT_FLOPS], t = dparm[DPARM_FACT_TIME];
     long nnzl = iparm[IPARM_NNZEROS], npiv = iparm[IPARM_STATIC_PIVOTING];

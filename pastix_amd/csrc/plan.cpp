@@ -1053,6 +1053,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           }
         }
       }
+      phase("run: ticket order");
       const size_t nr = order.size();
       const size_t nd = P.run_d.size();
       if (nr + nd > 0x7ffffff0ULL) return PASTIX_AMD_ERR_UNSUPPORTED;
@@ -1119,6 +1120,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           tile_ticket[(size_t)tt.tile] = (int32_t)i;
         }
       }
+      phase("run: tile chains");
       if (bad) {
         P.run_L0 = -1;
         P.run_tasks.clear();
@@ -1188,32 +1190,54 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           base += tw[(size_t)t].size();
           P.run_flops += trf[(size_t)t];
         }
-        // consumer lists of the panel-solve tickets (CSR by producer) and the counters of the readers
-        for (size_t i = 0; i < nr && !bad; i++) {
-          const RunCheck& ck = P.run_chk[i];
-          if (ck.wn < 0) continue;
-          for (int q = 0; q < ck.wn; q++) {
-            const int32_t pt2 = tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]];
-            if (pt2 < 0 || pt2 >= (int32_t)i) { bad = true; break; }   // (a source tile of the run has its ticket, in front of its readers)
-            P.run_info[(size_t)pt2].cn++;
-          }
-          P.run_dep[i] += ck.wn;
-        }
-        if (bad) return PASTIX_AMD_ERR_LAYOUT;
+        phase("run: source tiles");
+        // consumer lists of the panel-solve tickets (CSR by producer) and the counters of the readers.  On the host
+        // threads: counts and cursors with atomic adds, every list sorted afterwards -- the tables do not depend on the
+        // number of threads.
         {
+          std::atomic<int> abad{0};
+          auto par = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthr; t++) th.emplace_back(fn, t);
+            fn(0);
+            for (auto& x : th) x.join();
+          };
+          par([&](int t) {
+            for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
+              const RunCheck& ck = P.run_chk[i];
+              if (ck.wn < 0) continue;
+              for (int q = 0; q < ck.wn; q++) {
+                const int32_t pt2 = tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]];
+                if (pt2 < 0 || pt2 >= (int32_t)i) { abad = 1; break; }   // (a source tile of the run has its ticket, in front of its readers)
+                __atomic_fetch_add(&P.run_info[(size_t)pt2].cn, 1, __ATOMIC_RELAXED);
+              }
+              P.run_dep[i] += ck.wn;
+            }
+          });
+          if (abad) return PASTIX_AMD_ERR_LAYOUT;
           int64_t off = 0;
           for (size_t i = 0; i < nr; i++)
             if (P.run_info[i].kind & 4) { P.run_info[i].cptr = (int32_t)off; off += P.run_info[i].cn; P.run_info[i].cn = 0; }
+          if (off > 0x7fffffffLL) return PASTIX_AMD_ERR_UNSUPPORTED;
           P.run_cons.resize((size_t)off);
-          for (size_t i = 0; i < nr; i++) {
-            const RunCheck& ck = P.run_chk[i];
-            if (ck.wn < 0) continue;
-            for (int q = 0; q < ck.wn; q++) {
-              RunInfo& pi = P.run_info[(size_t)tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]]];
-              P.run_cons[(size_t)pi.cptr + (size_t)pi.cn++] = (int32_t)i;
+          par([&](int t) {
+            for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
+              const RunCheck& ck = P.run_chk[i];
+              if (ck.wn < 0) continue;
+              for (int q = 0; q < ck.wn; q++) {
+                RunInfo& pi = P.run_info[(size_t)tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]]];
+                P.run_cons[(size_t)pi.cptr + (size_t)__atomic_fetch_add(&pi.cn, 1, __ATOMIC_RELAXED)] = (int32_t)i;
+              }
             }
-          }
+          });
+          par([&](int t) {
+            for (size_t i = (size_t)t * per; i < std::min(nr, ((size_t)t + 1) * per); i++) {
+              const RunInfo& ri = P.run_info[i];
+              if ((ri.kind & 4) && ri.cn > 1) std::sort(P.run_cons.begin() + ri.cptr, P.run_cons.begin() + ri.cptr + ri.cn);
+            }
+          });
         }
+        phase("run: consumer lists");
         // what is ready when the run starts, in ticket order
         P.run_ready.clear();
         P.run_dready.clear();

@@ -84,3 +84,49 @@ def test_reference_fixture_matrices_through_the_gpu_engine(prec, name, facto, go
     assert gpu["residual"] <= max(1e-10, 10 * cpu["residual"])
     assert gpu["static_pivots"] == cpu["static_pivots"] == g["nbpivot"]
     assert gpu["cblknbr"] == len(g["cblk4"]) - 1                            # the layout blend made is the fixture's
+
+
+def _cmp(prec, kind, arg, facto, extra=(), threads=32, contig=True, timeout=1500):
+    exe = os.path.join(REF, "ref_harness_%s_ob_amd" % prec)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_harness_%s_ob_amd not built (needs /root/reference at build time)" % prec)
+    env = dict(os.environ, OPENBLAS_NUM_THREADS="1")
+    env.pop("PASTIX_AMD_ENGINE", None)
+    if contig:
+        env["REF_ORDER_CONTIG"] = "1"
+    ncpu = os.cpu_count() or 1
+    out = subprocess.run([exe, "cmp", kind, str(arg), facto, str(max(1, min(threads, ncpu))), "/dev/null"] + [str(x) for x in extra],
+                         env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    c = [j for j in js if j.get("cmp")][0]
+    return c, js[-1]
+
+
+# PARITY AT SCALE (the fixture files stop at 20^3): ONE analysis by the real kass + blend, the numerical factorization
+# twice on the same SolverMatrix -- the reference's CPU engine (its threads, its BLAS) and the MI355X engine through the
+# stub -- and the factors compared entry by entry inside the harness (oracle/ref_harness.c, mode cmp; sopalin3d.c:1388-1422
+# is the call that is swapped).  These sizes run the schedule of the big configurations on blend's own layouts: chunks of
+# 1024, tasks of up to 8 / 16 pieces, quadrant tasks at their production thresholds, re-cut cblks (blend leaves pieces of
+# 144 / 152 columns), the run launch over hundreds of thin levels.
+@pytest.mark.parametrize("prec,arg,facto,extra", [
+    ("d", 60, "llt", ()),
+    ("d", 60, "llt", (64, 128)),
+    ("d", 80, "llt", ()),
+    ("d", 60, "ldlt", ()),
+    ("d", 80, "ldlt", (64, 128)),
+    ("d", 60, "lu", ()),
+    ("d", 80, "lu", (64, 128)),
+    ("z", 24, "ldlt", ()),
+    ("z", 32, "ldlt", (64, 128)),
+    ("z", 24, "lu", ()),
+])
+def test_factors_equal_the_reference_cpu_engine_at_scale(prec, arg, facto, extra):
+    c, last = _cmp(prec, "rlap3d", arg, facto, extra)
+    assert c["gpu_engine_calls"] == 1 and c["gpu_engine_rc"] == 0
+    assert c["rel_L"] <= 1e-12, c                      # max |L_gpu - L_ref| / max |L_ref|  (SURVEY 8d tolerance)
+    if facto == "lu":
+        assert c["rel_U"] <= 1e-12, c
+    assert c["static_pivots_gpu"] == c["static_pivots_ref"]
+    assert c["inertia_gpu"] == c["inertia_ref"]
+    assert last["residual"] <= 1e-10                   # the reference's updo on the GPU's factors
