@@ -114,6 +114,11 @@ typedef struct pastix_amd_stats_s {
   pastix_amd_int_t nurgent_launches;
   double solve_time;         /* s, device time of the last pastix_amd_solve call's sweeps (no host transfers) */
   double nquadrant_tasks;    /* tasks of the plan that are 64x64 quadrant tasks (run by k_update_small) */
+  double run_time;           /* s, duration of the run launch (k_run_update: the update and panel-solve tasks of the thin levels
+                                in one dependency-driven launch, opts.run_schedule); 0 when the level-by-level schedule ran.
+                                It is one of the nupdate_launches and part of update_time_sum */
+  double run_flops;          /* update flops carried by that launch (part of update_flops) */
+  pastix_amd_int_t run_tickets, run_first_level;   /* its tasks; the first level it covers (-1: none) */
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;

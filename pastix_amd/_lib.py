@@ -45,7 +45,8 @@ class Stats(ctypes.Structure):
                 ("update_bytes", ctypes.c_double), ("full_flops", ctypes.c_double),
                 ("update_time_sum", ctypes.c_double), ("urgent_flops", ctypes.c_double),
                 ("urgent_time_sum", ctypes.c_double), ("nurgent_launches", ctypes.c_int64),
-                ("solve_time", ctypes.c_double), ("nquadrant_tasks", ctypes.c_double)]
+                ("solve_time", ctypes.c_double), ("nquadrant_tasks", ctypes.c_double),
+                ("run_time", ctypes.c_double), ("run_flops", ctypes.c_double), ("run_tickets", i64), ("run_first_level", i64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -1275,6 +1275,18 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   p->stats.nupdate_launches = two_kernels ? p->nupdB_run : p->nupd_run + p->nupdB_run;
   p->stats.nurgent_launches = two_kernels ? p->nupd_run : 0;
   p->stats.urgent_flops = two_kernels ? p->host.urgent_flops : 0.0;
+  p->stats.run_time = 0;
+  p->stats.run_flops = 0;
+  p->stats.run_tickets = 0;
+  p->stats.run_first_level = -1;
+  if (p->run_used && p->nupdB_run > 0 && p->launch_events) {
+    float m2 = 0;
+    HIPCHK(hipEventElapsedTime(&m2, p->evT[2 * (p->nupdB_run - 1)], p->evT[2 * (p->nupdB_run - 1) + 1]));
+    p->stats.run_time = m2 * 1e-3;
+    p->stats.run_flops = H.run_flops;
+    p->stats.run_tickets = p->run_nticket;
+    p->stats.run_first_level = H.run_L0;
+  }
   if (p->run_used) {
     // the run's update launch carries the urgent tasks of its levels too: update_time_sum = the bulk launches below the
     // run + the run launch, carrying update_flops - urgent_flops with urgent_flops = those of the levels below the run
@@ -1581,6 +1593,7 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     int64_t* droff = nullptr;
     size_t nTk = 0;
     const int64_t nthin = (int64_t)thin_tasks.size();
+    bool thin_ok = true;
     auto build = [&]() -> int {
       int r;
       if ((r = to_device(&dTF, thF))) return r;
@@ -1589,14 +1602,27 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
       if ((r = to_device(&dTg, thin_tgt))) return r;
       if ((r = to_device(&dEx, thin_expect))) return r;
       if (nthin > 0) {
+        // The thin levels' storage is 2 x 128 x 128 doubles + ~4 KB of flags per thin cblk whatever its width: a layout
+        // with long chains of narrow cblks (banded matrices, blend layouts cut fine) can ask for tens of GB.  It is an
+        // accelerator, not a requirement: beyond a quarter of the free memory, or if the allocation fails, the solve keeps
+        // the per-level kernels for every level (thin_ok = false below) instead of failing.
         const size_t ib = (size_t)nthin * 128 * 128 * sizeof(double);
-        HIPCHK(hipMalloc((void**)&dIF, ib));
-        HIPCHK(hipMalloc((void**)&dIB, ib));
-        HIPCHK(hipMemset(dIF, 0, ib));
-        HIPCHK(hipMemset(dIB, 0, ib));
-        // 2 x nthin tickets, nthin forward counters, the "stuck" flag, then per sweep nthin x 8 padded flags (kernels.hip)
         nTk = (size_t)nthin * 3 + 64 + 2 * (size_t)nthin * 64 * 8;
-        HIPCHK(hipMalloc((void**)&dTk, nTk * sizeof(int)));
+        size_t fr = 0, tot = 0;
+        bool ok = hipMemGetInfo(&fr, &tot) == hipSuccess && 2 * ib + nTk * sizeof(int) <= fr / 4;
+        ok = ok && hipMalloc((void**)&dIF, ib) == hipSuccess && hipMalloc((void**)&dIB, ib) == hipSuccess &&
+             // 2 x nthin tickets, nthin forward counters, the "stuck" flag, then per sweep nthin x 8 padded flags (kernels.hip)
+             hipMalloc((void**)&dTk, nTk * sizeof(int)) == hipSuccess;
+        if (ok) {
+          HIPCHK(hipMemset(dIF, 0, ib));
+          HIPCHK(hipMemset(dIB, 0, ib));
+        } else {
+          (void)hipGetLastError();
+          (void)hipFree(dIF); (void)hipFree(dIB); (void)hipFree(dTk);
+          dIF = dIB = nullptr; dTk = nullptr; nTk = 0;
+          thin_ok = false;
+          if (H.opts.verbose >= 1) fprintf(stderr, "pastix_amd: %lld thin cblks: no room for their inverses, the solve keeps per-level kernels\n", (long long)nthin);
+        }
       }
       if ((r = to_device(&dS, st))) return r;
       if ((r = to_device(&dB, bl))) return r;
@@ -1619,7 +1645,7 @@ int pai_solve_tables(pastix_amd_plan_t* p) {
     }
     p->dSolve = dS; p->dBlok = dB; p->dChunk = dC; p->dChunkB = dCB; p->dRidx = dR;
     p->dThinF = dTF; p->dThinB = dTB; p->dThinTasks = dTT; p->dInvF = dIF; p->dInvB = dIB; p->dTicket = dTk;
-    p->nthin = nthin;
+    p->nthin = thin_ok ? nthin : 0;                 // (0: every level through the per-level kernels)
     p->nTicket = nTk;
     p->dThinTgt = dTg; p->dThinExpect = dEx;
     p->inv_gen = -1;

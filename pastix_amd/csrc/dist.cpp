@@ -350,6 +350,8 @@ struct pastix_amd_dist_s {
   int64_t nsend = 0, nrecv = 0;
   double* dXs = nullptr;                    // solve: the rank's copy of the vector
   double* dSolveStage = nullptr;            // solve: received segments (forward sweep)
+  double* hXs = nullptr;                    // solve: pinned host staging of the vector (lives as long as the plan: an
+  size_t nXs = 0;                           // asynchronous copy may still target it when a run is abandoned, see dist_finish)
   std::vector<int64_t> solve_stage_off;     // per message: offset in dSolveStage (receive messages)
   // progress marks of the run in flight: one event behind every (level, peer) group on its channel stream and one
   // behind every level on the panel stream -- what the deadline handler reads to say where a rank is stuck
@@ -367,6 +369,8 @@ static void dist_free(pastix_amd_dist_s* D) {
   (void)hipFree(D->dRows);
   (void)hipFree(D->dXs);
   (void)hipFree(D->dSolveStage);
+  (void)hipDeviceSynchronize();                      // (nothing enqueued may still write the host staging)
+  if (D->hXs) (void)hipHostFree(D->hXs);
   for (hipEvent_t e : D->events) (void)hipEventDestroy(e);
   delete D;
 }
@@ -812,8 +816,16 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
       if (S.msgs[i].dir == 1) { D->solve_stage_off[i] = off; off += S.msgs[i].width; }
     HIPCHK(hipMalloc((void**)&D->dSolveStage, (size_t)std::max<int64_t>(off, 1) * sizeof(double)));
   }
-  // the rank's view of b: own columns only.  (hx outlives every copy: dist_finish drains the streams on every path)
-  std::vector<double> hx((size_t)n, 0.0);
+  // the rank's view of b: own columns only.  The staging buffer belongs to the plan's distributed state, not to this
+  // call: dist_finish's drain is bounded, so on the abandoned-run path an enqueued copy may still be in flight when this
+  // function returns -- it must not target memory that dies with the call.
+  if (D->nXs < (size_t)n) {
+    if (D->hXs) { HIPCHK(hipDeviceSynchronize()); (void)hipHostFree(D->hXs); D->hXs = nullptr; D->nXs = 0; }
+    HIPCHK(hipHostMalloc((void**)&D->hXs, (size_t)n * sizeof(double), hipHostMallocDefault));
+    D->nXs = (size_t)n;
+  }
+  struct { double* p; double* data() const { return p; } } hx{D->hXs};
+  std::memset(hx.data(), 0, (size_t)n * sizeof(double));
   for (int64_t k = 0; k < H.cblknbr; k++)
     if (H.role[k] == 1)
       std::memcpy(hx.data() + H.cblk[k].fcolnum, x + H.cblk[k].fcolnum,

@@ -1099,7 +1099,10 @@ __device__ __forceinline__ void thin_poll(const int* flag, const int t, int* stu
   const int* f = flag + ((int64_t)t * FLAG_REP + blockIdx.x % FLAG_REP) * FLAG_PAD;
   int it = 0;
   while (!__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    if (++it > SPIN_LIMIT) { *stuck = 1; break; }
+    if (++it > SPIN_LIMIT) { __hip_atomic_store(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    // (once ANY workgroup has given up the solve has failed: the others leave at once instead of spinning out their own
+    // limits one after the other down the chain of levels)
+    if ((it & 1023) == 0 && __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     if (it < 64) __builtin_amdgcn_s_sleep(8);                  // (~0.2 us, later ~1.3 us between polls)
     else __builtin_amdgcn_s_sleep(48);
   }
@@ -1205,7 +1208,8 @@ __global__ __launch_bounds__(256) void k_solve_thin_bwd(const T* __restrict__ B,
     if (tid == 0 && ck.nwg > 1) {
       int it = 0;
       while (__hip_atomic_load(&ticket[ck.thin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ck.nwg - 1) {
-        if (++it > SPIN_LIMIT) { *stuck = 1; break; }
+        if (++it > SPIN_LIMIT) { __hip_atomic_store(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((it & 1023) == 0 && __hip_atomic_load(stuck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         if (it < 64) __builtin_amdgcn_s_sleep(8);
         else __builtin_amdgcn_s_sleep(48);
       }

@@ -110,6 +110,9 @@ struct Dev {
     hipLaunchKernelGGL(k_axpby<T>, grid(), dim3(256), 0, s, n, toT(a), x, toT(b), y, b != H(0.0) ? 1 : 0);
   }
   void copy(const T* x, T* y) { (void)hipMemcpyAsync(y, x, (size_t)n * sizeof(T), hipMemcpyDeviceToDevice, s); }
+  // y = 0 whatever y or anything else holds (0 * NaN is NaN: a right-hand side that broke down must not poison the work
+  // vectors the next one starts from)
+  void zero(T* y) { (void)hipMemsetAsync(y, 0, (size_t)n * sizeof(T), s); }
   H dot(const T* u, const T* w) {                  // <u, w> = u^H w
     hipLaunchKernelGGL(k_dot<T>, dim3(DOT_BLOCKS), dim3(256), 0, s, n, u, w, partial);
     T hp[DOT_BLOCKS];
@@ -235,8 +238,8 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
     } else if (mode == 3) {                        // raff_bicgstab.c: right-preconditioned BiCGStab
       D.copy(r, r0);
       H rho = 1.0, alpha = 1.0, omega = 1.0;
-      D.axpby(H(0.0), r, H(0.0), pv);              // p = 0
-      D.axpby(H(0.0), r, H(0.0), v);               // v = 0
+      D.zero(pv);                                  // p = 0
+      D.zero(v);                                   // v = 0
       while (relerr >= eps && it < itermax) {
         const H rho1 = D.dot(r0, r);
         if (std::abs(rho1) == 0) break;            // breakdown: the true residual below decides
@@ -311,7 +314,7 @@ int refine_impl(pastix_amd_plan_t* p, int mode, int sym, int64_t n, const int64_
           for (int q = i + 1; q < j; q++) t -= Hm[(size_t)i * m + q] * y[(size_t)q];
           y[(size_t)i] = t / Hm[(size_t)i * m + i];
         }
-        D.axpby(H(0.0), r, H(0.0), w);
+        D.zero(w);
         for (int i = 0; i < j; i++) D.axpby(y[(size_t)i], V[(size_t)i], H(1.0), w);
         if ((rc = D.precond(w, z))) break;
         D.axpby(H(1.0), z, H(1.0), x);
