@@ -525,6 +525,8 @@ int main(int argc, char **argv)
       }
     }
     setenv("PASTIX_AMD_ENGINE", "1", 1);
+    iparm[IPARM_START_TASK] = API_TASK_NUMFACT;      /* (pastix() advances START_TASK past the step it has run) */
+    iparm[IPARM_END_TASK] = API_TASK_NUMFACT;
     pastix(&pd, 0, n, A.colptr, A.rows, A.vals, perm, invp, b, 1, iparm, dparm);
     sm = &pd->solvmatr;
     for (k = 0; k < nc; k++) {
