@@ -239,6 +239,15 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, co
  * every task can run when the tickets are served one at a time in order: the schedule cannot deadlock) */
 int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
                              pastix_amd_int_t *info);
+/* host-only: the multi-GPU driver's partition -- owner[k] = the rank (GPU) that factorizes cblk k, for `world` <= 64 ranks.
+ * Proportional mapping on the cblk elimination tree, blend's idea (splitpart.c:752-1012; GPU colouring
+ * blend_distributeOnGPU.c:59-317): a subtree gets a set of candidate ranks; the cblks of the separator at its top are dealt
+ * over the set, heaviest first onto the least loaded rank; at a branching the set is divided among the heavy children in
+ * proportion to their flops; a subtree with one candidate goes to it whole; side subtrees lighter than `light` (<= 0: 0.05)
+ * of their parent go whole to the least loaded candidate.  A rank then only contributes to separators on its own path to
+ * the root.  Deterministic: every rank computes the same map from the layout alone; its result is what
+ * pastix_amd_plan_create_dist / pastix_amd_fanin_touched / pastix_amd_dist_schedule take as `owner`. */
+int pastix_amd_dist_partition(const pastix_amd_layout_t *layout, int world, double light, int32_t *owner);
 /* ---- multi-GPU driver: asynchronous fan-in over RCCL point-to-point (csrc/dist.cpp) ------------------------------
  * One process per GPU.  Every rank: plan_create_dist (own arena), fill_csc, then ONCE pastix_amd_dist_attach_rccl,
  * then pastix_amd_factorize_dist as often as needed (pastix_amd_refill in between).  The reference's counterpart is the

@@ -78,7 +78,7 @@ EXPORTS = [
     "pastix_amd_plan_set_stream", "pastix_amd_factorize_begin", "pastix_amd_factorize_level",
     "pastix_amd_factorize_end", "pastix_amd_plan_profile", "pastix_amd_plan_run_info", "pastix_amd_fanin_touched", "pastix_amd_plan_fanin_add", "pastix_amd_download_cblk",
     "pastix_amd_dist_unique_id", "pastix_amd_dist_selftest_rccl", "pastix_amd_dist_attach_rccl", "pastix_amd_dist_attach_local", "pastix_amd_dist_info",
-    "pastix_amd_factorize_dist", "pastix_amd_factorize_dist_local", "pastix_amd_solve_dist", "pastix_amd_solve_dist_local", "pastix_amd_dist_schedule",
+    "pastix_amd_dist_partition", "pastix_amd_factorize_dist", "pastix_amd_factorize_dist_local", "pastix_amd_solve_dist", "pastix_amd_solve_dist_local", "pastix_amd_dist_schedule",
 ]
 # include/pastix_amd_symbolic.h and include/pastix_amd_driver.h
 EXPORTS_HOST = [

@@ -268,3 +268,23 @@ def test_schedule_handshake_over_gloo(poison):
     assert all(ok != poison for _r, ok, _m in res), res
     if poison:
         assert all("disagree" in m for _r, _ok, m in res)
+
+
+def test_c_abi_partition_equals_the_restatement_and_balances():
+    """pastix_amd_dist_partition (csrc/partition.cpp, what a C caller of INTEGRATION.md section 3 uses) against the test-side
+    numpy restatement of the same rule, rank for rank; every rank gets work; a subtree with one candidate rank is whole."""
+    import np_partition as ref
+    for N, bs in [(10, 16), (16, 32), (24, 64), (30, 128)]:
+        n, cp, r, v = sy.laplacian_3d(N)
+        perm, _ = sy.order_grid(N, N, N)
+        s = sy.symbolic(n, cp, r, perm, max_blocksize=bs)
+        c4, b4 = s["cblk4"], s["blok4"]
+        fl = ref.cblk_flops(c4, b4)
+        for W in (1, 2, 3, 4, 5, 8, 16):
+            ow = pd.partition(c4, b4, W)
+            assert np.array_equal(ow, ref.partition(c4, b4, W)), (N, bs, W)
+            assert ow.min() >= 0 and ow.max() < W
+            if W <= 8:
+                share = np.bincount(ow, weights=fl, minlength=W) / fl.sum()
+                assert share.min() > 0 and share.max() <= (0.75 if W > 1 else 1.0)
+
