@@ -149,9 +149,12 @@ int pastix_amd_z_ge_sopalin(const pastix_amd_layout_t *layout, void *const *coef
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 
 /* single precision (S_ / C_ {po,sy,he,ge}_sopalin_thread, sopalin3d.h:381-467 under -DPREC_SIMPLE): coeftab[k] are
- * `float` / interleaved `float complex` panels.  They are widened on the host, factorized by the fp64 engine and
- * rounded back (dtype of the arithmetic stays f64; an fp32-MFMA path is not built).  The staged API takes the
- * double types only. */
+ * `float` / interleaved `float complex` panels.
+ *   s_*: the native fp32 engine -- float arenas on the device, fp32 MFMA kernels (kernels_f32.hip); nothing is widened.
+ *        The staged API takes it too: pastix_amd_plan_create(..., PASTIX_AMD_REALSINGLE, ...) with float panels / CSC
+ *        values (the vectors of pastix_amd_solve stay double, so that refinement recovers double accuracy).
+ *   c_*: complex single is NOT native: the panels are widened to double complex on the host, factorized by the fp64 engine
+ *        and rounded back (the arithmetic is f64); plan_create(PASTIX_AMD_COMPLEXSINGLE) returns PASTIX_AMD_ERR_UNSUPPORTED. */
 int pastix_amd_s_po_sopalin(const pastix_amd_layout_t *layout, float *const *coeftab, double critere,
                             const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 int pastix_amd_s_sy_sopalin(const pastix_amd_layout_t *layout, float *const *coeftab, double critere,
@@ -186,7 +189,8 @@ int pastix_amd_fill_csc(pastix_amd_plan_t *plan, int sym, pastix_amd_int_t n, co
 /* IPARM_FILL_MATRIX = API_YES, the reference's structure-only "fake factorisation" fill (CoefMatrix_Init,
  * coefinit.c:343-443): no CSC; coeftab all 1, ucoeftab all 2, diagonals gnodenbr^2, LU: strictly upper part of
  * coeftab's diagonal bloks 2.  The matching pivot threshold is (gnodenbr^2 + gnodenbr) sqrt(eps)
- * (sopalin3d.c:597-598).  Cached like pastix_amd_fill_csc.  One-GPU plans with cblks <= 256 wide. */
+ * (sopalin3d.c:597-598).  Cached like pastix_amd_fill_csc.  One-GPU plans; any cblk width (cblks wider than 128 columns are
+ * re-cut into column groups inside the engine like everywhere else). */
 int pastix_amd_fill_fake(pastix_amd_plan_t *plan, pastix_amd_int_t gnodenbr);
 /* re-apply the fill cached by the last pastix_amd_fill_csc (device only: memset + scatter). */
 int pastix_amd_refill(pastix_amd_plan_t *plan);

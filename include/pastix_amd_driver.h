@@ -42,8 +42,11 @@ enum { API_ORDER_SCOTCH = 0, API_ORDER_METIS = 1, API_ORDER_PERSONAL = 2, API_OR
 
 typedef struct pastix_amd_data_s pastix_amd_data_t;
 
-/* avals / b: PASTIX_FLOAT arrays -- `double` (iparm[IPARM_FLOAT] = API_REALDOUBLE, the D_pastix build) or interleaved
- * `double complex` (API_COMPLEXDOUBLE, Z_pastix); single precision is not built. */
+/* avals / b: PASTIX_FLOAT arrays of the arithmetic iparm[IPARM_FLOAT] names (api.h:522-525) -- `double` (API_REALDOUBLE, the
+ * D_pastix build), interleaved `double complex` (API_COMPLEXDOUBLE, Z_pastix), `float` (API_REALSINGLE, S_pastix: the
+ * factorization runs on the native fp32 engine; norm, solve and refinement keep double vectors inside and the result is
+ * rounded to float) or interleaved `float complex` (API_COMPLEXSINGLE, C_pastix: no native complex-single engine -- the
+ * values are widened and the fp64 engine computes). */
 void pastix_amd_pastix(pastix_amd_data_t **pastix_data, int pastix_comm, pastix_amd_int_t n,
                        pastix_amd_int_t *colptr, pastix_amd_int_t *row, void *avals, pastix_amd_int_t *perm,
                        pastix_amd_int_t *invp, void *b, pastix_amd_int_t rhs, pastix_amd_int_t *iparm,

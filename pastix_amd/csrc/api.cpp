@@ -1000,7 +1000,7 @@ int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const
 // The reference's "fake factorisation" fill (CoefMatrix_Init with IPARM_FILL_MATRIX = API_YES, coefinit.c:343-443): no
 // CSC -- every entry of coeftab is 1, of ucoeftab 2, the diagonal of every diagonal blok gnodenbr^2, and for LU the
 // strictly upper part of coeftab's diagonal blok is 2 (the copy of ucoeftab's lower part, :431-441).  Cached like
-// pastix_amd_fill_csc (pastix_amd_refill re-applies it).  One GPU, cblks <= 256 wide.
+// pastix_amd_fill_csc (pastix_amd_refill re-applies it).  One GPU; cblks wider than 128 columns are re-cut like everywhere.
 int pastix_amd_fill_fake(pastix_amd_plan_t* p, pastix_amd_int_t gnodenbr) {
   if (!p || gnodenbr < 1) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_UNSUPPORTED;

@@ -105,12 +105,15 @@ inline double real_(const std::complex<double>& x) { return x.real(); }
 
 // T = double (D_pastix) or std::complex<double> (Z_pastix): the reference compiles pastix.c once per precision
 // (redefine_functions.h:73-98); here one template serves both.
+// vals32 != NULL (S_pastix): the caller's FLOAT values of a real matrix -- the numerical factorization then runs on the
+// native fp32 engine (float arenas, fp32 MFMA kernels) from them; `avals` / `b` are their double copies, which the norm,
+// the solve (float factors under double vectors) and the refinement work on.
 template <typename T>
 void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd_int_t* colptr, pastix_amd_int_t* row,
                  T* avals, pastix_amd_int_t* perm, pastix_amd_int_t* invp, T* b, pastix_amd_int_t rhs,
-                 pastix_amd_int_t* iparm, double* dparm) {
+                 pastix_amd_int_t* iparm, double* dparm, const float* vals32 = nullptr) {
   constexpr bool CPLX = !std::is_same<T, double>::value;
-  constexpr int floattype = CPLX ? PASTIX_AMD_COMPLEXDOUBLE : PASTIX_AMD_REALDOUBLE;
+  const int floattype = CPLX ? PASTIX_AMD_COMPLEXDOUBLE : vals32 ? PASTIX_AMD_REALSINGLE : PASTIX_AMD_REALDOUBLE;
   constexpr size_t TW = sizeof(T) / sizeof(double);
   iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_OK;
 #define FAIL(code) do { iparm[IPARM_ERROR_NUMBER] = (code); return; } while (0)
@@ -265,7 +268,7 @@ void pastix_impl(pastix_amd_data_t** pastix_data, pastix_amd_int_t n, pastix_amd
         D->norm1 = nrm;
         const double eps = dparm[DPARM_EPSILON_MAGN_CTRL];
         const double critere = eps < 0 ? -eps : nrm * std::sqrt(eps);
-        rc = pastix_amd_fill_csc(D->plan, sym, n, colptr, row, avals, D->perm.data());
+        rc = pastix_amd_fill_csc(D->plan, sym, n, colptr, row, vals32 ? (const void*)vals32 : (const void*)avals, D->perm.data());
         if (rc) FAIL(rc);
         pastix_amd_stats_t st{};
         rc = pastix_amd_factorize(D->plan, critere, &st);
@@ -340,8 +343,31 @@ void pastix_amd_pastix(pastix_amd_data_t** pastix_data, int pastix_comm, pastix_
   else if (iparm[IPARM_FLOAT] == PASTIX_AMD_COMPLEXDOUBLE)
     pastix_impl<std::complex<double>>(pastix_data, n, colptr, row, (std::complex<double>*)avals, perm, invp,
                                       (std::complex<double>*)b, rhs, iparm, dparm);
-  else
-    iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_ERR_UNSUPPORTED;      // single precision is not built
+  else if (iparm[IPARM_FLOAT] == PASTIX_AMD_REALSINGLE || iparm[IPARM_FLOAT] == PASTIX_AMD_COMPLEXSINGLE) {
+    // S_pastix / C_pastix (the reference's -DPREC_SIMPLE builds, redefine_functions.h:73-98): avals / b are float /
+    // float complex.  Real: the factorization runs on the native fp32 engine from the float values; complex: there is no
+    // native complex-single engine, the factorization runs in fp64 on the widened values.  Either way the vectors are
+    // double inside (norm, solve, refinement) and rounded to the caller's type at the end.
+    static const float k_no_values = 0.0f;
+    const bool cplx = iparm[IPARM_FLOAT] == PASTIX_AMD_COMPLEXSINGLE;
+    const int64_t nnz = (colptr && n > 0) ? (int64_t)(colptr[n] - colptr[0]) : 0;
+    const size_t w = cplx ? 2 : 1;
+    try {
+      std::vector<double> ad, bd;
+      if (avals) { ad.resize((size_t)nnz * w); for (size_t i = 0; i < ad.size(); i++) ad[i] = (double)((const float*)avals)[i]; }
+      if (b && rhs > 0) { bd.resize((size_t)n * (size_t)rhs * w); for (size_t i = 0; i < bd.size(); i++) bd[i] = (double)((const float*)b)[i]; }
+      if (cplx)
+        pastix_impl<std::complex<double>>(pastix_data, n, colptr, row, avals ? (std::complex<double>*)ad.data() : nullptr, perm, invp,
+                                          b ? (std::complex<double>*)bd.data() : nullptr, rhs, iparm, dparm);
+      else
+        pastix_impl<double>(pastix_data, n, colptr, row, avals ? ad.data() : nullptr, perm, invp, b ? bd.data() : nullptr, rhs, iparm,
+                            dparm, avals ? (const float*)avals : &k_no_values /* (steps without values: only the type counts) */);
+      if (b) for (size_t i = 0; i < bd.size(); i++) ((float*)b)[i] = (float)bd[i];
+    } catch (const std::bad_alloc&) {
+      iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_ERR_ALLOC;
+    }
+  } else
+    iparm[IPARM_ERROR_NUMBER] = PASTIX_AMD_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ API_SYM_YES, API_SYM_NO = 0, 1
 API_ORDER_SCOTCH, API_ORDER_PERSONAL = 0, 2
 API_FACT_LLT, API_FACT_LDLT, API_FACT_LU = 0, 1, 2
 API_RAF_GMRES, API_RAF_GRAD, API_RAF_PIVOT, API_RAF_BICGSTAB = 0, 1, 2, 3
-API_REALDOUBLE, API_COMPLEXDOUBLE = 1, 3          # api.h:522-525
+API_REALSINGLE, API_REALDOUBLE, API_COMPLEXSINGLE, API_COMPLEXDOUBLE = 0, 1, 2, 3          # api.h:522-525
 API_SYM_HER = 2
 API_FACT_LDLH = 3
 
@@ -58,8 +58,8 @@ def init_param():
 
 def pastix(pastix_data, n, colptr, rows, avals, perm, invp, b, nrhs, iparm, dparm):
     """void pastix(pastix_data_t**, MPI_Comm, n, colptr, row, avals, perm, invp, b, rhs, iparm, dparm)
-    (pastix.h:219-222).  Arrays are int64 / float64 numpy arrays (complex128 values and right-hand sides with
-    iparm[IPARM_FLOAT] = API_COMPLEXDOUBLE), modified in place."""
+    (pastix.h:219-222).  Arrays are int64 / float64 numpy arrays (complex128 / float32 / complex64 values and right-hand
+    sides with iparm[IPARM_FLOAT] = API_COMPLEXDOUBLE / API_REALSINGLE / API_COMPLEXSINGLE), modified in place."""
     pd = pastix_data if pastix_data is not None else PastixData()
     L = _lib.lib()
     L.pastix_amd_pastix.restype = None

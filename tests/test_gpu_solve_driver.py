@@ -592,3 +592,66 @@ def test_pastix_fill_matrix_mode(facto):
     assert iparm[px.IPARM["STATIC_PIVOTING"]] == 0 and dparm[px.DPARM["FACT_TIME"]] > 0
     iparm[px.IPARM["START_TASK"]] = iparm[px.IPARM["END_TASK"]] = px.API_TASK["CLEAN"]
     px.pastix(pd, n, cp, r, v, perm, invp, b, 1, iparm, dparm)
+
+
+@pytest.mark.parametrize("facto", ["LLT", "LDLT", "LU"])
+def test_s_pastix_entry_point(facto):
+    """S_pastix (iparm[IPARM_FLOAT] = API_REALSINGLE, api.h:522-525): float values and right-hand side through the entry
+    point; the factorization runs on the native fp32 engine, the refinement (double vectors inside) brings the residual
+    of the FLOAT system down to float rounding."""
+    import scipy.sparse as sp
+    N = 14
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm0, invp0 = sy.order_grid(N, N, N)
+    perm, invp = perm0 + 1, invp0 + 1
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    if facto == "LU":
+        Af = (A + sp.tril(A, -1).T + sp.triu(A + sp.tril(A, -1).T, 1).multiply(0.1)).tocsc()
+        Af.sort_indices()
+        cp, r, v = Af.indptr.astype(np.int64) + 1, Af.indices.astype(np.int64) + 1, Af.data
+    else:
+        Af = (A + sp.tril(A, -1).T).tocsc()
+    v32 = v.astype(np.float32)
+    b = np.random.default_rng(9).random(n).astype(np.float32)
+    rhs = b.copy()
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FLOAT"]] = px.API_REALSINGLE
+    iparm[px.IPARM["FACTORIZATION"]] = getattr(px, "API_FACT_" + facto)
+    iparm[px.IPARM["SYM"]] = px.API_SYM_NO if facto == "LU" else px.API_SYM_YES
+    iparm[px.IPARM["ORDERING"]] = px.API_ORDER_PERSONAL
+    iparm[px.IPARM["REFINEMENT"]] = px.API_RAF_GMRES
+    dparm[px.DPARM["EPSILON_REFINEMENT"]] = 1e-10
+    pd = _run_tasks(None, "ORDERING", "REFINE", n, cp, r, v32, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0 and b.dtype == np.float32
+    A32 = sp.csc_matrix((v32.astype(np.float64), Af.indices if facto == "LU" else A.indices, Af.indptr if facto == "LU" else A.indptr), shape=(n, n))
+    if facto != "LU":
+        A32 = A32 + sp.tril(A32, -1).T
+    res = np.linalg.norm(A32 @ b.astype(np.float64) - rhs) / np.linalg.norm(rhs)
+    assert res < 5e-6, res                                    # (x is rounded to float: ~1e-7 relative)
+    assert dparm[px.DPARM["RELATIVE_ERROR"]] < 1e-9            # the refinement itself converged in double
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v32, perm, invp, b, 1, iparm, dparm)
+
+
+def test_c_pastix_entry_point():
+    """C_pastix (API_COMPLEXSINGLE): float complex values; no native complex-single engine -- the fp64 engine computes on
+    the widened values, the solution is rounded to complex64."""
+    import scipy.sparse as sp
+    N = 5
+    n, cp, r, v, _ = sy.elasticity_3d(N)
+    v64 = v.astype(np.complex64)
+    A = sp.csc_matrix((v64.astype(np.complex128), r - 1, cp - 1), shape=(n, n))
+    Afull = (A + sp.tril(A, -1).T).tocsc()
+    rng = np.random.default_rng(3)
+    b = (rng.random(n) + 1j * rng.random(n)).astype(np.complex64)
+    rhs = b.copy()
+    iparm, dparm = px.init_param()
+    iparm[px.IPARM["FLOAT"]] = px.API_COMPLEXSINGLE
+    iparm[px.IPARM["FACTORIZATION"]] = px.API_FACT_LDLT
+    iparm[px.IPARM["SYM"]] = px.API_SYM_YES
+    perm = np.zeros(n, dtype=np.int64)
+    invp = np.zeros(n, dtype=np.int64)
+    pd = _run_tasks(None, "ORDERING", "SOLVE", n, cp, r, v64, perm, invp, b, 1, iparm, dparm)
+    assert iparm[px.IPARM["ERROR_NUMBER"]] == 0 and b.dtype == np.complex64
+    assert np.linalg.norm(Afull @ b.astype(np.complex128) - rhs) / np.linalg.norm(rhs) < 5e-6
+    _run_tasks(pd, "CLEAN", "CLEAN", n, cp, r, v64, perm, invp, b, 1, iparm, dparm)
+
