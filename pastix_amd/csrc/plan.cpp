@@ -254,9 +254,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // 130^3 512 -> 0.6015 s, 1024 -> 0.5873 s; 60^3 512 -> 19.6 ms, 1024 -> 20.2 ms).
   const double fl_total = fact_flops(L, factotype, floattype);
   const bool big = fl_total > 5e13;
-  if (P.opts.lookahead <= 0) P.opts.lookahead = big ? 2048 : fl_total > 1e12 ? 1024 : 512;
+  // Where the run schedule is built (below) launches have no tails to balance, and what a task costs besides its chunks
+  // weighs more than parallelism: longer tasks from 4e12 flop (MI355X, run schedule: 100^3 1024 -> 133.4 ms, 2048 -> 131.9;
+  // 130^3 548.6 -> 533.9; 160^3 1815 -> 1774; 80^3 43.8 -> 45.4: stays 1024; 60^3 512 -> 14.56, 1024 -> 14.38).
+  const bool run_built = !owner && floattype == PASTIX_AMD_REALDOUBLE && factotype == PASTIX_AMD_FACT_LLT && P.opts.run_schedule >= 0;
+  if (P.opts.lookahead <= 0)
+    P.opts.lookahead = run_built ? (fl_total > 4e12 ? 2048 : 1024) : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
-  const int max_pieces = big ? 16 : 8;
+  const int max_pieces = P.opts.lookahead >= 4096 ? 32 : P.opts.lookahead >= 2048 ? 16 : 8;
   const int64_t nc = L->cblknbr;
   P.cblknbr = nc;
   P.bloknbr = L->bloknbr;

@@ -17,6 +17,7 @@ ap.add_argument("--bs", type=int, default=128)
 ap.add_argument("--maxc", type=int, default=0)
 ap.add_argument("--tw", type=int, default=0)
 ap.add_argument("--dw", type=int, default=0)
+ap.add_argument("--look", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--nocheck", action="store_true")
 ap.add_argument("--verbose", type=int, default=0)
@@ -27,7 +28,7 @@ for N in a.n:
     s = sy.symbolic(n, cp, r, perm, max_blocksize=a.bs)
     c4, b4 = s["cblk4"], s["blok4"]
     fl = fact_flops(c4, b4, 0)
-    p = Plan(c4, b4, 0, run_max_cblks=a.maxc, run_t_workers=a.tw, run_d_workers=a.dw, verbose=a.verbose)
+    p = Plan(c4, b4, 0, run_max_cblks=a.maxc, run_t_workers=a.tw, run_d_workers=a.dw, lookahead=a.look, verbose=a.verbose)
     res = {}
     for mode in ("0", "1"):
         os.environ["PASTIX_AMD_RUN"] = mode
