@@ -1438,7 +1438,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
       }
     }
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
-    launch_run_update(s2, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunCons, p->runctl, p->dDinv,
+    launch_run_update(s2, H.factotype, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunCons, p->runctl, p->dDinv,
                       p->run_nticket, p->run_nwg, run_limit);
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
     p->nupdB_run++;

@@ -273,21 +273,16 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
 // packed lower triangle resident in LDS, the 16 x 16 tile factorized by wave 0 in registers (unit L, D on the diagonal,
 // static-pivot clamp and the count of positive pivots for IPARM_INERTIA), rows below solved thread-per-row, trailing
 // update (L D) L^T on the MFMA pipe with L D formed on the fly from L and the tile's diagonal.
-__global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
-                                                     double* __restrict__ dinv_ws, double critere,
-                                                     long long* __restrict__ nbpivot) {
-  // lower triangle of the blok, packed by columns (66 KB): with the 132 KB of a full square the workgroup could
-  // only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
-  // size fits beside one k_update workgroup.  Entries outside the w x w part are zero.
-  __shared__ double D[128 * 129 / 2];
+// (D: the packed lower triangle in LDS as in diag_llt_body; Ri: reciprocals of the tile's diagonal, Dd: the diagonal itself;
+// COH: results stored write-through for the run launch)
+template <bool COH>
+__device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* __restrict__ Ri, double* __restrict__ Dd,
+                                               double* __restrict__ L, const PanelTask& tk, double* __restrict__ dinv_ws,
+                                               const double critere, long long* __restrict__ nbpivot, const int tid) {
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
-  __shared__ double Ri[16];            // reciprocals of the tile's diagonal (1 / d)
-  __shared__ double Dd[16];            // the tile's diagonal d
-  PANEL_PRIO();
-  const PanelTask tk = tasks[blockIdx.x];
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   {
     // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
@@ -337,7 +332,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
     if (lane < 16) {
       double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
 #pragma unroll
-      for (int i = 0; i < 16; i++) dst[i + 16 * l15] = x[i];
+      for (int i = 0; i < 16; i++) pst<COH>(&dst[i + 16 * l15], x[i]);
     }
   };
   for (int kb = 0; kb < w; kb += 16) {
@@ -449,12 +444,22 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
-      if (r < w && r >= c) A[r + (int64_t)c * ld] = DP(c, r);
+      if (r < w && r >= c) pst<COH>(&A[r + (int64_t)c * ld], DP(c, r));
   }
   if (wave == 0 && lane == 0) {
     if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
     if (npos) atomicAdd((unsigned long long*)nbpivot + 1, (unsigned long long)npos);
   }
+}
+__global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, const PanelTask* __restrict__ tasks,
+                                                     double* __restrict__ dinv_ws, double critere,
+                                                     long long* __restrict__ nbpivot) {
+  __shared__ double D[DIAG_LDS_DOUBLES];
+  __shared__ double Ri[16];
+  __shared__ double Dd[16];
+  PANEL_PRIO();
+  const PanelTask tk = tasks[blockIdx.x];
+  diag_ldlt_body<false>(D, Ri, Dd, L, tk, dinv_ws, critere, nbpivot, threadIdx.x);
 }
 
 void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
@@ -544,11 +549,13 @@ __global__ __launch_bounds__(256, NT == 8 ? 4 : 1) void k_trsm_llt(double* __res
 // k_run_update because their code needs 128 VGPRs beside that kernel's 64 accumulation registers; a workgroup that is
 // resident never waits for a slot behind tickets that wait for it.  The host checks `resident` before it launches
 // k_run_update.)
-__global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L, const RunD* __restrict__ rd,
-                                                         const RunInfo* __restrict__ info, double* __restrict__ dinv_ws,
-                                                         const double critere, long long* __restrict__ nbpivot,
-                                                         int* __restrict__ errflag, const RunCtl rc,
-                                                         int* __restrict__ resident, const long long limit) {
+// FT: 0 LLt, 1 LDLt
+template <int FT>
+__global__ __launch_bounds__(512, 4) void k_run_diag(double* __restrict__ L, const RunD* __restrict__ rd,
+                                                     const RunInfo* __restrict__ info, double* __restrict__ dinv_ws,
+                                                     const double critere, long long* __restrict__ nbpivot,
+                                                     int* __restrict__ errflag, const RunCtl rc,
+                                                     int* __restrict__ resident, const long long limit) {
   __shared__ double D[DIAG_LDS_DOUBLES];
   __shared__ double Ri[2][16];
   __shared__ int s_task;
@@ -573,7 +580,8 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_llt(double* __restrict__ L,
     // and kept in registers across it -- 59 spilled VGPRs instead of the 17 of the same body in k_diag_llt_w)
     int ltid = threadIdx.x;
     asm volatile("" : "+v"(ltid));
-    diag_llt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, errflag, ltid);
+    if constexpr (FT == 0) diag_llt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, errflag, ltid);
+    else diag_ldlt_body<true>(D, &Ri[0][0], &Ri[1][0], L, d.pt, dinv_ws, critere, nbpivot, ltid);
     run_drain();
     __syncthreads();
     if (tid < 64) {
@@ -1418,12 +1426,19 @@ void launch_solve_dscale(hipStream_t s, const double* L, const SolveTask* tasks,
 __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = v;
 }
+void launch_run_diag_lu(hipStream_t sd, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                        double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit);   // kernels_var.hip
 void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                       double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit) {
-  (void)factotype;
-  if (gd > 0)
-    hipLaunchKernelGGL(k_run_diag_llt, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag,
-                       rc, resident, limit);
+  if (gd <= 0) return;
+  if (factotype == PASTIX_AMD_FACT_LLT)
+    hipLaunchKernelGGL(k_run_diag<0>, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag, rc,
+                       resident, limit);
+  else if (factotype == PASTIX_AMD_FACT_LDLT)
+    hipLaunchKernelGGL(k_run_diag<1>, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag, rc,
+                       resident, limit);
+  else
+    launch_run_diag_lu(sd, ar, rd, info, gd, dinv, critere, nbpivot, rc, resident, limit);
 }
 
 void launch_fill_const(hipStream_t s, double* dst, int64_t n, double v) {

@@ -431,9 +431,14 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
-template <bool COH>
-__device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const TrsmTask& tk, const double* __restrict__ dinv_ws,
-                                                const int tid) {
+// MODE as in kernels_var.hip k_trsm_var (kernel_trsm, compute_trsm.c:58-114):
+//   0 LLt   X = A L_d^-T                     (T = L_d read plain, Tinv = inverses of its 16 x 16 diagonal tiles)
+//   1 LDLt  Y = A L_d^-T with unit L_d, then L = Y D^-1 into the L arena and Y = L D into the second arena (:92-113)
+//   2 LU    L side: X = A U_d^-1              (T = U_d read transposed from the factored blok)
+//   3 LU    U side: X = A' (L_d^T)^-1, unit   (in / out in the U arena, the second set of tile inverses)
+template <int MODE, bool COH>
+__device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __restrict__ U, const TrsmTask& tk,
+                                            const double* __restrict__ dinv_ws, const int tid) {
   constexpr int NT = 8;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -441,10 +446,11 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
   const int rloc = wave * 16 + l15;
   if (wave * 16 >= tk.nrows) return;
   const bool rvalid = rloc < tk.nrows;
-  double* Ap = L + tk.off + tk.row0 + rloc;          // panel row of this lane
-  const double* Apc = L + tk.off + tk.row0 + min(rloc, tk.nrows - 1);   // clamped: always readable
-  const double* Ld = L + tk.off;                     // diagonal blok (factored)
-  const double* Ti = dinv_ws + tk.dinv_off;
+  double* X = (MODE == 3 ? U : L) + tk.off + tk.row0;
+  double* Ap = X + rloc;                             // panel row of this lane
+  const double* Apc = X + min(rloc, tk.nrows - 1);   // clamped: always readable
+  const double* Ld = L + tk.off;                     // diagonal blok (factored; always in the L arena)
+  const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)((w + 15) >> 4) * 256 : 0);
   static_for<NT>([&](auto CT) {
     constexpr int ct = decltype(CT)::value;
     double v[4];
@@ -459,7 +465,7 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
     if (ct & 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' loads in flight at a time: the registers are few)
   });
   // 36 steps in order: for ct = 0..7 the products with the finished tiles p < ct, then the tile's own step with Tinv[ct].
-  // Every step multiplies four operand entries per lane read from memory (L[ct, p] or Tinv[ct]): the loads of step i + 1
+  // Every step multiplies four operand entries per lane read from memory (T[ct, p] or Tinv[ct]): the loads of step i + 1
   // are issued in front of the MFMAs of step i (two operand sets live; the scheduling barrier per step keeps the compiler
   // from hoisting more and spilling).
   constexpr int NSTEP = NT * (NT + 1) / 2;
@@ -476,7 +482,8 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
       const int li = ct * 16 + l15, lic = min(li, ws - 1);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const double lv = Ld[lic + (int64_t)min(p * 16 + g + 4 * q, ws - 1) * lds];
+        const int lc = min(p * 16 + g + 4 * q, ws - 1);
+        const double lv = (MODE == 2) ? Ld[lc + (int64_t)lic * lds] : Ld[lic + (int64_t)lc * lds];
         o[q] = (li < ws) ? -lv : 0.0;
       }
     } else {
@@ -515,10 +522,22 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
     constexpr int ct = decltype(CT)::value;
     int lds = ld, gs = (tid & 63) >> 4;
     asm volatile("" : "+s"(lds), "+v"(gs));
-    if (rvalid && ct * 16 + gs + 0 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 0) * lds], acc_read<ct, 0>());
-    if (rvalid && ct * 16 + gs + 4 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 4) * lds], acc_read<ct, 1>());
-    if (rvalid && ct * 16 + gs + 8 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 8) * lds], acc_read<ct, 2>());
-    if (rvalid && ct * 16 + gs + 12 < w) pst<COH>(&Ap[(int64_t)(ct * 16 + gs + 12) * lds], acc_read<ct, 3>());
+    auto put = [&](auto QQ) {
+      constexpr int q = decltype(QQ)::value;
+      const int col = ct * 16 + gs + 4 * q;
+      if constexpr (MODE == 1) {
+        const double dv = Ld[(int64_t)min(col, w - 1) * (int64_t)(lds + 1)];
+        if (rvalid && col < w) {
+          const double y = acc_read<ct, q>();
+          pst<COH>(&(U + tk.off + tk.row0 + rloc)[(int64_t)col * lds], y);           // L*D (compute_trsm.c:108-109)
+          pst<COH>(&Ap[(int64_t)col * lds], y * fast_rcp(dv));                       // L   (:110)
+        }
+      } else {
+        if (rvalid && col < w) pst<COH>(&Ap[(int64_t)col * lds], acc_read<ct, q>());
+      }
+    };
+    put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
+    put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{});
   });
 }
 
@@ -531,6 +550,8 @@ __device__ __forceinline__ void trsm_llt_parked(double* __restrict__ L, const Tr
 // tickets are ever held, so the launch needs no assumption about the order in which the hardware starts workgroups and
 // cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
 // the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
+// FT: 0 LLt, 1 LDLt, 2 LU (which panel solve a panel-solve ticket runs)
+template <int FT>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
                                                                const RunInfo* __restrict__ info,
@@ -566,7 +587,14 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       // a panel-solve ticket (the Task record holds a TrsmTask): 128 panel rows, a wave per 16
       TrsmTask tt;
       __builtin_memcpy(&tt, &tk, sizeof(tt));
-      trsm_llt_parked<true>(ar.p[0], tt, dinv, tid);
+      if constexpr (FT == 0) trsm_parked<0, true>(ar.p[0], ar.p[1], tt, dinv, tid);
+      else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid);
+      else {
+        trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
+        int tid2 = threadIdx.x;                    // (laundered again: the two solves must not share hoisted index arithmetic)
+        asm volatile("" : "+v"(tid2));
+        trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2);
+      }
       run_drain();
       __syncthreads();
       if (wave == 0) {
@@ -609,11 +637,13 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   }
 }
 
-void launch_run_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
+void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
                        const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit) {
   if (ntasks <= 0) return;
-  hipLaunchKernelGGL(k_run_update, dim3((unsigned)std::min<int64_t>(ntasks, std::max(nwg, 1))), dim3(64 * UW), 0, s, ar, tasks, pieces,
-                     info, cons, rc, dinv, limit);
+  const dim3 g((unsigned)std::min<int64_t>(ntasks, std::max(nwg, 1))), b(64 * UW);
+  if (factotype == PASTIX_AMD_FACT_LLT) hipLaunchKernelGGL(k_run_update<0>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+  else if (factotype == PASTIX_AMD_FACT_LDLT) hipLaunchKernelGGL(k_run_update<1>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+  else hipLaunchKernelGGL(k_run_update<2>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
 }
 
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,

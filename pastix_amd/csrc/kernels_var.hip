@@ -13,6 +13,7 @@
 
 #include "plan.h"
 #include "devmath.h"
+#include "run_sync.h"
 
 namespace pastix_amd {
 
@@ -20,7 +21,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 // forward substitution for the inverse of a 16x16 lower-triangular tile held in LDS (identity padding
 // beyond nb); thread c computes column c.  lower(i,p) is read through the functor.
-template <class F>
+template <bool COH = false, class F>
 __device__ __forceinline__ void tile_inverse(F lower, bool unit, int nb, int c, double (*Ti)[17], double* dst) {
   for (int i = 0; i < 16; i++) {
     double x;
@@ -33,31 +34,34 @@ __device__ __forceinline__ void tile_inverse(F lower, bool unit, int nb, int c, 
     }
     Ti[i][c] = x;
   }
-  for (int i = 0; i < 16; i++) dst[i + 16 * c] = Ti[i][c];
+  for (int i = 0; i < 16; i++) pst<COH>(&dst[i + 16 * c], Ti[i][c]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // LU diagonal blok (full w x w square in the L arena; transposed copy into the U arena at the end)
 // workspace: [nbk blocks: inverse of (U tile)^T, lower non-unit][nbk blocks: inverse of the unit L tile]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double* __restrict__ U,
-                                                 const PanelTask* __restrict__ tasks, double* __restrict__ dinv_ws,
-                                                 double critere, long long* __restrict__ nbpivot) {
-  PANEL_PRIO();
-  __shared__ double Ts[16][17];
-  __shared__ double Lo[16][17];    // tile after getrf: unit L strictly below, U on and above the diagonal
-  __shared__ double Ti[16][17];
-  __shared__ double Xs[16][244];   // L rows below the tile   Xs[p][r] = L[r][p]
-  __shared__ double Ys[16][244];   // U columns right of tile Ys[p][c] = U[p][c]
-  const PanelTask tk = tasks[blockIdx.x];
+struct DiagLuLds {
+  double Ts[16][17];
+  double Lo[16][17];    // tile after getrf: unit L strictly below, U on and above the diagonal
+  double Ti[16][17];
+  double Xs[16][244];   // L rows below the tile   Xs[p][r] = L[r][p]
+  double Ys[16][244];   // U columns right of tile Ys[p][c] = U[p][c]
+};
+// (256 threads; COH: every store of the blok is write-through -- the run launch hands it to other workgroups)
+template <bool COH>
+__device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ L, double* __restrict__ U, const PanelTask& tk,
+                                             double* __restrict__ dinv_ws, const double critere,
+                                             long long* __restrict__ nbpivot, const int tid) {
+  auto& Ts = S.Ts; auto& Lo = S.Lo; auto& Ti = S.Ti; auto& Xs = S.Xs; auto& Ys = S.Ys;
   double* A = L + tk.off;
   const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x, ti = tid & 15, tc = tid >> 4;
+  const int ti = tid & 15, tc = tid >> 4;
   const int nbk = (w + 15) >> 4;
   int npiv = 0;
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
-    if (ti < nb && tc < nb) Ts[ti][tc] = A[(kb + ti) + (int64_t)(kb + tc) * ld];
+    if (ti < nb && tc < nb) Ts[ti][tc] = pld<COH>(&A[(kb + ti) + (int64_t)(kb + tc) * ld]);
     for (int j = 0; j < nb; j++) {                       // PASTIX_getrf, compute_diag.c:432-469
       __syncthreads();
       double d = Ts[j][j];
@@ -70,10 +74,10 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
       }
     }
     __syncthreads();
-    if (ti < nb && tc < nb) A[(kb + ti) + (int64_t)(kb + tc) * ld] = Lo[ti][tc];
+    if (ti < nb && tc < nb) pst<COH>(&A[(kb + ti) + (int64_t)(kb + tc) * ld], Lo[ti][tc]);
     if (tid < 16) {
       // inverse of (U tile)^T : lower, non-unit, element (i,p) = U[p][i]
-      tile_inverse([&](int i, int p) { return Lo[p][i]; }, false, nb, tid, Ti,
+      tile_inverse<COH>([&](int i, int p) { return Lo[p][i]; }, false, nb, tid, Ti,
                    dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256);
     } else if (tid - 16 < rem) {
       // rows below: X = A U_T^-1  (TRSM inside getrf_block's panel, compute_diag.c:496-499 via getrf on m rows)
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
       double* ap = A + (kb + nb + rr) + (int64_t)kb * ld;
       double x[16];
 #pragma unroll
-      for (int c = 0; c < 16; c++) x[c] = ap[(int64_t)min(c, nb - 1) * ld];
+      for (int c = 0; c < 16; c++) x[c] = pld<COH>(&ap[(int64_t)min(c, nb - 1) * ld]);
 #pragma unroll
       for (int c = 0; c < 16; c++) {
         if (c < nb) {
@@ -95,13 +99,13 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
 #pragma unroll
       for (int c = 0; c < 16; c++) {
         Xs[c][rr] = (c < nb) ? x[c] : 0.0;
-        if (c < nb) ap[(int64_t)c * ld] = x[c];
+        if (c < nb) pst<COH>(&ap[(int64_t)c * ld], x[c]);
       }
     }
     __syncthreads();
     if (tid < 16) {
       // inverse of the unit-lower L tile
-      tile_inverse([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
+      tile_inverse<COH>([&](int i, int p) { return Lo[i][p]; }, true, nb, tid, Ti,
                    dinv_ws + tk.dinv_off + (int64_t)(nbk + (kb >> 4)) * 256);
     } else if (tid - 16 < rem) {
       // columns right of the tile: Y = L_T^-1 B  (TRSM "L","L","N","U", compute_diag.c:505-508)
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
       double* bp = A + kb + (int64_t)(kb + nb + cc) * ld;
       double y[16];
 #pragma unroll
-      for (int r = 0; r < 16; r++) y[r] = bp[min(r, nb - 1)];
+      for (int r = 0; r < 16; r++) y[r] = pld<COH>(&bp[min(r, nb - 1)]);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         if (r < nb) {
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         Ys[r][cc] = (r < nb) ? y[r] : 0.0;
-        if (r < nb) bp[r] = y[r];
+        if (r < nb) pst<COH>(&bp[r], y[r]);
       }
     }
     __syncthreads();
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
 #pragma unroll
           for (int a = 0; a < 4; a++) {
             const int r = 4 * tr + a, cc = 4 * tcc + b;
-            if (r < rem && cc < rem) Cb[r + (int64_t)cc * ld] -= c[a][b];
+            if (r < rem && cc < rem) pst<COH>(&Cb[r + (int64_t)cc * ld], pld<COH>(&Cb[r + (int64_t)cc * ld]) - c[a][b]);
           }
       }
     }
@@ -164,10 +168,62 @@ __global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double*
   double* Ud = U + tk.off;
   for (int id = tid; id < w * w; id += 256) {
     const int a = id % w, b = id / w;
-    Ud[b + (int64_t)a * ld] = A[a + (int64_t)b * ld];
+    pst<COH>(&Ud[b + (int64_t)a * ld], pld<COH>(&A[a + (int64_t)b * ld]));
   }
   if (tid == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
 }
+__global__ __launch_bounds__(256) void k_diag_lu(double* __restrict__ L, double* __restrict__ U,
+                                                 const PanelTask* __restrict__ tasks, double* __restrict__ dinv_ws,
+                                                 double critere, long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
+  __shared__ DiagLuLds S;
+  const PanelTask tk = tasks[blockIdx.x];
+  diag_lu_body<false>(S, L, U, tk, dinv_ws, critere, nbpivot, threadIdx.x);
+}
+// the run's diagonal kernel for LU (see k_run_diag, kernels.hip): resident workgroups popping ready diagonal tasks
+__global__ __launch_bounds__(256) void k_run_diag_lu(double* __restrict__ L, double* __restrict__ U, const RunD* __restrict__ rd,
+                                                     const RunInfo* __restrict__ info, double* __restrict__ dinv_ws,
+                                                     const double critere, long long* __restrict__ nbpivot, const RunCtl rc,
+                                                     int* __restrict__ resident, const long long limit) {
+  PANEL_PRIO();
+  __shared__ DiagLuLds S;
+  __shared__ int s_task;
+  const int tid = threadIdx.x;
+  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  (void)limit;
+  for (;;) {
+    if (tid == 0) {
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 0);
+      s_task = v;
+      if (v >= 0) run_acquire();
+    }
+    __syncthreads();
+    const int di = s_task;
+    if (di < 0) break;
+    const RunD d = rd[di];
+    long long tp = 0;
+    if (rc.prof && tid == 0) tp = wall_clock64();
+    int ltid = threadIdx.x;
+    asm volatile("" : "+v"(ltid));
+    diag_lu_body<true>(S, L, U, d.pt, dinv_ws, critere, nbpivot, ltid);
+    run_drain();
+    __syncthreads();
+    if (tid < 64) {
+      for (int i = tid; i < d.tn; i += 64) run_dec_ticket(rc, info, d.t0 + i);
+      if (rc.prof && tid == 0) {
+        long long* pr = rc.prof + 4 * ((int64_t)rc.nticket + di);
+        pr[0] = tp; pr[1] = tp; pr[2] = wall_clock64();
+      }
+    }
+    __syncthreads();
+  }
+}
+void launch_run_diag_lu(hipStream_t sd, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                        double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit) {
+  hipLaunchKernelGGL(k_run_diag_lu, dim3((unsigned)gd), dim3(256), 0, sd, ar.p[0], ar.p[1], rd, info, dinv, critere, nbpivot, rc,
+                     resident, limit);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // generalized panel solve  X^T[ct] = Tinv[ct] (A^T[ct] - sum_{p<ct} T[ct,p] X^T[p])   (see k_trsm_llt)

@@ -257,7 +257,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // Where the run schedule is built (below) launches have no tails to balance, and what a task costs besides its chunks
   // weighs more than parallelism: longer tasks from 4e12 flop (MI355X, run schedule: 100^3 1024 -> 133.4 ms, 2048 -> 131.9;
   // 130^3 548.6 -> 533.9; 160^3 1815 -> 1774; 80^3 43.8 -> 45.4: stays 1024; 60^3 512 -> 14.56, 1024 -> 14.38).
-  const bool run_built = !owner && floattype == PASTIX_AMD_REALDOUBLE && factotype == PASTIX_AMD_FACT_LLT && P.opts.run_schedule >= 0;
+  const bool run_built = !owner && floattype == PASTIX_AMD_REALDOUBLE && P.opts.run_schedule >= 0 &&
+                         (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LU);
   if (P.opts.lookahead <= 0)
     P.opts.lookahead = run_built ? (fl_total > 4e12 ? 2048 : 1024) : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
@@ -313,11 +314,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }
 
   // ---- the run: the longest suffix of levels with at most run_max_cblks cblks each (plan.h, RunInfo) -----------------
-  // Built for one GPU, real double LLt (v1).  The plan carries BOTH schedules: the level-by-level launches work on
+  // Built for one GPU, real double (LLt, LDLt, LU).  The plan carries BOTH schedules: the level-by-level launches work on
   // the same tables, which of the two runs is decided per factorization (api.cpp).
   P.run_L0 = -1;
   {
-    const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE && factotype == PASTIX_AMD_FACT_LLT;
+    const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE &&
+                       (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LU);
     if (built && P.opts.run_schedule >= 0) {
       const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
       int L0 = NL;
@@ -988,7 +990,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     // A(s) behind B(s-1).next (same tiles, older sources) and B(s) behind T(s-1) (it reads level s-1): a topological order,
     // in which the counters and consumer lists are built; at run time the order of execution is the order of readiness.
     P.ntile = ntile;
-    P.nplanes = (lu ? 2 : 1) * (cplx ? 2 : 1);
+    P.nplanes = cplx ? 4 : (lu ? 2 : 1);          // target planes are indexed by arena number: L, U (LU), their imaginary parts
     if (P.run_L0 >= 0 && (int64_t)ntile * P.nplanes > 0x7fffffffLL) P.run_L0 = -1;
     if (P.run_L0 >= 0) {
       const int L0 = P.run_L0;
@@ -1118,10 +1120,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           if (d.tn == 0) d.t0 = (int32_t)i;
           if (d.t0 + d.tn != (int32_t)i) { bad = true; break; }       // (the tickets of a cblk are consecutive)
           d.tn++;
-          if (tt.tile != dtile0[(size_t)tt.dtask] && last[(size_t)tt.tile] >= 0) {
-            P.run_info[(size_t)last[(size_t)tt.tile]].succ = (int32_t)i;
-            P.run_dep[i]++;
-          }
+          if (tt.tile != dtile0[(size_t)tt.dtask])
+            for (int pl = 0; pl < P.nplanes; pl++) {
+              const int32_t lu2 = last[(size_t)tt.tile + (size_t)pl * (size_t)ntile];
+              if (lu2 >= 0) { P.run_info[(size_t)lu2].succ = (int32_t)i; P.run_dep[i]++; }
+            }
           tile_ticket[(size_t)tt.tile] = (int32_t)i;
         }
       }
@@ -1137,9 +1140,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         // a diagonal task waits for the last update of the diagonal tile
         P.run_dchk.resize(nd);
         for (size_t d = 0; d < nd; d++) {
-          const int32_t l0 = last[(size_t)dtile0[d]];
-          if (l0 >= 0) { P.run_info[(size_t)l0].succ = -2 - (int32_t)d; P.run_dep[nr + d] = 1; }
-          P.run_dchk[d] = {dtile0[d], tcount[(size_t)dtile0[d]]};
+          for (int pl = 0; pl < P.nplanes; pl++) {       // (every plane of the diagonal tile that the run updates)
+            const int32_t l0 = last[(size_t)dtile0[d] + (size_t)pl * (size_t)ntile];
+            if (l0 >= 0) { P.run_info[(size_t)l0].succ = -2 - (int32_t)d; P.run_dep[nr + d]++; }
+          }
+          P.run_dchk[d] = {dtile0[d], 0};
         }
         // source tiles an update ticket reads: the 128-row tiles of the source panels of its pieces (A rows, B rows),
         // sources of the run's levels only -- older panels are final when the run starts
@@ -1299,7 +1304,19 @@ int64_t run_verify(const Plan& P) {
   const size_t nr = P.run_tasks.size(), nd = P.run_d.size();
   if (P.run_info.size() != nr || P.run_chk.size() != nr || P.run_dep.size() != nr + nd) return -1;
   std::vector<int32_t> cnt(P.run_dep);
+  if (P.ntile <= 0) return -1;
   std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl(std::max<size_t>(nd, 1), 0);
+  std::vector<int32_t> total(seq.size(), 0);           // update tickets of the run per tile counter
+  for (size_t i = 0; i < nr; i++)
+    if (!(P.run_info[i].kind & 4)) {
+      if (P.run_chk[i].tile < 0 || (size_t)P.run_chk[i].tile >= total.size()) return -1;
+      total[(size_t)P.run_chk[i].tile]++;
+    }
+  auto tile_complete = [&](int32_t tile) {
+    for (int pl = 0; pl < P.nplanes; pl++)
+      if (seq[(size_t)tile + (size_t)pl * (size_t)P.ntile] != total[(size_t)tile + (size_t)pl * (size_t)P.ntile]) return false;
+    return true;
+  };
   std::vector<int32_t> q(P.run_ready), qd(P.run_dready);
   size_t head = 0, hd = 0, done = 0, doned = 0;
   auto dec_ticket = [&](int32_t c) {
@@ -1311,7 +1328,7 @@ int64_t run_verify(const Plan& P) {
     while (hd < qd.size()) {                         // diagonal tasks first (resident workers)
       const int32_t d = qd[hd++];
       if (d < 0 || (size_t)d >= nd || dfl[(size_t)d] || P.run_dchk.size() != nd) return -1;
-      if (seq[(size_t)P.run_dchk[(size_t)d].first] != P.run_dchk[(size_t)d].second) return -3 - (int64_t)d;
+      if (!tile_complete(P.run_dchk[(size_t)d].first)) return -3 - (int64_t)d;
       dfl[(size_t)d] = 1;
       doned++;
       const RunD& rd = P.run_d[(size_t)d];
@@ -1324,14 +1341,14 @@ int64_t run_verify(const Plan& P) {
     done++;
     if (ri.kind & 4) {
       if (ck.tile < 0 || (size_t)ck.tile >= fin.size() || ck.wptr < 0 || (size_t)ck.wptr >= nd) return -1;
-      if (!dfl[(size_t)ck.wptr] || seq[(size_t)ck.tile] != ck.seq || fin[(size_t)ck.tile]) return (int64_t)i + 1;
+      if (!dfl[(size_t)ck.wptr] || !tile_complete(ck.tile) || fin[(size_t)ck.tile]) return (int64_t)i + 1;
       fin[(size_t)ck.tile] = 1;
       if (ri.cptr < 0 || (size_t)ri.cptr + (size_t)ri.cn > P.run_cons.size()) return -1;
       for (int z = 0; z < ri.cn; z++) if (!dec_ticket(P.run_cons[(size_t)ri.cptr + (size_t)z])) return -1;
     } else {
       if (ck.tile < 0 || (size_t)ck.tile >= seq.size() || ck.wptr < 0 || (size_t)ck.wptr + (size_t)ck.wn > P.run_waits.size()) return -1;
       if (seq[(size_t)ck.tile] != ck.seq) return (int64_t)i + 1;
-      if ((size_t)ck.tile < fin.size() && fin[(size_t)ck.tile]) return (int64_t)i + 1;     // (written after it was solved)
+      if (fin[(size_t)ck.tile % (size_t)P.ntile]) return (int64_t)i + 1;                   // (written after it was solved)
       for (int z = 0; z < ck.wn; z++) {
         const int32_t f = P.run_waits[(size_t)ck.wptr + (size_t)z];
         if (f < 0 || (size_t)f >= fin.size()) return -1;

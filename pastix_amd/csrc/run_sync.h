@@ -79,4 +79,12 @@ __device__ __forceinline__ void pst(double* p, const double v) {
   else *p = v;
 }
 
+// a load that must see what another wave of this workgroup has stored write-through since (bodies that re-read their own
+// stores from memory: the write-through store does not refresh the CU's vector L1)
+template <bool COH>
+__device__ __forceinline__ double pld(const double* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
 }  // namespace pastix_amd

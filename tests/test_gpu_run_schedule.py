@@ -116,3 +116,70 @@ def test_solve_after_a_run_factorization(run_env):
         bp[s["perm"]] = b
         x = p.solve(bp)[s["perm"]]
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
+
+
+def _lower_mask(c4):
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    parts = []
+    for k in range(len(w)):
+        wk, sk = int(w[k]), int(c4[k, 3])
+        m = np.ones((wk, sk), dtype=bool)
+        m[:, :wk] = np.triu(np.ones((wk, wk), dtype=bool))
+        parts.append(m.ravel())
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("maxc", [0, 100000])
+@pytest.mark.parametrize("name", golden_names("ldlt") + golden_names("lu"))
+def test_run_ldlt_lu_match_reference_golden_and_the_level_schedule(name, maxc, golden, run_env):
+    """LDLt (panel solve with the scaling by D and the L D copy in the second arena) and LU (two planes of update tasks,
+    two solves per panel-solve ticket, the first-generation diagonal kernel as the resident worker) through the run."""
+    g = golden(name)
+    lu = g["facto"] == 2
+    with Plan(g["cblk4"], g["blok4"], g["facto"], run_schedule=1, run_max_cblks=maxc) as p:
+        out = {}
+        for mode in ("0", "1"):
+            run_env["PASTIX_AMD_RUN"] = mode
+            p.upload(g["L0"], g["U0"] if lu else None)
+            st = p.factorize(g["critere"])
+            out[mode] = (p.download(), st)
+    (L1, U1), st = out["1"]
+    m = np.ones(L1.size, bool) if lu else _lower_mask(g["cblk4"])
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    if lu:
+        assert np.abs(U1 - g["U1"]).max() <= TOL * max(scale, np.abs(g["U1"]).max())
+    assert st["nbpivot"] == g["nbpivot"] == out["0"][1]["nbpivot"]
+    assert st["inertia"] == out["0"][1]["inertia"]
+    assert np.array_equal(L1[m], out["0"][0][0][m])
+    if lu:
+        assert np.array_equal(U1, out["0"][0][1])
+
+
+@pytest.mark.parametrize("facto", [1, 2])
+def test_run_ldlt_lu_bitwise_on_a_produced_layout(facto, run_env):
+    N = 30
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    c4, b4 = s["cblk4"], s["blok4"]
+    if facto == 2:
+        import scipy.sparse as sp
+        A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+        Af = (A + sp.tril(A, -1).T).tocsc()
+        Af = (Af + sp.triu(Af, 1).multiply(0.2)).tocsc()
+        Af.sort_indices()
+        cp, r, v = Af.indptr.astype(np.int64) + 1, Af.indices.astype(np.int64) + 1, Af.data.copy()
+    with Plan(c4, b4, facto) as p:
+        out = {}
+        for mode in ("0", "1"):
+            run_env["PASTIX_AMD_RUN"] = mode
+            p.fill_csc(0 if facto == 2 else 1, n, cp, r, v, s["perm"])
+            st = p.factorize(1e-14)
+            out[mode] = (p.download(), st)
+    assert out["1"][1]["run_tickets"] > 0 and out["0"][1]["run_tickets"] == 0
+    m = np.ones(out["1"][0][0].size, bool) if facto == 2 else _lower_mask(c4)
+    assert np.array_equal(out["0"][0][0][m], out["1"][0][0][m])
+    if facto == 2:
+        assert np.array_equal(out["0"][0][1], out["1"][0][1])
+

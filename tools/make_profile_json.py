@@ -14,7 +14,7 @@ pdir = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(pdir, exist_ok=True)
 tpath = os.path.join(pdir, "traffic_k_update.json")
 d = json.load(open(tpath)) if os.path.exists(tpath) else {}
-d["_doc"] = ("HBM-side traffic of the bulk update launches (k_update<0> + k_update_small<0>) from rocprofv3 --pmc FETCH_SIZE / "
+d["_doc"] = ("HBM-side traffic of the bulk update kernels (k_run_update + k_update<0> + k_update_small<0>) from rocprofv3 --pmc FETCH_SIZE / "
              "WRITE_SIZE (separate passes, no other tracing, one factorization each: tools/profile_round.sh -> bench.py "
              "--steps 1 --warmup 0).  Counters are KiB summed over all launches.  bytes_per_factorization = (2*FETCH_SIZE + "
              "WRITE_SIZE)*1024: FETCH_SIZE is doubled (gfx950 reports half of coalesced reads; calibrated on an 8-B/lane "
@@ -36,8 +36,7 @@ for tag in sys.argv[2:]:
     kt = 0.0
     with open(os.path.join(src, "kernel_stats.csv"), newline="") as fh:
         for row in csv.DictReader(fh):
-            if row["Name"].startswith(("void pastix_amd::k_update<0>", "void pastix_amd::k_update_small<0>")) or \
-               "k_update<0>" in row["Name"] or "k_update_small<0>" in row["Name"]:
+            if "k_update<0>" in row["Name"] or "k_update_small<0>" in row["Name"] or "k_run_update" in row["Name"]:
                 kt += float(row["TotalDurationNs"]) * 1e-9
     out["kernel_time_s"] = kt
     if f and w:

@@ -14,8 +14,10 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# the bulk launches: k_update<0> and, where a slot has quadrant tasks, k_update_small<0> right behind it
-KERNELS="k_update<0>,k_update_small<0>"
+# the bulk update kernels: the run launch (k_run_update: the thin levels in one dependency-driven launch, where the run
+# schedule is built) and the per-level launches below it, k_update<0> and -- where a slot has quadrant tasks --
+# k_update_small<0> right behind it
+KERNELS="k_run_update,k_update<0>,k_update_small<0>"
 ARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --grid $G $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
