@@ -83,8 +83,9 @@ typedef struct pastix_amd_options_s {
                             chunks k_update would run for them; <= 0 = default (25) */
   int run_schedule;      /* the thin levels at the top of the elimination tree (at most run_max_cblks cblks each) as ONE
                             dependency-driven launch -- tasks gated by tile counters, the way the reference's tasks wait
-                            for TASK_CTRBCNT (sopalin3d.c:790-1025) -- instead of launches per level: 0 = default (on
-                            where it is built: real double, one GPU), 1 = on, -1 = off (the level-by-level schedule) */
+                            for TASK_CTRBCNT (sopalin3d.c:790-1025) -- instead of launches per level: 0 = default (on for
+                            real double LLt / LDLt on one GPU), 1 = on wherever it is built (also real double LU), -1 = off
+                            (the level-by-level schedule) */
   int run_max_cblks;     /* <= 0 = default (32) */
   int run_t_workers;     /* resident workgroups of the run's panel kernel that solve panel rows; <= 0 = default (48) */
   int run_d_workers;     /* ... that factorize diagonal bloks (a level's cblks are dealt round-robin); <= 0 = default (8) */

@@ -258,7 +258,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // weighs more than parallelism: longer tasks from 4e12 flop (MI355X, run schedule: 100^3 1024 -> 133.4 ms, 2048 -> 131.9;
   // 130^3 548.6 -> 533.9; 160^3 1815 -> 1774; 80^3 43.8 -> 45.4: stays 1024; 60^3 512 -> 14.56, 1024 -> 14.38).
   const bool run_built = !owner && floattype == PASTIX_AMD_REALDOUBLE && P.opts.run_schedule >= 0 &&
-                         (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LU);
+                         (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
+                          (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
   if (P.opts.lookahead <= 0)
     P.opts.lookahead = run_built ? (fl_total > 4e12 ? 2048 : 1024) : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
@@ -318,8 +319,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // the same tables, which of the two runs is decided per factorization (api.cpp).
   P.run_L0 = -1;
   {
+    // (LU: built, but on request only -- run_schedule = 1: its diagonal kernel is the first-generation one, 2-3 times the
+    // time of the LLt / LDLt ones per blok, and as the resident worker it is what the whole run waits for: 60^3 -14 %,
+    // 100^3 / 130^3 +-1 %)
     const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE &&
-                       (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LU);
+                       (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
+                        (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
     if (built && P.opts.run_schedule >= 0) {
       const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
       int L0 = NL;

@@ -170,7 +170,7 @@ def test_run_ldlt_lu_bitwise_on_a_produced_layout(facto, run_env):
         Af = (Af + sp.triu(Af, 1).multiply(0.2)).tocsc()
         Af.sort_indices()
         cp, r, v = Af.indptr.astype(np.int64) + 1, Af.indices.astype(np.int64) + 1, Af.data.copy()
-    with Plan(c4, b4, facto) as p:
+    with Plan(c4, b4, facto, run_schedule=1) as p:
         out = {}
         for mode in ("0", "1"):
             run_env["PASTIX_AMD_RUN"] = mode

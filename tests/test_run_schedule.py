@@ -56,8 +56,9 @@ def test_run_can_be_switched_off_and_covers_the_real_factorizations():
     assert run_info(c4, b4, 0, run_schedule=-1)["L0"] == -1
     llt = run_info(c4, b4, 0)
     assert llt["L0"] >= 0
+    assert run_info(c4, b4, 2)["L0"] == -1     # LU: on request only
     for facto in (1, 2):                       # LDLt: the same tickets; LU: a second plane of update tasks
-        ri = run_info(c4, b4, facto)
+        ri = run_info(c4, b4, facto, run_schedule=1)
         assert ri["L0"] == llt["L0"] and ri["verify"] == 0 and ri["solves"] == llt["solves"]
         assert ri["tickets"] == llt["tickets"] if facto == 1 else ri["tickets"] > llt["tickets"]
 
@@ -67,7 +68,7 @@ def test_replay_on_the_reference_layouts_ldlt_lu(name, golden):
     g = golden(name)
     if (g["cblk4"][:-1, 1] - g["cblk4"][:-1, 0] + 1).max() > 256:
         pytest.skip("cblks wider than 256 columns reach the planner re-cut (api.cpp build_split): covered on the GPU")
-    for kw in ({}, {"run_max_cblks": 1000, "run_d_workers": 2}):
+    for kw in ({"run_schedule": 1}, {"run_schedule": 1, "run_max_cblks": 1000, "run_d_workers": 2}):
         r = run_info(g["cblk4"], g["blok4"], g["facto"], **kw)
         assert r["verify"] == 0, (name, kw, r)
 
