@@ -261,7 +261,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
                          (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
                           (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
   if (P.opts.lookahead <= 0)
-    P.opts.lookahead = run_built ? (fl_total > 4e12 ? 2048 : 1024) : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
+    P.opts.lookahead = (run_built && (P.opts.run_schedule == 1 || fl_total <= 2e14)) ? (fl_total > 4e12 ? 2048 : 1024)
+                                                                                     : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
   const int max_pieces = P.opts.lookahead >= 4096 ? 32 : P.opts.lookahead >= 2048 ? 16 : 8;
   const int64_t nc = L->cblknbr;
@@ -325,7 +326,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE &&
                        (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
                         (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
-    if (built && P.opts.run_schedule >= 0) {
+    // Above 2e14 flop (200^3: 4.1e14) the run is on request only: launches of tens of rounds of workgroups have little to
+    // gain (200^3: +0.6 %) and the run's tables cost there (366 M dependency edges: 1.8 s of analysis, 3 GB).
+    if (built && P.opts.run_schedule >= 0 && (P.opts.run_schedule == 1 || fl_total <= 2e14)) {
       const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
       int L0 = NL;
       auto narrow = [&](int l) {       // (the run's panel kernel takes cblks of at most 128 columns, like k_diag_llt_w)
