@@ -242,7 +242,7 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, co
  * launch) and its replay check.  info[0..7] = first level of the run (-1: none), levels, update tasks in the run, source-tile
  * waits, resident workgroups for diagonal bloks, panel-solve tasks, update flops inside the run, result of the replay (0 =
  * every task can run when the tickets are served one at a time in order: the schedule cannot deadlock) */
-int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
+int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, int floattype, const pastix_amd_options_t *opts,
                              pastix_amd_int_t *info);
 /* host-only: the multi-GPU driver's partition -- owner[k] = the rank (GPU) that factorizes cblk k, for `world` <= 64 ranks.
  * Proportional mapping on the cblk elimination tree, blend's idea (splitpart.c:752-1012; GPU colouring

@@ -442,13 +442,13 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
 // Host-only (tests, capacity planning): the run schedule of a layout (plan.h RunInfo) and its replay check.
 // info[0..7] = first level of the run (-1: none), levels, update tasks in the run, source-tile waits, diagonal workers,
 // panel-solve tasks, update flops inside the run (rounded), result of run_verify (0 = every ticket can run).
-int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, const pastix_amd_options_t* opts,
+int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, int floattype, const pastix_amd_options_t* opts,
                              pastix_amd_int_t* info) {
   if (!layout || !info) return PASTIX_AMD_ERR_BADPARAMETER;
   Plan P;
   int rc;
   try {
-    rc = build_plan(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, nullptr, 0, P);
+    rc = build_plan(layout, factotype, floattype, opts, nullptr, 0, P);
     if (rc) return rc;
     info[0] = P.run_L0;
     info[1] = P.nlevels;

@@ -1428,10 +1428,14 @@ __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
 }
 void launch_run_diag_lu(hipStream_t sd, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                         double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit);   // kernels_var.hip
+void launch_run_diag_z(hipStream_t sd, bool herm, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                       double critere, long long* nbpivot, const RunCtl& rc, int* resident);                      // kernels_z.hip
 void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                       double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit) {
   if (gd <= 0) return;
-  if (factotype == PASTIX_AMD_FACT_LLT)
+  if (ar.p[2])                                     // complex double (split planes): LDLt / LDLh
+    launch_run_diag_z(sd, factotype == PASTIX_AMD_FACT_LDLH, ar, rd, info, gd, dinv, critere, nbpivot, rc, resident);
+  else if (factotype == PASTIX_AMD_FACT_LLT)
     hipLaunchKernelGGL(k_run_diag<0>, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag, rc,
                        resident, limit);
   else if (factotype == PASTIX_AMD_FACT_LDLT)

@@ -541,6 +541,141 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
   });
 }
 
+// ---- the complex panel solve as a ticket (z LDLt / LDLh; kernels_z.hip k_trsm_zsy's algorithm) ----------------------------------
+// Y = A L_d^-T (unit lower; HERM: L_d^-H) on split planes, then L = Y D^-1 into the L planes and Y = L D into the second
+// arena's planes (compute_trsm.c:92-113).  A wave's eight column tiles are 2 x 64 registers (re, im): tiles 0-3 rest in the
+// accumulation registers a[0:63] (re of tile p in slot 2p, im in 2p + 1), tiles 4-7 in LDS -- the update path's operand
+// buffers, idle in a panel-solve ticket: 16 KB per wave, room for FOUR waves, hence 64 rows per complex ticket (waves 4-7
+// of the workgroup sit it out).  A complex product is four real MFMAs.
+template <bool HERM, bool COH>
+__device__ __forceinline__ void trsm_zsy_parked(const Arenas& ar, double* __restrict__ lds, const TrsmTask& tk,
+                                                const double* __restrict__ dinv_ws, const int tid) {
+  constexpr int NT = 8;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ld = tk.stride, w = tk.width;
+  const int rloc = wave * 16 + l15;
+  if (wave >= 4 || wave * 16 >= tk.nrows) return;
+  const bool rvalid = rloc < tk.nrows;
+  const int64_t xo = tk.off + tk.row0 + min(rloc, tk.nrows - 1);
+  const double* Tr = ar.p[0] + tk.off;
+  const double* Tim = ar.p[2] + tk.off;
+  const double* Ti = dinv_ws + tk.dinv_off;
+  double* lw = lds + wave * 2048 + lane;             // this lane's column of the wave's 16 KB: [tile - 4][plane][q][lane]
+  auto park = [&](auto CT, const d4_t& re, const d4_t& im, auto FRESH) {
+    constexpr int ct = decltype(CT)::value;
+    constexpr bool fresh = decltype(FRESH)::value;
+    if constexpr (ct < 4) {
+      acc_write<2 * ct, 0, fresh>(re[0]); acc_write<2 * ct, 1>(re[1]); acc_write<2 * ct, 2>(re[2]); acc_write<2 * ct, 3>(re[3]);
+      acc_write<2 * ct + 1, 0>(im[0]); acc_write<2 * ct + 1, 1>(im[1]); acc_write<2 * ct + 1, 2>(im[2]); acc_write<2 * ct + 1, 3>(im[3]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { lw[((ct - 4) * 2 + 0) * 256 + q * 64] = re[q]; lw[((ct - 4) * 2 + 1) * 256 + q * 64] = im[q]; }
+    }
+  };
+  auto fetch = [&](auto PP, auto QQ, double& re, double& im) {
+    constexpr int p = decltype(PP)::value, q = decltype(QQ)::value;
+    if constexpr (p < 4) { re = acc_read_m<2 * p, q>(); im = acc_read_m<2 * p + 1, q>(); }
+    else { re = lw[((p - 4) * 2 + 0) * 256 + q * 64]; im = lw[((p - 4) * 2 + 1) * 256 + q * 64]; }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  static_for<NT>([&](auto CT) {
+    constexpr int ct = decltype(CT)::value;
+    d4_t vr, vi;
+    int lds2 = ld;
+    asm volatile("" : "+s"(lds2));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = ct * 16 + g + 4 * q;
+      const int64_t o = xo + (int64_t)min(col, w - 1) * lds2;
+      const double a = ar.p[0][o], b = ar.p[2][o];
+      vr[q] = (rvalid && col < w) ? a : 0.0;
+      vi[q] = (rvalid && col < w) ? b : 0.0;
+    }
+    park(CT, vr, vi, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  static_for<NT>([&](auto CT) {
+    constexpr int ct = decltype(CT)::value;
+    d4_t yr, yi;
+    {
+      double r0, i0, r1, i1, r2, i2, r3, i3;
+      fetch(CT, I0{}, r0, i0); fetch(CT, I1{}, r1, i1); fetch(CT, I2{}, r2, i2); fetch(CT, I3{}, r3, i3);
+      yr = d4_t{r0, r1, r2, r3}; yi = d4_t{i0, i1, i2, i3};
+    }
+    static_for<ct>([&](auto PP) {
+      constexpr int p = decltype(PP)::value;
+      int lds2 = ld, ws = w;
+      asm volatile("" : "+s"(lds2), "+s"(ws));
+      const int li = ct * 16 + l15, lic = min(li, ws - 1);
+      double tr[4], tm[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int64_t o = lic + (int64_t)min(p * 16 + g + 4 * q, ws - 1) * lds2;
+        const double a = Tr[o], b = Tim[o];
+        tr[q] = (li < ws) ? a : 0.0;
+        tm[q] = (li < ws) ? (HERM ? -b : b) : 0.0;
+      }
+      auto prod = [&](auto QQ) {                     // y[ct] -= t * y[p]
+        constexpr int q = decltype(QQ)::value;
+        double pr, pi;
+        fetch(PP, QQ, pr, pi);
+        yr = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr[q], pr, yr, 0, 0, 0);
+        yr = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[q], pi, yr, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f64_16x16x4f64(-tr[q], pi, yi, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f64_16x16x4f64(-tm[q], pr, yi, 0, 0, 0);
+      };
+      prod(I0{}); prod(I1{}); prod(I2{}); prod(I3{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    d4_t nr = d4_t{0, 0, 0, 0}, ni = d4_t{0, 0, 0, 0};
+    {
+      int ws = w;
+      asm volatile("" : "+s"(ws));
+      const int cb = min(ct, ((ws + 15) >> 4) - 1);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double ar_ = Ti[cb * 512 + l15 + 16 * (g + 4 * q)];
+        const double ai0 = Ti[cb * 512 + 256 + l15 + 16 * (g + 4 * q)];
+        const double ai_ = HERM ? -ai0 : ai0;                  // (conj L)^-1 = conj(L^-1)
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yr[q], nr, 0, 0, 0);
+        nr = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai_, yi[q], nr, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ar_, yi[q], ni, 0, 0, 0);
+        ni = __builtin_amdgcn_mfma_f64_16x16x4f64(ai_, yr[q], ni, 0, 0, 0);
+      }
+    }
+    park(CT, nr, ni, std::true_type{});
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  const int64_t so = tk.off + tk.row0 + rloc;
+  static_for<NT>([&](auto CT) {
+    constexpr int ct = decltype(CT)::value;
+    int lds2 = ld, gs = (tid & 63) >> 4;
+    asm volatile("" : "+s"(lds2), "+v"(gs));
+    auto put = [&](auto QQ) {
+      constexpr int q = decltype(QQ)::value;
+      const int col = ct * 16 + gs + 4 * q;
+      const int64_t dd = (int64_t)min(col, w - 1) * (lds2 + 1);
+      const double dr = Tr[dd], di = Tim[dd];
+      // 1 / d as kernels_z.hip cinv (Smith)
+      double ir, ii;
+      if (fabs(dr) >= fabs(di)) { const double r = di / dr, dn = dr + di * r; ir = 1.0 / dn; ii = -r / dn; }
+      else { const double r = dr / di, dn = dr * r + di; ir = r / dn; ii = -1.0 / dn; }
+      double yre, yim;
+      fetch(CT, QQ, yre, yim);
+      if (rvalid && col < w) {
+        const int64_t o = so + (int64_t)col * lds2;
+        pst<COH>(&ar.p[1][o], yre);                 // L*D (compute_trsm.c:108-109)
+        pst<COH>(&ar.p[3][o], yim);
+        pst<COH>(&ar.p[0][o], yre * ir - yim * ii); // L   (:110)
+        pst<COH>(&ar.p[2][o], yre * ii + yim * ir);
+      }
+    };
+    put(I0{}); put(I1{}); put(I2{}); put(I3{});
+  });
+}
+
 // ---- the run launch ------------------------------------------------------------------------------
 // The update and panel-solve tasks of the thin levels at the top of the tree, all in ONE launch (plan.h RunInfo; the
 // reference's tasks wait for TASK_CTRBCNT == 0 and are queued by the last contributor the same way, sopalin3d.c:790-1025 /
@@ -550,7 +685,7 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
 // tickets are ever held, so the launch needs no assumption about the order in which the hardware starts workgroups and
 // cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
 // the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
-// FT: 0 LLt, 1 LDLt, 2 LU (which panel solve a panel-solve ticket runs)
+// FT: 0 LLt, 1 LDLt, 2 LU, 3 complex LDLt, 4 complex LDLh (which panel solve a panel-solve ticket runs)
 template <int FT>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
@@ -589,11 +724,13 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       __builtin_memcpy(&tt, &tk, sizeof(tt));
       if constexpr (FT == 0) trsm_parked<0, true>(ar.p[0], ar.p[1], tt, dinv, tid);
       else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid);
-      else {
+      else if constexpr (FT == 2) {
         trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
         int tid2 = threadIdx.x;                    // (laundered again: the two solves must not share hoisted index arithmetic)
         asm volatile("" : "+v"(tid2));
         trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2);
+      } else {
+        trsm_zsy_parked<FT == 4, true>(ar, &sh[0][0][0], tt, dinv, tid);
       }
       run_drain();
       __syncthreads();
@@ -629,7 +766,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     run_drain();
     __syncthreads();
     if (tid == 0) {
-      if (ri.succ >= 0) run_dec_ticket(rc, info, ri.succ);
+      if (ri.succ >= 0) { for (int z = 0; z < ri.cn; z++) run_dec_ticket(rc, info, ri.succ + z); }
       else if (ri.succ <= -2) run_dec_diag(rc, -2 - ri.succ);
       if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
     }
@@ -641,7 +778,10 @@ void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Tas
                        const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit) {
   if (ntasks <= 0) return;
   const dim3 g((unsigned)std::min<int64_t>(ntasks, std::max(nwg, 1))), b(64 * UW);
-  if (factotype == PASTIX_AMD_FACT_LLT) hipLaunchKernelGGL(k_run_update<0>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+  if (ar.p[2]) {                                   // complex double (split planes)
+    if (factotype == PASTIX_AMD_FACT_LDLH) hipLaunchKernelGGL(k_run_update<4>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+    else hipLaunchKernelGGL(k_run_update<3>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+  } else if (factotype == PASTIX_AMD_FACT_LLT) hipLaunchKernelGGL(k_run_update<0>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
   else if (factotype == PASTIX_AMD_FACT_LDLT) hipLaunchKernelGGL(k_run_update<1>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
   else hipLaunchKernelGGL(k_run_update<2>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
 }

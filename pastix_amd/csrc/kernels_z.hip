@@ -9,6 +9,7 @@
 
 #include "plan.h"
 #include "devmath.h"
+#include "run_sync.h"
 
 namespace pastix_amd {
 
@@ -633,22 +634,23 @@ __device__ __forceinline__ double zreadlane(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-template <bool HERM>
-__global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const PanelTask* __restrict__ tasks,
-                                                    double* __restrict__ dinv_ws, double critere,
-                                                    long long* __restrict__ nbpivot) {
-  PANEL_PRIO();
-  constexpr int XR = 116, NBLK = 5, NT = 448;      // 64*65/2 = 2080 blocks of 2x2 <= 5 * 448
-  __shared__ cz Ts[16][17];
-  __shared__ cz Lo[16][17];
-  __shared__ cz Li[16];
-  __shared__ cz Xs[16][XR];
-  __shared__ cz Ws[16][XR];
-  const PanelTask tk = tasks[blockIdx.x];
+struct DiagZLds {
+  static constexpr int XR = 116;
+  cz Ts[16][17];
+  cz Lo[16][17];
+  cz Li[16];
+  cz Xs[16][XR];
+  cz Ws[16][XR];
+};
+// (COH: results stored write-through -- the run launch hands the blok to other workgroups, run_sync.h)
+template <bool HERM, bool COH>
+__device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, const PanelTask& tk, double* __restrict__ dinv_ws,
+                                              const double critere, long long* __restrict__ nbpivot, const int tid) {
+  constexpr int XR = DiagZLds::XR, NBLK = 5, NT = 448;      // 64*65/2 = 2080 blocks of 2x2 <= 5 * 448
+  auto& Ts = S.Ts; auto& Lo = S.Lo; auto& Li = S.Li; auto& Xs = S.Xs; auto& Ws = S.Ws;
   double* Ar = ar.p[0] + tk.off;
   double* Ai = ar.p[2] + tk.off;
   const int ld = tk.stride, w = tk.width;
-  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nb2 = (w + 1) >> 1, nblk = nb2 * (nb2 + 1) / 2;
   if (wave == 0) {
@@ -689,8 +691,8 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
           if (c <= l15 && l15 < nb) {
             Lo[l15][c] = a[c];
             const int64_t o = (kb + l15) + (int64_t)(kb + c) * ld;
-            Ar[o] = a[c].re;
-            Ai[o] = a[c].im;
+            pst<COH>(&Ar[o], a[c].re);
+            pst<COH>(&Ai[o], a[c].im);
           }
         }
       }
@@ -712,8 +714,8 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
             x = sacc;
           }
           Ts[i][l15] = x;
-          dst[i + 16 * l15] = x.re;
-          dst[256 + i + 16 * l15] = x.im;
+          pst<COH>(&dst[i + 16 * l15], x.re);
+          pst<COH>(&dst[256 + i + 16 * l15], x.im);
         }
       }
       __syncthreads();                                   // (C) rows below solved
@@ -800,8 +802,8 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
             const cz sc = cmul(v, Li[cc]);
             Ws[cc][rr] = v;
             Xs[cc][rr] = sc;
-            Ar[o0 + (int64_t)cc * ld] = sc.re;
-            Ai[o0 + (int64_t)cc * ld] = sc.im;
+            pst<COH>(&Ar[o0 + (int64_t)cc * ld], sc.re);
+            pst<COH>(&Ai[o0 + (int64_t)cc * ld], sc.im);
           }
         }
       }
@@ -846,6 +848,58 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
     }
     __syncthreads();                                     // (D)
   }
+}
+template <bool HERM>
+__global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const PanelTask* __restrict__ tasks,
+                                                    double* __restrict__ dinv_ws, double critere,
+                                                    long long* __restrict__ nbpivot) {
+  PANEL_PRIO();
+  __shared__ DiagZLds S;
+  const PanelTask tk = tasks[blockIdx.x];
+  diag_zsy_body<HERM, false>(S, ar, tk, dinv_ws, critere, nbpivot, threadIdx.x);
+}
+// the run's diagonal kernel for complex LDLt / LDLh (see k_run_diag, kernels.hip): resident workgroups popping ready tasks
+template <bool HERM>
+__global__ __launch_bounds__(512, 4) void k_run_diag_z(const Arenas ar, const RunD* __restrict__ rd, const RunInfo* __restrict__ info,
+                                                       double* __restrict__ dinv_ws, const double critere,
+                                                       long long* __restrict__ nbpivot, const RunCtl rc, int* __restrict__ resident) {
+  PANEL_PRIO();
+  __shared__ DiagZLds S;
+  __shared__ int s_task;
+  const int tid = threadIdx.x;
+  if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (;;) {
+    if (tid == 0) {
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 0);
+      s_task = v;
+      if (v >= 0) run_acquire();
+    }
+    __syncthreads();
+    const int di = s_task;
+    if (di < 0) break;
+    const RunD d = rd[di];
+    long long tp = 0;
+    if (rc.prof && tid == 0) tp = wall_clock64();
+    int ltid = threadIdx.x;                           // (laundered per task, as in k_run_diag)
+    asm volatile("" : "+v"(ltid));
+    diag_zsy_body<HERM, true>(S, ar, d.pt, dinv_ws, critere, nbpivot, ltid);
+    run_drain();
+    __syncthreads();
+    if (tid < 64) {
+      for (int i = tid; i < d.tn; i += 64) run_dec_ticket(rc, info, d.t0 + i);
+      if (rc.prof && tid == 0) {
+        long long* pr = rc.prof + 4 * ((int64_t)rc.nticket + di);
+        pr[0] = tp; pr[1] = tp; pr[2] = wall_clock64();
+      }
+    }
+    __syncthreads();
+  }
+}
+void launch_run_diag_z(hipStream_t sd, bool herm, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
+                       double critere, long long* nbpivot, const RunCtl& rc, int* resident) {
+  if (gd <= 0) return;
+  if (herm) hipLaunchKernelGGL((k_run_diag_z<true>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident);
+  else hipLaunchKernelGGL((k_run_diag_z<false>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident);
 }
 
 // (cblks are at most 128 columns wide -- api.cpp build_split --: one kernel per role)

@@ -257,9 +257,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // Where the run schedule is built (below) launches have no tails to balance, and what a task costs besides its chunks
   // weighs more than parallelism: longer tasks from 4e12 flop (MI355X, run schedule: 100^3 1024 -> 133.4 ms, 2048 -> 131.9;
   // 130^3 548.6 -> 533.9; 160^3 1815 -> 1774; 80^3 43.8 -> 45.4: stays 1024; 60^3 512 -> 14.56, 1024 -> 14.38).
-  const bool run_built = !owner && floattype == PASTIX_AMD_REALDOUBLE && P.opts.run_schedule >= 0 &&
-                         (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
-                          (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
+  const bool run_built = !owner && P.opts.run_schedule >= 0 &&
+                         ((floattype == PASTIX_AMD_REALDOUBLE &&
+                           (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
+                            (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1))) ||
+                          (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
   if (P.opts.lookahead <= 0)
     P.opts.lookahead = (run_built && (P.opts.run_schedule == 1 || fl_total <= 2e14)) ? (fl_total > 4e12 ? 2048 : 1024)
                                                                                      : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
@@ -323,9 +325,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     // (LU: built, but on request only -- run_schedule = 1: its diagonal kernel is the first-generation one, 2-3 times the
     // time of the LLt / LDLt ones per blok, and as the resident worker it is what the whole run waits for: 60^3 -14 %,
     // 100^3 / 130^3 +-1 %)
-    const bool built = !owner && floattype == PASTIX_AMD_REALDOUBLE &&
-                       (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
-                        (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1));
+    const bool built = !owner && ((floattype == PASTIX_AMD_REALDOUBLE &&
+                                   (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
+                                    (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1))) ||
+                                  (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
     // Above 2e14 flop (200^3: 4.1e14) the run is on request only: launches of tens of rounds of workgroups have little to
     // gain (200^3: +0.6 %) and the run's tables cost there (366 M dependency edges: 1.8 s of analysis, 3 GB).
     if (built && P.opts.run_schedule >= 0 && (P.opts.run_schedule == 1 || fl_total <= 2e14)) {
@@ -1022,14 +1025,18 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           const int32_t di = (int32_t)P.run_d.size();
           P.run_d.push_back(d);
           dtile0.push_back((int32_t)tile_base[(size_t)k]);
+          // (complex: 64 rows per panel-solve ticket -- the parked solve keeps half of a wave's tiles in LDS and has
+          // room for four waves' worth --, i.e. up to two tickets per 128-row tile, consecutive)
+          const int32_t trows = cplx ? 64 : TM;
           for (int32_t r = w / TM; (int64_t)r * TM < st; r++) {
             const int32_t r0 = std::max<int32_t>(w, r * TM), r1 = std::min<int32_t>(st, (r + 1) * TM);
-            if (r1 <= r0) continue;
-            RunT tt{};
-            tt.tt = TrsmTask{pt.off, st, w, r0, r1 - r0, pt.dinv_off};
-            tt.tile = (int32_t)(tile_base[(size_t)k] + r);
-            tt.dtask = di;
-            rt.push_back(tt);
+            for (int32_t q0 = r0; q0 < r1; q0 += trows) {
+              RunT tt{};
+              tt.tt = TrsmTask{pt.off, st, w, q0, std::min(trows, r1 - q0), pt.dinv_off};
+              tt.tile = (int32_t)(tile_base[(size_t)k] + r);
+              tt.dtask = di;
+              rt.push_back(tt);
+            }
           }
         }
       }
@@ -1095,7 +1102,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       P.run_dep.assign(nr + nd, 0);
       std::vector<int32_t> tcount((size_t)ntile * (size_t)P.nplanes, 0);      // update tickets so far per tile counter
       std::vector<int32_t> last((size_t)ntile * (size_t)P.nplanes, -1);       // ... and the last of them
-      std::vector<int32_t> tile_ticket((size_t)ntile, -1);                    // the panel-solve ticket of a tile
+      std::vector<int32_t> tile_ticket((size_t)ntile, -1);                    // the first panel-solve ticket of a tile ...
+      std::vector<uint8_t> tile_nt((size_t)ntile, 0);                         // ... and how many it has (consecutive)
       bool bad = false;
       for (size_t i = 0; i < nr && !bad; i++) {
         const int64_t q = order[i];
@@ -1109,7 +1117,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           ri.kind = q < P.slot_urgent_end[sl] ? 0 : q < P.slot_next_end[sl] ? 1 : 2;
           ck.tile = (int32_t)tl;
           ck.seq = tcount[(size_t)tl]++;
-          if (last[(size_t)tl] >= 0) { P.run_info[(size_t)last[(size_t)tl]].succ = (int32_t)i; P.run_dep[i]++; }
+          if (last[(size_t)tl] >= 0) { P.run_info[(size_t)last[(size_t)tl]].succ = (int32_t)i; P.run_info[(size_t)last[(size_t)tl]].cn = 1; P.run_dep[i]++; }
           last[(size_t)tl] = (int32_t)i;
         } else {
           // the panel-solve ticket of a tile: every update ticket of the run on that tile precedes it (A(s) is the last
@@ -1131,9 +1139,15 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           if (tt.tile != dtile0[(size_t)tt.dtask])
             for (int pl = 0; pl < P.nplanes; pl++) {
               const int32_t lu2 = last[(size_t)tt.tile + (size_t)pl * (size_t)ntile];
-              if (lu2 >= 0) { P.run_info[(size_t)lu2].succ = (int32_t)i; P.run_dep[i]++; }
+              if (lu2 < 0) continue;
+              RunInfo& pu = P.run_info[(size_t)lu2];             // the tile's last update on this plane: its successors are
+              if (tile_nt[(size_t)tt.tile] == 0) { pu.succ = (int32_t)i; pu.cn = 1; }   // the tile's panel-solve tickets
+              else pu.cn++;
+              P.run_dep[i]++;
             }
-          tile_ticket[(size_t)tt.tile] = (int32_t)i;
+          if (tile_nt[(size_t)tt.tile] == 0) tile_ticket[(size_t)tt.tile] = (int32_t)i;
+          else if (tile_ticket[(size_t)tt.tile] + tile_nt[(size_t)tt.tile] != (int32_t)i) { bad = true; break; }
+          tile_nt[(size_t)tt.tile]++;
         }
       }
       phase("run: tile chains");
@@ -1150,7 +1164,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         for (size_t d = 0; d < nd; d++) {
           for (int pl = 0; pl < P.nplanes; pl++) {       // (every plane of the diagonal tile that the run updates)
             const int32_t l0 = last[(size_t)dtile0[d] + (size_t)pl * (size_t)ntile];
-            if (l0 >= 0) { P.run_info[(size_t)l0].succ = -2 - (int32_t)d; P.run_dep[nr + d]++; }
+            if (l0 >= 0) { P.run_info[(size_t)l0].succ = -2 - (int32_t)d; P.run_info[(size_t)l0].cn = 1; P.run_dep[nr + d]++; }
           }
           P.run_dchk[d] = {dtile0[d], 0};
         }
@@ -1225,11 +1239,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
               const RunCheck& ck = P.run_chk[i];
               if (ck.wn < 0) continue;
               for (int q = 0; q < ck.wn; q++) {
-                const int32_t pt2 = tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]];
-                if (pt2 < 0 || pt2 >= (int32_t)i) { abad = 1; break; }   // (a source tile of the run has its ticket, in front of its readers)
-                __atomic_fetch_add(&P.run_info[(size_t)pt2].cn, 1, __ATOMIC_RELAXED);
+                const int32_t tl2 = P.run_waits[(size_t)ck.wptr + (size_t)q];
+                const int32_t pt2 = tile_ticket[(size_t)tl2];
+                if (pt2 < 0 || pt2 >= (int32_t)i) { abad = 1; break; }   // (a source tile of the run has its tickets, in front of its readers)
+                for (int z = 0; z < tile_nt[(size_t)tl2]; z++) {
+                  __atomic_fetch_add(&P.run_info[(size_t)pt2 + (size_t)z].cn, 1, __ATOMIC_RELAXED);
+                  P.run_dep[i]++;
+                }
               }
-              P.run_dep[i] += ck.wn;
             }
           });
           if (abad) return PASTIX_AMD_ERR_LAYOUT;
@@ -1243,8 +1260,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
               const RunCheck& ck = P.run_chk[i];
               if (ck.wn < 0) continue;
               for (int q = 0; q < ck.wn; q++) {
-                RunInfo& pi = P.run_info[(size_t)tile_ticket[(size_t)P.run_waits[(size_t)ck.wptr + (size_t)q]]];
-                P.run_cons[(size_t)pi.cptr + (size_t)__atomic_fetch_add(&pi.cn, 1, __ATOMIC_RELAXED)] = (int32_t)i;
+                const int32_t tl2 = P.run_waits[(size_t)ck.wptr + (size_t)q];
+                for (int z = 0; z < tile_nt[(size_t)tl2]; z++) {
+                  RunInfo& pi = P.run_info[(size_t)tile_ticket[(size_t)tl2] + (size_t)z];
+                  P.run_cons[(size_t)pi.cptr + (size_t)__atomic_fetch_add(&pi.cn, 1, __ATOMIC_RELAXED)] = (int32_t)i;
+                }
               }
             }
           });
@@ -1256,6 +1276,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           });
         }
         phase("run: consumer lists");
+        P.run_tile_nt.assign(tile_nt.begin(), tile_nt.end());
         // what is ready when the run starts, in ticket order
         P.run_ready.clear();
         P.run_dready.clear();
@@ -1310,7 +1331,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
 int64_t run_verify(const Plan& P) {
   if (P.run_L0 < 0) return 0;
   const size_t nr = P.run_tasks.size(), nd = P.run_d.size();
-  if (P.run_info.size() != nr || P.run_chk.size() != nr || P.run_dep.size() != nr + nd) return -1;
+  if (P.run_info.size() != nr || P.run_chk.size() != nr || P.run_dep.size() != nr + nd || P.run_tile_nt.size() != (size_t)P.ntile) return -1;
   std::vector<int32_t> cnt(P.run_dep);
   if (P.ntile <= 0) return -1;
   std::vector<int32_t> seq((size_t)P.ntile * (size_t)P.nplanes, 0), fin((size_t)P.ntile, 0), dfl(std::max<size_t>(nd, 1), 0);
@@ -1349,8 +1370,8 @@ int64_t run_verify(const Plan& P) {
     done++;
     if (ri.kind & 4) {
       if (ck.tile < 0 || (size_t)ck.tile >= fin.size() || ck.wptr < 0 || (size_t)ck.wptr >= nd) return -1;
-      if (!dfl[(size_t)ck.wptr] || !tile_complete(ck.tile) || fin[(size_t)ck.tile]) return (int64_t)i + 1;
-      fin[(size_t)ck.tile] = 1;
+      if (!dfl[(size_t)ck.wptr] || !tile_complete(ck.tile) || fin[(size_t)ck.tile] >= P.run_tile_nt[(size_t)ck.tile]) return (int64_t)i + 1;
+      fin[(size_t)ck.tile]++;
       if (ri.cptr < 0 || (size_t)ri.cptr + (size_t)ri.cn > P.run_cons.size()) return -1;
       for (int z = 0; z < ri.cn; z++) if (!dec_ticket(P.run_cons[(size_t)ri.cptr + (size_t)z])) return -1;
     } else {
@@ -1360,10 +1381,10 @@ int64_t run_verify(const Plan& P) {
       for (int z = 0; z < ck.wn; z++) {
         const int32_t f = P.run_waits[(size_t)ck.wptr + (size_t)z];
         if (f < 0 || (size_t)f >= fin.size()) return -1;
-        if (!fin[(size_t)f]) return (int64_t)i + 1;
+        if (fin[(size_t)f] != P.run_tile_nt[(size_t)f] || !fin[(size_t)f]) return (int64_t)i + 1;
       }
       seq[(size_t)ck.tile] = ck.seq + 1;
-      if (ri.succ >= 0) { if (!dec_ticket(ri.succ)) return -1; }
+      if (ri.succ >= 0) { for (int z = 0; z < std::max(ri.cn, 1); z++) if (!dec_ticket(ri.succ + z)) return -1; }
       else if (ri.succ <= -2) {
         const size_t d = (size_t)(-2 - ri.succ);
         if (d >= nd || cnt[nr + d] <= 0) return -1;

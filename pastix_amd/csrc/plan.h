@@ -95,8 +95,8 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
 // a panel-solve task for its cblk's diagonal blok and the last update of its tile; a diagonal task for the last update
 // of the diagonal tile.
 struct RunInfo {             // per ticket of the run
-  int32_t succ;              // update ticket: who waits for this write of the tile: >= 0 a ticket (the tile's next update or
-                             // its panel solve), <= -2 the diagonal task -2 - succ, -1 nobody
+  int32_t succ;              // update ticket: who waits for this write of the tile: >= 0 the tickets [succ, succ + cn) (the
+                             // tile's next update, or its panel solves), <= -2 the diagonal task -2 - succ, -1 nobody
   int32_t cptr, cn;          // panel-solve ticket: run_cons[cptr .. +cn) = the update tickets that read its tile
   int32_t kind;              // bits 0-1: 0 on the chain (urgent updates, panel solves), 1 updates of the next level's panels,
                              // 2 the rest (statistics); bit 2: panel-solve ticket (the Task record holds a TrsmTask)
@@ -198,6 +198,7 @@ struct Plan {
   int32_t run_gd = 0;                    // resident workgroups for the diagonal tasks
   double run_flops = 0;                  // update flops inside the run
   std::vector<RunCheck> run_chk;         // host only (run_verify)
+  std::vector<uint8_t> run_tile_nt;      // ... panel-solve tickets per tile
   std::vector<std::pair<int32_t, int32_t>> run_dchk;   // ... per diagonal task: its tile counter and the value it must find
   std::vector<int32_t> run_waits;
   std::vector<uint8_t> run_cat;          // (PASTIX_AMD_RUN_PROF) per ticket: 0 A, 1 B.next, 2 B.rest, 3 panel solve; its slot / level

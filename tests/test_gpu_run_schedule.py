@@ -183,3 +183,28 @@ def test_run_ldlt_lu_bitwise_on_a_produced_layout(facto, run_env):
     if facto == 2:
         assert np.array_equal(out["0"][0][1], out["1"][0][1])
 
+
+@pytest.mark.parametrize("maxc", [0, 100000])
+@pytest.mark.parametrize("name", golden_names("ldlt", prec="z") + golden_names("ldlh", prec="z"))
+def test_run_complex_ldlt_ldlh_match_reference_golden_and_the_level_schedule(name, maxc, golden, run_env):
+    """complex LDLt / LDLh through the run: update tasks on the real and imaginary planes of a tile are two chains, the panel
+    solve is the parked complex solve (64 rows per ticket), the diagonal workers run k_diag_zsy_w's body."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE, run_schedule=1, run_max_cblks=maxc) as p:
+        out = {}
+        for mode in ("0", "1"):
+            run_env["PASTIX_AMD_RUN"] = mode
+            p.upload(g["L0"])
+            st = p.factorize(g["critere"])
+            out[mode] = (p.download()[0], st)
+        assert out["1"][1]["run_tickets"] > 0 and out["0"][1]["run_tickets"] == 0
+    L1, st = out["1"]
+    m = _lower_mask(g["cblk4"])
+    scale = np.abs(g["L1"][m]).max()
+    assert np.abs(L1 - g["L1"])[m].max() <= TOL * scale
+    assert st["nbpivot"] == g["nbpivot"] == out["0"][1]["nbpivot"]
+    # (not bit for bit here: the two panel-solve kernels are different code around the same operations -- the complex
+    # scaling by 1 / d is contracted into fused multiply-adds differently -- so the factors agree to rounding)
+    assert np.abs(L1 - out["0"][0])[m].max() <= 1e-14 * scale, np.abs(L1 - out["0"][0])[m].max() / scale
+

@@ -14,13 +14,13 @@ from pastix_amd import symbolic as sy
 from pastix_amd.solver import LayoutArrays
 
 
-def run_info(c4, b4, facto=0, **kw):
+def run_info(c4, b4, facto=0, floattype=1, **kw):
     la = LayoutArrays(c4, b4)
     o = _lib.Options()
     for k, v in kw.items():
         setattr(o, k, v)
     info = (ctypes.c_int64 * 8)()
-    rc = _lib.lib().pastix_amd_plan_run_info(ctypes.byref(la.c), facto, ctypes.byref(o), info)
+    rc = _lib.lib().pastix_amd_plan_run_info(ctypes.byref(la.c), facto, floattype, ctypes.byref(o), info)
     assert rc == 0
     return dict(zip(("L0", "levels", "tickets", "edges", "dworkers", "solves", "flops", "verify"), list(info)))
 
@@ -77,3 +77,16 @@ def test_schur_layout_keeps_its_last_cblk_out_of_the_diagonal_tasks(golden):
     g = golden("rlap3d_12_llt")
     r = run_info(g["cblk4"], g["blok4"], 0, schur=1)
     assert r["verify"] == 0
+
+
+@pytest.mark.parametrize("name", golden_names("ldlt", prec="z") + golden_names("ldlh", prec="z"))
+def test_replay_on_the_reference_layouts_complex(name, golden):
+    """complex LDLt / LDLh: update tasks on the real and imaginary planes of a tile are two chains; a panel solve is two
+    64-row tickets per 128-row tile."""
+    g = golden(name)
+    if (g["cblk4"][:-1, 1] - g["cblk4"][:-1, 0] + 1).max() > 256:
+        pytest.skip("re-cut layouts: covered on the GPU")
+    for kw in ({}, {"run_max_cblks": 1000, "run_d_workers": 2}):
+        r = run_info(g["cblk4"], g["blok4"], g["facto"], floattype=3, **kw)
+        assert r["verify"] == 0, (name, kw, r)
+

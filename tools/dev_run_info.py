@@ -10,5 +10,5 @@ la=LayoutArrays(s["cblk4"],s["blok4"])
 o=Options(); o.run_max_cblks=maxc
 info=(ctypes.c_int64*8)()
 t=time.time()
-rc=_lib.lib().pastix_amd_plan_run_info(ctypes.byref(la.c),0,ctypes.byref(o),info)
+rc=_lib.lib().pastix_amd_plan_run_info(ctypes.byref(la.c),0,1,ctypes.byref(o),info)
 print("rc",rc,"L0 %d levels %d run tasks %d waits %d gd %d Ttasks %d runflops %.3e verify %d"%tuple(info), "%.2fs"%(time.time()-t))
