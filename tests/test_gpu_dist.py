@@ -13,6 +13,7 @@ import pytest
 
 from conftest import HERE, ROOT, recut_mask
 from pastix_amd import dist as pd
+from pastix_amd import symbolic as sy
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
@@ -250,6 +251,7 @@ import numpy as np
 import fixture_io
 from pastix_amd import _lib
 from pastix_amd import dist as pd
+from pastix_amd import symbolic as sy
 g = fixture_io.load_npz(os.path.join(%r, "golden", "rlap3d_14_llt_bs24.npz"))
 c4, b4 = g["cblk4"], g["blok4"]
 owner = pd.partition(c4, b4, 2)
@@ -293,3 +295,38 @@ def test_loopback_attach_rejects_mismatched_schedules(golden):
     finally:
         for p in plans:
             p.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_config2_lu_across_ranks_at_a_size_one_gpu_holds(world):
+    """BASELINE configs[2] -- 200^3 dLU, 2 x 150 GB of panels: a 2-GPU job (`bench.py --gpus 2 --facto lu --grid 200`) --
+    through exactly that path (partition, per-rank LU plans with two planes of fan-in blocks, the native driver, the
+    distributed solve) at 48^3 with the ranks sharing this GPU over the loopback transport: residual of the unsymmetric
+    system, no static pivot, every rank's share of the flops positive."""
+    import scipy.sparse as sp
+    N = 48
+    n, cp, r, v = sy.laplacian_3d(N, full=True)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    c4, b4 = s["cblk4"], s["blok4"]
+    owner = pd.partition(c4, b4, world)
+    table = [pd.schedule_hashes(c4, b4, owner, q, world, factotype=2) for q in range(world)]
+    assert pd.mismatched_channels(table) == []
+    plans = [pd.DistPlan(c4, b4, owner, q, 0, factotype=2) for q in range(world)]
+    try:
+        pd.attach_local(plans)
+        for p in plans:
+            p.fill_csc(0, n, cp, r, v, s["perm"])
+        sts = pd.factorize_local(plans, 6.0 * 2 * np.sqrt(1e-31))
+        assert sum(st["nbpivot"] for st in sts) == 0
+        assert all(p.stats()["local_flops"] > 0 for p in plans)
+        b = np.random.default_rng(2).random(n)
+        bp = np.empty(n)
+        bp[s["perm"]] = b
+        x = pd.solve_local(plans, bp)[s["perm"]]
+        A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+        assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
+    finally:
+        for p in plans:
+            p.close()
+

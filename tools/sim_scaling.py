@@ -13,7 +13,10 @@ Two models of the same plans (pastix_amd_plan_profile per rank + the fan-in mess
                  P(l) = diag + panel solve      starts after A(l) and the arrival (+ add) of every block for level l
                  B(l) = bulk contributions      starts after P(l-1) and B(l-1)               (second stream)
              nothing else couples the ranks.
-A launch of F flops whose largest task has W multiply-adds takes max(F / R_chip, 2 W / R_wg) + t0.
+A launch of F flops whose largest task has W multiply-adds takes max(F / R(F), 2 W / R_wg) + t0, where R(F) is the MEASURED
+rate of a bulk launch of that size on one MI355X (profiles/rNN/launch_rate_curve.json, tools/launch_curve.py: 4 TFLOP/s at 1e8
+flop ... 63 at 5e11) when that file exists (argv[3] or the newest profiles/r*/launch_rate_curve.json), else a flat 60 TFLOP/s --
+which is what round 3's 6.35x at 8 GPUs assumed although an eighth of a 200^3 launch runs at 45-56.
 """
 import os
 import sys
@@ -44,8 +47,27 @@ cb = np.repeat(np.arange(len(c4) - 1), np.diff(c4[:, 2]))
 h = b4[:, 1] - b4[:, 0] + 1
 
 
+import glob  # noqa: E402
+import json  # noqa: E402
+curve_file = sys.argv[3] if len(sys.argv) > 3 else (sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "profiles", "r*", "launch_rate_curve.json"))) or [None])[-1]
+CURVE = None
+if curve_file and os.path.exists(curve_file):
+    cj = json.load(open(curve_file))["curve"]
+    CURVE = (np.array([c["log10_flops"] for c in cj]), np.array([c["median_TFLOPs"] * 1e12 for c in cj]))
+    print("launch rate curve: %s (%d bins, %.1f ... %.1f TFLOP/s)" % (curve_file, len(cj), CURVE[1].min() * 1e-12, CURVE[1].max() * 1e-12))
+else:
+    print("launch rate curve: none found, flat %.0f TFLOP/s" % (R_chip * 1e-12))
+
+
+def rate(F):
+    if CURVE is None:
+        return R_chip
+    return float(np.interp(np.log10(max(F, 1.0)), CURVE[0], CURVE[1]))
+
+
 def launch(F, W):
-    return max(F / R_chip, 2 * W / R_wg) + t0 if F > 0 else 0.0
+    return max(F / rate(F), 2 * W / R_wg) + t0 if F > 0 else 0.0
 
 
 base = {}
