@@ -295,7 +295,8 @@ int pastix_amd_factorize_dist(pastix_amd_plan_t *plan, double critere, pastix_am
 /* drives the plans of pastix_amd_dist_attach_local with one host thread per rank; stats / rcs: [world] or NULL */
 int pastix_amd_factorize_dist_local(pastix_amd_plan_t *const *plans, int32_t world, double critere,
                                     pastix_amd_stats_t *stats, int32_t *rcs);
-/* Triangular solves on the distributed factors (real arithmetic, one right-hand side; the data flow of updo.c with
+/* Triangular solves on the distributed factors (one right-hand side; real plans: x is n doubles, complex plans: the
+ * reference's interleaved n `double complex`; the data flow of updo.c with
  * several processes, updo_sendrecv.c): x (host, permuted numbering): in the right-hand side (full length on every
  * rank), out the solution on the columns of the cblks this rank owns and zeros elsewhere -- the sum over the ranks is
  * the solution.  Forward sweep: fan-in of the vector contributions at the target's level; backward sweep: the same

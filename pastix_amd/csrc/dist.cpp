@@ -799,8 +799,10 @@ extern "C" {
 // values on the columns this rank owns and zeros elsewhere -- the sum over the ranks is the solution.
 int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
   if (!p || !x || !p->distributed || !p->dist) return PASTIX_AMD_ERR_BADPARAMETER;
-  if (p->cplx) return PASTIX_AMD_ERR_UNSUPPORTED;
   if (!p->factored || p->dist->failed) return PASTIX_AMD_ERR_BADPARAMETER;
+  // complex plans: x is the reference's interleaved `double complex` vector; on the device (and in the staging buffer)
+  // the real and imaginary parts are two planes of n doubles, and every message carries both
+  const int np_ = p->cplx ? 2 : 1;
   pastix_amd_dist_s* D = p->dist;
   const DistSchedule& S = D->S;
   const Plan& H = p->host;
@@ -808,26 +810,28 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
   int rc = pai_solve_tables(p);
   if (rc) return rc;
   const int64_t n = H.ncol;
-  if (!D->dXs) HIPCHK(hipMalloc((void**)&D->dXs, (size_t)n * sizeof(double)));
+  if (!D->dXs) HIPCHK(hipMalloc((void**)&D->dXs, (size_t)n * np_ * sizeof(double)));
   if (D->solve_stage_off.empty() && !S.msgs.empty()) {
     D->solve_stage_off.assign(S.msgs.size(), 0);
     int64_t off = 0;
     for (size_t i = 0; i < S.msgs.size(); i++)
-      if (S.msgs[i].dir == 1) { D->solve_stage_off[i] = off; off += S.msgs[i].width; }
+      if (S.msgs[i].dir == 1) { D->solve_stage_off[i] = off; off += S.msgs[i].width * np_; }
     HIPCHK(hipMalloc((void**)&D->dSolveStage, (size_t)std::max<int64_t>(off, 1) * sizeof(double)));
   }
   // the rank's view of b: own columns only.  The staging buffer belongs to the plan's distributed state, not to this
   // call: dist_finish's drain is bounded, so on the abandoned-run path an enqueued copy may still be in flight when this
   // function returns -- it must not target memory that dies with the call.
-  if (D->nXs < (size_t)n) {
+  if (D->nXs < (size_t)n * np_) {
     if (D->hXs) { HIPCHK(hipDeviceSynchronize()); (void)hipHostFree(D->hXs); D->hXs = nullptr; D->nXs = 0; }
-    HIPCHK(hipHostMalloc((void**)&D->hXs, (size_t)n * sizeof(double), hipHostMallocDefault));
-    D->nXs = (size_t)n;
+    HIPCHK(hipHostMalloc((void**)&D->hXs, (size_t)n * np_ * sizeof(double), hipHostMallocDefault));
+    D->nXs = (size_t)n * np_;
   }
   struct { double* p; double* data() const { return p; } } hx{D->hXs};
-  std::memset(hx.data(), 0, (size_t)n * sizeof(double));
+  std::memset(hx.data(), 0, (size_t)n * np_ * sizeof(double));
   for (int64_t k = 0; k < H.cblknbr; k++)
-    if (H.role[k] == 1)
+    if (H.role[k] == 1 && p->cplx) {
+      for (int64_t j = H.cblk[k].fcolnum; j <= H.cblk[k].lcolnum; j++) { hx.data()[j] = x[2 * j]; hx.data()[n + j] = x[2 * j + 1]; }
+    } else if (H.role[k] == 1)
       std::memcpy(hx.data() + H.cblk[k].fcolnum, x + H.cblk[k].fcolnum,
                   (size_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1) * sizeof(double));
   hipStream_t s1 = p->stream;
@@ -861,11 +865,13 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
       bool gr = false;
       for (size_t i = g0; i < g1; i++) {
         const DistMsg& m = S.msgs[i];
-        double* seg = dx + H.cblk[m.cblk].fcolnum;
         const bool send = fwd ? m.dir == 0 : m.dir == 1;
-        if (send) r = D->T->send(peer, seg, m.width, cs);
-        else { r = D->T->recv(peer, fwd ? D->dSolveStage + D->solve_stage_off[i] : seg, m.width, cs); gr = true; }
-        if (r) { (void)D->T->group_end(peer); return r; }
+        for (int pl = 0; pl < np_; pl++) {                 // (complex: the real plane, then the imaginary one)
+          double* seg = dx + (int64_t)pl * n + H.cblk[m.cblk].fcolnum;
+          if (send) r = D->T->send(peer, seg, m.width, cs);
+          else { r = D->T->recv(peer, fwd ? D->dSolveStage + D->solve_stage_off[i] + (int64_t)pl * m.width : seg, m.width, cs); gr = true; }
+          if (r) { (void)D->T->group_end(peer); return r; }
+        }
       }
       if ((r = D->T->group_end(peer))) return r;
       hipEvent_t evC;
@@ -879,8 +885,10 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
       for (size_t i = m0; i < m1; i++) {
         const DistMsg& m = S.msgs[i];
         if (m.dir != 1) continue;
-        hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((m.width + 255) / 256)), dim3(256), 0, s1,
-                           dx + H.cblk[m.cblk].fcolnum, D->dSolveStage + D->solve_stage_off[i], m.width);
+        for (int pl = 0; pl < np_; pl++)
+          hipLaunchKernelGGL(k_vec_add, dim3((unsigned)((m.width + 255) / 256)), dim3(256), 0, s1,
+                             dx + (int64_t)pl * n + H.cblk[m.cblk].fcolnum, D->dSolveStage + D->solve_stage_off[i] + (int64_t)pl * m.width,
+                             m.width);
       }
     return 0;
   };
@@ -896,14 +904,24 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
   hipEvent_t fin = nullptr;
   auto enqueue = [&]() -> int {
     int rc = 0;
-    HIPCHK(hipMemcpyAsync(dx, hx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s1));
+    HIPCHK(hipMemcpyAsync(dx, hx.data(), (size_t)n * np_ * sizeof(double), hipMemcpyHostToDevice, s1));
+    auto level = [&](bool fwd, int l) {
+      if (!p->cplx) { pai_solve_level(p, fwd, l, dx, 1); return; }
+      launch_zsolve_level(s1, fwd, H.factotype, p->arenas(), p->dSolve + H.lvl_cblk_ptr[l], H.lvl_cblk_ptr[l + 1] - H.lvl_cblk_ptr[l],
+                          fwd ? p->dChunk + p->lvl_chunk_ptr[l] : p->dChunkB + p->lvl_chunkB_ptr[l],
+                          fwd ? p->lvl_chunk_ptr[l + 1] - p->lvl_chunk_ptr[l] : p->lvl_chunkB_ptr[l + 1] - p->lvl_chunkB_ptr[l], p->dBlok,
+                          p->dRidx, dx, dx + n, p->maxw);
+    };
     for (int l = 0; l < H.nlevels; l++) {
       if ((rc = exchange(l, true, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
-      pai_solve_level(p, true, l, dx, 1);
+      level(true, l);
     }
-    if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, 1);
+    if (p->cplx) {
+      if (H.factotype == PASTIX_AMD_FACT_LDLT || H.factotype == PASTIX_AMD_FACT_LDLH)
+        launch_zsolve_dscale(s1, p->arenas(), p->dSolve, H.lvl_cblk_ptr[H.nlevels], dx, dx + n);
+    } else if (H.factotype == PASTIX_AMD_FACT_LDLT) pai_solve_dscale(p, dx, 1);
     for (int l = H.nlevels - 1; l >= 0; l--) {
-      pai_solve_level(p, false, l, dx, 1);
+      level(false, l);
       if ((rc = exchange(l, false, lvl_m[(size_t)l], lvl_m[(size_t)l + 1]))) return rc;
     }
     for (auto& c : D->chan) {                               // sends of the last levels have left
@@ -912,7 +930,7 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
       HIPCHK(hipEventRecord(e, c.second));
       HIPCHK(hipStreamWaitEvent(s1, e, 0));
     }
-    HIPCHK(hipMemcpyAsync(hx.data(), dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s1));
+    HIPCHK(hipMemcpyAsync(hx.data(), dx, (size_t)n * np_ * sizeof(double), hipMemcpyDeviceToHost, s1));
     if ((rc = new_event(&fin))) return rc;
     HIPCHK(hipEventRecord(fin, s1));
     return 0;
@@ -921,9 +939,11 @@ int pastix_amd_solve_dist(pastix_amd_plan_t* p, double* x) {
   if ((rc = dist_finish(p, rc, fin, "pastix_amd_solve_dist"))) { p->factored = true; return rc; }
   HIPCHK(hipStreamSynchronize(s1));
   HIPCHK(hipGetLastError());
-  std::memset(x, 0, (size_t)n * sizeof(double));
+  std::memset(x, 0, (size_t)n * np_ * sizeof(double));
   for (int64_t k = 0; k < H.cblknbr; k++)
-    if (H.role[k] == 1)
+    if (H.role[k] == 1 && p->cplx) {
+      for (int64_t j = H.cblk[k].fcolnum; j <= H.cblk[k].lcolnum; j++) { x[2 * j] = hx.data()[j]; x[2 * j + 1] = hx.data()[n + j]; }
+    } else if (H.role[k] == 1)
       std::memcpy(x + H.cblk[k].fcolnum, hx.data() + H.cblk[k].fcolnum,
                   (size_t)(H.cblk[k].lcolnum - H.cblk[k].fcolnum + 1) * sizeof(double));
   return PASTIX_AMD_OK;

@@ -539,7 +539,8 @@ def factorize_local(plans, critere):
 def solve_local(plans, b):
     """Distributed solve of the rank plans of this process (attach_local): returns the assembled solution."""
     n = len(plans)
-    xs = [np.ascontiguousarray(b, dtype=np.float64).copy() for _ in plans]
+    dt = np.complex128 if np.iscomplexobj(b) else np.float64        # (complex plans: the reference's interleaved vector)
+    xs = [np.ascontiguousarray(b, dtype=dt).copy() for _ in plans]
     arr = (ctypes.c_void_p * n)(*[p._h for p in plans])
     xp = (ctypes.c_void_p * n)(*[x.ctypes.data for x in xs])
     check(_lib.lib().pastix_amd_solve_dist_local(arr, ctypes.c_int32(n), xp), "pastix_amd_solve_dist_local")
