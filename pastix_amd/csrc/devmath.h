@@ -1,5 +1,6 @@
 // devmath.h -- device-only scalar helpers (include after <hip/hip_runtime.h>)
 #pragma once
+#include <type_traits>
 
 // The kernels of the panel stream (urgent updates, diagonal bloks, panel solves) share their CUs with a bulk k_update
 // workgroup; their waves are dependent chains, the bulk waves are MFMA-bound: the instruction arbiter is told so.
@@ -32,6 +33,28 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs)
   r = __builtin_fma(__builtin_fma(-r, r, x), 0.5 * y, r);   // one correction of the root
   s = r;
   rs = y;
+}
+
+// Broadcast of lane K of every row of 16 lanes to the lanes of that row (DPP row_newbcast; gfx90a+ also on 64-bit
+// operands: one v_mov_b64_dpp).  The tile kernels keep row (lane & 15) of a 16 x 16 tile on every lane, i.e. the four
+// rows of a wave hold copies, so this is "entry of tile row K" for every lane -- what two v_readlane + a wait state into
+// a scalar pair did before, without leaving the vector pipe.  Source lanes must be ACTIVE (a disabled source lane leaves
+// the destination unchanged): callers keep the whole wave in the computation and predicate only their stores.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false);
+}
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0xf, false);
+}
+// compile-time loop over [B, E): f(std::integral_constant<int, i>)
+template <int B, int E, class F>
+__device__ __forceinline__ void unroll_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    unroll_for<B + 1, E>(f);
+  }
 }
 
 }  // namespace pastix_amd

@@ -61,7 +61,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 // COH: the results are stored write-through (the run launch, run_sync.h).
 constexpr int DIAG_LDS_DOUBLES = 128 * 129 / 2;
 template <bool COH>
-__device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double (*__restrict__ Ri)[16], double* __restrict__ L,
+__device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double* __restrict__ Wl, double* __restrict__ L,
                                               const PanelTask& tk, double* __restrict__ dinv_ws, const double critere,
                                               long long* __restrict__ nbpivot, int* __restrict__ errflag, const int tid) {
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
@@ -104,145 +104,123 @@ __device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double (*_
   STAMP(0)
   int npiv = 0;
   bool bad = false;
-  // (B') inverse of the factored tile at column kt for k_trsm: lane c = l15 computes column c of inv(tile) by forward
-  // substitution; L(i, p) is register t[p] of lane i.  Run by WAVE 1 from the tile in LDS while wave 0 factorizes the
-  // next tile (the inverse feeds only the panel solve of a later kernel: off the critical path of this one, where it
-  // used to cost as much as the factorization of the tile itself, ~11 k cycles of a dependent fp64 chain).
-  auto tile_inverse = [&](const int kt) {
-    const int nbt = min(16, w - kt);
-    double t[16], rt[16];
+  const double cmin = fmax(critere, 2.2250738585072014e-308);   // pivots >= cmin take the short path
+  // One 16 x 16 tile of the trailing update A22 -= X X^T (SYRK "L","N", compute_diag.c:197-200), X = columns kb .. kb+15:
+  // MFMA "i" = column, "j" = row as in k_update; rows beyond w are zeros.
+  auto syrk_tile = [&](const int kb, const int rb, const int cb) {
+    d4 c;
+    const int row = rb + l15;
 #pragma unroll
-    for (int c = 0; c < 16; c++) t[c] = (c <= l15) ? DP(kt + c, kt + l15) : 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; c++) rt[c] = Ri[(kt >> 4) & 1][c];
-    double x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      double sacc = (i == l15) ? 1.0 : 0.0;
-#pragma unroll
-      for (int p2 = 0; p2 < 16; p2++)
-        if (p2 < i) {
-          const double lip = (i < nbt) ? readlane_f64(t[p2], i) : 0.0;
-          sacc = __builtin_fma(-lip, x[p2], sacc);
-        }
-      x[i] = (i < nbt && l15 < nbt) ? ((i >= l15) ? sacc * rt[i] : 0.0) : ((i == l15) ? 1.0 : 0.0);
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      c[q] = (row >= col) ? DP(col, row) : 0.0;              // (diagonal tiles: the upper part is not stored)
     }
-    if (lane < 16) {
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
+    double xc[4], xr[4];
 #pragma unroll
-      for (int i = 0; i < 16; i++) pst<COH>(&dst[i + 16 * l15], x[i]);
+    for (int ks = 0; ks < 4; ks++) {
+      xc[ks] = DP(kb + 4 * ks + g, cb + l15);
+      xr[ks] = DP(kb + 4 * ks + g, rb + l15);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc[ks], xr[ks], c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      if (row >= col) DP(col, row) = c[q];
     }
   };
+  // Per 16-column step kb:
+  //   (S1) wave 0 factorizes the 16 x 16 tile in registers, held as the MFMA accumulator holds it -- lane (l15, g),
+  //        register q = entry (row l15, column g + 4q) -- so that the rank-1 update of column j, a(r, c) -= l(r, j) l(c, j),
+  //        is ONE v_mfma_f64_16x16x4: both operands are column j itself, which sits in register j / 4 of lane group j % 4,
+  //        exactly where k-slice j % 4 of an operand is read (the other three slices are zeros).  No barrier, no LDS and no
+  //        scalar broadcast but the pivot's inside the tile (PASTIX_potrf, compute_diag.c:124-153: the same products
+  //        subtracted in the same order).  Beside it, off the chain, the transpose W of the tile's inverse (W = I; column
+  //        j scaled; W(:, i) -= W(:, j) l(i, j)): a second MFMA per column.  W goes to k_trsm AND to LDS for (S2).
+  //        Meanwhile waves 1-7 finish the PREVIOUS step's trailing update (S3b: the tiles right of its first column band).
+  //   (S2) the rows below the tile, 16 per wave: X = A21 W (TRSM "R","L","T","N", compute_diag.c:191-195, as the product
+  //        with the tile's inverse -- what k_trsm does with every blok below): 4 MFMAs.
+  //   (S3a) the first column band of the trailing update (what the next tile and its rows need), one tile per wave.
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
-    if (wave == 1 && kb > 0) tile_inverse(kb - 16);
     if (wave == 0) {
-      double a[16];                                      // row l15 of the tile
-      double ri[16];                                     // (uniform) reciprocals of the diagonal
+      d4 T, W;
+      double dsq = 1.0;                                        // the diagonal entry of column l15 (lanes with g == l15 % 4)
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {                     // PASTIX_potrf (compute_diag.c:124-153)
-        if (j < nb) {
-          double d = readlane_f64(a[j], j);
-          if (fabs(d) < critere) { d = critere; npiv++; }
-          if (!(d > 0.0)) bad = true;
-          double inv;
-          fast_sqrt_rsqrt(d, d, inv);
-          ri[j] = inv;
-          a[j] = (l15 == j) ? d : a[j] * inv;            // (lanes above the diagonal carry zeros)
-#pragma unroll
-          for (int k = j + 1; k < 16; k++) {
-            const double lkj = readlane_f64(a[j], k);
-            a[k] = __builtin_fma(-a[j], lkj, a[k]);     // row i, column k: only i >= k is meaningful
-          }
-        } else {
-          ri[j] = 1.0;
-        }
+      for (int q = 0; q < 4; q++) {
+        T[q] = (g + 4 * q <= l15) ? DP(kb + g + 4 * q, kb + l15) : 0.0;
+        W[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
       }
-      if (lane < 16) {
+      unroll_for<0, 16>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
+        if (j < nb) {
+          // the chain of a column: pivot -> 1/sqrt -> scaled column -> MFMA; everything else is issued behind the MFMA
+          double d = readlane_f64(T[qj], j + 16 * gj);
+          double y = __builtin_amdgcn_rsq(d);
+          if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere, d <= 0 or NaN: compute_diag.c:133-137
+            if (fabs(d) < critere) { d = critere; npiv++; }
+            if (!(d > 0.0)) bad = true;
+            y = __builtin_amdgcn_rsq(d);
+          }
+          y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+          y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+          const bool ing = (g == gj), below = ing && l15 > j;
+          const double tj = T[qj] * y, ntj = T[qj] * -y;
+          const double x = below ? tj : 0.0, nx = below ? ntj : 0.0;   // column j below the diagonal, as MFMA operands
+          T[qj] = below ? tj : T[qj];                        // (x(c) = 0 for c <= j: the MFMA leaves column j and the rows
+          if (j < 15) T = __builtin_amdgcn_mfma_f64_16x16x4f64(nx, x, T, 0, 0, 0);       // above it alone)
+          __builtin_amdgcn_sched_barrier(0);
+          double r = d * y;
+          r = __builtin_fma(__builtin_fma(-r, r, d), 0.5 * y, r);      // sqrt(d), one correction
+          dsq = (ing && l15 == j) ? r : dsq;
+          const double wc = ing ? W[qj] * y : 0.0;
+          W[qj] = ing ? wc : W[qj];
+          if (j < 15) W = __builtin_amdgcn_mfma_f64_16x16x4f64(nx, wc, W, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
 #pragma unroll
-        for (int c = 0; c < 16; c++)
-          if (c <= l15) DP(kb + c, kb + l15) = a[c];
-        double rmine = 1.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) if (c == l15) rmine = ri[c];
-        Ri[(kb >> 4) & 1][l15] = rmine;
+      for (int q = 0; q < 4; q++) {
+        const int c = g + 4 * q;
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = (c == l15) ? dsq : T[q];
+        Wl[l15 * 16 + c] = W[q];                               // W(k = l15, i = c) = inv(tile)(i, k)
+        pst<COH>(&dst[c + 16 * l15], W[q]);
+      }
+    } else if (kb > 0) {
+      const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
+      const int ntile = nbd * (nbd - 1) / 2;
+      for (int t = wave - 1; t < ntile; t += 7) {
+        int bj = 1, rest = t;                                  // t -> (bi >= bj >= 1): column band bj holds nbd - bj tiles
+        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
+        syrk_tile(kb - 16, kb + (bj + rest) * 16, kb + bj * 16);
       }
     }
     STAMP(1)
     __syncthreads();
-    if (wave >= 1 && (wave - 1) * 64 < rem) {
-      // (B) rows below the tile: x = A21 L11^-T, one thread per row (TRSM "R","L","T","N", compute_diag.c:191-195).
-      // The tile's entries are wave-uniform operands: every wave with rows keeps row l15 of the tile in registers and
-      // broadcasts L(c, p) with v_readlane (a dependent LDS read per multiply-add cost ~10 k cycles per tile).
-      double tl[16];
+    if (wave * 16 < rem) {
+      const int rbase = kb + 16 + 16 * wave;
+      d4 X = {0.0, 0.0, 0.0, 0.0};
+      double wa[4], ar[4];
 #pragma unroll
-      for (int c = 0; c < 16; c++) tl[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
-      double rmine = Ri[(kb >> 4) & 1][l15];
-      // (pin the loads here, with every lane of the wave active: v_readlane reads lanes that are inactive inside the
-      // divergent part below, and the compiler would otherwise sink the loads into it -- they are only "used" there)
-#pragma unroll
-      for (int c = 0; c < 16; c++) asm volatile("" : "+v"(tl[c]));
-      asm volatile("" : "+v"(rmine));
-      if (tid - 64 < rem) {
-        const int rr = kb + nb + tid - 64;
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          if (c < nb) {
-            double sacc = x[c];
-#pragma unroll
-            for (int p2 = 0; p2 < 16; p2++)
-              if (p2 < c) sacc = __builtin_fma(-x[p2], readlane_f64(tl[p2], c), sacc);
-            x[c] = sacc * readlane_f64(rmine, c);
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 16; c++)
-          if (c < nb) DP(kb + c, rr) = x[c];
+      for (int ks = 0; ks < 4; ks++) {
+        wa[ks] = Wl[(4 * ks + g) * 16 + l15];                  // inv(tile)(c = l15, k = 4 ks + g)
+        ar[ks] = DP(kb + 4 * ks + g, rbase + l15);             // A21(r = l15, k)
       }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], ar[ks], X, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (g + 4 * q < nb) DP(kb + g + 4 * q, rbase + l15) = X[q];
     }
     STAMP(2)
     __syncthreads();
-    if (rem > 0) {
-      // (C) A22 -= X X^T on the lower 16x16 tiles (SYRK "L","N", compute_diag.c:197-200); MFMA "i" = column,
-      // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros
-      const int nbd = (rem + 15) >> 4, r0 = kb + nb;
-      const int ntile = nbd * (nbd + 1) / 2;
-      for (int t = wave; t < ntile; t += 8) {
-        int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
-        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
-        const int bi = bj + rest;
-        const int rb = r0 + bi * 16, cb = r0 + bj * 16;
-        d4 c;
-        const int row = rb + l15;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int col = cb + g + 4 * q;
-          c[q] = (row >= col) ? DP(col, row) : 0.0;          // (diagonal tiles: the upper part is not stored)
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-          const double xc = DP(kb + 4 * ks + g, cb + l15);
-          const double xr = DP(kb + 4 * ks + g, rb + l15);
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc, xr, c, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int col = cb + g + 4 * q;
-          if (row >= col) DP(col, row) = c[q];
-        }
-      }
-    }
+    if (wave * 16 < rem) syrk_tile(kb, kb + nb + wave * 16, kb + nb);   // (S3a)
     STAMP(3)
   }
   STAMP(4)
   __syncthreads();
-  if (wave == 1) tile_inverse(((w - 1) >> 4) << 4);      // the last tile's
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
@@ -263,10 +241,10 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
                                                     double* __restrict__ dinv_ws, double critere,
                                                     long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   __shared__ double D[DIAG_LDS_DOUBLES];
-  __shared__ double Ri[2][16];
+  __shared__ double Wl[256];
   PANEL_PRIO();
   const PanelTask tk = tasks[blockIdx.x];
-  diag_llt_body<false>(D, Ri, L, tk, dinv_ws, critere, nbpivot, errflag, threadIdx.x);
+  diag_llt_body<false>(D, Wl, L, tk, dinv_ws, critere, nbpivot, errflag, threadIdx.x);
 }
 
 // k_diag_ldlt_w : the same organisation for the LDLt diagonal blok (PASTIX_sytrf_block, compute_diag.c:262-307), w <= 128:
@@ -276,7 +254,7 @@ __global__ __launch_bounds__(512, 4) void k_diag_llt_w(double* __restrict__ L, c
 // (D: the packed lower triangle in LDS as in diag_llt_body; Ri: reciprocals of the tile's diagonal, Dd: the diagonal itself;
 // COH: results stored write-through for the run launch)
 template <bool COH>
-__device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* __restrict__ Ri, double* __restrict__ Dd,
+__device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* __restrict__ S,
                                                double* __restrict__ L, const PanelTask& tk, double* __restrict__ dinv_ws,
                                                const double critere, long long* __restrict__ nbpivot, const int tid) {
 #define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
@@ -310,137 +288,117 @@ __device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* _
     }
   }
   int npiv = 0, npos = 0;
-  // (B') inverse of the factored (unit lower) tile at column kt for k_trsm, by WAVE 1 from the tile in LDS while wave 0
-  // factorizes the next tile -- as in k_diag_llt_w
-  auto tile_inverse = [&](const int kt) {
-    const int nbt = min(16, w - kt);
-    double t[16];
+  const double cmin = fmax(critere, 2.2250738585072014e-308);   // pivots >= cmin take the short path
+  // LDS scratch S: the diagonal of the tile (two halves: steps alternate), its reciprocals (ditto), the tile's inverse
+  double* const Dd = S, * const Ri = S + 32, * const Wl = S + 64;
+  // one 16 x 16 tile of A22 -= (L D) L^T (GEMM with the L D copy, compute_diag.c:299-304); MFMA "i" = column, "j" = row as
+  // in k_update; rows beyond w are zeros; L D is L times the tile's diagonal
+  auto gemm_tile = [&](const int kb, const int rb, const int cb) {
+    const double* Dk = Dd + ((kb >> 4) & 1) * 16;
+    d4 c;
+    const int row = rb + l15;
 #pragma unroll
-    for (int c = 0; c < 16; c++) t[c] = (c < l15) ? DP(kt + c, kt + l15) : 0.0;
-    double x[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      double sacc = (i == l15) ? 1.0 : 0.0;
-#pragma unroll
-      for (int p2 = 0; p2 < 16; p2++)
-        if (p2 < i) {
-          const double lip = (i < nbt) ? readlane_f64(t[p2], i) : 0.0;
-          sacc = __builtin_fma(-lip, x[p2], sacc);
-        }
-      x[i] = (i < nbt && l15 < nbt) ? ((i >= l15) ? sacc : 0.0) : ((i == l15) ? 1.0 : 0.0);      // unit diagonal
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      c[q] = (row >= col) ? DP(col, row) : 0.0;              // (diagonal tiles: the upper part is not stored)
     }
-    if (lane < 16) {
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kt >> 4) * 256;
+    double xc[4], xr[4];
 #pragma unroll
-      for (int i = 0; i < 16; i++) pst<COH>(&dst[i + 16 * l15], x[i]);
+    for (int ks = 0; ks < 4; ks++) {
+      xc[ks] = DP(kb + 4 * ks + g, cb + l15);
+      xr[ks] = DP(kb + 4 * ks + g, rb + l15) * Dk[4 * ks + g];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc[ks], xr[ks], c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      if (row >= col) DP(col, row) = c[q];
     }
   };
+  // The organisation of diag_llt_body: (S1) wave 0 factorizes the tile in the accumulator layout, one MFMA per column for
+  // a(r, c) -= (L D)(r, j) L(c, j) (PASTIX_sytrf, compute_diag.c:223-242) and one for the transposed inverse of the unit
+  // lower tile, while waves 1-7 finish the previous step's trailing update; (S2) rows below: (L D) = A21 W, L = (L D) / d
+  // (compute_diag.c:284-298); (S3a) the first column band of the trailing update.  The previous step's diagonal is still
+  // read by its (S3b) while wave 0 produces the next one: Dd / Ri alternate between two halves.
   for (int kb = 0; kb < w; kb += 16) {
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
-    if (wave == 1 && kb > 0) tile_inverse(kb - 16);
-    double a[16];                                        // wave 0: row l15 of the tile
-    double ri[16], dd[16];                               // (uniform) reciprocals of the diagonal, the diagonal
     if (wave == 0) {
+      d4 T, W;
+      double dmine = 1.0, rmine = 1.0;                         // d and 1/d of column l15 (lanes with g == l15 % 4)
 #pragma unroll
-      for (int c = 0; c < 16; c++) a[c] = (c <= l15) ? DP(kb + c, kb + l15) : 0.0;
-#pragma unroll
-      for (int j = 0; j < 16; j++) {                     // PASTIX_potrf (compute_diag.c:124-153)
+      for (int q = 0; q < 4; q++) {
+        T[q] = (g + 4 * q <= l15) ? DP(kb + g + 4 * q, kb + l15) : 0.0;
+        W[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
+      }
+      unroll_for<0, 16>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
         if (j < nb) {
-          double d = readlane_f64(a[j], j);                // PASTIX_sytrf (compute_diag.c:223-242)
-          if (fabs(d) < critere) { d = critere; npiv++; }
-          if (d > 0.0) npos++;                             // inertia (sopalin3d.c:1144-1160)
-          const double inv = fast_rcp(d);
-          ri[j] = inv;
-          dd[j] = d;
-          const double t = a[j];                           // (L D)(i, j), unscaled
-          a[j] = (l15 == j) ? d : t * inv;                 // unit L below, D on the diagonal
-#pragma unroll
-          for (int k = j + 1; k < 16; k++) {
-            const double lkj = readlane_f64(a[j], k);      // L(k, j)
-            a[k] = __builtin_fma(-t, lkj, a[k]);           // SYR alpha = -d: a(i,k) -= (L D)(i,j) L(k,j)
+          double d = readlane_f64(T[qj], j + 16 * gj);
+          double y = __builtin_amdgcn_rcp(d);
+          if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere or d <= 0 (or NaN)
+            if (fabs(d) < critere) { d = critere; npiv++; }
+            if (d > 0.0) npos++;
+            y = __builtin_amdgcn_rcp(d);
+          } else {
+            npos++;                                            // inertia (sopalin3d.c:1144-1160)
           }
-        } else {
-          ri[j] = 1.0;
-          dd[j] = 1.0;
+          y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+          y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+          const bool ing = (g == gj), below = ing && l15 > j;
+          const double t = T[qj];                              // (L D)(i, j), unscaled
+          const double lj = t * y, nlj = t * -y;
+          const double nl = below ? nlj : 0.0, td = below ? t : 0.0;
+          T[qj] = below ? lj : T[qj];                          // unit L below the diagonal
+          if (j < 15) T = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, td, T, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          dmine = (ing && l15 == j) ? d : dmine;
+          rmine = (ing && l15 == j) ? y : rmine;
+          const double wc = ing ? W[qj] : 0.0;
+          if (j < 15) W = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, wc, W, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      });
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+      double* const Dk = Dd + ((kb >> 4) & 1) * 16, * const Rk = Ri + ((kb >> 4) & 1) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = g + 4 * q;
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = (c == l15) ? dmine : T[q];
+        Wl[l15 * 16 + c] = W[q];
+        pst<COH>(&dst[c + 16 * l15], W[q]);
       }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++)
-          if (c <= l15) DP(kb + c, kb + l15) = a[c];
-        double rmine = 1.0, dmine = 1.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) if (c == l15) { rmine = ri[c]; dmine = dd[c]; }
-        Ri[l15] = rmine;
-        Dd[l15] = dmine;
-      }
-    }
-    __syncthreads();
-    if (wave >= 1 && (wave - 1) * 64 < rem) {
-      // (B) rows below the tile: TRSM "R","L","T","U" gives L D (compute_diag.c:284-288), scaled by 1/d it is L (:289-298).
-      // Tile entries by v_readlane from registers (loads pinned in front of the divergent part), as in k_diag_llt_w.
-      double tl[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) tl[c] = (c < l15) ? DP(kb + c, kb + l15) : 0.0;
-      double rmine = Ri[l15];
-#pragma unroll
-      for (int c = 0; c < 16; c++) asm volatile("" : "+v"(tl[c]));
-      asm volatile("" : "+v"(rmine));
-      if (tid - 64 < rem) {
-        const int rr = kb + nb + tid - 64;
-        double x[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) x[c] = DP(kb + c, rr);
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          if (c < nb) {
-            double sacc = x[c];
-#pragma unroll
-            for (int p2 = 0; p2 < 16; p2++)
-              if (p2 < c) sacc = __builtin_fma(-x[p2], readlane_f64(tl[p2], c), sacc);
-            x[c] = sacc;                                   // (L D)(rr, c)
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 16; c++)
-          if (c < nb) DP(kb + c, rr) = x[c] * readlane_f64(rmine, c);        // L(rr, c)
-      }
-    }
-    __syncthreads();
-    if (rem > 0) {
-      // (C) A22 -= (L D) L^T on the lower 16x16 tiles (GEMM with the L D copy, compute_diag.c:299-304); MFMA "i" = column,
-      // "j" = row as in k_update; k-lines beyond nb and rows beyond w are zeros; L D is L times the tile's diagonal
-      const int nbd = (rem + 15) >> 4, r0 = kb + nb;
-      const int ntile = nbd * (nbd + 1) / 2;
-      for (int t = wave; t < ntile; t += 8) {
-        int bj = 0, rest = t;                            // t -> (bi >= bj): column band bj holds nbd - bj tiles
+      if (g == (l15 & 3)) { Dk[l15] = dmine; Rk[l15] = rmine; }
+    } else if (kb > 0) {
+      const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
+      const int ntile = nbd * (nbd - 1) / 2;
+      for (int t = wave - 1; t < ntile; t += 7) {
+        int bj = 1, rest = t;
         while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
-        const int bi = bj + rest;
-        const int rb = r0 + bi * 16, cb = r0 + bj * 16;
-        d4 c;
-        const int row = rb + l15;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int col = cb + g + 4 * q;
-          c[q] = (row >= col) ? DP(col, row) : 0.0;          // (diagonal tiles: the upper part is not stored)
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-          const double xc = DP(kb + 4 * ks + g, cb + l15);
-          const double xr = DP(kb + 4 * ks + g, rb + l15) * Dd[4 * ks + g];
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc, xr, c, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int col = cb + g + 4 * q;
-          if (row >= col) DP(col, row) = c[q];
-        }
+        gemm_tile(kb - 16, kb + (bj + rest) * 16, kb + bj * 16);
       }
     }
+    __syncthreads();
+    if (wave * 16 < rem) {
+      const int rbase = kb + 16 + 16 * wave;
+      d4 X = {0.0, 0.0, 0.0, 0.0};
+      double wa[4], ar[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        wa[ks] = Wl[(4 * ks + g) * 16 + l15];
+        ar[ks] = DP(kb + 4 * ks + g, rbase + l15);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], ar[ks], X, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (g + 4 * q < nb) DP(kb + g + 4 * q, rbase + l15) = X[q] * Ri[((kb >> 4) & 1) * 16 + g + 4 * q];   // L = (L D) / d
+    }
+    __syncthreads();
+    if (wave * 16 < rem) gemm_tile(kb, kb + nb + wave * 16, kb + nb);   // (S3a)
   }
   __syncthreads();
-  if (wave == 1) tile_inverse(((w - 1) >> 4) << 4);      // the last tile's
   {
     const int r = tid & 127, ch = tid >> 7;
     for (int c = ch; c < w; c += 4)
@@ -455,11 +413,10 @@ __global__ __launch_bounds__(512, 4) void k_diag_ldlt_w(double* __restrict__ L, 
                                                      double* __restrict__ dinv_ws, double critere,
                                                      long long* __restrict__ nbpivot) {
   __shared__ double D[DIAG_LDS_DOUBLES];
-  __shared__ double Ri[16];
-  __shared__ double Dd[16];
+  __shared__ double S[320];
   PANEL_PRIO();
   const PanelTask tk = tasks[blockIdx.x];
-  diag_ldlt_body<false>(D, Ri, Dd, L, tk, dinv_ws, critere, nbpivot, threadIdx.x);
+  diag_ldlt_body<false>(D, S, L, tk, dinv_ws, critere, nbpivot, threadIdx.x);
 }
 
 void launch_diag_ldlt_w(hipStream_t s, double* L, const PanelTask* tasks, int64_t n, double* dinv, double critere,
@@ -557,7 +514,7 @@ __global__ __launch_bounds__(512, 4) void k_run_diag(double* __restrict__ L, con
                                                      int* __restrict__ errflag, const RunCtl rc,
                                                      int* __restrict__ resident, const long long limit) {
   __shared__ double D[DIAG_LDS_DOUBLES];
-  __shared__ double Ri[2][16];
+  __shared__ double Ri[320];                         // (LLt: the tile's inverse; LDLt: diagonal, reciprocals, inverse)
   __shared__ int s_task;
   PANEL_PRIO();
   const int tid = threadIdx.x;
@@ -581,7 +538,7 @@ __global__ __launch_bounds__(512, 4) void k_run_diag(double* __restrict__ L, con
     int ltid = threadIdx.x;
     asm volatile("" : "+v"(ltid));
     if constexpr (FT == 0) diag_llt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, errflag, ltid);
-    else diag_ldlt_body<true>(D, &Ri[0][0], &Ri[1][0], L, d.pt, dinv_ws, critere, nbpivot, ltid);
+    else diag_ldlt_body<true>(D, Ri, L, d.pt, dinv_ws, critere, nbpivot, ltid);
     run_drain();
     __syncthreads();
     if (tid < 64) {
