@@ -346,6 +346,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
   }
   const int RL0 = P.run_L0 >= 0 ? P.run_L0 : NL + 1;
+  const int near = getenv("PASTIX_AMD_NEAR") ? atoi(getenv("PASTIX_AMD_NEAR")) : 3;
+  const int64_t nearc = getenv("PASTIX_AMD_NEARC") ? atoi(getenv("PASTIX_AMD_NEARC")) : 1;
 
   // ---- panel / trsm tasks per level ------------------------------------------------------------
   P.lvl_panel_ptr.assign(NL + 1, 0);
@@ -716,6 +718,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         // flush everything older one slot earlier, where it overlaps with the panel kernels (api.cpp, two streams)
         if (e < qe && raw[e].tile == raw[q].tile && raw[e].lvl == tlev - 1 &&
             raw[e - 1].lvl < tlev - 1) break;
+        // run levels: a task computes all its pieces when its LAST source is solved, and the dependency chain reaches a
+        // target k levels above that source k periods (~100 us) later -- sixteen accumulated pieces (~230 us) in front of
+        // the urgent task of a tile were what the chain of the top separator waited for.  The sources of the last `near`
+        // levels below the target stay in tasks of their own level.
+        if (near > 0 && tlev >= RL0 && P.lvl_cblk_ptr[tlev + 1] - P.lvl_cblk_ptr[tlev] <= nearc && e < qe && raw[e].tile == raw[q].tile && raw[e].lvl != raw[e - 1].lvl &&
+            raw[e].lvl >= tlev - near) break;
       }
       int slot = raw[e - 1].lvl + 1;
       int64_t tile = raw[q].tile;

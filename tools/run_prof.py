@@ -67,3 +67,20 @@ for i, (s, a0, ar, ad, k, td, tw) in enumerate(rows):
         per = (ad - rows[i - 1][3]) if i > 0 else 0
         print("  %4d: n=%4d drawn %10.1f ready %10.1f done %10.1f | T done %10.1f (mean wait %6.1f) | A spin %7.1f period %7.1f" % (
             s, k, a0, ar, ad, td, tw, ar - a0, per))
+if len(sys.argv) > 2:   # chain detail of the last K levels: every stamp relative to the level's first event
+    K = int(sys.argv[2])
+    print("chain detail (us from run start): D start/end | T ready(min) done(min,max) run(mean) | A ready(min,max) done(min,max)")
+    Dl = D[-K:] if nd else []
+    for i, s in enumerate(range(int(lvl.max()) - K + 1, int(lvl.max()) + 1)):
+        a = (cat == 0) & (lvl == s); t = (cat == 3) & (lvl == s)
+        f = lambda x: (x - t0) * 1e-2
+        ds = " D %9.1f %9.1f (%5.1f)" % (f(Dl[i][1]), f(Dl[i][2]), (Dl[i][2] - Dl[i][1]) * 1e-2) if nd else ""
+        ts = " | T n=%3d ready %9.1f done %9.1f..%9.1f run %5.1f" % (t.sum(), f(U[t, 1].min()), f(U[t, 2].min()), f(U[t, 2].max()), (U[t, 2] - U[t, 1]).mean() * 1e-2) if t.any() else ""
+        as_ = " | A n=%3d ready %9.1f..%9.1f done %9.1f..%9.1f" % (a.sum(), f(U[a, 1].min()), f(U[a, 1].max()), f(U[a, 2].min()), f(U[a, 2].max())) if a.any() else ""
+        print("  %4d:%s%s%s" % (s, ds, ts, as_))
+if len(sys.argv) > 4:   # every ticket that became ready in [a, b] us
+    a, b = float(sys.argv[3]), float(sys.argv[4])
+    r = (U[:, 1] - t0) * 1e-2
+    sel = np.where((r >= a) & (r <= b))[0]
+    for i in sel[np.argsort(r[sel])]:
+        print("   ticket %7d cat %d lvl %4d drawn %10.1f ready %10.1f done %10.1f (run %5.1f) cu %x" % (i, cat[i], lvl[i], (U[i, 0] - t0) * 1e-2, r[i], (U[i, 2] - t0) * 1e-2, (U[i, 2] - U[i, 1]) * 1e-2, cu[i]))
