@@ -145,38 +145,38 @@ __device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double* __
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
     if (wave == 0) {
-      d4 T, W;
-      double dsq = 1.0;                                        // the diagonal entry of column l15 (lanes with g == l15 % 4)
+      // (the wave issues in order and every instruction of a column sits between two pivots: the tile and the inverse are
+      // held NEGATED -- S = -T, V = -W -- so that the operands of the accumulating MFMA, -l(:, j) = S(:, j) / sqrt(d), need no
+      // second, negated copy, and the diagonal lane of the scaled column is -sqrt(d) itself)
+      d4 S, V;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        T[q] = (g + 4 * q <= l15) ? DP(kb + g + 4 * q, kb + l15) : 0.0;
-        W[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
+        S[q] = (g + 4 * q <= l15) ? -DP(kb + g + 4 * q, kb + l15) : 0.0;
+        V[q] = (g + 4 * q == l15) ? -1.0 : 0.0;
       }
       unroll_for<0, 16>([&](auto J) {
         constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
         if (j < nb) {
-          // the chain of a column: pivot -> 1/sqrt -> scaled column -> MFMA; everything else is issued behind the MFMA
-          double d = readlane_f64(T[qj], j + 16 * gj);
+          // the chain of a column: pivot -> 1/sqrt -> scaled column -> MFMA; the inverse's column is issued behind the MFMA
+          const bool ing = (g == gj);
+          double d = -readlane_f64(S[qj], j + 16 * gj);
           double y = __builtin_amdgcn_rsq(d);
           if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere, d <= 0 or NaN: compute_diag.c:133-137
             if (fabs(d) < critere) { d = critere; npiv++; }
             if (!(d > 0.0)) bad = true;
             y = __builtin_amdgcn_rsq(d);
+            S[qj] = (ing && l15 == j) ? -d : S[qj];
           }
           y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
           y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
-          const bool ing = (g == gj), below = ing && l15 > j;
-          const double tj = T[qj] * y, ntj = T[qj] * -y;
-          const double x = below ? tj : 0.0, nx = below ? ntj : 0.0;   // column j below the diagonal, as MFMA operands
-          T[qj] = below ? tj : T[qj];                        // (x(c) = 0 for c <= j: the MFMA leaves column j and the rows
-          if (j < 15) T = __builtin_amdgcn_mfma_f64_16x16x4f64(nx, x, T, 0, 0, 0);       // above it alone)
+          const double sm = S[qj] * y;                         // -l(:, j); on the diagonal lane -d / sqrt(d)
+          const double xm = (ing && l15 > j) ? sm : 0.0;       // below the diagonal, as the MFMA operand (both sides)
+          S[qj] = (ing && l15 >= j) ? sm : S[qj];              // (x(c) = 0 for c <= j: the MFMA leaves column j and the rows
+          if (j < 15) S = __builtin_amdgcn_mfma_f64_16x16x4f64(xm, xm, S, 0, 0, 0);       // above it alone)
           __builtin_amdgcn_sched_barrier(0);
-          double r = d * y;
-          r = __builtin_fma(__builtin_fma(-r, r, d), 0.5 * y, r);      // sqrt(d), one correction
-          dsq = (ing && l15 == j) ? r : dsq;
-          const double wc = ing ? W[qj] * y : 0.0;
-          W[qj] = ing ? wc : W[qj];
-          if (j < 15) W = __builtin_amdgcn_mfma_f64_16x16x4f64(nx, wc, W, 0, 0, 0);
+          const double vm = ing ? V[qj] * y : 0.0;
+          V[qj] = ing ? vm : V[qj];
+          if (j < 15) V = __builtin_amdgcn_mfma_f64_16x16x4f64(xm, vm, V, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       });
@@ -184,9 +184,9 @@ __device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double* __
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = g + 4 * q;
-        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = (c == l15) ? dsq : T[q];
-        Wl[l15 * 16 + c] = W[q];                               // W(k = l15, i = c) = inv(tile)(i, k)
-        pst<COH>(&dst[c + 16 * l15], W[q]);
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = -S[q];
+        Wl[l15 * 16 + c] = -V[q];                              // W(k = l15, i = c) = inv(tile)(i, k)
+        pst<COH>(&dst[c + 16 * l15], -V[q]);
       }
     } else if (kb > 0) {
       const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
@@ -325,51 +325,49 @@ __device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* _
     const int nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();
     if (wave == 0) {
-      d4 T, W;
-      double dmine = 1.0, rmine = 1.0;                         // d and 1/d of column l15 (lanes with g == l15 % 4)
+      d4 S, V;                                                 // the tile and the inverse, negated (see diag_llt_body)
+      double* const Dk = Dd + ((kb >> 4) & 1) * 16, * const Rk = Ri + ((kb >> 4) & 1) * 16;
+      if (lane < 16) { Dk[lane] = 1.0; Rk[lane] = 1.0; }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        T[q] = (g + 4 * q <= l15) ? DP(kb + g + 4 * q, kb + l15) : 0.0;
-        W[q] = (g + 4 * q == l15) ? 1.0 : 0.0;
+        S[q] = (g + 4 * q <= l15) ? -DP(kb + g + 4 * q, kb + l15) : 0.0;
+        V[q] = (g + 4 * q == l15) ? -1.0 : 0.0;
       }
       unroll_for<0, 16>([&](auto J) {
         constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
         if (j < nb) {
-          double d = readlane_f64(T[qj], j + 16 * gj);
+          const bool ing = (g == gj), below = ing && l15 > j;
+          double d = -readlane_f64(S[qj], j + 16 * gj);
           double y = __builtin_amdgcn_rcp(d);
           if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere or d <= 0 (or NaN)
             if (fabs(d) < critere) { d = critere; npiv++; }
             if (d > 0.0) npos++;
             y = __builtin_amdgcn_rcp(d);
+            S[qj] = (ing && l15 == j) ? -d : S[qj];
           } else {
             npos++;                                            // inertia (sopalin3d.c:1144-1160)
           }
           y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
           y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
-          const bool ing = (g == gj), below = ing && l15 > j;
-          const double t = T[qj];                              // (L D)(i, j), unscaled
-          const double lj = t * y, nlj = t * -y;
-          const double nl = below ? nlj : 0.0, td = below ? t : 0.0;
-          T[qj] = below ? lj : T[qj];                          // unit L below the diagonal
-          if (j < 15) T = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, td, T, 0, 0, 0);
+          const double sy = S[qj] * y;                         // -L(:, j): (L D)(i, j) / d
+          const double am = below ? sy : 0.0, bm = below ? S[qj] : 0.0;   // -L(c, j) and -(L D)(r, j): a(r, c) -= (L D)(r, j) L(c, j)
+          S[qj] = below ? sy : S[qj];                          // unit L below the diagonal, -d stays on it
+          if (j < 15) S = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm, S, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          dmine = (ing && l15 == j) ? d : dmine;
-          rmine = (ing && l15 == j) ? y : rmine;
-          const double wc = ing ? W[qj] : 0.0;
-          if (j < 15) W = __builtin_amdgcn_mfma_f64_16x16x4f64(nl, wc, W, 0, 0, 0);
+          if (lane == 0) { Dk[j] = d; Rk[j] = y; }
+          const double vm = ing ? V[qj] : 0.0;                 // (unit diagonal: the inverse's column is not scaled)
+          if (j < 15) V = __builtin_amdgcn_mfma_f64_16x16x4f64(am, vm, V, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       });
       double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
-      double* const Dk = Dd + ((kb >> 4) & 1) * 16, * const Rk = Ri + ((kb >> 4) & 1) * 16;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = g + 4 * q;
-        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = (c == l15) ? dmine : T[q];
-        Wl[l15 * 16 + c] = W[q];
-        pst<COH>(&dst[c + 16 * l15], W[q]);
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = -S[q];
+        Wl[l15 * 16 + c] = -V[q];
+        pst<COH>(&dst[c + 16 * l15], -V[q]);
       }
-      if (g == (l15 & 3)) { Dk[l15] = dmine; Rk[l15] = rmine; }
     } else if (kb > 0) {
       const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
       const int ntile = nbd * (nbd - 1) / 2;
