@@ -260,7 +260,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   const bool run_built = !owner && P.opts.run_schedule >= 0 &&
                          ((floattype == PASTIX_AMD_REALDOUBLE &&
                            (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
-                            (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1))) ||
+                            factotype == PASTIX_AMD_FACT_LU)) ||
                           (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
   if (P.opts.lookahead <= 0)
     P.opts.lookahead = (run_built && (P.opts.run_schedule == 1 || fl_total <= 2e14)) ? (fl_total > 4e12 ? 2048 : 1024)
@@ -322,12 +322,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // the same tables, which of the two runs is decided per factorization (api.cpp).
   P.run_L0 = -1;
   {
-    // (LU: built, but on request only -- run_schedule = 1: its diagonal kernel is the first-generation one, 2-3 times the
-    // time of the LLt / LDLt ones per blok, and as the resident worker it is what the whole run waits for: 60^3 -14 %,
-    // 100^3 / 130^3 +-1 %)
     const bool built = !owner && ((floattype == PASTIX_AMD_REALDOUBLE &&
                                    (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
-                                    (factotype == PASTIX_AMD_FACT_LU && P.opts.run_schedule == 1))) ||
+                                    factotype == PASTIX_AMD_FACT_LU)) ||
                                   (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
     // Above 2e14 flop (200^3: 4.1e14) the run is on request only: launches of tens of rounds of workgroups have little to
     // gain (200^3: +0.6 %) and the run's tables cost there (366 M dependency edges: 1.8 s of analysis, 3 GB).
