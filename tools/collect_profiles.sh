@@ -1,6 +1,6 @@
 #!/bin/bash
-# After `gpurun -- 'bash tools/round_final.sh'`: fold gpurun_out/ into profiles/rNN/ (usage: collect_profiles.sh r03)
-R=${1:?round directory name, e.g. r03}
+# After `gpurun -- 'bash tools/round_final.sh'`: fold gpurun_out/ into profiles/rNN/ (usage: collect_profiles.sh r04)
+R=${1:?round directory name, e.g. r04}
 cd "$(dirname "$0")/.."
 python3 tools/make_profile_json.py $R 200 100 48workloadelasticity > /dev/null
 P=profiles/$R
@@ -14,4 +14,5 @@ cp gpurun_out/bench_default.json $P/bench_default_run.json
 cp gpurun_out/bench_f32_200.json $P/bench_f32_200cube.json
 cp gpurun_out/bench_f32_100.json $P/bench_f32_100cube.json
 cp gpurun_out/bench_100_ldlt.json gpurun_out/bench_100_lu.json gpurun_out/bench_z40.json gpurun_out/bench_z56.json $P/
+[ -d gpurun_out/final ] && cp gpurun_out/final/*.txt gpurun_out/final/*.json $P/ 2>/dev/null
 cat gpurun_out/profile_200/source_sha.txt
