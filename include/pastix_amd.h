@@ -84,11 +84,12 @@ typedef struct pastix_amd_options_s {
   int run_schedule;      /* the thin levels at the top of the elimination tree (at most run_max_cblks cblks each) as ONE
                             dependency-driven launch -- tasks gated by tile counters, the way the reference's tasks wait
                             for TASK_CTRBCNT (sopalin3d.c:790-1025) -- instead of launches per level: 0 = default (on for
-                            real double LLt / LDLt on one GPU), 1 = on wherever it is built (also real double LU), -1 = off
-                            (the level-by-level schedule) */
+                            real double LLt / LDLt / LU and complex double LDLt / LDLh on one GPU up to 2e14 flop),
+                            1 = on wherever it is built, whatever the size, -1 = off (the level-by-level schedule) */
   int run_max_cblks;     /* <= 0 = default (32) */
-  int run_t_workers;     /* resident workgroups of the run's panel kernel that solve panel rows; <= 0 = default (48) */
-  int run_d_workers;     /* ... that factorize diagonal bloks (a level's cblks are dealt round-robin); <= 0 = default (8) */
+  int run_t_workers;     /* unused (kept for the layout of the struct): panel solves are tickets of the run launch */
+  int run_d_workers;     /* resident workgroups of the run's diagonal-blok kernel (they pop ready diagonal tasks);
+                            <= 0 = default (8) */
   int reserved[5];
 } pastix_amd_options_t;
 

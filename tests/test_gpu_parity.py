@@ -5,7 +5,7 @@ import pytest
 
 import oracle_lib
 from conftest import golden_names, recut_mask
-from pastix_amd import Plan, sopalin_tabs
+from pastix_amd import COMPLEXDOUBLE, Plan, sopalin_tabs
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,30 @@ def test_static_pivot_clamp_matches_oracle(golden):
     assert nbo >= 10 and st["nbpivot"] == nbo
     assert np.isfinite(Lo).all()
     assert np.abs(L1 - Lo).max() <= TOL * np.abs(Lo).max()
+
+
+@pytest.mark.parametrize("name,crit", [("rlap3d_12_ldlt", 5.9), ("rlap3d_20_lu_bs128", 5.9), ("rlap3d_20_llt_bs128", 5.9),
+                                       ("zrlap3d_20_ldlt_bs128", 5.9), ("zrlap3d_12_ldlh", 5.9)])
+def test_static_pivot_clamp_of_every_diagonal_kernel_matches_oracle(name, crit, golden):
+    """The clamp is a rarely taken branch of the round-4 diagonal kernels (pivot read from the accumulator layout, the
+    clamped value written back into the tile before the column is scaled): LDLt, LU, LLt on 128-wide cblks and complex
+    LDLt / LDLh with critere above the natural pivots -- clamp counts and factors equal the oracle's."""
+    g = golden(name)
+    c4, b4, facto = g["cblk4"], g["blok4"], int(g["facto"])
+    cz = np.iscomplexobj(g["L0"])
+    U0 = g["U0"] if facto == 2 else None
+    Lo, Uo, nbo = oracle_lib.sopalin(facto, c4, b4, g["L0"], U0, crit)
+    kw = {"floattype": COMPLEXDOUBLE} if cz else {}
+    with Plan(c4, b4, facto, **kw) as p:
+        p.upload(g["L0"], U0) if facto == 2 else p.upload(g["L0"])
+        st = p.factorize(crit)
+        L1, U1 = p.download()
+    assert nbo >= 10 and st["nbpivot"] == nbo
+    m = _lower_mask(c4) if facto in (1, 3) else np.ones(len(Lo), bool)
+    assert np.isfinite(Lo[m]).all()
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
+    if facto == 2:
+        assert np.abs(U1 - Uo).max() <= TOL * max(np.abs(Uo).max(), np.abs(Lo).max())
 
 
 def _lower_mask(c4):
