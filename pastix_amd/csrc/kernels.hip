@@ -519,9 +519,10 @@ __global__ __launch_bounds__(512, 4) void k_run_diag(double* __restrict__ L, con
   if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (;;) {
     if (tid == 0) {
-      // (no time limit of its own: a diagonal worker may legitimately find nothing for most of the factorization; the
-      // tickets' limit raises RUN_STUCK if the run stops moving, and then the workers leave too)
-      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 0);
+      // (bounded like the tickets' wait, three times as long: a diagonal worker legitimately finds nothing while the levels
+      // below the run are factorized; but a tool that serializes kernel launches -- rocprofv3 --pmc does -- never starts the
+      // tickets' kernel beside this one, and the workers must not spin for ever: RUN_STUCK, everybody leaves, ERR_DEVICE)
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit);
       s_task = v;
       if (v >= 0) run_acquire();
     }
@@ -1384,12 +1385,12 @@ __global__ void k_fill_const(double* __restrict__ dst, int64_t n, double v) {
 void launch_run_diag_lu(hipStream_t sd, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                         double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit);   // kernels_var.hip
 void launch_run_diag_z(hipStream_t sd, bool herm, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
-                       double critere, long long* nbpivot, const RunCtl& rc, int* resident);                      // kernels_z.hip
+                       double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit);                      // kernels_z.hip
 void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                       double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit) {
   if (gd <= 0) return;
   if (ar.p[2])                                     // complex double (split planes): LDLt / LDLh
-    launch_run_diag_z(sd, factotype == PASTIX_AMD_FACT_LDLH, ar, rd, info, gd, dinv, critere, nbpivot, rc, resident);
+    launch_run_diag_z(sd, factotype == PASTIX_AMD_FACT_LDLH, ar, rd, info, gd, dinv, critere, nbpivot, rc, resident, limit);
   else if (factotype == PASTIX_AMD_FACT_LLT)
     hipLaunchKernelGGL(k_run_diag<0>, dim3((unsigned)gd), dim3(512), 0, sd, ar.p[0], rd, info, dinv, critere, nbpivot, errflag, rc,
                        resident, limit);

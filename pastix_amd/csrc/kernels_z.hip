@@ -881,7 +881,8 @@ __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const Pa
 template <bool HERM>
 __global__ __launch_bounds__(512, 4) void k_run_diag_z(const Arenas ar, const RunD* __restrict__ rd, const RunInfo* __restrict__ info,
                                                        double* __restrict__ dinv_ws, const double critere,
-                                                       long long* __restrict__ nbpivot, const RunCtl rc, int* __restrict__ resident) {
+                                                       long long* __restrict__ nbpivot, const RunCtl rc, int* __restrict__ resident,
+                                                       const long long limit) {
   PANEL_PRIO();
   __shared__ DiagZLds S;
   __shared__ int s_task;
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_z(const Arenas ar, const Ru
   if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (;;) {
     if (tid == 0) {
-      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 0);
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit);   // (see k_run_diag)
       s_task = v;
       if (v >= 0) run_acquire();
     }
@@ -915,10 +916,10 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_z(const Arenas ar, const Ru
   }
 }
 void launch_run_diag_z(hipStream_t sd, bool herm, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
-                       double critere, long long* nbpivot, const RunCtl& rc, int* resident) {
+                       double critere, long long* nbpivot, const RunCtl& rc, int* resident, long long limit) {
   if (gd <= 0) return;
-  if (herm) hipLaunchKernelGGL((k_run_diag_z<true>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident);
-  else hipLaunchKernelGGL((k_run_diag_z<false>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident);
+  if (herm) hipLaunchKernelGGL((k_run_diag_z<true>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident, limit);
+  else hipLaunchKernelGGL((k_run_diag_z<false>), dim3((unsigned)gd), dim3(512), 0, sd, ar, rd, info, dinv, critere, nbpivot, rc, resident, limit);
 }
 
 // (cblks are at most 128 columns wide -- api.cpp build_split --: one kernel per role)

@@ -80,7 +80,7 @@ def test_static_pivot_clamp_of_every_diagonal_kernel_matches_oracle(name, crit, 
         st = p.factorize(crit)
         L1, U1 = p.download()
     assert nbo >= 10 and st["nbpivot"] == nbo
-    m = _lower_mask(c4) if facto in (1, 3) else np.ones(len(Lo), bool)
+    m = _lower_mask(c4) if facto in (1, 3) else recut_mask(c4) if facto == 0 else np.ones(len(Lo), bool)
     assert np.isfinite(Lo[m]).all()
     assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
     if facto == 2:

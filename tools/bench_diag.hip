@@ -6,7 +6,7 @@
 #include <vector>
 namespace pastix_amd {   // (defined in kernels_var.hip / kernels_z.hip; not linked into this tool)
 void launch_run_diag_lu(hipStream_t, const Arenas&, const RunD*, const RunInfo*, int, double*, double, long long*, const RunCtl&, int*, long long) {}
-void launch_run_diag_z(hipStream_t, bool, const Arenas&, const RunD*, const RunInfo*, int, double*, double, long long*, const RunCtl&, int*) {}
+void launch_run_diag_z(hipStream_t, bool, const Arenas&, const RunD*, const RunInfo*, int, double*, double, long long*, const RunCtl&, int*, long long) {}
 }
 using namespace pastix_amd;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
