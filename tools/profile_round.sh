@@ -19,13 +19,18 @@ export TMPDIR=/tmp
 # k_update_small<0> right behind it
 KERNELS="k_run_update,k_update<0>,k_update_small<0>"
 ARGS="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs --grid $G $EXTRA"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats
 if [ -z "$NO_PMC" ]; then
+# The counter passes run the LEVEL-BY-LEVEL schedule (PASTIX_AMD_RUN=0): rocprofv3 --pmc serializes kernel launches, and the
+# run schedule needs its two kernels (tickets + resident diagonal workers) on the chip together -- under the counters it
+# stops after PASTIX_AMD_RUN_TIMEOUT with PASTIX_AMD_ERR_DEVICE.  Same kernels' bodies, same tasks, same flops; at 200^3 the
+# level schedule is the product's default anyway.
+export PASTIX_AMD_RUN=0
 pass() {   # name, counters
   rm -rf /tmp/pmc_pass
-  rocprofv3 --pmc $2 --output-format csv -d /tmp/pmc_pass -- python3 $ARGS > $OUT/bench_pmc_$1.json 2> $OUT/pmc_$1.err
+  timeout 600 rocprofv3 --pmc $2 --output-format csv -d /tmp/pmc_pass -- python3 $ARGS > $OUT/bench_pmc_$1.json 2> $OUT/pmc_$1.err
   python3 tools/pmc_sum.py /tmp/pmc_pass "$KERNELS" > $OUT/sum_$1.json
   rm -rf /tmp/pmc_pass
 }
@@ -34,6 +39,7 @@ pass WRITE_SIZE "WRITE_SIZE"
 pass busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64"
 pass waves "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 pass l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+unset PASTIX_AMD_RUN
 fi
 python3 -c "import bench; print(bench.engine_source_sha())" > $OUT/source_sha.txt
 cat $OUT/sum_*.json 2>/dev/null
