@@ -163,6 +163,10 @@ struct pastix_amd_plan_s {
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   // the run schedule: device tables, the synchronisation words (zeroed per factorization), the panel kernels' streams
   bool run_ready = false, run_used = false;
+  // PASTIX_AMD_RUN_DEBUG: host copies of the run's dependency tables, for the report of a stuck run (api.cpp)
+  std::vector<RunInfo> dbg_info;
+  std::vector<int32_t> dbg_cons, dbg_dep;
+  std::vector<RunD> dbg_d;
   Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunCons = nullptr;
   RunD* dRunD = nullptr;
   int32_t *dRunState = nullptr, *dRunImage = nullptr;   // the counters / rings / control words and their initial image

@@ -40,9 +40,27 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
   int it = 0;
   while ((v = run_ld(ring + h)) < 0) {
     ++it;
+    // Every fourth poll is a read-modify-write (or with 0): an agent-scope LOAD may be served by this XCD's L2, and a line
+    // of the ring that got there before the push (a neighbouring slot was polled) stays stale until something evicts or
+    // invalidates it -- update traffic and the other workgroups' acquires do, within microseconds, as long as the chip is
+    // busy.  When the run drains towards a chain-bound phase nothing does: about one factorization in a hundred stopped
+    // with every workgroup polling, one of them on a slot that had been filled long ago.  Atomics execute at the
+    // coherence point.
+    if ((it & 3) == 0 && (v = __hip_atomic_fetch_or(const_cast<int32_t*>(ring) + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) break;
     if ((it & 63) == 0) {
-      if (run_ld(stuck)) return -1;
-      if (limit > 0 && wall_clock64() - t0 > limit) { run_st(stuck, 1); return -1; }
+      if (__hip_atomic_fetch_or(stuck, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+      const long long now = wall_clock64();
+      if (limit > 0 && now - t0 > limit) {
+        // (the first one to give up leaves a note for the host: which slot it waited for, how long)
+        if (__hip_atomic_exchange(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          run_st(stuck + 2, h);
+          run_st(stuck + 3, n);
+          run_st(stuck + 4, (int)((now - t0) / 100000));            // ms
+          run_st(stuck + 5, (int)(limit / 100000));
+          run_st(stuck + 6, it);
+        }
+        return -1;
+      }
     }
     if (it < 16) __builtin_amdgcn_s_sleep(4);
     else __builtin_amdgcn_s_sleep(32);
@@ -51,7 +69,11 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
 }
 __device__ __forceinline__ void run_push(int32_t* ring, int32_t* tail, const int task) {
   const int pos = __hip_atomic_fetch_add(tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  run_st(ring + pos, task);
+  // (an exchange, not a store: about one factorization in a hundred stopped with up to fifteen neighbouring slots of
+  // the ring filled -- as the host read them afterwards -- and the workgroups polling those very slots, loads and
+  // read-modify-writes alike, seeing -1 for seconds: agent-scope STORES into a line that pollers on several XCDs keep
+  // touching did not reach the coherence point.  Read-modify-writes do: the counters and the heads / tails never erred.)
+  (void)__hip_atomic_exchange(ring + pos, task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // an input of ticket c exists now
 __device__ __forceinline__ void run_dec_ticket(const RunCtl& rc, const RunInfo* __restrict__ info, const int c) {
