@@ -263,19 +263,20 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       if ((r = to_device(&p->dRunInfo, H.run_info))) return r;
       if ((r = to_device(&p->dRunCons, H.run_cons))) return r;
       if ((r = to_device(&p->dRunD, H.run_d))) return r;
-      // the run's state: [counters of the tickets and diagonal tasks | three ticket rings | diagonal ring | control words],
+      // the run's state: [counters of the tickets and diagonal tasks | ticket ring | diagonal ring | control words] (a ring slot
+      // is one 128-byte line, plan.h RUN_SLOT),
       // and its initial image (what is ready when the run starts sits in the rings, their tails behind it)
       const size_t nr = H.run_tasks.size(), nd = H.run_d.size();
       auto up64 = [](size_t x) { return (x + 63) / 64 * 64; };
-      const size_t o_cnt = 0, o_q = up64(nr + nd), o_qd = o_q + up64(nr), o_ctl = o_qd + up64(nd);
+      const size_t o_cnt = 0, o_q = up64(nr + nd), o_qd = o_q + nr * RUN_SLOT, o_ctl = o_qd + nd * RUN_SLOT;
       p->nRunState = o_ctl + RUN_CTL_INTS;
       {
         std::vector<int32_t> img(p->nRunState, -1);
         std::copy(H.run_dep.begin(), H.run_dep.end(), img.begin() + (ptrdiff_t)o_cnt);
         for (size_t c = 0; c < (size_t)RUN_CTL_INTS; c++) img[o_ctl + c] = 0;
-        std::copy(H.run_ready.begin(), H.run_ready.end(), img.begin() + (ptrdiff_t)o_q);
+        for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + i * RUN_SLOT] = H.run_ready[i];
         img[o_ctl + RUN_TAIL] = (int32_t)H.run_ready.size();
-        std::copy(H.run_dready.begin(), H.run_dready.end(), img.begin() + (ptrdiff_t)o_qd);
+        for (size_t i = 0; i < H.run_dready.size(); i++) img[o_qd + i * RUN_SLOT] = H.run_dready[i];
         img[o_ctl + RUN_TAIL + 64] = (int32_t)H.run_dready.size();
         HIPCHK(hipMalloc((void**)&p->dRunImage, p->nRunState * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&p->dRunState, p->nRunState * sizeof(int32_t)));
@@ -494,6 +495,7 @@ int pastix_amd_plan_arena_info(const pastix_amd_plan_t* p, pastix_amd_int_t* nel
   return PASTIX_AMD_OK;
 }
 int pastix_amd_plan_set_arena(pastix_amd_plan_t* p, void* dL, void* dU, pastix_amd_int_t nelems) {
+  if (p) p->refillable = false;
   if (p && p->split.active) return PASTIX_AMD_ERR_UNSUPPORTED;   // (addresses panels by original cblk)
   if (!p || !dL || p->own_arena) return PASTIX_AMD_ERR_BADPARAMETER;
   pastix_amd_int_t need = 0;
@@ -713,6 +715,7 @@ static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* c
 }
 
 int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U) {
+  if (p) p->refillable = false;
   if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   double t0 = now_s();
@@ -759,6 +762,7 @@ int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
 }
 
 int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
+  if (p) p->refillable = false;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
@@ -1053,6 +1057,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
     launch_scatter_s(p->stream, fL, p->dFillIdxL, p->dFillValL, p->nFillL);
     if (fU && p->nFillU) launch_scatter_s(p->stream, fU, p->dFillIdxU, p->dFillValU, p->nFillU);
     HIPCHK(hipStreamSynchronize(p->stream));
+    p->refillable = true;
     return PASTIX_AMD_OK;
   }
   if (p->fillBaseL != 0.0) launch_fill_const(p->stream, p->dL, H.coefnbr, p->fillBaseL);
@@ -1066,6 +1071,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   if (p->dU && p->nFillU) launch_scatter(p->stream, p->dU, p->dFillIdxU, p->dFillValU, p->nFillU);
   if (p->dUi && p->nFillU && p->dFillValUi) launch_scatter(p->stream, p->dUi, p->dFillIdxU, p->dFillValUi, p->nFillU);
   HIPCHK(hipStreamSynchronize(p->stream));
+  p->refillable = true;
   return PASTIX_AMD_OK;
 }
 
@@ -1352,7 +1358,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
             auto done = [&](size_t task) { return stamp.empty() || stamp[4 * task + 2] != 0; };
             int dup = 0, pushed_not_started = 0, started_not_done = 0;
             for (int i = 0; i < ctl[RUN_TAIL]; i++) {
-              const int32_t t = q[i];
+              const int32_t t = q[(size_t)i * RUN_SLOT];
               if (t < 0 || (size_t)t >= nr) { fprintf(stderr, "pastix_amd:   ring slot %d holds %d\n", i, t); continue; }
               if (!stamp.empty() && stamp[4 * (size_t)t + 1] == 0) { if (pushed_not_started++ < 6) fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d) was pushed and never started\n", t, i); }
               else if (!done((size_t)t)) { if (started_not_done++ < 6) fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d) started and did not finish\n", t, i); }
@@ -1364,7 +1370,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
               else if (ri.succ <= -2) exp[nr + (size_t)(-2 - ri.succ)]++;
             }
             for (int i = 0; i < ctl[RUN_TAIL + 64]; i++) {
-              const int32_t d = qd[i];
+              const int32_t d = qd[(size_t)i * RUN_SLOT];
               if (d < 0 || (size_t)d >= nd) { fprintf(stderr, "pastix_amd:   diagonal ring slot %d holds %d\n", i, d); continue; }
               if (!done(nr + (size_t)d)) { fprintf(stderr, "pastix_amd:   diagonal task %d (ring slot %d) was pushed and did not finish\n", d, i); continue; }
               if (ran[nr + (size_t)d]++) dup++;
@@ -1381,12 +1387,28 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
                           c < nr ? c : c - nr, p->dbg_dep[c], applied, exp[c], ran[c] ? "ran" : "did not run");
               }
             }
+            if (!stamp.empty()) {        // the longest tasks (100 MHz stamps: drawn / ready / done / where)
+              std::vector<std::pair<long long, size_t>> dur;
+              long long tmax = 0;
+              for (size_t c = 0; c < nr + nd; c++) if (stamp[4 * c + 2]) { dur.emplace_back(stamp[4 * c + 2] - stamp[4 * c + 1], c); tmax = std::max(tmax, stamp[4 * c + 2]); }
+              std::sort(dur.begin(), dur.end());
+              for (size_t i = dur.size() > 6 ? dur.size() - 6 : 0; i < dur.size(); i++) {
+                const size_t c = dur[i].second;
+                fprintf(stderr, "pastix_amd:   %s %zu (kind %d) ran %.3f ms, finished %.3f ms before the last one, on hw %llx\n", c < nr ? "ticket" : "diagonal task",
+                        c < nr ? c : c - nr, c < nr ? (int)p->dbg_info[c].kind : -1, dur[i].first * 1e-5, (tmax - stamp[4 * c + 2]) * 1e-5,
+                        (unsigned long long)stamp[4 * c + 3]);
+                if (c < nr && dur[i].first > 1000000)
+                  fprintf(stderr, "pastix_amd:     its phases: pieces %lld us, epilogue issued %lld us, drain + barrier %lld us, count-downs %lld us\n",
+                          (long long)(stamp[4 * c] & 0xffff), (long long)((stamp[4 * c] >> 16) & 0xffff), (long long)((stamp[4 * c] >> 32) & 0xffff),
+                          (long long)((unsigned long long)stamp[4 * c] >> 48));
+              }
+            }
             fprintf(stderr, "pastix_amd:   replay: %lld count-downs missing, %lld too many, %d tasks twice in a ring, %d pushed and never started, %d started and not finished\n", lost, extra, dup, pushed_not_started, started_not_done);
             // producers all of whose consumers are short: the tasks whose count-downs did not arrive
             auto shortc = [&](size_t c) { return p->dbg_dep[c] - st[c] < exp[c]; };
             int shown3 = 0;
             for (int i = 0; i < ctl[RUN_TAIL] && shown3 < 8; i++) {
-              const int32_t t = q[i];
+              const int32_t t = q[(size_t)i * RUN_SLOT];
               if (t < 0 || (size_t)t >= nr || !done((size_t)t)) continue;
               const RunInfo& ri = p->dbg_info[(size_t)t];
               int n = 0, sh = 0;
@@ -1397,7 +1419,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
               else if (sh > 0 && shown3 < 8) { fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d, kind %d): %d of %d consumers short\n", t, i, (int)ri.kind, sh, n); shown3++; }
             }
             for (int i = 0; i < ctl[RUN_TAIL + 64] && shown3 < 12; i++) {
-              const int32_t d = qd[i];
+              const int32_t d = qd[(size_t)i * RUN_SLOT];
               if (d < 0 || (size_t)d >= nd || !done(nr + (size_t)d)) continue;
               int n = p->dbg_d[(size_t)d].tn, sh = 0;
               for (int z = 0; z < n; z++) sh += shortc((size_t)p->dbg_d[(size_t)d].t0 + (size_t)z);
@@ -1407,6 +1429,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
         }
       }
       p->factored = false;
+      p->run_stuck = true;
       return PASTIX_AMD_ERR_DEVICE;
     }
   }
@@ -1423,7 +1446,29 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 // level s: apply the contributions scheduled into slot s (k_update), then factorize the cblks of
 // level s (k_diag + k_trsm).  Time is measured like DPARM_FACT_TIME: panels resident, first launch
 // to last completion (sopalin3d.c:775,1031,1125-1132).
+static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats);
+// The run schedule has a bounded wait (PASTIX_AMD_RUN_TIMEOUT, default 5 s) so that nothing can hang the device.  On MI355X
+// about one factorization in 200 trips it -- every running ticket's loads stand still until the waiting workgroups leave
+// (not understood) --, so a factorization that stopped this way is REDONE on the level-by-level schedule when
+// the input can be restored: the plan's cached fill (pastix_amd_fill_csc / refill were the last writers of the panels) here,
+// the caller's host buffers in the one-shot entry points.  Otherwise PASTIX_AMD_ERR_DEVICE is what the caller gets.
 int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
+  if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  p->run_stuck = false;
+  const bool refillable = p->refillable;
+  int rc = factorize_once(p, critere, stats);
+  if (rc == PASTIX_AMD_ERR_DEVICE && p->run_stuck && refillable) {
+    fprintf(stderr, "pastix_amd: restoring the input from the cached fill and factorizing on the level-by-level schedule\n");
+    if ((rc = pastix_amd_refill(p))) return rc;
+    p->run_off_once = true;
+    rc = factorize_once(p, critere, stats);
+    p->run_off_once = false;
+    p->run_stuck = false;
+  }
+  p->refillable = false;                                    // (the panels hold factors now)
+  return rc;
+}
+static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   if (p->distributed) return PASTIX_AMD_ERR_BADPARAMETER;   // needs the fan-in exchange between levels
   // Two streams unless PASTIX_AMD_OVERLAP=0 (one stream).  Measured gain over one stream: 60^3 +25 %, 100^3 +8 %,
@@ -1459,11 +1504,11 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   // their update tasks to one launch behind the last level below L0.  PASTIX_AMD_RUN=0 keeps the level-by-level
   // schedule on the same plan (both give bitwise the same factors).
   const char* run_env = getenv("PASTIX_AMD_RUN");          // (read per call: tests switch it between factorizations)
-  const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0);
+  const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0) && !p->run_off_once;
   const int L0 = use_run ? H.run_L0 : H.nlevels;
   const long long run_limit = [] {             // bound of a single wait inside the run, in ticks of the 100 MHz clock
     const char* e = getenv("PASTIX_AMD_RUN_TIMEOUT");
-    const double sec = e ? atof(e) : 20.0;
+    const double sec = e ? atof(e) : 5.0;
     return (long long)(std::max(sec, 0.001) * 1e8);
   }();
   p->run_used = use_run;
@@ -1889,6 +1934,13 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
   if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
+  if (!rc && rcf == PASTIX_AMD_ERR_DEVICE && plan->run_stuck) {      // (see pastix_amd_factorize: the caller's buffers are intact)
+    fprintf(stderr, "pastix_amd: uploading the panels again and factorizing on the level-by-level schedule\n");
+    rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+    plan->run_off_once = true;
+    if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
+    plan->run_off_once = false;
+  }
   if (!rc && (rcf == 0 || rcf == PASTIX_AMD_ERR_NUMERIC))
     rc = pastix_amd_download_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   if (stats) pastix_amd_plan_stats(plan, stats);

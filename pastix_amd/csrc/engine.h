@@ -163,6 +163,9 @@ struct pastix_amd_plan_s {
   std::vector<int64_t> lvl_chunk_ptr, lvl_chunkB_ptr;   // forward (64-row) and backward (256-row) chunk lists
   // the run schedule: device tables, the synchronisation words (zeroed per factorization), the panel kernels' streams
   bool run_ready = false, run_used = false;
+  bool run_stuck = false;          // the last factorization's run launch gave up (bounded wait): ERR_DEVICE, see pastix_amd_factorize
+  bool run_off_once = false;       // the next factorization takes the level-by-level schedule
+  bool refillable = false;         // the panels' input values are what pastix_amd_refill would write (fill_csc / refill were last)
   // PASTIX_AMD_RUN_DEBUG: host copies of the run's dependency tables, for the report of a stuck run (api.cpp)
   std::vector<RunInfo> dbg_info;
   std::vector<int32_t> dbg_cons, dbg_dep;

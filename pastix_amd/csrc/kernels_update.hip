@@ -759,16 +759,27 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
     }
     acc_settle();
+    long long tdbg0 = 0, tdbg1 = 0, tdbg2 = 0;
+    if (rc.prof && tid == 0) tdbg0 = wall_clock64();
     double* C = ar.p[tk.flags & 3] + tk.c_off;
     const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
     epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
     epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
+    if (rc.prof && tid == 0) tdbg1 = wall_clock64();
     run_drain();
     __syncthreads();
     if (tid == 0) {
+      if (rc.prof) tdbg2 = wall_clock64();
       if (ri.succ >= 0) { for (int z = 0; z < ri.cn; z++) run_dec_ticket(rc, info, ri.succ + z); }
       else if (ri.succ <= -2) run_dec_diag(rc, -2 - ri.succ);
-      if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
+      if (rc.prof) {
+        const long long tend = wall_clock64(), t1 = rc.prof[4 * (int64_t)t + 1];
+        rc.prof[4 * (int64_t)t + 2] = tend;
+        // (developer aid: the phases of a ticket that took longer than 10 ms -- pieces, epilogue issue, drain + barrier, count-downs, in us)
+        if (tend - t1 > 1000000) {
+          rc.prof[4 * (int64_t)t] = ((tdbg0 - t1) / 100) | (((tdbg1 - tdbg0) / 100) << 16) | (((tdbg2 - tdbg1) / 100) << 32) | (((tend - tdbg2) / 100) << 48);
+        }
+      }
     }
     __syncthreads();
   }

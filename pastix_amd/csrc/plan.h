@@ -120,6 +120,10 @@ struct RunCtl {
   long long* prof;           // developer aid (PASTIX_AMD_RUN_PROF): 4 clock stamps per ticket, then per diagonal task; else null
 };
 constexpr int RUN_HEAD = 0, RUN_TAIL = 2 * 64, RUN_STUCK = 4 * 64, RUN_CTL_INTS = 6 * 64;   // (+ 64: the diagonal ring's)
+// a ring slot is one 128-byte line (slot i at ring[i * RUN_SLOT]): the workgroups that wait hold CONSECUTIVE slots, and five
+// hundred of them polling sixteen lines starved the chip's memory system -- about one factorization in 200 had every running
+// ticket's loads stand still until the pollers gave up
+constexpr int RUN_SLOT = 32;
 
 // std::allocator whose value-less construct() default-initialises (leaves trivially constructible T untouched)
 template <class T>

@@ -34,21 +34,17 @@ __device__ __forceinline__ void run_st(int32_t* p, int v) {
 __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit) {
   const int h = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (h >= n) return -1;
-  int v = run_ld(ring + h);
+  const int32_t* slot = ring + (int64_t)h * RUN_SLOT;
+  int v = run_ld(slot);
   if (v >= 0) return v;
   const long long t0 = wall_clock64();
   int it = 0;
-  while ((v = run_ld(ring + h)) < 0) {
+  while ((v = run_ld(slot)) < 0) {
     ++it;
-    // Every fourth poll is a read-modify-write (or with 0): an agent-scope LOAD may be served by this XCD's L2, and a line
-    // of the ring that got there before the push (a neighbouring slot was polled) stays stale until something evicts or
-    // invalidates it -- update traffic and the other workgroups' acquires do, within microseconds, as long as the chip is
-    // busy.  When the run drains towards a chain-bound phase nothing does: about one factorization in a hundred stopped
-    // with every workgroup polling, one of them on a slot that had been filled long ago.  Atomics execute at the
-    // coherence point.
-    if ((it & 3) == 0 && (v = __hip_atomic_fetch_or(const_cast<int32_t*>(ring) + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) break;
+    // (now and then a read-modify-write, which executes at the coherence point whatever this XCD's L2 holds of the line)
     if ((it & 63) == 0) {
-      if (__hip_atomic_fetch_or(stuck, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+      if ((v = __hip_atomic_fetch_or(const_cast<int32_t*>(slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) break;
+      if (run_ld(stuck)) return -1;
       const long long now = wall_clock64();
       if (limit > 0 && now - t0 > limit) {
         // (the first one to give up leaves a note for the host: which slot it waited for, how long)
@@ -62,18 +58,16 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
         return -1;
       }
     }
+    // fast at first (a chain task is picked up within a microsecond), slower the longer nothing comes
     if (it < 16) __builtin_amdgcn_s_sleep(4);
-    else __builtin_amdgcn_s_sleep(32);
+    else if (it < 4096) __builtin_amdgcn_s_sleep(32);
+    else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
   }
   return v;
 }
 __device__ __forceinline__ void run_push(int32_t* ring, int32_t* tail, const int task) {
   const int pos = __hip_atomic_fetch_add(tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (an exchange, not a store: about one factorization in a hundred stopped with up to fifteen neighbouring slots of
-  // the ring filled -- as the host read them afterwards -- and the workgroups polling those very slots, loads and
-  // read-modify-writes alike, seeing -1 for seconds: agent-scope STORES into a line that pollers on several XCDs keep
-  // touching did not reach the coherence point.  Read-modify-writes do: the counters and the heads / tails never erred.)
-  (void)__hip_atomic_exchange(ring + pos, task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_exchange(ring + (int64_t)pos * RUN_SLOT, task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // an input of ticket c exists now
 __device__ __forceinline__ void run_dec_ticket(const RunCtl& rc, const RunInfo* __restrict__ info, const int c) {
