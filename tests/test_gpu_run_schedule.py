@@ -118,6 +118,43 @@ def test_solve_after_a_run_factorization(run_env):
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-10
 
 
+def test_a_run_that_trips_its_bounded_wait_is_redone_on_the_level_schedule(run_env):
+    """PASTIX_AMD_RUN_TIMEOUT far below what the resident diagonal workers wait while the levels below the run are
+    factorized: the run gives up.  After fill_csc the library restores the input from the cached fill and redoes the
+    factorization on the level-by-level schedule -- the factors are bitwise those of PASTIX_AMD_RUN=0 and the plan reports
+    that no run launch was used; after an upload there is nothing to restore from and PASTIX_AMD_ERR_DEVICE is returned."""
+    N = 40
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    with Plan(s["cblk4"], s["blok4"], 0) as p:
+        run_env["PASTIX_AMD_RUN"] = "0"
+        p.fill_csc(1, n, cp, r, v, s["perm"])
+        L_in, _ = p.download()
+        p.factorize(1e-14)
+        L_level, _ = p.download()
+        run_env["PASTIX_AMD_RUN"] = "1"
+        p.refill()
+        st = p.factorize(1e-14)
+        assert st["run_tickets"] > 0                       # (this plan has a run, and it works)
+        L_run, _ = p.download()
+        assert np.array_equal(L_run, L_level)
+        run_env["PASTIX_AMD_RUN_TIMEOUT"] = "0.00001"      # 10 us (clamped to 1 ms inside; the diagonal workers: 3 ms)
+        p.refill()
+        st = p.factorize(1e-14)
+        L_back, _ = p.download()
+        assert np.array_equal(L_back, L_level)
+        assert st["run_time"] == 0.0                       # the second attempt was the level schedule
+        p.upload(L_in)
+        with pytest.raises(PastixAmdError) as e:
+            p.factorize(1e-14)
+        assert e.value.code == -3
+        run_env["PASTIX_AMD_RUN_TIMEOUT"] = "5"
+        p.refill()
+        p.factorize(1e-14)
+        assert np.array_equal(p.download()[0], L_level)
+
+
 def _lower_mask(c4):
     w = c4[:-1, 1] - c4[:-1, 0] + 1
     parts = []
