@@ -1447,7 +1447,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
 // level s (k_diag + k_trsm).  Time is measured like DPARM_FACT_TIME: panels resident, first launch
 // to last completion (sopalin3d.c:775,1031,1125-1132).
 static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats_t* stats);
-// The run schedule has a bounded wait (PASTIX_AMD_RUN_TIMEOUT, default 5 s) so that nothing can hang the device.  On MI355X
+// The run schedule has a bounded wait (PASTIX_AMD_RUN_TIMEOUT, default 1 s + 1 s per 1e14 flop) so that nothing can hang the device.  On MI355X
 // about one factorization in 200 trips it -- every running ticket's loads stand still until the waiting workgroups leave
 // (not understood) --, so a factorization that stopped this way is REDONE on the level-by-level schedule when
 // the input can be restored: the plan's cached fill (pastix_amd_fill_csc / refill were the last writers of the panels) here,
@@ -1506,9 +1506,12 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
   const char* run_env = getenv("PASTIX_AMD_RUN");          // (read per call: tests switch it between factorizations)
   const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0) && !p->run_off_once;
   const int L0 = use_run ? H.run_L0 : H.nlevels;
-  const long long run_limit = [] {             // bound of a single wait inside the run, in ticks of the 100 MHz clock
+  // bound of a single wait inside the run, in ticks of the 100 MHz clock.  Default: 1 s + 1 s per 1e14 flop of the
+  // factorization (100^3: 1.06 s, 160^3: 2.8 s) -- no ticket waits longer than the levels below the run take, and a
+  // factorization that trips the wait is redone (pastix_amd_factorize), so the wait is what the rare stop costs
+  const long long run_limit = [&] {
     const char* e = getenv("PASTIX_AMD_RUN_TIMEOUT");
-    const double sec = e ? atof(e) : 5.0;
+    const double sec = e ? atof(e) : 1.0 + H.fact_flops * 1e-14;
     return (long long)(std::max(sec, 0.001) * 1e8);
   }();
   p->run_used = use_run;
