@@ -373,7 +373,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   // system takes 0.4 s at 200^3: a thread of its own does it.)
   {
     struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks, rtasks; std::vector<RunInfo> rinfo; std::vector<int32_t> rwaits, rcons, rdep; std::vector<RunCheck> rchk; };
-    if (getenv("PASTIX_AMD_RUN_DEBUG") && H.run_L0 >= 0) { p->dbg_info = H.run_info; p->dbg_cons = H.run_cons; p->dbg_dep = H.run_dep; p->dbg_d = H.run_d; }
+    if (getenv("PASTIX_AMD_RUN_DEBUG") && H.run_L0 >= 0) { p->dbg_info = H.run_info; p->dbg_cons = H.run_cons; p->dbg_dep = H.run_dep; p->dbg_d = H.run_d; p->dbg_tasks = H.run_tasks; p->dbg_pieces.assign(H.pieces.begin(), H.pieces.end()); }
     Junk* junk = new (std::nothrow) Junk();
     if (junk) {
       junk->pieces.swap(H.pieces);
@@ -1392,11 +1392,21 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
               long long tmax = 0;
               for (size_t c = 0; c < nr + nd; c++) if (stamp[4 * c + 2]) { dur.emplace_back(stamp[4 * c + 2] - stamp[4 * c + 1], c); tmax = std::max(tmax, stamp[4 * c + 2]); }
               std::sort(dur.begin(), dur.end());
-              for (size_t i = dur.size() > 6 ? dur.size() - 6 : 0; i < dur.size(); i++) {
+              { size_t nlong = 0; for (auto& d2 : dur) nlong += d2.first > 1000000; fprintf(stderr, "pastix_amd:   %zu tasks took longer than 10 ms\n", nlong); }
+              for (size_t i = dur.size() > 12 ? dur.size() - 12 : 0; i < dur.size(); i++) {
                 const size_t c = dur[i].second;
                 fprintf(stderr, "pastix_amd:   %s %zu (kind %d) ran %.3f ms, finished %.3f ms before the last one, on hw %llx\n", c < nr ? "ticket" : "diagonal task",
                         c < nr ? c : c - nr, c < nr ? (int)p->dbg_info[c].kind : -1, dur[i].first * 1e-5, (tmax - stamp[4 * c + 2]) * 1e-5,
                         (unsigned long long)stamp[4 * c + 3]);
+                if (c < nr && dur[i].first > 1000000 && !(p->dbg_info[c].kind & 4) && !p->dbg_tasks.empty()) {
+                  const Task& tk = p->dbg_tasks[c];
+                  auto cblk_of = [&](int64_t off) { return (long long)(std::upper_bound(p->host.poff.begin(), p->host.poff.end(), off) - p->host.poff.begin() - 1); };
+                  const Piece& p0 = p->dbg_pieces[(size_t)tk.p0];
+                  const Piece& p1 = p->dbg_pieces[(size_t)tk.p0 + (size_t)tk.pn - 1];
+                  fprintf(stderr, "pastix_amd:     %d pieces, target cblk %lld (level %d), first source cblk %lld (level %d), last source cblk %lld (level %d); ready %.3f ms before the end\n",
+                          tk.pn, cblk_of(tk.c_off), (int)p->host.level[(size_t)cblk_of(tk.c_off)], cblk_of(p0.a_off), (int)p->host.level[(size_t)cblk_of(p0.a_off)],
+                          cblk_of(p1.a_off), (int)p->host.level[(size_t)cblk_of(p1.a_off)], (tmax - stamp[4 * c + 1]) * 1e-5);
+                }
                 if (c < nr && dur[i].first > 1000000)
                   fprintf(stderr, "pastix_amd:     its phases: pieces %lld us, epilogue issued %lld us, drain + barrier %lld us, count-downs %lld us\n",
                           (long long)(stamp[4 * c] & 0xffff), (long long)((stamp[4 * c] >> 16) & 0xffff), (long long)((stamp[4 * c] >> 32) & 0xffff),

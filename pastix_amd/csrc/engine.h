@@ -170,6 +170,8 @@ struct pastix_amd_plan_s {
   std::vector<RunInfo> dbg_info;
   std::vector<int32_t> dbg_cons, dbg_dep;
   std::vector<RunD> dbg_d;
+  std::vector<Task> dbg_tasks;
+  std::vector<Piece> dbg_pieces;
   Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunCons = nullptr;
   RunD* dRunD = nullptr;
   int32_t *dRunState = nullptr, *dRunImage = nullptr;   // the counters / rings / control words and their initial image
