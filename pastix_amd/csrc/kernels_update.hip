@@ -686,6 +686,9 @@ __device__ __forceinline__ void trsm_zsy_parked(const Arenas& ar, double* __rest
 // cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
 // the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
 // FT: 0 LLt, 1 LDLt, 2 LU, 3 complex LDLt, 4 complex LDLh (which panel solve a panel-solve ticket runs)
+#ifndef RUN_ROOM
+#define RUN_ROOM 72          // workgroups that leave rather than wait when everybody else already does (run_sync.h)
+#endif
 template <int FT>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     long long tdraw = 0;
     if (tid == 0) {
       if (rc.prof) tdraw = wall_clock64();
-      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, rc.nticket, rc.ctl + RUN_STUCK, limit);
+      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, rc.nticket, rc.ctl + RUN_STUCK, limit, (int)gridDim.x - RUN_ROOM);
       run_acquire();
     }
     __syncthreads();

@@ -31,7 +31,17 @@ __device__ __forceinline__ void run_st(int32_t* p, int v) {
 // there are exactly as many workgroups as tickets, so every reservation is served; a slot of the chip is idle only while
 // fewer tasks are ready than workgroups are waiting.  Returns -1 when the ring is used up or the run is stuck.
 // `limit` > 0 bounds the wait (100 MHz ticks; on expiry RUN_STUCK is raised), 0 = no bound of its own.
-__device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit) {
+// `maxwait` > 0: at most that many workgroups wait at a time -- one that would be the next leaves for good instead (returns
+// -1 without a reservation).  Workgroups that never end leave no room on the chip: waves the hardware scheduler has taken off
+// a CU (CWSR; it happens about once in 500 runs of 0.1 s, more often with more queues in flight) can only come back where
+// something has left, and until then their tickets stand still and everything behind them drains -- which is when the
+// waiting ones pile up and the surplus makes room.
+__device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit,
+                                       const int maxwait = 0) {
+  if (maxwait > 0) {
+    const int waiting = run_ld(head) - run_ld(head + (RUN_TAIL - RUN_HEAD));
+    if (waiting >= maxwait) return -1;
+  }
   const int h = __hip_atomic_fetch_add(head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (h >= n) return -1;
   const int32_t* slot = ring + (int64_t)h * RUN_SLOT;
