@@ -155,6 +155,33 @@ def test_a_run_that_trips_its_bounded_wait_is_redone_on_the_level_schedule(run_e
         assert np.array_equal(p.download()[0], L_level)
 
 
+@pytest.mark.parametrize("name", ["rlap3d_20_lu_bs128", "rlap3d_12_ldlt", "zrlap3d_20_ldlt_bs128", "zrlap3d_12_ldlh"])
+def test_the_way_back_restores_every_arena(name, golden, run_env):
+    """The same forced expiry for LU (two arenas), LDLt and complex LDLt / LDLh (Re / Im planes, the L D copies): the cached
+    fill restores every plane and the level schedule's factors come back."""
+    from pastix_amd import COMPLEXDOUBLE
+    g = golden(name)
+    cz = np.iscomplexobj(g["L0"])
+    kw = {"floattype": COMPLEXDOUBLE} if cz else {}
+    with Plan(g["cblk4"], g["blok4"], int(g["facto"]), run_max_cblks=100000, **kw) as p:
+        run_env["PASTIX_AMD_RUN"] = "0"
+        p.fill_csc(g["sym"], g["n"], g["colptr"], g["rows"], g["vals"], g["perm"])
+        p.factorize(g["critere"])
+        ref = p.download()
+        run_env["PASTIX_AMD_RUN"] = "1"
+        p.refill()
+        st = p.factorize(g["critere"])
+        assert st["run_tickets"] > 0
+        run_env["PASTIX_AMD_RUN_TIMEOUT"] = "0.00001"
+        p.refill()
+        st = p.factorize(g["critere"])
+        assert st["run_time"] == 0.0
+        back = p.download()
+    for a, b in zip(back, ref):
+        if a is not None:
+            assert np.array_equal(a, b)
+
+
 def _lower_mask(c4):
     w = c4[:-1, 1] - c4[:-1, 0] + 1
     parts = []
