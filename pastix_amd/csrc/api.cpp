@@ -268,16 +268,31 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       // and its initial image (what is ready when the run starts sits in the rings, their tails behind it)
       const size_t nr = H.run_tasks.size(), nd = H.run_d.size();
       auto up64 = [](size_t x) { return (x + 63) / 64 * 64; };
-      const size_t o_cnt = 0, o_q = up64(nr + nd), o_qd = o_q + nr * RUN_SLOT, o_ctl = o_qd + nd * RUN_SLOT;
+      const size_t o_cnt = 0, o_q = up64(nr + nd), o_qd = o_q + (nr + nd) * RUN_SLOT, o_ctl = o_qd + nd * RUN_SLOT;
       p->nRunState = o_ctl + RUN_CTL_INTS;
+      // one kernel (the diagonal tasks are tickets of k_run_update: real LLt / LDLt) unless PASTIX_AMD_RUN_ONEK=0
+      {
+        const char* er = getenv("PASTIX_AMD_RUN_ROOM");     // (developer switch; 72: see run_sync.h run_pop)
+        p->runctl.room = er ? atoi(er) : 72;
+        const char* e = getenv("PASTIX_AMD_RUN_ONEK");
+        p->runctl.onek = (!p->cplx && (H.factotype == PASTIX_AMD_FACT_LLT || H.factotype == PASTIX_AMD_FACT_LDLT) && !(e && atoi(e) == 0)) ? 1 : 0;
+      }
       {
         std::vector<int32_t> img(p->nRunState, -1);
         std::copy(H.run_dep.begin(), H.run_dep.end(), img.begin() + (ptrdiff_t)o_cnt);
         for (size_t c = 0; c < (size_t)RUN_CTL_INTS; c++) img[o_ctl + c] = 0;
-        for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + i * RUN_SLOT] = H.run_ready[i];
-        img[o_ctl + RUN_TAIL] = (int32_t)H.run_ready.size();
-        for (size_t i = 0; i < H.run_dready.size(); i++) img[o_qd + i * RUN_SLOT] = H.run_dready[i];
-        img[o_ctl + RUN_TAIL + 64] = (int32_t)H.run_dready.size();
+        if (p->runctl.onek) {
+          // (the diagonal tasks that are ready at the start come first: they head the chains)
+          size_t n = 0;
+          for (size_t i = 0; i < H.run_dready.size(); i++) img[o_q + (n++) * RUN_SLOT] = (int32_t)nr + H.run_dready[i];
+          for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + (n++) * RUN_SLOT] = H.run_ready[i];
+          img[o_ctl + RUN_TAIL] = (int32_t)n;
+        } else {
+          for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + i * RUN_SLOT] = H.run_ready[i];
+          img[o_ctl + RUN_TAIL] = (int32_t)H.run_ready.size();
+          for (size_t i = 0; i < H.run_dready.size(); i++) img[o_qd + i * RUN_SLOT] = H.run_dready[i];
+          img[o_ctl + RUN_TAIL + 64] = (int32_t)H.run_dready.size();
+        }
         HIPCHK(hipMalloc((void**)&p->dRunImage, p->nRunState * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&p->dRunState, p->nRunState * sizeof(int32_t)));
         HIPCHK(hipMemcpy(p->dRunImage, img.data(), p->nRunState * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1525,17 +1540,19 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
     return (long long)(std::max(sec, 0.001) * 1e8);
   }();
   p->run_used = use_run;
-  const int run_nwk = use_run ? H.run_gd : 0;
+  const int run_nwk = (use_run && !p->runctl.onek) ? H.run_gd : 0;
   if (use_run) {
     HIPCHK(hipMemcpyAsync(p->dRunState, p->dRunImage, p->nRunState * sizeof(int32_t), hipMemcpyDeviceToDevice, s1));
     if (p->dRunProf && getenv("PASTIX_AMD_RUN_DEBUG")) HIPCHK(hipMemsetAsync(p->dRunProf, 0, p->nRunProf * sizeof(long long), s1));
     *(volatile int*)p->hResident = 0;
     HIPCHK(hipEventRecord(p->evZ, s1));
-    HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));
+    if (!p->runctl.onek) HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));
     HIPCHK(hipStreamWaitEvent(s2, p->evZ, 0));
-    launch_run_panel(p->stream3, H.factotype, p->arenas(), p->dRunD, p->dRunInfo, H.run_gd, p->dDinv, critere, p->dNbpivot,
-                     p->dErr, p->runctl, p->hResident, run_limit);
-    HIPCHK(hipEventRecord(p->evS3, p->stream3));
+    if (!p->runctl.onek) {
+      launch_run_panel(p->stream3, H.factotype, p->arenas(), p->dRunD, p->dRunInfo, H.run_gd, p->dDinv, critere, p->dNbpivot,
+                       p->dErr, p->runctl, p->hResident, run_limit);
+      HIPCHK(hipEventRecord(p->evS3, p->stream3));
+    }
   }
   for (int l = 0; l < L0; l++) {
     const int64_t t0 = H.slot_task_ptr[l], tu = H.slot_urgent_end[l], t1 = H.slot_task_ptr[l + 1];
@@ -1580,11 +1597,11 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
     }
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
     launch_run_update(s2, H.factotype, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunCons, p->runctl, p->dDinv,
-                      p->run_nticket, p->run_nwg, run_limit);
+                      p->run_nticket, p->run_nwg, run_limit, p->dRunD, critere, p->dNbpivot, p->dErr);
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run + 1], s2));
     p->nupdB_run++;
     s2_used = true;
-    HIPCHK(hipStreamWaitEvent(s1, p->evS3, 0));
+    if (!p->runctl.onek) HIPCHK(hipStreamWaitEvent(s1, p->evS3, 0));
   }
   if (s2_used) {
     HIPCHK(hipEventRecord(p->evB[0], s2));

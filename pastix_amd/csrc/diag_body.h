@@ -1,0 +1,377 @@
+// diag_body.h -- device-only: the diagonal-blok factorizations (real LLt / LDLt, w <= 128, packed lower triangle resident in
+// LDS) as device functions: the bodies of k_diag_llt_w / k_diag_ldlt_w (kernels.hip) and of the diagonal tickets of the run
+// launch (kernels_update.hip k_run_update).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plan.h"
+#include "devmath.h"
+#include "run_sync.h"
+
+namespace pastix_amd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// k_diag_llt_w : the diagonal-blok factorization for w <= 128 with the blok resident in LDS (the global-memory
+// version above spends ~170 us per 128-wide blok on dependent L2 accesses; this is the latency-critical kernel
+// of every level).  Per 16-column block step:
+//   (A) wave 0 factors the 16x16 tile in registers, row i in lane i, columns broadcast with v_readlane
+//       (no barrier per column), and keeps the rows for (B');
+//   (B) waves 1-3: thread-per-row solve of the rows below against the tile (in LDS);
+//   (B') wave 0, meanwhile: the tile's inverse for k_trsm, again from registers;
+//   (C) all waves: trailing update of the resident blok on the MFMA pipe, 16x16 tiles of the lower part.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), srclane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// D: lower triangle of the blok, packed by columns (66 KB of LDS): with the 132 KB of a full square the workgroup could
+// only start on an EMPTY CU, i.e. never while a k_update launch of the other stream keeps the chip full; this
+// size fits beside one k_update workgroup.  Entries outside the w x w part are zero.  Ri: reciprocals of the tile's
+// diagonal (two tiles: wave 1 inverts the previous tile while wave 0 factorizes the next one).
+// COH: the results are stored write-through (the run launch, run_sync.h).
+constexpr int DIAG_LDS_DOUBLES = 128 * 129 / 2;
+template <bool COH>
+__device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double* __restrict__ Wl, double* __restrict__ L,
+                                              const PanelTask& tk, double* __restrict__ dinv_ws, const double critere,
+                                              long long* __restrict__ nbpivot, int* __restrict__ errflag, const int tid) {
+#define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  {
+    // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
+    // the kernel must stay within 128 VGPRs -- a workgroup on the panel stream only gets a slot beside a running bulk
+    // launch if its waves fit the 128-register holes a retiring k_update workgroup leaves)
+    // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
+    // the compiler honour the 128-register bound)
+    const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
+    const int w16 = (w + 15) & ~15;                       // (nothing reads LDS rows or columns beyond the last 16-band of w:
+                                                          // narrow cblks -- the leaf levels have thousands -- skip the rest)
+    for (int c0 = 0; c0 < w16; c0 += 64) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        if (c0 + 4 * q >= w16) break;
+        const int c = min(c0 + ch + 4 * q, w - 1);
+        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (c0 + 4 * q >= w16) break;
+        const int c = c0 + ch + 4 * q;
+        if (c <= r && r < w16) DP(c, r) = (r < w) ? v[q] : 0.0;
+      }
+    }
+  }
+#ifdef DIAG_PROFILE
+  long long st[6] = {0, 0, 0, 0, 0, 0};
+  long long t_prev = __builtin_readcyclecounter();
+#define STAMP(i) { __syncthreads(); long long t_now = __builtin_readcyclecounter(); st[i] += t_now - t_prev; t_prev = t_now; }
+#else
+#define STAMP(i)
+#endif
+  STAMP(0)
+  int npiv = 0;
+  bool bad = false;
+  const double cmin = fmax(critere, 2.2250738585072014e-308);   // pivots >= cmin take the short path
+  // One 16 x 16 tile of the trailing update A22 -= X X^T (SYRK "L","N", compute_diag.c:197-200), X = columns kb .. kb+15:
+  // MFMA "i" = column, "j" = row as in k_update; rows beyond w are zeros.
+  auto syrk_tile = [&](const int kb, const int rb, const int cb) {
+    d4 c;
+    const int row = rb + l15;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      c[q] = (row >= col) ? DP(col, row) : 0.0;              // (diagonal tiles: the upper part is not stored)
+    }
+    double xc[4], xr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      xc[ks] = DP(kb + 4 * ks + g, cb + l15);
+      xr[ks] = DP(kb + 4 * ks + g, rb + l15);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc[ks], xr[ks], c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      if (row >= col) DP(col, row) = c[q];
+    }
+  };
+  // Per 16-column step kb:
+  //   (S1) wave 0 factorizes the 16 x 16 tile in registers, held as the MFMA accumulator holds it -- lane (l15, g),
+  //        register q = entry (row l15, column g + 4q) -- so that the rank-1 update of column j, a(r, c) -= l(r, j) l(c, j),
+  //        is ONE v_mfma_f64_16x16x4: both operands are column j itself, which sits in register j / 4 of lane group j % 4,
+  //        exactly where k-slice j % 4 of an operand is read (the other three slices are zeros).  No barrier, no LDS and no
+  //        scalar broadcast but the pivot's inside the tile (PASTIX_potrf, compute_diag.c:124-153: the same products
+  //        subtracted in the same order).  Beside it, off the chain, the transpose W of the tile's inverse (W = I; column
+  //        j scaled; W(:, i) -= W(:, j) l(i, j)): a second MFMA per column.  W goes to k_trsm AND to LDS for (S2).
+  //        Meanwhile waves 1-7 finish the PREVIOUS step's trailing update (S3b: the tiles right of its first column band).
+  //   (S2) the rows below the tile, 16 per wave: X = A21 W (TRSM "R","L","T","N", compute_diag.c:191-195, as the product
+  //        with the tile's inverse -- what k_trsm does with every blok below): 4 MFMAs.
+  //   (S3a) the first column band of the trailing update (what the next tile and its rows need), one tile per wave.
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    __syncthreads();
+    if (wave == 0) {
+      // (the wave issues in order and every instruction of a column sits between two pivots: the tile and the inverse are
+      // held NEGATED -- S = -T, V = -W -- so that the operands of the accumulating MFMA, -l(:, j) = S(:, j) / sqrt(d), need no
+      // second, negated copy, and the diagonal lane of the scaled column is -sqrt(d) itself)
+      d4 S, V;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        S[q] = (g + 4 * q <= l15) ? -DP(kb + g + 4 * q, kb + l15) : 0.0;
+        V[q] = (g + 4 * q == l15) ? -1.0 : 0.0;
+      }
+      unroll_for<0, 16>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
+        if (j < nb) {
+          // the chain of a column: pivot -> 1/sqrt -> scaled column -> MFMA; the inverse's column is issued behind the MFMA
+          const bool ing = (g == gj);
+          double d = -readlane_f64(S[qj], j + 16 * gj);
+          double y = __builtin_amdgcn_rsq(d);
+          if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere, d <= 0 or NaN: compute_diag.c:133-137
+            if (fabs(d) < critere) { d = critere; npiv++; }
+            if (!(d > 0.0)) bad = true;
+            y = __builtin_amdgcn_rsq(d);
+            S[qj] = (ing && l15 == j) ? -d : S[qj];
+          }
+          y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+          y = __builtin_fma(0.5 * y, __builtin_fma(-d * y, y, 1.0), y);
+          const double sm = S[qj] * y;                         // -l(:, j); on the diagonal lane -d / sqrt(d)
+          const double xm = (ing && l15 > j) ? sm : 0.0;       // below the diagonal, as the MFMA operand (both sides)
+          S[qj] = (ing && l15 >= j) ? sm : S[qj];              // (x(c) = 0 for c <= j: the MFMA leaves column j and the rows
+          if (j < 15) S = __builtin_amdgcn_mfma_f64_16x16x4f64(xm, xm, S, 0, 0, 0);       // above it alone)
+          __builtin_amdgcn_sched_barrier(0);
+          const double vm = ing ? V[qj] * y : 0.0;
+          V[qj] = ing ? vm : V[qj];
+          if (j < 15) V = __builtin_amdgcn_mfma_f64_16x16x4f64(xm, vm, V, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = g + 4 * q;
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = -S[q];
+        Wl[l15 * 16 + c] = -V[q];                              // W(k = l15, i = c) = inv(tile)(i, k)
+        pst<COH>(&dst[c + 16 * l15], -V[q]);
+      }
+    } else if (kb > 0) {
+      const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
+      const int ntile = nbd * (nbd - 1) / 2;
+      for (int t = wave - 1; t < ntile; t += 7) {
+        int bj = 1, rest = t;                                  // t -> (bi >= bj >= 1): column band bj holds nbd - bj tiles
+        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
+        syrk_tile(kb - 16, kb + (bj + rest) * 16, kb + bj * 16);
+      }
+    }
+    STAMP(1)
+    __syncthreads();
+    if (wave * 16 < rem) {
+      const int rbase = kb + 16 + 16 * wave;
+      d4 X = {0.0, 0.0, 0.0, 0.0};
+      double wa[4], ar[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        wa[ks] = Wl[(4 * ks + g) * 16 + l15];                  // inv(tile)(c = l15, k = 4 ks + g)
+        ar[ks] = DP(kb + 4 * ks + g, rbase + l15);             // A21(r = l15, k)
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], ar[ks], X, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (g + 4 * q < nb) DP(kb + g + 4 * q, rbase + l15) = X[q];
+    }
+    STAMP(2)
+    __syncthreads();
+    if (wave * 16 < rem) syrk_tile(kb, kb + nb + wave * 16, kb + nb);   // (S3a)
+    STAMP(3)
+  }
+  STAMP(4)
+  __syncthreads();
+  {
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c = ch; c < w; c += 4)
+      if (r < w && r >= c) pst<COH>(&A[r + (int64_t)c * ld], DP(c, r));
+  }
+  STAMP(5)
+#ifdef DIAG_PROFILE
+  if (tid == 0) for (int i = 0; i < 6; i++) dinv_ws[8192 + i] = (double)st[i];
+#endif
+  if (wave == 0 && lane == 0) {
+    if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+    if (bad) atomicOr(errflag, 1);
+  }
+#undef DP
+}
+
+// k_diag_ldlt_w : the same organisation for the LDLt diagonal blok (PASTIX_sytrf_block, compute_diag.c:262-307), w <= 128:
+// packed lower triangle resident in LDS, the 16 x 16 tile factorized by wave 0 in registers (unit L, D on the diagonal,
+// static-pivot clamp and the count of positive pivots for IPARM_INERTIA), rows below solved thread-per-row, trailing
+// update (L D) L^T on the MFMA pipe with L D formed on the fly from L and the tile's diagonal.
+// (D: the packed lower triangle in LDS as in diag_llt_body; Ri: reciprocals of the tile's diagonal, Dd: the diagonal itself;
+// COH: results stored write-through for the run launch)
+template <bool COH>
+__device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* __restrict__ S,
+                                               double* __restrict__ L, const PanelTask& tk, double* __restrict__ dinv_ws,
+                                               const double critere, long long* __restrict__ nbpivot, const int tid) {
+#define DP(c, r) D[(c) * 128 - (((c) * ((c) + 1)) >> 1) + (r)]
+  double* A = L + tk.off;
+  const int ld = tk.stride, w = tk.width;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  {
+    // blok -> LDS: thread = (row r, column parity); 16 columns per pass, loads issued before the stores.  (16, not 32:
+    // the kernel must stay within 128 VGPRs -- a workgroup on the panel stream only gets a slot beside a running bulk
+    // launch if its waves fit the 128-register holes a retiring k_update workgroup leaves)
+    // 512 threads (eight waves: with 66 KB of LDS two such workgroups per CU are four waves per SIMD, which is what lets
+    // the compiler honour the 128-register bound)
+    const int r = tid & 127, ch = tid >> 7;               // ch = 0..3
+    const int w16 = (w + 15) & ~15;                       // (nothing reads LDS rows or columns beyond the last 16-band of w:
+                                                          // narrow cblks -- the leaf levels have thousands -- skip the rest)
+    for (int c0 = 0; c0 < w16; c0 += 64) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
+        if (c0 + 4 * q >= w16) break;
+        const int c = min(c0 + ch + 4 * q, w - 1);
+        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (c0 + 4 * q >= w16) break;
+        const int c = c0 + ch + 4 * q;
+        if (c <= r && r < w16) DP(c, r) = (r < w) ? v[q] : 0.0;
+      }
+    }
+  }
+  int npiv = 0, npos = 0;
+  const double cmin = fmax(critere, 2.2250738585072014e-308);   // pivots >= cmin take the short path
+  // LDS scratch S: the diagonal of the tile (two halves: steps alternate), its reciprocals (ditto), the tile's inverse
+  double* const Dd = S, * const Ri = S + 32, * const Wl = S + 64;
+  // one 16 x 16 tile of A22 -= (L D) L^T (GEMM with the L D copy, compute_diag.c:299-304); MFMA "i" = column, "j" = row as
+  // in k_update; rows beyond w are zeros; L D is L times the tile's diagonal
+  auto gemm_tile = [&](const int kb, const int rb, const int cb) {
+    const double* Dk = Dd + ((kb >> 4) & 1) * 16;
+    d4 c;
+    const int row = rb + l15;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      c[q] = (row >= col) ? DP(col, row) : 0.0;              // (diagonal tiles: the upper part is not stored)
+    }
+    double xc[4], xr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      xc[ks] = DP(kb + 4 * ks + g, cb + l15);
+      xr[ks] = DP(kb + 4 * ks + g, rb + l15) * Dk[4 * ks + g];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc[ks], xr[ks], c, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int col = cb + g + 4 * q;
+      if (row >= col) DP(col, row) = c[q];
+    }
+  };
+  // The organisation of diag_llt_body: (S1) wave 0 factorizes the tile in the accumulator layout, one MFMA per column for
+  // a(r, c) -= (L D)(r, j) L(c, j) (PASTIX_sytrf, compute_diag.c:223-242) and one for the transposed inverse of the unit
+  // lower tile, while waves 1-7 finish the previous step's trailing update; (S2) rows below: (L D) = A21 W, L = (L D) / d
+  // (compute_diag.c:284-298); (S3a) the first column band of the trailing update.  The previous step's diagonal is still
+  // read by its (S3b) while wave 0 produces the next one: Dd / Ri alternate between two halves.
+  for (int kb = 0; kb < w; kb += 16) {
+    const int nb = min(16, w - kb), rem = w - kb - nb;
+    __syncthreads();
+    if (wave == 0) {
+      d4 S, V;                                                 // the tile and the inverse, negated (see diag_llt_body)
+      double* const Dk = Dd + ((kb >> 4) & 1) * 16, * const Rk = Ri + ((kb >> 4) & 1) * 16;
+      if (lane < 16) { Dk[lane] = 1.0; Rk[lane] = 1.0; }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        S[q] = (g + 4 * q <= l15) ? -DP(kb + g + 4 * q, kb + l15) : 0.0;
+        V[q] = (g + 4 * q == l15) ? -1.0 : 0.0;
+      }
+      unroll_for<0, 16>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
+        if (j < nb) {
+          const bool ing = (g == gj), below = ing && l15 > j;
+          double d = -readlane_f64(S[qj], j + 16 * gj);
+          double y = __builtin_amdgcn_rcp(d);
+          if (__builtin_expect(!(d >= cmin), 0)) {             // |d| < critere or d <= 0 (or NaN)
+            if (fabs(d) < critere) { d = critere; npiv++; }
+            if (d > 0.0) npos++;
+            y = __builtin_amdgcn_rcp(d);
+            S[qj] = (ing && l15 == j) ? -d : S[qj];
+          } else {
+            npos++;                                            // inertia (sopalin3d.c:1144-1160)
+          }
+          y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+          y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+          const double sy = S[qj] * y;                         // -L(:, j): (L D)(i, j) / d
+          const double am = below ? sy : 0.0, bm = below ? S[qj] : 0.0;   // -L(c, j) and -(L D)(r, j): a(r, c) -= (L D)(r, j) L(c, j)
+          S[qj] = below ? sy : S[qj];                          // unit L below the diagonal, -d stays on it
+          if (j < 15) S = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bm, S, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (lane == 0) { Dk[j] = d; Rk[j] = y; }
+          const double vm = ing ? V[qj] : 0.0;                 // (unit diagonal: the inverse's column is not scaled)
+          if (j < 15) V = __builtin_amdgcn_mfma_f64_16x16x4f64(am, vm, V, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      double* dst = dinv_ws + tk.dinv_off + (int64_t)(kb >> 4) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = g + 4 * q;
+        if (c <= l15 && c < nb) DP(kb + c, kb + l15) = -S[q];
+        Wl[l15 * 16 + c] = -V[q];
+        pst<COH>(&dst[c + 16 * l15], -V[q]);
+      }
+    } else if (kb > 0) {
+      const int remp = w - kb, nbd = (remp + 15) >> 4;       // (S3b) of step kb - 16: bands bj >= 1
+      const int ntile = nbd * (nbd - 1) / 2;
+      for (int t = wave - 1; t < ntile; t += 7) {
+        int bj = 1, rest = t;
+        while (rest >= nbd - bj) { rest -= nbd - bj; bj++; }
+        gemm_tile(kb - 16, kb + (bj + rest) * 16, kb + bj * 16);
+      }
+    }
+    __syncthreads();
+    if (wave * 16 < rem) {
+      const int rbase = kb + 16 + 16 * wave;
+      d4 X = {0.0, 0.0, 0.0, 0.0};
+      double wa[4], ar[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        wa[ks] = Wl[(4 * ks + g) * 16 + l15];
+        ar[ks] = DP(kb + 4 * ks + g, rbase + l15);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], ar[ks], X, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (g + 4 * q < nb) DP(kb + g + 4 * q, rbase + l15) = X[q] * Ri[((kb >> 4) & 1) * 16 + g + 4 * q];   // L = (L D) / d
+    }
+    __syncthreads();
+    if (wave * 16 < rem) gemm_tile(kb, kb + nb + wave * 16, kb + nb);   // (S3a)
+  }
+  __syncthreads();
+  {
+    const int r = tid & 127, ch = tid >> 7;
+    for (int c = ch; c < w; c += 4)
+      if (r < w && r >= c) pst<COH>(&A[r + (int64_t)c * ld], DP(c, r));
+  }
+  if (wave == 0 && lane == 0) {
+    if (npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
+    if (npos) atomicAdd((unsigned long long*)nbpivot + 1, (unsigned long long)npos);
+  }
+}
+#undef DP
+
+}  // namespace pastix_amd

@@ -20,7 +20,8 @@ void launch_update_small(hipStream_t s, const Arenas& ar, const Task* tasks, con
 // the run schedule (plan.h RunInfo): the update tasks of the thin levels in one launch, their panel tasks on resident
 // workgroups of two kernels on streams of their own
 void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit);
+                       const int32_t* cons, const RunCtl& rc, double* dinv, int64_t ntasks, int nwg, long long limit, const RunD* rd,
+                       double critere, long long* nbpivot, int* errflag);
 void launch_run_panel(hipStream_t sd, int factotype, const Arenas& ar, const RunD* rd, const RunInfo* info, int gd, double* dinv,
                       double critere, long long* nbpivot, int* errflag, const RunCtl& rc, int* resident, long long limit);
 void launch_diag_zsy(hipStream_t s, bool herm, const Arenas& ar, const PanelTask* tasks, int64_t n, double* dinv, double critere,

@@ -36,6 +36,7 @@
 #include "plan.h"
 #include "devmath.h"
 #include "run_sync.h"
+#include "diag_body.h"
 
 namespace pastix_amd {
 
@@ -686,17 +687,21 @@ __device__ __forceinline__ void trsm_zsy_parked(const Arenas& ar, double* __rest
 // cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
 // the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
 // FT: 0 LLt, 1 LDLt, 2 LU, 3 complex LDLt, 4 complex LDLh (which panel solve a panel-solve ticket runs)
-#ifndef RUN_ROOM
-#define RUN_ROOM 72          // workgroups that leave rather than wait when everybody else already does (run_sync.h)
-#endif
-template <int FT>
+// ONEK: the diagonal-blok tasks are tickets of this launch too (ring entries >= rc.nticket; plan.h RunCtl::onek) -- one
+// kernel, one queue, no second kernel that has to be resident beside this one.  The blok's packed lower triangle takes the
+// place of the operand buffers in LDS (66 of the 73.7 KB), the accumulation registers are idle in such a ticket.
+template <int FT, bool ONEK>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
                                                                const RunInfo* __restrict__ info,
                                                                const int32_t* __restrict__ cons, const RunCtl rc,
-                                                               const double* __restrict__ dinv, const long long limit) {
+                                                               double* __restrict__ dinv, const long long limit,
+                                                               const RunD* __restrict__ rd, const double critere,
+                                                               long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh), "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
+  const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
   for (;;) {
     // (the thread index is laundered per ticket: what is derived from it is recomputed, not kept in registers across the loop)
     int tid = threadIdx.x;
@@ -705,12 +710,38 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     long long tdraw = 0;
     if (tid == 0) {
       if (rc.prof) tdraw = wall_clock64();
-      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, rc.nticket, rc.ctl + RUN_STUCK, limit, (int)gridDim.x - RUN_ROOM);
+      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, nring, rc.ctl + RUN_STUCK, limit, (int)gridDim.x - rc.room);
       run_acquire();
     }
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(*tick);
     if (t < 0) return;                           // (every ticket is taken, or the run is stuck)
+    if constexpr (ONEK) {
+      if (t >= rc.nticket) {
+        // a diagonal-blok ticket: k_diag_llt_w / k_diag_ldlt_w's body on this workgroup, then the cblk's panel solves count down
+        __syncthreads();                         // (the ticket word in LDS is dead from here on)
+        __builtin_amdgcn_s_setprio(3);
+        const int di = t - rc.nticket;
+        const RunD d = rd[di];
+        long long tp = 0;
+        if (rc.prof && tid == 0) tp = wall_clock64();
+        double* const Dl = &sh[0][0][0];
+        if constexpr (FT == 0) diag_llt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, errflag, tid);
+        else diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
+        run_drain();
+        __syncthreads();
+        if (wave == 0) {
+          for (int i = lane; i < d.tn; i += 64) run_dec_ticket(rc, info, d.t0 + i);
+          if (rc.prof && lane == 0) {
+            long long* pr = rc.prof + 4 * (int64_t)t;
+            pr[0] = tdraw; pr[1] = tp; pr[2] = wall_clock64();
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        continue;
+      }
+    }
     const Task tk = tasks[t];
     const RunInfo ri = info[t];
     __syncthreads();                             // (the ticket word in LDS is dead from here on)
@@ -789,15 +820,18 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
 }
 
 void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
-                       const int32_t* cons, const RunCtl& rc, const double* dinv, int64_t ntasks, int nwg, long long limit) {
+                       const int32_t* cons, const RunCtl& rc, double* dinv, int64_t ntasks, int nwg, long long limit, const RunD* rd,
+                       double critere, long long* nbpivot, int* errflag) {
   if (ntasks <= 0) return;
-  const dim3 g((unsigned)std::min<int64_t>(ntasks, std::max(nwg, 1))), b(64 * UW);
+  const dim3 g((unsigned)std::min<int64_t>(ntasks + (rc.onek ? rc.nd : 0), std::max(nwg, 1))), b(64 * UW);
+#define PA_RUN(FT, ONEK) hipLaunchKernelGGL((k_run_update<FT, ONEK>), g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit, rd, critere, nbpivot, errflag)
   if (ar.p[2]) {                                   // complex double (split planes)
-    if (factotype == PASTIX_AMD_FACT_LDLH) hipLaunchKernelGGL(k_run_update<4>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
-    else hipLaunchKernelGGL(k_run_update<3>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
-  } else if (factotype == PASTIX_AMD_FACT_LLT) hipLaunchKernelGGL(k_run_update<0>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
-  else if (factotype == PASTIX_AMD_FACT_LDLT) hipLaunchKernelGGL(k_run_update<1>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
-  else hipLaunchKernelGGL(k_run_update<2>, g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit);
+    if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN(4, false);
+    else PA_RUN(3, false);
+  } else if (factotype == PASTIX_AMD_FACT_LLT) { if (rc.onek) PA_RUN(0, true); else PA_RUN(0, false); }
+  else if (factotype == PASTIX_AMD_FACT_LDLT) { if (rc.onek) PA_RUN(1, true); else PA_RUN(1, false); }
+  else PA_RUN(2, false);
+#undef PA_RUN
 }
 
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,

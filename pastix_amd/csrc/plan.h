@@ -117,6 +117,9 @@ struct RunCtl {
   int32_t* qd;               // ready ring of the diagonal tasks
   int32_t* ctl;              // heads, tails, the "stuck" flag: RUN_* below, one 256-byte line each
   int32_t nd, nticket;       // ring sizes
+  int32_t room;              // workgroups of the run launch that leave rather than wait when everybody else already waits (run_sync.h)
+  int32_t onek;              // 1: the diagonal tasks are tickets of k_run_update too -- a diagonal task d that becomes ready is
+                             // pushed into the TICKET ring as nticket + d (the ring has nticket + nd slots), no second kernel
   long long* prof;           // developer aid (PASTIX_AMD_RUN_PROF): 4 clock stamps per ticket, then per diagonal task; else null
 };
 constexpr int RUN_HEAD = 0, RUN_TAIL = 2 * 64, RUN_STUCK = 4 * 64, RUN_CTL_INTS = 6 * 64;   // (+ 64: the diagonal ring's)

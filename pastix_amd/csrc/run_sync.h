@@ -86,8 +86,10 @@ __device__ __forceinline__ void run_dec_ticket(const RunCtl& rc, const RunInfo* 
     run_push(rc.q, rc.ctl + RUN_TAIL, c);
 }
 __device__ __forceinline__ void run_dec_diag(const RunCtl& rc, const int d) {
-  if (__hip_atomic_fetch_add(rc.cnt + rc.nticket + d, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)
-    run_push(rc.qd, rc.ctl + RUN_TAIL + 64, d);
+  if (__hip_atomic_fetch_add(rc.cnt + rc.nticket + d, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+    if (rc.onek) run_push(rc.q, rc.ctl + RUN_TAIL, rc.nticket + d);
+    else run_push(rc.qd, rc.ctl + RUN_TAIL + 64, d);
+  }
 }
 // consumer side, after the pop: acquire + wait (the caller's barrier follows)
 __device__ __forceinline__ void run_acquire() {
