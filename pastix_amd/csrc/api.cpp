@@ -1,6 +1,7 @@
 // api.cpp -- the C ABI declared in include/pastix_amd.h: plan life cycle, panel transfers, the device
 // factorization driver (the GPU replacement of sopalin_thread / sopalin_smp, sopalin3d.c:666-1422).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <chrono>
 #include <cmath>
@@ -492,6 +493,7 @@ int pastix_amd_plan_fanin_add(pastix_amd_plan_t* p, pastix_amd_int_t cblk, const
   if (!p || !src || !rows || cblk < 0 || cblk >= p->host.cblknbr || nrows < 0) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (H.role[cblk] != 1 || p->cplx || p->f32 || !p->dL) return PASTIX_AMD_ERR_BADPARAMETER;
+  p->refillable = false;                                     // (the panels are no longer what pastix_amd_refill would write)
   HIPCHK(hipSetDevice(p->device));
   const int64_t w = H.cblk[cblk].lcolnum - H.cblk[cblk].fcolnum + 1;
   launch_fanin_add(p->stream, p->dL + H.poff[cblk], H.cblk[cblk].stride, (const double*)src, rows, nrows, w);
@@ -588,6 +590,7 @@ int pastix_amd_plan_stats(const pastix_amd_plan_t* p, pastix_amd_stats_t* stats)
 
 int pastix_amd_device_arenas(pastix_amd_plan_t* p, void** dL, void** dU) {
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
+  p->refillable = false;                                     // (the caller may write through these pointers)
   if (dL) *dL = p->dL;
   if (dU) *dU = p->dU;
   return PASTIX_AMD_OK;
@@ -1072,7 +1075,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
     launch_scatter_s(p->stream, fL, p->dFillIdxL, p->dFillValL, p->nFillL);
     if (fU && p->nFillU) launch_scatter_s(p->stream, fU, p->dFillIdxU, p->dFillValU, p->nFillU);
     HIPCHK(hipStreamSynchronize(p->stream));
-    p->refillable = true;
+    p->refillable = p->own_arena;                              // (an external arena is the caller's to write at any time)
     return PASTIX_AMD_OK;
   }
   if (p->fillBaseL != 0.0) launch_fill_const(p->stream, p->dL, H.coefnbr, p->fillBaseL);
@@ -1086,7 +1089,7 @@ int pastix_amd_refill(pastix_amd_plan_t* p) {
   if (p->dU && p->nFillU) launch_scatter(p->stream, p->dU, p->dFillIdxU, p->dFillValU, p->nFillU);
   if (p->dUi && p->nFillU && p->dFillValUi) launch_scatter(p->stream, p->dUi, p->dFillIdxU, p->dFillValUi, p->nFillU);
   HIPCHK(hipStreamSynchronize(p->stream));
-  p->refillable = true;
+  p->refillable = p->own_arena;
   return PASTIX_AMD_OK;
 }
 
@@ -1113,6 +1116,7 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   HIPCHK(hipMemsetAsync(p->dNbpivot, 0, 2 * sizeof(long long), s));
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
+  p->refillable = false;                                     // (from here on the panels are being overwritten)
   p->nupd_run = 0;
   p->run_used = false;
   p->launch_events = true;
@@ -1481,6 +1485,7 @@ int pastix_amd_factorize(pastix_amd_plan_t* p, double critere, pastix_amd_stats_
   if (!p) return PASTIX_AMD_ERR_BADPARAMETER;
   p->run_stuck = false;
   const bool refillable = p->refillable;
+  p->restorable = refillable || p->caller_restores;
   int rc = factorize_once(p, critere, stats);
   if (rc == PASTIX_AMD_ERR_DEVICE && p->run_stuck && refillable) {
     fprintf(stderr, "pastix_amd: restoring the input from the cached fill and factorizing on the level-by-level schedule\n");
@@ -1528,8 +1533,16 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
   // resident workgroups started NOW (streams 3 and 4: the chip is idle or about to be, they are placed at once and stay),
   // their update tasks to one launch behind the last level below L0.  PASTIX_AMD_RUN=0 keeps the level-by-level
   // schedule on the same plan (both give bitwise the same factors).
+  // Which factorizations take it: the ONE-kernel form (runctl.onek: every task of the run is a ticket of one launch on one
+  // queue; real LLt / LDLt) always -- its soak is in profiles/r05/soak_*.txt --; the two-kernel form (LU, complex: resident
+  // diagonal workers beside the tickets' launch), whose rare stop is not understood, only when a stopped
+  // factorization can be REDONE, i.e. when the input can be restored (`restorable`: the plan's cached fill or the one-shot
+  // entry's host buffers), or on request (options.run_schedule = 1, PASTIX_AMD_RUN=1): no caller sees PASTIX_AMD_ERR_DEVICE
+  // for a well-posed input because of the schedule.
   const char* run_env = getenv("PASTIX_AMD_RUN");          // (read per call: tests switch it between factorizations)
-  const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0) && !p->run_off_once;
+  const bool run_asked = H.opts.run_schedule == 1 || (run_env && atoi(run_env) == 1);
+  const bool use_run = p->run_ready && H.run_L0 >= 0 && !(run_env && atoi(run_env) == 0) && !p->run_off_once &&
+                       (p->runctl.onek || p->restorable || run_asked);
   const int L0 = use_run ? H.run_L0 : H.nlevels;
   // bound of a single wait inside the run, in ticks of the 100 MHz clock.  Default: 1 s + 1 s per 1e14 flop of the
   // factorization (100^3: 1.06 s, 160^3: 2.8 s) -- no ticket waits longer than the levels below the run take, and a
@@ -1592,8 +1605,11 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
         (void)hipStreamSynchronize(s2);
         (void)hipStreamSynchronize(p->stream3);
         (void)hipStreamSynchronize(s1);
+        p->run_stuck = true;                             // (pastix_amd_factorize / the one-shot entries redo it level by level)
+        p->factored = false;
         return PASTIX_AMD_ERR_DEVICE;
       }
+      sched_yield();
     }
     if (tev) HIPCHK(hipEventRecord(p->evT[2 * p->nupdB_run], s2));
     launch_run_update(s2, H.factotype, p->arenas(), p->dRunTasks, p->dPieces, p->dRunInfo, p->dRunCons, p->runctl, p->dDinv,
@@ -1963,6 +1979,7 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   if (rc) return rc;
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
+  plan->caller_restores = true;                             // (a stopped run is redone below from the caller's buffers)
   if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
   if (!rc && rcf == PASTIX_AMD_ERR_DEVICE && plan->run_stuck) {      // (see pastix_amd_factorize: the caller's buffers are intact)
     fprintf(stderr, "pastix_amd: uploading the panels again and factorizing on the level-by-level schedule\n");

@@ -166,6 +166,8 @@ struct pastix_amd_plan_s {
   bool run_ready = false, run_used = false;
   bool run_stuck = false;          // the last factorization's run launch gave up (bounded wait): ERR_DEVICE, see pastix_amd_factorize
   bool run_off_once = false;       // the next factorization takes the level-by-level schedule
+  bool restorable = false;         // this factorization's input can be restored if the run stops (refillable, or the caller does it)
+  bool caller_restores = false;    // the one-shot entry points: the caller's host buffers still hold the input
   bool refillable = false;         // the panels' input values are what pastix_amd_refill would write (fill_csc / refill were last)
   // PASTIX_AMD_RUN_DEBUG: host copies of the run's dependency tables, for the report of a stuck run (api.cpp)
   std::vector<RunInfo> dbg_info;

@@ -699,7 +699,8 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
                                                                const RunD* __restrict__ rd, const double critere,
                                                                long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
-  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh), "the diagonal blok must fit the operand buffers");
+  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh) && sizeof(DiagLuLds) <= sizeof(sh),
+                "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
   for (;;) {
@@ -727,7 +728,8 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
         if (rc.prof && tid == 0) tp = wall_clock64();
         double* const Dl = &sh[0][0][0];
         if constexpr (FT == 0) diag_llt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, errflag, tid);
-        else diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
+        else if constexpr (FT == 1) diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
+        else diag_lu_body<true>(*reinterpret_cast<DiagLuLds*>(Dl), ar.p[0], ar.p[1], d.pt, dinv, critere, nbpivot, tid);
         run_drain();
         __syncthreads();
         if (wave == 0) {
@@ -830,7 +832,7 @@ void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Tas
     else PA_RUN(3, false);
   } else if (factotype == PASTIX_AMD_FACT_LLT) { if (rc.onek) PA_RUN(0, true); else PA_RUN(0, false); }
   else if (factotype == PASTIX_AMD_FACT_LDLT) { if (rc.onek) PA_RUN(1, true); else PA_RUN(1, false); }
-  else PA_RUN(2, false);
+  else { if (rc.onek) PA_RUN(2, true); else PA_RUN(2, false); }
 #undef PA_RUN
 }
 
