@@ -115,7 +115,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   if (!p) return PASTIX_AMD_ERR_ALLOC;
   int rc;
   double oflops = 0;
-  const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+  const bool ptime = dev_opt("plan_timing") != nullptr;
   double tph = now_s();
   auto phase = [&](const char* name) { if (ptime) { const double t = now_s(); fprintf(stderr, "[create] %-28s %.2f s\n", name, t - tph); tph = t; } };
   struct { std::thread th; int rc = 0, n = 0, device = 0; size_t bytes = 0; char* raw[4] = {nullptr, nullptr, nullptr, nullptr}; } pre;
@@ -273,10 +273,10 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       p->nRunState = o_ctl + RUN_CTL_INTS;
       // one kernel (the diagonal tasks are tickets of k_run_update: real LLt / LDLt) unless PASTIX_AMD_RUN_ONEK=0
       {
-        const char* er = getenv("PASTIX_AMD_RUN_ROOM");     // (developer switch; 72: see run_sync.h run_pop)
+        const char* er = dev_opt("room");                    // (72: see run_sync.h run_pop)
         p->runctl.room = er ? atoi(er) : 72;
-        const char* e = getenv("PASTIX_AMD_RUN_ONEK");
-        p->runctl.onek = (!p->cplx && (H.factotype == PASTIX_AMD_FACT_LLT || H.factotype == PASTIX_AMD_FACT_LDLT) && !(e && atoi(e) == 0)) ? 1 : 0;
+        const char* e = dev_opt("onek");
+        p->runctl.onek = !(e && atoi(e) == 0) ? 1 : 0;
       }
       {
         std::vector<int32_t> img(p->nRunState, -1);
@@ -318,7 +318,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       HIPCHK(hipEventCreateWithFlags(&p->evZ, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&p->evS3, hipEventDisableTiming));
       p->run_nticket = (int64_t)H.run_tasks.size();
-      if (getenv("PASTIX_AMD_RUN_PROF") || getenv("PASTIX_AMD_RUN_DEBUG")) {
+      if (dev_opt("run_prof") || dev_opt("run_debug")) {
         p->nRunProf = 4 * (H.run_tasks.size() + H.run_d.size());
         HIPCHK(hipMalloc((void**)&p->dRunProf, p->nRunProf * sizeof(long long)));
         HIPCHK(hipMemset(p->dRunProf, 0, p->nRunProf * sizeof(long long)));
@@ -348,7 +348,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   S.urgent_flops = H.urgent_flops;
   // developer aid (tools/replay_slot.hip): PASTIX_AMD_DUMP_SLOT=<slot>[:file] writes the bulk tasks of one launch slot
   // with their pieces, to replay that launch alone under different task orders / kernel variants
-  if (const char* ds = getenv("PASTIX_AMD_DUMP_SLOT")) {
+  if (const char* ds = dev_opt("dump_slot")) {
     const int sl = atoi(ds);
     const char* fn = strchr(ds, ':') ? strchr(ds, ':') + 1 : "/tmp/pastix_amd_slot.bin";
     if (sl >= 0 && sl < H.nlevels) {
@@ -389,7 +389,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
   // system takes 0.4 s at 200^3: a thread of its own does it.)
   {
     struct Junk { decltype(H.pieces) pieces; std::vector<Task> tasks, rtasks; std::vector<RunInfo> rinfo; std::vector<int32_t> rwaits, rcons, rdep; std::vector<RunCheck> rchk; };
-    if (getenv("PASTIX_AMD_RUN_DEBUG") && H.run_L0 >= 0) { p->dbg_info = H.run_info; p->dbg_cons = H.run_cons; p->dbg_dep = H.run_dep; p->dbg_d = H.run_d; p->dbg_tasks = H.run_tasks; p->dbg_pieces.assign(H.pieces.begin(), H.pieces.end()); }
+    if (dev_opt("run_debug") && H.run_L0 >= 0) { p->dbg_info = H.run_info; p->dbg_cons = H.run_cons; p->dbg_dep = H.run_dep; p->dbg_d = H.run_d; }
     Junk* junk = new (std::nothrow) Junk();
     if (junk) {
       junk->pieces.swap(H.pieces);
@@ -1331,7 +1331,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
   if (p->run_used && p->dRunProf) {
     // developer aid: [n update tickets, n diagonal tasks, n panel-solve tasks] then 4 stamps each (drawn, ready, done, 0),
     // 100 MHz ticks; tools/run_prof.py reads it
-    if (const char* fn = getenv("PASTIX_AMD_RUN_PROF")) {
+    if (const char* fn = dev_opt("run_prof")) {
       std::vector<long long> h(p->nRunProf);
       HIPCHK(hipMemcpy(h.data(), p->dRunProf, p->nRunProf * sizeof(long long), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(fn, "wb")) {
@@ -1350,113 +1350,7 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
     HIPCHK(hipMemcpy(&stuck, p->runctl.ctl + RUN_STUCK, sizeof(int), hipMemcpyDeviceToHost));
     if (stuck) {
       fprintf(stderr, "pastix_amd: a wait inside the run launch expired (PASTIX_AMD_RUN_TIMEOUT): the factorization failed\n");
-      {   // where it stopped: the rings' heads and tails, the tasks whose inputs never all arrived
-        std::vector<int32_t> st(p->nRunState);
-        if (hipMemcpy(st.data(), p->dRunState, p->nRunState * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess) {
-          const size_t nr = (size_t)p->runctl.nticket, nd = (size_t)p->runctl.nd;
-          const int32_t* ctl = st.data() + (p->runctl.ctl - p->dRunState);
-          size_t wt = 0, wd = 0;
-          for (size_t i = 0; i < nr; i++) wt += st[i] > 0;
-          for (size_t i = 0; i < nd; i++) wd += st[nr + i] > 0;
-          fprintf(stderr, "pastix_amd:   the first to give up waited for slot %d of a ring of %d for %d ms (limit %d ms, %d polls)\n",
-                  ctl[RUN_STUCK + 2], ctl[RUN_STUCK + 3], ctl[RUN_STUCK + 4], ctl[RUN_STUCK + 5], ctl[RUN_STUCK + 6]);
-          fprintf(stderr, "pastix_amd:   tickets %zu: popped %d, pushed %d, %zu never ready; diagonal tasks %zu: popped %d, pushed %d, %zu never ready;"
-                  " resident workers %d of %d\n", nr, ctl[RUN_HEAD], ctl[RUN_TAIL], wt, nd, ctl[RUN_HEAD + 64], ctl[RUN_TAIL + 64], wd,
-                  *(volatile int*)p->hResident, (int)p->host.run_gd);
-          int shown = 0;
-          for (size_t i = 0; i < nd && shown < 4; i++) if (st[nr + i] > 0) { fprintf(stderr, "pastix_amd:   diagonal task %zu waits for %d input(s)\n", i, st[nr + i]); shown++; }
-          shown = 0;
-          for (size_t i = 0; i < nr && shown < 6; i++) if (st[i] > 0) { fprintf(stderr, "pastix_amd:   ticket %zu waits for %d input(s)\n", i, st[i]); shown++; }
-          if (!p->dbg_info.empty()) {     // replay: what the tasks that ran should have counted down
-            const int32_t* q = st.data() + (p->runctl.q - p->dRunState);
-            const int32_t* qd = st.data() + (p->runctl.qd - p->dRunState);
-            std::vector<int32_t> exp(nr + nd, 0);
-            std::vector<uint8_t> ran(nr + nd, 0);
-            std::vector<long long> stamp;
-            if (p->dRunProf) { stamp.resize(p->nRunProf); (void)hipMemcpy(stamp.data(), p->dRunProf, p->nRunProf * sizeof(long long), hipMemcpyDeviceToHost); }
-            auto done = [&](size_t task) { return stamp.empty() || stamp[4 * task + 2] != 0; };
-            int dup = 0, pushed_not_started = 0, started_not_done = 0;
-            for (int i = 0; i < ctl[RUN_TAIL]; i++) {
-              const int32_t t = q[(size_t)i * RUN_SLOT];
-              if (t < 0 || (size_t)t >= nr) { fprintf(stderr, "pastix_amd:   ring slot %d holds %d\n", i, t); continue; }
-              if (!stamp.empty() && stamp[4 * (size_t)t + 1] == 0) { if (pushed_not_started++ < 6) fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d) was pushed and never started\n", t, i); }
-              else if (!done((size_t)t)) { if (started_not_done++ < 6) fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d) started and did not finish\n", t, i); }
-              if (!done((size_t)t)) continue;
-              if (ran[(size_t)t]++) dup++;
-              const RunInfo& ri = p->dbg_info[(size_t)t];
-              if (ri.kind & 4) { for (int z = 0; z < ri.cn; z++) exp[(size_t)p->dbg_cons[(size_t)ri.cptr + (size_t)z]]++; }
-              else if (ri.succ >= 0) { for (int z = 0; z < ri.cn; z++) exp[(size_t)ri.succ + (size_t)z]++; }
-              else if (ri.succ <= -2) exp[nr + (size_t)(-2 - ri.succ)]++;
-            }
-            for (int i = 0; i < ctl[RUN_TAIL + 64]; i++) {
-              const int32_t d = qd[(size_t)i * RUN_SLOT];
-              if (d < 0 || (size_t)d >= nd) { fprintf(stderr, "pastix_amd:   diagonal ring slot %d holds %d\n", i, d); continue; }
-              if (!done(nr + (size_t)d)) { fprintf(stderr, "pastix_amd:   diagonal task %d (ring slot %d) was pushed and did not finish\n", d, i); continue; }
-              if (ran[nr + (size_t)d]++) dup++;
-              for (int z = 0; z < p->dbg_d[(size_t)d].tn; z++) exp[(size_t)p->dbg_d[(size_t)d].t0 + (size_t)z]++;
-            }
-            long long lost = 0, extra = 0;
-            int shown2 = 0;
-            for (size_t c = 0; c < nr + nd; c++) {
-              const int applied = p->dbg_dep[c] - st[c];
-              if (applied != exp[c]) {
-                (applied < exp[c] ? lost : extra) += std::abs(exp[c] - applied);
-                if (shown2++ < 12)
-                  fprintf(stderr, "pastix_amd:   %s %zu: %d inputs, %d counted down, %d of its producers ran (it %s)\n", c < nr ? "ticket" : "diagonal task",
-                          c < nr ? c : c - nr, p->dbg_dep[c], applied, exp[c], ran[c] ? "ran" : "did not run");
-              }
-            }
-            if (!stamp.empty()) {        // the longest tasks (100 MHz stamps: drawn / ready / done / where)
-              std::vector<std::pair<long long, size_t>> dur;
-              long long tmax = 0;
-              for (size_t c = 0; c < nr + nd; c++) if (stamp[4 * c + 2]) { dur.emplace_back(stamp[4 * c + 2] - stamp[4 * c + 1], c); tmax = std::max(tmax, stamp[4 * c + 2]); }
-              std::sort(dur.begin(), dur.end());
-              { size_t nlong = 0; for (auto& d2 : dur) nlong += d2.first > 1000000; fprintf(stderr, "pastix_amd:   %zu tasks took longer than 10 ms\n", nlong); }
-              for (size_t i = dur.size() > 12 ? dur.size() - 12 : 0; i < dur.size(); i++) {
-                const size_t c = dur[i].second;
-                fprintf(stderr, "pastix_amd:   %s %zu (kind %d) ran %.3f ms, finished %.3f ms before the last one, on hw %llx\n", c < nr ? "ticket" : "diagonal task",
-                        c < nr ? c : c - nr, c < nr ? (int)p->dbg_info[c].kind : -1, dur[i].first * 1e-5, (tmax - stamp[4 * c + 2]) * 1e-5,
-                        (unsigned long long)stamp[4 * c + 3]);
-                if (c < nr && dur[i].first > 1000000 && !(p->dbg_info[c].kind & 4) && !p->dbg_tasks.empty()) {
-                  const Task& tk = p->dbg_tasks[c];
-                  auto cblk_of = [&](int64_t off) { return (long long)(std::upper_bound(p->host.poff.begin(), p->host.poff.end(), off) - p->host.poff.begin() - 1); };
-                  const Piece& p0 = p->dbg_pieces[(size_t)tk.p0];
-                  const Piece& p1 = p->dbg_pieces[(size_t)tk.p0 + (size_t)tk.pn - 1];
-                  fprintf(stderr, "pastix_amd:     %d pieces, target cblk %lld (level %d), first source cblk %lld (level %d), last source cblk %lld (level %d); ready %.3f ms before the end\n",
-                          tk.pn, cblk_of(tk.c_off), (int)p->host.level[(size_t)cblk_of(tk.c_off)], cblk_of(p0.a_off), (int)p->host.level[(size_t)cblk_of(p0.a_off)],
-                          cblk_of(p1.a_off), (int)p->host.level[(size_t)cblk_of(p1.a_off)], (tmax - stamp[4 * c + 1]) * 1e-5);
-                }
-                if (c < nr && dur[i].first > 1000000)
-                  fprintf(stderr, "pastix_amd:     its phases: pieces %lld us, epilogue issued %lld us, drain + barrier %lld us, count-downs %lld us\n",
-                          (long long)(stamp[4 * c] & 0xffff), (long long)((stamp[4 * c] >> 16) & 0xffff), (long long)((stamp[4 * c] >> 32) & 0xffff),
-                          (long long)((unsigned long long)stamp[4 * c] >> 48));
-              }
-            }
-            fprintf(stderr, "pastix_amd:   replay: %lld count-downs missing, %lld too many, %d tasks twice in a ring, %d pushed and never started, %d started and not finished\n", lost, extra, dup, pushed_not_started, started_not_done);
-            // producers all of whose consumers are short: the tasks whose count-downs did not arrive
-            auto shortc = [&](size_t c) { return p->dbg_dep[c] - st[c] < exp[c]; };
-            int shown3 = 0;
-            for (int i = 0; i < ctl[RUN_TAIL] && shown3 < 8; i++) {
-              const int32_t t = q[(size_t)i * RUN_SLOT];
-              if (t < 0 || (size_t)t >= nr || !done((size_t)t)) continue;
-              const RunInfo& ri = p->dbg_info[(size_t)t];
-              int n = 0, sh = 0;
-              if (ri.kind & 4) { for (int z = 0; z < ri.cn; z++) { n++; sh += shortc((size_t)p->dbg_cons[(size_t)ri.cptr + (size_t)z]); } }
-              else if (ri.succ >= 0) { for (int z = 0; z < ri.cn; z++) { n++; sh += shortc((size_t)ri.succ + (size_t)z); } }
-              else if (ri.succ <= -2) { n = 1; sh = shortc(nr + (size_t)(-2 - ri.succ)); }
-              if (n > 0 && sh == n) { fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d, kind %d, %d consumers): none of them counted it\n", t, i, (int)ri.kind, n); shown3++; }
-              else if (sh > 0 && shown3 < 8) { fprintf(stderr, "pastix_amd:   ticket %d (ring slot %d, kind %d): %d of %d consumers short\n", t, i, (int)ri.kind, sh, n); shown3++; }
-            }
-            for (int i = 0; i < ctl[RUN_TAIL + 64] && shown3 < 12; i++) {
-              const int32_t d = qd[(size_t)i * RUN_SLOT];
-              if (d < 0 || (size_t)d >= nd || !done(nr + (size_t)d)) continue;
-              int n = p->dbg_d[(size_t)d].tn, sh = 0;
-              for (int z = 0; z < n; z++) sh += shortc((size_t)p->dbg_d[(size_t)d].t0 + (size_t)z);
-              if (sh > 0) { fprintf(stderr, "pastix_amd:   diagonal task %d (ring slot %d): %d of %d consumers short\n", d, i, sh, n); shown3++; }
-            }
-          }
-        }
-      }
+      run_debug_report(p);                               // (run_debug.cpp: where it stopped; the full replay with PASTIX_AMD_DEV=run_debug)
       p->factored = false;
       p->run_stuck = true;
       return PASTIX_AMD_ERR_DEVICE;
@@ -1556,7 +1450,7 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
   const int run_nwk = (use_run && !p->runctl.onek) ? H.run_gd : 0;
   if (use_run) {
     HIPCHK(hipMemcpyAsync(p->dRunState, p->dRunImage, p->nRunState * sizeof(int32_t), hipMemcpyDeviceToDevice, s1));
-    if (p->dRunProf && getenv("PASTIX_AMD_RUN_DEBUG")) HIPCHK(hipMemsetAsync(p->dRunProf, 0, p->nRunProf * sizeof(long long), s1));
+    if (p->dRunProf && dev_opt("run_debug")) HIPCHK(hipMemsetAsync(p->dRunProf, 0, p->nRunProf * sizeof(long long), s1));
     *(volatile int*)p->hResident = 0;
     HIPCHK(hipEventRecord(p->evZ, s1));
     if (!p->runctl.onek) HIPCHK(hipStreamWaitEvent(p->stream3, p->evZ, 0));

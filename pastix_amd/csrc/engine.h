@@ -173,8 +173,6 @@ struct pastix_amd_plan_s {
   std::vector<RunInfo> dbg_info;
   std::vector<int32_t> dbg_cons, dbg_dep;
   std::vector<RunD> dbg_d;
-  std::vector<Task> dbg_tasks;
-  std::vector<Piece> dbg_pieces;
   Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunCons = nullptr;
   RunD* dRunD = nullptr;
   int32_t *dRunState = nullptr, *dRunImage = nullptr;   // the counters / rings / control words and their initial image
@@ -192,6 +190,8 @@ struct pastix_amd_plan_s {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   pastix_amd_stats_t stats{};
 };
+
+void run_debug_report(pastix_amd_plan_t* p);   // run_debug.cpp: what a stopped run looked like (developer aid)
 
 #define HIPCHK(x)                                                                        \
   do {                                                                                   \

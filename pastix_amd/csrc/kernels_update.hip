@@ -36,6 +36,7 @@
 #include "plan.h"
 #include "devmath.h"
 #include "run_sync.h"
+#include "acc_regs.h"
 #include "diag_body.h"
 
 namespace pastix_amd {
@@ -54,41 +55,6 @@ __device__ double g_zero_line[128];
 #define PASTIX_AMD_GLDS(gptr, lptr)                                                              \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-// ---- accumulators in a[0:63] ---------------------------------------------------------------------
-#define PA_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define PA_ACC_CLOBBER                                                                                           \
-  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", PA_A8(1), PA_A8(2), PA_A8(3), PA_A8(4), PA_A8(5), \
-      "a60", "a61", "a62", "a63"
-
-// sub-tile T = 4 mi + ni:  acc[T] += an (MFMA "A": target columns) x bm (MFMA "B": target rows)
-template <int T>
-__device__ __forceinline__ void acc_mfma(const double an, const double bm) {
-  asm volatile("v_mfma_f64_16x16x4_f64 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(an), "v"(bm), "n"(8 * T), "n"(8 * T + 7)
-               : PA_ACC_CLOBBER);
-}
-#define PA_Z4(i) "v_accvgpr_write_b32 a" #i "0, 0\n\tv_accvgpr_write_b32 a" #i "1, 0\n\tv_accvgpr_write_b32 a" #i "2, 0\n\tv_accvgpr_write_b32 a" #i "3, 0\n\t" \
-                 "v_accvgpr_write_b32 a" #i "4, 0\n\tv_accvgpr_write_b32 a" #i "5, 0\n\tv_accvgpr_write_b32 a" #i "6, 0\n\tv_accvgpr_write_b32 a" #i "7, 0\n\t" \
-                 "v_accvgpr_write_b32 a" #i "8, 0\n\tv_accvgpr_write_b32 a" #i "9, 0\n\t"
-__device__ __forceinline__ void acc_zero() {
-  asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\t"
-               "v_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\t"
-               "v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\t" PA_Z4(1) PA_Z4(2) PA_Z4(3) PA_Z4(4) PA_Z4(5)
-               "v_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\t"
-               "s_nop 7" ::: PA_ACC_CLOBBER);          // (v_accvgpr_write -> MFMA SrcC)
-}
-// every MFMA has retired its D before anything but an MFMA reads the accumulators (16-pass DGEMM: 19 states)
-__device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 7" ::: PA_ACC_CLOBBER); }
-// register q (0..3) of sub-tile T: rows l15 of band mi, column g + 4 q of band ni
-template <int T, int Q>
-__device__ __forceinline__ double acc_read() {
-  int lo, hi;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]"
-               : "=v"(lo), "=v"(hi)
-               : "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
-               : PA_ACC_CLOBBER);
-  return __hiloint2double(hi, lo);
-}
 
 // the MFMAs of one k-step for the sub-tiles RM (row bands, MI bits) x CM (col bands, NI bits) of this wave
 template <unsigned RM, unsigned CM>
@@ -400,30 +366,6 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
 // (With compiler-allocated tiles the routine needs 109 VGPRs beside the update path's 64 AGPRs: it spilled.)  The MFMAs
 // here work on VGPRs only, so the AGPR traffic is plain VALU moves without MFMA hazards.
 typedef double d4_t __attribute__((ext_vector_type(4)));
-// Wait states are ours on both sides of an asm statement (cdna_hip_programming.md 5.7 item 2): FRESH = the value was just
-// produced by an MFMA of the compiler's (its D must have retired before a VALU move reads it: the nops lead the string);
-// acc_read_m = the value feeds an MFMA of the compiler's next (VALU write -> MFMA operand: the nops end the string).
-template <int T, int Q, bool FRESH = false>
-__device__ __forceinline__ void acc_write(const double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  if constexpr (FRESH)
-    asm volatile("s_nop 15\n\ts_nop 7\n\tv_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(lo), "v"(hi),
-                 "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
-                 : PA_ACC_CLOBBER);
-  else
-    asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(lo), "v"(hi), "n"(8 * T + 2 * Q),
-                 "n"(8 * T + 2 * Q + 1)
-                 : PA_ACC_CLOBBER);
-}
-template <int T, int Q>
-__device__ __forceinline__ double acc_read_m() {
-  int lo, hi;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]\n\ts_nop 3"
-               : "=v"(lo), "=v"(hi)
-               : "n"(8 * T + 2 * Q), "n"(8 * T + 2 * Q + 1)
-               : PA_ACC_CLOBBER);
-  return __hiloint2double(hi, lo);
-}
 template <int N, class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -699,7 +641,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
                                                                const RunD* __restrict__ rd, const double critere,
                                                                long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
-  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh) && sizeof(DiagLuLds) <= sizeof(sh),
+  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh) && sizeof(DiagLuLds) <= sizeof(sh) && sizeof(DiagZLds) <= sizeof(sh),
                 "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
@@ -708,11 +650,19 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
-    long long tdraw = 0;
     if (tid == 0) {
-      if (rc.prof) tdraw = wall_clock64();
-      *tick = run_pop(rc.q, rc.ctl + RUN_HEAD, nring, rc.ctl + RUN_STUCK, limit, (int)gridDim.x - rc.room);
+      // (the stamps of the developer profile are written here, at once: nothing of them is live across the ticket)
+      const long long tdraw = rc.prof ? wall_clock64() : 0;
+      const int tk0 = run_pop(rc.q, rc.ctl + RUN_HEAD, nring, rc.ctl + RUN_STUCK, limit, (int)gridDim.x - rc.room);
+      *tick = tk0;
       run_acquire();
+      if (rc.prof && tk0 >= 0) {
+        rc.prof[4 * (int64_t)tk0] = tdraw;
+        rc.prof[4 * (int64_t)tk0 + 1] = wall_clock64();
+        unsigned hw, xcc;                        // which CU ran the ticket (tools/run_prof.py: idle time per CU)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        rc.prof[4 * (int64_t)tk0 + 3] = ((long long)(xcc & 0xf) << 32) | hw;
+      }
     }
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(*tick);
@@ -724,21 +674,19 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
         __builtin_amdgcn_s_setprio(3);
         const int di = t - rc.nticket;
         const RunD d = rd[di];
-        long long tp = 0;
-        if (rc.prof && tid == 0) tp = wall_clock64();
+        asm volatile(";;#PASTIX_AMD_DIAG_TICKET_BEGIN");   // (tests/test_kernel_audit.py: what lies between the two markers)
         double* const Dl = &sh[0][0][0];
         if constexpr (FT == 0) diag_llt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, errflag, tid);
         else if constexpr (FT == 1) diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
-        else diag_lu_body<true>(*reinterpret_cast<DiagLuLds*>(Dl), ar.p[0], ar.p[1], d.pt, dinv, critere, nbpivot, tid);
+        else if constexpr (FT == 2) diag_lu_body<true, true>(*reinterpret_cast<DiagLuLds*>(Dl), ar.p[0], ar.p[1], d.pt, dinv, critere, nbpivot, tid);
+        else diag_zsy_body<FT == 4, true, true>(*reinterpret_cast<DiagZLds*>(Dl), ar, d.pt, dinv, critere, nbpivot, tid);
         run_drain();
         __syncthreads();
         if (wave == 0) {
           for (int i = lane; i < d.tn; i += 64) run_dec_ticket(rc, info, d.t0 + i);
-          if (rc.prof && lane == 0) {
-            long long* pr = rc.prof + 4 * (int64_t)t;
-            pr[0] = tdraw; pr[1] = tp; pr[2] = wall_clock64();
-          }
+          if (rc.prof && lane == 0) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
         }
+        asm volatile(";;#PASTIX_AMD_DIAG_TICKET_END");
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         continue;
@@ -747,13 +695,6 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     const Task tk = tasks[t];
     const RunInfo ri = info[t];
     __syncthreads();                             // (the ticket word in LDS is dead from here on)
-    if (rc.prof && tid == 0) {
-      rc.prof[4 * (int64_t)t] = tdraw;
-      rc.prof[4 * (int64_t)t + 1] = wall_clock64();
-      unsigned hw, xcc;                          // which CU ran the ticket (tools/run_prof.py: idle time per CU)
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-      rc.prof[4 * (int64_t)t + 3] = ((long long)(xcc & 0xf) << 32) | hw;
-    }
     if (ri.kind & 4) {
       // a panel-solve ticket (the Task record holds a TrsmTask): 128 panel rows, a wave per 16
       TrsmTask tt;
@@ -795,27 +736,16 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
     }
     acc_settle();
-    long long tdbg0 = 0, tdbg1 = 0, tdbg2 = 0;
-    if (rc.prof && tid == 0) tdbg0 = wall_clock64();
     double* C = ar.p[tk.flags & 3] + tk.c_off;
     const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
     epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
     epilogue_band<1, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
-    if (rc.prof && tid == 0) tdbg1 = wall_clock64();
     run_drain();
     __syncthreads();
     if (tid == 0) {
-      if (rc.prof) tdbg2 = wall_clock64();
       if (ri.succ >= 0) { for (int z = 0; z < ri.cn; z++) run_dec_ticket(rc, info, ri.succ + z); }
       else if (ri.succ <= -2) run_dec_diag(rc, -2 - ri.succ);
-      if (rc.prof) {
-        const long long tend = wall_clock64(), t1 = rc.prof[4 * (int64_t)t + 1];
-        rc.prof[4 * (int64_t)t + 2] = tend;
-        // (developer aid: the phases of a ticket that took longer than 10 ms -- pieces, epilogue issue, drain + barrier, count-downs, in us)
-        if (tend - t1 > 1000000) {
-          rc.prof[4 * (int64_t)t] = ((tdbg0 - t1) / 100) | (((tdbg1 - tdbg0) / 100) << 16) | (((tdbg2 - tdbg1) / 100) << 32) | (((tend - tdbg2) / 100) << 48);
-        }
-      }
+      if (rc.prof) rc.prof[4 * (int64_t)t + 2] = wall_clock64();
     }
     __syncthreads();
   }
@@ -827,12 +757,14 @@ void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Tas
   if (ntasks <= 0) return;
   const dim3 g((unsigned)std::min<int64_t>(ntasks + (rc.onek ? rc.nd : 0), std::max(nwg, 1))), b(64 * UW);
 #define PA_RUN(FT, ONEK) hipLaunchKernelGGL((k_run_update<FT, ONEK>), g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit, rd, critere, nbpivot, errflag)
+#define PA_RUN2(FT) do { if (rc.onek) PA_RUN(FT, true); else PA_RUN(FT, false); } while (0)
   if (ar.p[2]) {                                   // complex double (split planes)
-    if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN(4, false);
-    else PA_RUN(3, false);
-  } else if (factotype == PASTIX_AMD_FACT_LLT) { if (rc.onek) PA_RUN(0, true); else PA_RUN(0, false); }
-  else if (factotype == PASTIX_AMD_FACT_LDLT) { if (rc.onek) PA_RUN(1, true); else PA_RUN(1, false); }
-  else { if (rc.onek) PA_RUN(2, true); else PA_RUN(2, false); }
+    if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN2(4);
+    else PA_RUN2(3);
+  } else if (factotype == PASTIX_AMD_FACT_LLT) PA_RUN2(0);
+  else if (factotype == PASTIX_AMD_FACT_LDLT) PA_RUN2(1);
+  else PA_RUN2(2);
+#undef PA_RUN2
 #undef PA_RUN
 }
 

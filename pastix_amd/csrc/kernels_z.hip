@@ -10,10 +10,10 @@
 #include "plan.h"
 #include "devmath.h"
 #include "run_sync.h"
+#include "diag_body.h"
 
 namespace pastix_amd {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct cz {
   double re, im;
@@ -617,257 +617,6 @@ __global__ void k_merge(double* __restrict__ z, const double* __restrict__ re, c
   for (; i < n; i += stride) { z[2 * i] = re[i]; z[2 * i + 1] = im[i]; }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_diag_zsy_w (round 4): the complex diagonal blok on the MFMA pipe.  The blok does not fit LDS twice (Re / Im planes:
-// 132 KB, and the workgroup must fit beside a k_update workgroup), so its 16 x 16 tiles live in REGISTERS, in the
-// accumulator layout of v_mfma_f64_16x16x4 -- lane (l15, g), register q = entry (row l15, column g + 4q) -- five tiles
-// (Re + Im: 80 VGPRs) per wave on waves 1-7; wave 0 carries the dependency chain.  Per 16-column step t:
-//   (S1) wave 0 factorizes the diagonal tile as diag_ldlt_body does (kernels.hip): tile and inverse held negated, one
-//        complex rank-1 update = four MFMAs whose operands are column j itself, the pivot's reciprocal and the scaled
-//        column on the vector pipe in between (PASTIX_sytrf / hetrf, compute_diag.c:223-242, :326-345); the transposed
-//        inverse of the unit-lower tile rides along (four more MFMAs per column).  Meanwhile waves 1-7 apply the PREVIOUS
-//        step's trailing update to their tiles right of the next column band (S3b).
-//   (S2) rows below the tile, one 16-row block per wave: (L D) = A21 inv(tile)^T|^H (16 MFMAs), L = (L D) / d
-//        (TRSM "R","L","T"|"C","U" + the scaling, compute_diag.c:284-298), to global memory and to LDS.
-//   (S3a) the trailing update of the next column band (one tile per wave), handed to wave 0 / the next (S2) through LDS.
-// LDS: the step's diagonal tile, its inverse, d and 1/d, the unsolved and the solved rows below (66.8 KB).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double zreadlane(double v, int srclane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-
-struct DiagZLds {
-  static constexpr int XR = 112;
-  double Ts[2][16][17];        // the step's diagonal tile [plane][row][column]
-  double Wl[2][256];           // inv(tile)^T [plane][k * 16 + i]
-  double Dd[2][2][16];         // the tile's diagonal [step parity][plane][column] (read by the next step's S3b too)
-  double Rr[2][16];            // its reciprocals [plane][column]
-  double Ps[2][16][XR];        // rows below the tile, unsolved [plane][column][row]
-  double Xs[2][16][XR];        // rows below the tile, solved: L [plane][column][row]
-};
-// (COH: results stored write-through -- the run launch hands the blok to other workgroups, run_sync.h)
-template <bool HERM, bool COH>
-__device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, const PanelTask& tk, double* __restrict__ dinv_ws,
-                                              const double critere, long long* __restrict__ nbpivot, const int tid) {
-  constexpr int NS = 5;
-  double* Ar = ar.p[0] + tk.off;
-  double* Ai = ar.p[2] + tk.off;
-  const int ld = tk.stride, w = tk.width;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const int nbt = (w + 15) >> 4;                             // 16-column steps
-  typedef double d4v __attribute__((ext_vector_type(4)));
-  // tiles (bi >= bj) but (0, 0), column by column: ids 0-6 (1..7, 0), 7-13 (1..7, 1), 14-19 (2..7, 2), ... 34 (7, 7);
-  // wave 1 + id % 7 holds tile id in slot id / 7 -- every column band is spread over the waves
-  d4v Cr[NS], Ci[NS];
-  int tbi[NS], tbj[NS];
-  if (wave > 0) {
-#pragma unroll
-    for (int sl = 0; sl < NS; sl++) {
-      int id = (wave - 1) + 7 * sl, bj = 0, cnt = 7;
-      if (id >= 14) { id -= 14; bj = 2; cnt = 6; while (id >= cnt) { id -= cnt; bj++; cnt--; } }
-      else if (id >= 7) { id -= 7; bj = 1; }
-      const int bi = (bj < 2 ? 1 : bj) + id;
-      const bool on = bi < nbt;
-      tbi[sl] = on ? bi : -1;
-      tbj[sl] = bj;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int row = 16 * bi + l15, col = 16 * bj + g + 4 * q;
-        const bool v = on && row < w && col < w && row >= col;
-        const int64_t o = (int64_t)min(row, w - 1) + (int64_t)min(col, w - 1) * ld;
-        const double re = Ar[o], im = Ai[o];
-        Cr[sl][q] = v ? re : 0.0;
-        Ci[sl][q] = v ? im : 0.0;
-      }
-      if (on && bj == 0) {                                   // the rows below the first tile go to LDS at once
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          S.Ps[0][g + 4 * q][16 * (bi - 1) + l15] = Cr[sl][q];
-          S.Ps[1][g + 4 * q][16 * (bi - 1) + l15] = Ci[sl][q];
-        }
-      }
-    }
-  }
-  // the trailing update of one resident tile with the solved rows of step tp (in Xs): C -= (L D)(rows) L(cols)^T|^H
-  auto update = [&](d4v& cr, d4v& ci, const int bi, const int bj, const int tp) {
-    const int ro = 16 * (bi - tp - 1) + l15, co = 16 * (bj - tp - 1) + l15;
-    const double (*Dk)[16] = S.Dd[tp & 1];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const int k = 4 * ks + g;
-      const double lr = S.Xs[0][k][co], li = S.Xs[1][k][co];                 // L(c, k)
-      const double xr = S.Xs[0][k][ro], xi = S.Xs[1][k][ro];                 // L(r, k)
-      const double dr = Dk[0][k], di = Dk[1][k];
-      if (!HERM) {
-        const double ldr = xr * dr - xi * di, ldi = xr * di + xi * dr;       // (L D)(r, k)
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-lr, ldr, cr, 0, 0, 0);
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(li, ldi, cr, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, ldr, ci, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-lr, ldi, ci, 0, 0, 0);
-      } else {
-        const double ldr = xr * dr, ldi = xi * dr;                           // L(r, k) Re d;  times conj(L(c, k))
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-lr, ldr, cr, 0, 0, 0);
-        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-li, ldi, cr, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-lr, ldi, ci, 0, 0, 0);
-        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(li, ldr, ci, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);                     // (one k-slice's operands at a time: 80 VGPRs are resident)
-    }
-  };
-  int npiv = 0;
-  const double c2 = critere * critere, cmin2 = fmax(c2, 2.2250738585072014e-308);
-  // (the two roles are separate loops with the same barriers: the resident tiles are not live in wave 0's code)
-  if (wave == 0) {
-    for (int t = 0; t < nbt; t++) {
-      const int kb = 16 * t, nb = min(16, w - kb);
-      __syncthreads();                                       // (A) Ts / Ps hold column band t
-      d4v Sr, Si, Vr, Vi;                                    // the tile and the inverse, negated (see diag_llt_body)
-      if (lane < 16) { S.Dd[t & 1][0][lane] = 1.0; S.Dd[t & 1][1][lane] = 0.0; S.Rr[0][lane] = 1.0; S.Rr[1][lane] = 0.0; }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = g + 4 * q;
-        double re, im;
-        if (t == 0) {
-          const int64_t o = (int64_t)min(l15, w - 1) + (int64_t)min(c, w - 1) * ld;
-          re = Ar[o]; im = Ai[o];
-          if (l15 >= w || c >= w) { re = 0.0; im = 0.0; }
-        } else {
-          re = S.Ts[0][l15][c]; im = S.Ts[1][l15][c];
-        }
-        Sr[q] = (c <= l15) ? -re : 0.0;
-        Si[q] = (c <= l15) ? -im : 0.0;
-        Vr[q] = (c == l15) ? -1.0 : 0.0;
-        Vi[q] = 0.0;
-      }
-      unroll_for<0, 16>([&](auto J) {
-        constexpr int j = decltype(J)::value, qj = j >> 2, gj = j & 3;
-        if (j < nb) {
-          const bool ing = (g == gj), below = ing && l15 > j;
-          double dr = -zreadlane(Sr[qj], j + 16 * gj);
-          double di = HERM ? 0.0 : -zreadlane(Si[qj], j + 16 * gj);
-          double m = HERM ? dr * dr : __builtin_fma(dr, dr, di * di);
-          double y = __builtin_amdgcn_rcp(m);
-          if (__builtin_expect(!(m >= cmin2), 0)) {            // |d| < critere (or NaN)
-            if (m < c2) { dr = critere; di = 0.0; npiv++; }
-            m = __builtin_fma(dr, dr, di * di);
-            y = __builtin_amdgcn_rcp(m);
-            Sr[qj] = (ing && l15 == j) ? -dr : Sr[qj];
-            Si[qj] = (ing && l15 == j) ? -di : Si[qj];
-          }
-          y = __builtin_fma(__builtin_fma(-m, y, 1.0), y, y);
-          y = __builtin_fma(__builtin_fma(-m, y, 1.0), y, y);
-          const double ivr = dr * y, ivi = -di * y;            // 1 / d
-          // -L(:, j) = S(:, j) / d
-          const double syr = HERM ? Sr[qj] * ivr : __builtin_fma(Sr[qj], ivr, -Si[qj] * ivi);
-          const double syi = HERM ? Si[qj] * ivr : __builtin_fma(Sr[qj], ivi, Si[qj] * ivr);
-          const double amr = below ? syr : 0.0, ami = below ? syi : 0.0, nami = -ami;
-          // sy: a(r, c) -= (L D)(r, j) L(c, j), with -(L D)(:, j) = S(:, j);  he: a(r, c) -= (L(r, j) Re d) conj(L(c, j))
-          const double bmr = below ? (HERM ? syr * dr : Sr[qj]) : 0.0, bmi = below ? (HERM ? syi * dr : Si[qj]) : 0.0;
-          Sr[qj] = below ? syr : Sr[qj];
-          Si[qj] = below ? syi : ((HERM && ing && l15 == j) ? 0.0 : Si[qj]);
-          if (j < 15) {
-            if (!HERM) {
-              Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, bmr, Sr, 0, 0, 0);
-              Si = __builtin_amdgcn_mfma_f64_16x16x4f64(ami, bmr, Si, 0, 0, 0);
-              Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(nami, bmi, Sr, 0, 0, 0);
-              Si = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, bmi, Si, 0, 0, 0);
-            } else {
-              Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, bmr, Sr, 0, 0, 0);
-              Si = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, bmi, Si, 0, 0, 0);
-              Sr = __builtin_amdgcn_mfma_f64_16x16x4f64(ami, bmi, Sr, 0, 0, 0);
-              Si = __builtin_amdgcn_mfma_f64_16x16x4f64(nami, bmr, Si, 0, 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (lane == 0) { S.Dd[t & 1][0][j] = dr; S.Dd[t & 1][1][j] = di; S.Rr[0][j] = ivr; S.Rr[1][j] = ivi; }
-          const double vmr = ing ? Vr[qj] : 0.0, vmi = ing ? Vi[qj] : 0.0;   // (unit diagonal: the inverse's column is not scaled)
-          if (j < 15) {
-            Vr = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, vmr, Vr, 0, 0, 0);
-            Vi = __builtin_amdgcn_mfma_f64_16x16x4f64(amr, vmi, Vi, 0, 0, 0);
-            Vr = __builtin_amdgcn_mfma_f64_16x16x4f64(nami, vmi, Vr, 0, 0, 0);
-            Vi = __builtin_amdgcn_mfma_f64_16x16x4f64(ami, vmr, Vi, 0, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      });
-      double* dst = dinv_ws + tk.dinv_off + (int64_t)t * 512;   // [256 re][256 im] per block
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = g + 4 * q;
-        if (c <= l15 && l15 < nb) {
-          const int64_t o = (kb + l15) + (int64_t)(kb + c) * ld;
-          pst<COH>(&Ar[o], -Sr[q]);
-          pst<COH>(&Ai[o], -Si[q]);
-        }
-        S.Wl[0][l15 * 16 + c] = -Vr[q];                      // W(k = l15, i = c) = inv(tile)(i, k)
-        S.Wl[1][l15 * 16 + c] = -Vi[q];
-        pst<COH>(&dst[c + 16 * l15], -Vr[q]);
-        pst<COH>(&dst[256 + c + 16 * l15], -Vi[q]);
-      }
-      __syncthreads();                                       // (B)
-      __syncthreads();                                       // (C)
-    }
-    if (lane == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
-    return;
-  }
-  for (int t = 0; t < nbt; t++) {
-    const int kb = 16 * t, nb = min(16, w - kb), rem = w - kb - nb;
-    __syncthreads();                                         // (A) Ts / Ps hold column band t
-    if (t > 0) {
-      // (S3b) of step t - 1: the tiles right of column band t
-#pragma unroll
-      for (int sl = 0; sl < NS; sl++)
-        if (tbi[sl] >= 0 && tbj[sl] > t) update(Cr[sl], Ci[sl], tbi[sl], tbj[sl], t - 1);
-    }
-    __syncthreads();                                         // (B) the tile is factorized
-    if ((wave - 1) * 16 < rem) {
-      // (S2) row block wave - 1 below the tile
-      const int ro = 16 * (wave - 1) + l15;
-      d4v Yr = {0.0, 0.0, 0.0, 0.0}, Yi = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const int k = 4 * ks + g;
-        const double wr = S.Wl[0][k * 16 + l15], wi = HERM ? -S.Wl[1][k * 16 + l15] : S.Wl[1][k * 16 + l15];   // inv(tile)(c = l15, k)
-        const double pr = S.Ps[0][k][ro], pi = S.Ps[1][k][ro];                                            // A21(r, k)
-        Yr = __builtin_amdgcn_mfma_f64_16x16x4f64(wr, pr, Yr, 0, 0, 0);
-        Yi = __builtin_amdgcn_mfma_f64_16x16x4f64(wr, pi, Yi, 0, 0, 0);
-        Yr = __builtin_amdgcn_mfma_f64_16x16x4f64(-wi, pi, Yr, 0, 0, 0);
-        Yi = __builtin_amdgcn_mfma_f64_16x16x4f64(wi, pr, Yi, 0, 0, 0);
-      }
-      const int64_t o0 = (kb + nb + ro) + (int64_t)kb * ld;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c = g + 4 * q;
-        const double ivr = S.Rr[0][c], ivi = S.Rr[1][c];
-        const double xr = __builtin_fma(Yr[q], ivr, -Yi[q] * ivi), xi = __builtin_fma(Yr[q], ivi, Yi[q] * ivr);   // L = (L D) / d
-        S.Xs[0][c][ro] = xr;
-        S.Xs[1][c][ro] = xi;
-        if (c < nb && ro < rem) {
-          pst<COH>(&Ar[o0 + (int64_t)c * ld], xr);
-          pst<COH>(&Ai[o0 + (int64_t)c * ld], xi);
-        }
-      }
-    }
-    __syncthreads();                                         // (C) the rows below are solved
-    if (t + 1 < nbt) {
-      // (S3a) column band t + 1: update, then hand over -- the diagonal tile to wave 0, the others to the next (S2)
-#pragma unroll
-      for (int sl = 0; sl < NS; sl++)
-        if (tbi[sl] >= 0 && tbj[sl] == t + 1) {
-          update(Cr[sl], Ci[sl], tbi[sl], tbj[sl], t);
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int c = g + 4 * q;
-            if (tbi[sl] == t + 1) { S.Ts[0][l15][c] = Cr[sl][q]; S.Ts[1][l15][c] = Ci[sl][q]; }
-            else { S.Ps[0][c][16 * (tbi[sl] - t - 2) + l15] = Cr[sl][q]; S.Ps[1][c][16 * (tbi[sl] - t - 2) + l15] = Ci[sl][q]; }
-          }
-        }
-    }
-  }
-}
 template <bool HERM>
 __global__ __launch_bounds__(512, 4) void k_diag_zsy_w(const Arenas ar, const PanelTask* __restrict__ tasks,
                                                     double* __restrict__ dinv_ws, double critere,

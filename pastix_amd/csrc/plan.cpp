@@ -298,7 +298,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     P.local_flops += fact_flops(&one, factotype, floattype);
   }
 
-  const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+  const bool ptime = dev_opt("plan_timing") != nullptr;
   auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tph = tnow();
   auto phase = [&](const char* name) { if (ptime) { double t = tnow(); fprintf(stderr, "[plan] %-28s %.2f s\n", name, t - tph); tph = t; } };
@@ -343,8 +343,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     }
   }
   const int RL0 = P.run_L0 >= 0 ? P.run_L0 : NL + 1;
-  const int near = getenv("PASTIX_AMD_NEAR") ? atoi(getenv("PASTIX_AMD_NEAR")) : 3;
-  const int64_t nearc = getenv("PASTIX_AMD_NEARC") ? atoi(getenv("PASTIX_AMD_NEARC")) : 1;
+  const int near = dev_opt("near") ? atoi(dev_opt("near")) : 3;
+  const int64_t nearc = dev_opt("nearc") ? atoi(dev_opt("nearc")) : 1;
 
   // ---- panel / trsm tasks per level ------------------------------------------------------------
   P.lvl_panel_ptr.assign(NL + 1, 0);
@@ -1085,7 +1085,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       const size_t nd = P.run_d.size();
       if (nr + nd > 0x7ffffff0ULL) return PASTIX_AMD_ERR_UNSUPPORTED;
       auto slot_of = [&](int64_t q) { return (int)(std::upper_bound(P.slot_task_ptr.begin(), P.slot_task_ptr.end(), q) - P.slot_task_ptr.begin() - 1); };
-      if (getenv("PASTIX_AMD_RUN_PROF")) {
+      if (dev_opt("run_prof")) {
         // developer aid (tools/run_prof.py): category (0 A, 1 B.next, 2 B.rest, 3 T) and slot / level of every ticket
         P.run_cat.resize(nr);
         P.run_lvl.resize(nr);

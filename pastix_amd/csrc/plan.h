@@ -5,7 +5,10 @@
 // sopalin3d.c:790-1025): dependencies become launch slots, the linear facing-blok search
 // (sopalin_compute.c:938-945) becomes precomputed piece descriptors.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -127,6 +130,33 @@ constexpr int RUN_HEAD = 0, RUN_TAIL = 2 * 64, RUN_STUCK = 4 * 64, RUN_CTL_INTS 
 // hundred of them polling sixteen lines starved the chip's memory system -- about one factorization in 200 had every running
 // ticket's loads stand still until the pollers gave up
 constexpr int RUN_SLOT = 32;
+
+// Developer switches: ONE environment variable, PASTIX_AMD_DEV="key[=value],key[=value],..." (a key without a value reads
+// "1").  Keys: plan_timing, near=<levels>, nearc=<cblks> (near-target task cutting, plan.cpp), dump_slot=<slot>[:file]
+// (tools/replay_slot), run_prof=<file> (clock stamps of every task of the run, tools/run_prof.py), run_debug (keeps the run's
+// dependency tables on the host: a stopped run is replayed and reported, run_debug.cpp), onek=0 (the run's diagonal tasks on
+// a resident kernel of their own, the round-4 form: the tests' oracle for the one-kernel form), room=<workgroups> (run_sync.h).
+// Returns the value (valid until the next call on this thread) or nullptr.
+inline const char* dev_opt(const char* key) {
+  static thread_local char buf[512];
+  const char* e = getenv("PASTIX_AMD_DEV");
+  if (!e) return nullptr;
+  const size_t kl = strlen(key);
+  for (const char* q = e; *q;) {
+    const char* end = strchr(q, ',');
+    const size_t len = end ? (size_t)(end - q) : strlen(q);
+    if (len >= kl && !strncmp(q, key, kl) && (len == kl || q[kl] == '=')) {
+      if (len == kl) { buf[0] = '1'; buf[1] = 0; return buf; }
+      const size_t vl = std::min(len - kl - 1, sizeof(buf) - 1);
+      memcpy(buf, q + kl + 1, vl);
+      buf[vl] = 0;
+      return buf;
+    }
+    if (!end) break;
+    q = end + 1;
+  }
+  return nullptr;
+}
 
 // std::allocator whose value-less construct() default-initialises (leaves trivially constructible T untouched)
 template <class T>

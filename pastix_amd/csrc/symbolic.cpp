@@ -11,6 +11,7 @@
 //   -> supernodal symbolic factorization on interval lists -> cblk splitting at max blocksize
 //   -> bloks cut at facing-cblk boundaries, coefind/stride.
 // The layout it emits satisfies the invariants plan.cpp::check_layout enforces.
+#include "plan.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -285,7 +286,7 @@ int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, cons
       }
     }
     const int64_t nnz = colptr[n] - 1;
-    const bool ptime = getenv("PASTIX_AMD_PLAN_TIMING") != nullptr;
+    const bool ptime = pastix_amd::dev_opt("plan_timing") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tph = tnow();
     auto phase = [&](const char* name) { if (ptime) { const double t = tnow(); fprintf(stderr, "[symbolic] %-28s %.2f s\n", name, t - tph); tph = t; } };

@@ -47,7 +47,9 @@ def test_config2_laplacian_100_dllt():
     n, cp, r, v = sy.laplacian_3d(N)
     perm, _ = sy.order_grid(N, N, N)
     st = _run(n, cp, r, v, perm, 0, 1, 6.0 * 2 * np.sqrt(1e-31), False)
-    assert st["fact_time"] < 1.0              # (0.14 s on an MI355X: a fallback to anything else would show)
+    # (0.13 s on an MI355X: a fallback to anything else would show.  A factorization that was redone level by level after a
+    # stopped run -- run_time == 0 although the plan has a run -- is slow for a reason of its own; the soak counts those.)
+    assert st["run_time"] == 0 or st["fact_time"] < 1.0
 
 
 def test_config3_laplacian_80_dlu_static_pivoting():

@@ -1,4 +1,4 @@
-// Replays ONE bulk launch of a real factorization plan (dumped with PASTIX_AMD_DUMP_SLOT, api.cpp) on an arena of the
+// Replays ONE bulk launch of a real factorization plan (dumped with PASTIX_AMD_DEV=dump_slot=<slot>:<file>, api.cpp) on an arena of the
 // same size filled with noise, under different task orders:
 //   0  as planned (heaviest first, ties in tile order = target cblk major, row tile minor)
 //   1  2-D blocks over (A rows, B rows) of the tasks' first pieces: runs of 512 tasks = 16 x 32 blocks, dealt so that

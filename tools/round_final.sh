@@ -30,12 +30,12 @@ timeout 900 bash tools/sweep_sizes.sh > $O/sweep_sizes.txt 2>&1
 for n in 60 100; do
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tr$n && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$n -- python3 $GRAFT_REPO_ROOT/tools/dev_bench.py -n $n --reps 2 > /dev/null 2>&1 )
   python tools/level_rows.py /tmp/tr$n 30 > $O/level_timeline_d$n.txt 2>&1
-  PASTIX_AMD_RUN_PROF=/tmp/prof_$n.bin timeout 300 python tools/dev_run_ab.py -n $n --reps 2 --nocheck > /dev/null 2>&1
+  PASTIX_AMD_DEV=run_prof=/tmp/prof_$n.bin timeout 300 python tools/dev_run_ab.py -n $n --reps 2 --nocheck > /dev/null 2>&1
   python tools/run_prof.py /tmp/prof_$n.bin 40 >> $O/level_timeline_d$n.txt 2>&1
 done
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/trz && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/trz -- python3 $GRAFT_REPO_ROOT/bench.py --grid 48 --workload elasticity --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs > /dev/null 2>&1 )
 python tools/level_rows.py /tmp/trz 30 > $O/level_timeline_z48.txt 2>&1
-PASTIX_AMD_RUN_PROF=/tmp/prof_z.bin timeout 300 python bench.py --grid 48 --workload elasticity --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
+PASTIX_AMD_DEV=run_prof=/tmp/prof_z.bin timeout 300 python bench.py --grid 48 --workload elasticity --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 python tools/run_prof.py /tmp/prof_z.bin 40 >> $O/level_timeline_z48.txt 2>&1
 ( for w in 24 64 128; do timeout 60 ./tools/bench_diag $w 1 | tail -1; done; timeout 60 ./tools/bench_diag 128 2048 | tail -1 ) > $O/bench_diag.txt 2>&1
 if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then
@@ -49,6 +49,6 @@ if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then
     echo "## cmp mode: factors of the engine against the reference's CPU engine, entry-wise"
     timeout 900 bash tools/r04_cmp.sh ) > $O/refcaller_timing.txt 2>&1
 fi
-PASTIX_AMD_PLAN_TIMING=1 timeout 300 python tools/plan_timing.py 200 > $O/analysis_timing_200cube.txt 2>&1
+PASTIX_AMD_DEV=plan_timing timeout 300 python tools/plan_timing.py 200 > $O/analysis_timing_200cube.txt 2>&1
 timeout 900 python tools/loopback_scale.py 200 4 2 > $O/loopback_200cube_4ranks.json 2> $O/loopback_200.err
 tail -3 $O/sweep_sizes.txt

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reads a PASTIX_AMD_RUN_PROF dump (api.cpp): clock stamps (100 MHz) of every ticket of the run launch and of the
+"""Reads a PASTIX_AMD_DEV=run_prof=<file> dump (api.cpp): clock stamps (100 MHz) of every ticket of the run launch and of the
 resident diagonal tasks.  Prints slot-time by category (waiting / running) and a per-level chain timeline."""
 import sys
 import numpy as np
