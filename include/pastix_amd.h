@@ -121,6 +121,10 @@ typedef struct pastix_amd_stats_s {
                                 It is one of the nupdate_launches and part of update_time_sum */
   double run_flops;          /* update flops carried by that launch (part of update_flops) */
   pastix_amd_int_t run_tickets, run_first_level;   /* its tasks; the first level it covers (-1: none) */
+  /* the one-shot entry points ({po,sy,he,ge}_sopalin): what the caller of the drop-in pays besides fact_time */
+  double plan_time;          /* s, analysis of the layout + device tables + arenas (0 when the cached plan of the previous call
+                                with the same layout, factorization and options was reused) */
+  double total_time;         /* s, wall time of the whole call: plan_time + h2d_time + factorization + d2h_time */
 } pastix_amd_stats_t;
 
 typedef struct pastix_amd_plan_s pastix_amd_plan_t;
@@ -169,6 +173,12 @@ int pastix_amd_c_he_sopalin(const pastix_amd_layout_t *layout, void *const *coef
                             const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 int pastix_amd_c_ge_sopalin(const pastix_amd_layout_t *layout, void *const *coeftab, void *const *ucoeftab,
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
+
+/* The one-shot entry points keep the plan of their last call (host analysis, device tables AND the device arenas): a call
+ * with the same layout, factorization, arithmetic and options -- what pastix() does when it re-factorizes on one analysis,
+ * pastix.c:3439-3575 -- skips the analysis and the allocations.  This releases it (device memory included); it is also
+ * released when a call with a different layout replaces it and at process exit. */
+void pastix_amd_release_cached_plan(void);
 
 /* ---- staged API (analysis once, many factorizations; panels may stay on the device) -------- */
 int pastix_amd_plan_create(const pastix_amd_layout_t *layout, int factotype, int floattype,

@@ -30,6 +30,9 @@ void AMD_HOOK(void *sopalin_data,
 
 extern int pastix_amd_hook_calls;       /* ref_harness.c: how many factorizations went to the GPU engine */
 extern int pastix_amd_hook_last_rc;
+extern double pastix_amd_hook_wall;     /* wall time of the last factorization at this launch, either engine */
+#include <sys/time.h>
+static double amd_hook_now(void) { struct timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + 1e-6 * tv.tv_usec; }
 
 void AMD_HOOK(void *sopalin_data,
               PASTIX_INT procnum, PASTIX_INT procnbr, void *ptr, PASTIX_INT verbose,
@@ -37,12 +40,14 @@ void AMD_HOOK(void *sopalin_data,
               PASTIX_INT comm_thrdnbr, void * (*comm_routine)(void *), void *comm_data,
               PASTIX_INT ooc_thrdnbr,  void * (*ooc_routine) (void *), void *ooc_data)
 {
+  const double t0 = amd_hook_now();
   if (calc_routine == API_CALL(sopalin_smp) && getenv("PASTIX_AMD_ENGINE") != NULL) {
     int rc = API_CALL(sopalin_amd)((Sopalin_Data_t *)calc_data);
     pastix_amd_hook_last_rc = rc;
-    if (rc == PASTIX_AMD_OK) { pastix_amd_hook_calls++; return; }
+    if (rc == PASTIX_AMD_OK) { pastix_amd_hook_calls++; pastix_amd_hook_wall = amd_hook_now() - t0; return; }
     fprintf(stderr, "pastix_amd engine returned %d: falling back to the CPU engine\n", rc);
   }
   sopalin_launch_thread(sopalin_data, procnum, procnbr, ptr, verbose, calc_thrdnbr, calc_routine, calc_data,
                         comm_thrdnbr, comm_routine, comm_data, ooc_thrdnbr, ooc_routine, ooc_data);
+  if (calc_routine == API_CALL(sopalin_smp)) pastix_amd_hook_wall = amd_hook_now() - t0;
 }

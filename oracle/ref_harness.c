@@ -298,6 +298,8 @@ static void wints(FILE *f, const PASTIX_INT *p, long cnt, long add)
 /* set by oracle/ref_amd_sopalin3d.c (the *_amd build): factorizations handed to the MI355X engine */
 int pastix_amd_hook_calls = 0;
 int pastix_amd_hook_last_rc = 0;
+double pastix_amd_hook_wall = 0;        /* wall time of the last numerical-factorization call at the hooked launch: the GPU
+                                           engine's whole replacement (plan + host <-> device + factorization) or the CPU engine's threads */
 
 int main(int argc, char **argv)
 {
@@ -511,6 +513,7 @@ int main(int argc, char **argv)
     const long nc = sm->cblknbr;
     PASTIX_FLOAT **refL = malloc(nc * sizeof(*refL)), **refU = malloc(nc * sizeof(*refU));
     const double t_ref = dparm[DPARM_FACT_TIME];
+    const double wall_ref = pastix_amd_hook_wall;
     const long npiv_ref = iparm[IPARM_STATIC_PIVOTING], inertia_ref = iparm[IPARM_INERTIA];
     double maxL = 0, maxU = 0, dL = 0, dU = 0;
     long worst_k = -1;
@@ -550,10 +553,10 @@ int main(int argc, char **argv)
     free(refL); free(refU);
     OUT("{\"cmp\": 1, \"maxabs_L\": %.6e, \"maxdiff_L\": %.6e, \"rel_L\": %.3e, \"maxabs_U\": %.6e, \"maxdiff_U\": %.6e, "
         "\"rel_U\": %.3e, \"worst_cblk\": %ld, \"static_pivots_ref\": %ld, \"static_pivots_gpu\": %ld, \"inertia_ref\": %ld, "
-        "\"inertia_gpu\": %ld, \"time_ref\": %.6f, \"time_gpu\": %.6f, \"gpu_engine_calls\": %d, \"gpu_engine_rc\": %d}\n",
+        "\"inertia_gpu\": %ld, \"time_ref\": %.6f, \"time_gpu\": %.6f, \"wall_ref\": %.6f, \"wall_gpu\": %.6f, \"gpu_engine_calls\": %d, \"gpu_engine_rc\": %d}\n",
         maxL, dL, dL / (maxL > 0 ? maxL : 1), maxU, dU, dU / (maxU > 0 ? maxU : 1), worst_k, npiv_ref,
         (long)iparm[IPARM_STATIC_PIVOTING], inertia_ref, (long)iparm[IPARM_INERTIA], t_ref, dparm[DPARM_FACT_TIME],
-        pastix_amd_hook_calls, pastix_amd_hook_last_rc);
+        wall_ref, pastix_amd_hook_wall, pastix_amd_hook_calls, pastix_amd_hook_last_rc);
   }
   {
     double flops = dparm[DPARM_FACT_FLOPS], t = dparm[DPARM_FACT_TIME];
@@ -602,9 +605,9 @@ int main(int argc, char **argv)
     OUT("{\"kind\": \"%s\", \"arg\": \"%s\", \"facto\": \"%s\", \"n\": %ld, \"threads\": %d, "
         "\"cblknbr\": %ld, \"bloknbr\": %ld, \"nnzl\": %ld, \"flops\": %.6e, \"time\": %.6f, "
         "\"gflops\": %.3f, \"static_pivots\": %ld, \"residual\": %.3e, \"gpu_engine_calls\": %d, "
-        "\"gpu_engine_rc\": %d, \"inertia\": %ld}\n",
+        "\"gpu_engine_rc\": %d, \"inertia\": %ld, \"wall_sopalin\": %.6f}\n",
         kind, argv[3], argv[4], n, nthr, (long)sm->cblknbr, (long)sm->bloknbr, nnzl, flops, t,
-        flops / t * 1e-9, npiv, resid, pastix_amd_hook_calls, pastix_amd_hook_last_rc, (long)iparm[IPARM_INERTIA]);
+        flops / t * 1e-9, npiv, resid, pastix_amd_hook_calls, pastix_amd_hook_last_rc, (long)iparm[IPARM_INERTIA], pastix_amd_hook_wall);
   }
   iparm[IPARM_START_TASK] = API_TASK_CLEAN;
   iparm[IPARM_END_TASK] = API_TASK_CLEAN;

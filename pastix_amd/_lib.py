@@ -46,7 +46,8 @@ class Stats(ctypes.Structure):
                 ("update_time_sum", ctypes.c_double), ("urgent_flops", ctypes.c_double),
                 ("urgent_time_sum", ctypes.c_double), ("nurgent_launches", ctypes.c_int64),
                 ("solve_time", ctypes.c_double), ("nquadrant_tasks", ctypes.c_double),
-                ("run_time", ctypes.c_double), ("run_flops", ctypes.c_double), ("run_tickets", i64), ("run_first_level", i64)]
+                ("run_time", ctypes.c_double), ("run_flops", ctypes.c_double), ("run_tickets", i64), ("run_first_level", i64),
+                ("plan_time", ctypes.c_double), ("total_time", ctypes.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -66,7 +67,7 @@ _lib = None
 
 # every symbol include/pastix_amd.h declares
 EXPORTS = [
-    "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
+    "pastix_amd_release_cached_plan", "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
     "pastix_amd_z_he_sopalin", "pastix_amd_z_ge_sopalin",
     "pastix_amd_s_po_sopalin", "pastix_amd_s_sy_sopalin", "pastix_amd_s_ge_sopalin",
     "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",

@@ -12,6 +12,8 @@
 #include <new>
 #include <system_error>
 #include <thread>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "engine.h"
@@ -732,6 +734,90 @@ static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* c
   return 0;
 }
 
+// Host panels <-> device arena through pinned staging, for the one-buffer-per-cblk arrays of the reference (pageable
+// memory, thousands of panels from a few KB to hundreds of MB): the panels of consecutive cblks are adjacent in the arena,
+// so a CHUNK of them is packed by host threads into one pinned buffer and travels as one copy; four buffers, so that the
+// packing of the next chunks runs beside the copies in flight (per-cblk copies from pageable memory: 100^3, 16 k panels of
+// 9 GB in all, took 0.9 s each way).  Real arithmetic, cblks not re-cut; everything else keeps the per-cblk path.
+static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab) {
+  const Plan& H = p->host;
+  constexpr int NBUF = 4;
+  const size_t CH = (size_t)96 << 20;                    // bytes per staging buffer
+  struct Stage { char* buf = nullptr; hipEvent_t ev = nullptr; bool busy = false; int64_t k0 = 0, k1 = 0; int arena = 0; };
+  static thread_local Stage st[NBUF];                    // (kept for the thread's life: pinning 384 MB costs ~0.1 s)
+  for (auto& x : st) {
+    if (!x.buf) { HIPCHK(hipHostMalloc((void**)&x.buf, CH, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming)); }
+    x.busy = false;
+  }
+  const int nthr = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  // pack / unpack the panels [k0, k1) of one arena between the caller's buffers and a staging buffer
+  auto move = [&](const Stage& x, bool to_stage) {
+    void* const* tab = x.arena ? ucoeftab : coeftab;
+    const int64_t base = H.poff[x.k0];
+    std::atomic<int64_t> next{x.k0};
+    auto work = [&] {
+      for (;;) {
+        const int64_t k = next.fetch_add(16);
+        if (k >= x.k1) break;
+        for (int64_t q = k; q < std::min(x.k1, k + 16); q++) {
+          if (H.role[q] != 1) continue;
+          const size_t bytes = (size_t)(H.poff[q + 1] - H.poff[q]) * p->esz;
+          char* sp = x.buf + (size_t)(H.poff[q] - base) * p->esz;
+          if (to_stage) memcpy(sp, tab[q], bytes); else memcpy(tab[q], sp, bytes);
+        }
+      }
+    };
+    const size_t total = (size_t)(H.poff[x.k1] - base) * p->esz;
+    const int nt = total < ((size_t)4 << 20) ? 1 : nthr;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  };
+  auto drain = [&](Stage& x) -> int {
+    if (!x.busy) return 0;
+    HIPCHK(hipEventSynchronize(x.ev));
+    if (!up) move(x, false);
+    x.busy = false;
+    return 0;
+  };
+  int cur = 0;
+  for (int arena = 0; arena < ((p->dU && ucoeftab) ? 2 : 1); arena++) {
+    double* dev = arena ? p->dU : p->dL;
+    for (int64_t k0 = 0; k0 < H.cblknbr;) {
+      int64_t k1 = k0 + 1;                                 // (a panel larger than the buffer travels alone, below)
+      while (k1 < H.cblknbr && (size_t)(H.poff[k1 + 1] - H.poff[k0]) * p->esz <= CH) k1++;
+      const size_t bytes = (size_t)(H.poff[k1] - H.poff[k0]) * p->esz;
+      if (bytes > CH) {                                    // one huge panel: straight from / to the caller's memory
+        if (H.role[k0] == 1) {
+          void* h = (arena ? ucoeftab : coeftab)[k0];
+          if (up) HIPCHK(hipMemcpyAsync(p->at(dev, H.poff[k0]), h, bytes, hipMemcpyHostToDevice, p->stream));
+          else HIPCHK(hipMemcpyAsync(h, p->at(dev, H.poff[k0]), bytes, hipMemcpyDeviceToHost, p->stream));
+        }
+        k0 = k1;
+        continue;
+      }
+      Stage& x = st[cur];
+      cur = (cur + 1) % NBUF;
+      int r = drain(x);
+      if (r) return r;
+      x.k0 = k0; x.k1 = k1; x.arena = arena;
+      if (up) {
+        move(x, true);
+        HIPCHK(hipMemcpyAsync(p->at(dev, H.poff[k0]), x.buf, bytes, hipMemcpyHostToDevice, p->stream));
+      } else {
+        HIPCHK(hipMemcpyAsync(x.buf, p->at(dev, H.poff[k0]), bytes, hipMemcpyDeviceToHost, p->stream));
+      }
+      HIPCHK(hipEventRecord(x.ev, p->stream));
+      x.busy = true;
+      k0 = k1;
+    }
+  }
+  for (int i = 0; i < NBUF; i++) { int r = drain(st[(cur + i) % NBUF]); if (r) return r; }
+  HIPCHK(hipStreamSynchronize(p->stream));
+  return PASTIX_AMD_OK;
+}
+
 int pastix_amd_upload_packed(pastix_amd_plan_t* p, const void* L, const void* U) {
   if (p) p->refillable = false;
   if (!p || !L) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -791,6 +877,13 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
     p->stats.h2d_time = now_s() - t0;
     return r;
   }
+  if (!p->cplx) {
+    for (int64_t k = 0; k < H.cblknbr; k++)
+      if (H.role[k] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k]))) return PASTIX_AMD_ERR_BADPARAMETER;
+    const int r = staged_tabs_io(p, true, coeftab, ucoeftab);
+    p->stats.h2d_time = now_s() - t0;
+    return r;
+  }
   for (int64_t k = 0; k < H.cblknbr; k++) {
     size_t bytes = (size_t)(H.poff[k + 1] - H.poff[k]) * p->esz;
     if (H.role[k] != 1) continue;
@@ -820,6 +913,13 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
   if (p->split.active) {
     HIPCHK(hipStreamSynchronize(p->stream));
     int r = split_io(p, false, coeftab, ucoeftab, nullptr, nullptr);
+    p->stats.d2h_time = now_s() - t0;
+    return r;
+  }
+  if (!p->cplx) {
+    for (int64_t k = 0; k < H.cblknbr; k++)
+      if (H.role[k] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k]))) return PASTIX_AMD_ERR_BADPARAMETER;
+    const int r = staged_tabs_io(p, false, coeftab, ucoeftab);
     p->stats.d2h_time = now_s() - t0;
     return r;
   }
@@ -1865,12 +1965,59 @@ int pastix_amd_solve(pastix_amd_plan_t* p, void* x, pastix_amd_int_t nrhs) { ret
 // what the device-resident refinement (refine.hip) preconditions with
 int pastix_amd_solve_device(pastix_amd_plan_t* p, void* dx, pastix_amd_int_t nrhs) { return solve_impl(p, dx, nrhs, true); }
 
+// The one-shot entry points keep the plan of their last call: pastix() re-factorizes on one analysis (pastix.c:3439-3575 --
+// same SolverMatrix, new values), and the plan is a pure function of the layout, so the second and later calls of a
+// time-stepping or Newton loop skip the host analysis (seconds at 100^3), the device tables and the allocation of the
+// arenas.  The key is a fingerprint of everything the plan depends on; one plan is kept (pastix_amd_release_cached_plan).
+namespace {
+struct OneShotCache {
+  std::mutex mu;
+  pastix_amd_plan_t* plan = nullptr;
+  uint64_t key = 0;
+  ~OneShotCache() { /* (the process is ending: the runtime may already be gone -- nothing is released here) */ }
+} g_one_shot;
+uint64_t fnv(uint64_t h, const void* d, size_t n) {
+  const unsigned char* q = (const unsigned char*)d;
+  for (size_t i = 0; i < n; i++) { h ^= q[i]; h *= 1099511628211ull; }
+  return h;
+}
+uint64_t one_shot_key(int factotype, int floattype, const pastix_amd_layout_t* L, const pastix_amd_options_t* opts) {
+  uint64_t h = 1469598103934665603ull;
+  const int64_t head[4] = {factotype, floattype, L->cblknbr, L->bloknbr};
+  h = fnv(h, head, sizeof(head));
+  h = fnv(h, L->cblktab, (size_t)(L->cblknbr + 1) * sizeof(pastix_amd_cblk_t));
+  h = fnv(h, L->bloktab, (size_t)L->bloknbr * sizeof(pastix_amd_blok_t));
+  if (opts) h = fnv(h, opts, sizeof(*opts));
+  if (const char* e = getenv("PASTIX_AMD_DEV")) h = fnv(h, e, strlen(e));
+  return h;
+}
+}  // namespace
+void pastix_amd_release_cached_plan(void) {
+  std::lock_guard<std::mutex> g(g_one_shot.mu);
+  if (g_one_shot.plan) pastix_amd_plan_destroy(g_one_shot.plan);
+  g_one_shot.plan = nullptr;
+}
+
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                     pastix_amd_stats_t* stats, int floattype = PASTIX_AMD_REALDOUBLE) {
+  if (!layout || !layout->cblktab || (layout->bloknbr > 0 && !layout->bloktab) || layout->cblknbr < 0) return PASTIX_AMD_ERR_BADPARAMETER;
+  std::lock_guard<std::mutex> g(g_one_shot.mu);            // (one one-shot call at a time: they share the cached plan)
+  const double t0 = now_s();
+  const uint64_t key = one_shot_key(factotype, floattype, layout, opts);
   pastix_amd_plan_t* plan = nullptr;
-  int rc = pastix_amd_plan_create(layout, factotype, floattype, opts, &plan);
-  if (rc) return rc;
+  int rc = 0;
+  double plan_time = 0;
+  if (g_one_shot.plan && g_one_shot.key == key) {
+    plan = g_one_shot.plan;
+  } else {
+    if (g_one_shot.plan) { pastix_amd_plan_destroy(g_one_shot.plan); g_one_shot.plan = nullptr; }
+    rc = pastix_amd_plan_create(layout, factotype, floattype, opts, &plan);
+    if (rc) return rc;
+    plan_time = now_s() - t0;
+    g_one_shot.plan = plan;
+    g_one_shot.key = key;
+  }
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
   plan->caller_restores = true;                             // (a stopped run is redone below from the caller's buffers)
@@ -1884,8 +2031,18 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   }
   if (!rc && (rcf == 0 || rcf == PASTIX_AMD_ERR_NUMERIC))
     rc = pastix_amd_download_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+  plan->stats.plan_time = plan_time;
+  plan->stats.total_time = now_s() - t0;
   if (stats) pastix_amd_plan_stats(plan, stats);
-  pastix_amd_plan_destroy(plan);
+  static const bool verbose = getenv("PASTIX_AMD_VERBOSE") != nullptr;
+  if (verbose)
+    fprintf(stderr, "pastix_amd: one-shot call: plan %.3f s%s, host -> device %.3f s, factorization %.3f s, device -> host %.3f s, in all %.3f s\n",
+            plan_time, plan_time == 0 ? " (cached)" : "", plan->stats.h2d_time, plan->stats.fact_time, plan->stats.d2h_time,
+            plan->stats.total_time);
+  if (rc || (rcf && rcf != PASTIX_AMD_ERR_NUMERIC)) {        // (a plan that failed is not kept)
+    pastix_amd_plan_destroy(plan);
+    g_one_shot.plan = nullptr;
+  }
   return rc ? rc : rcf;
 }
 

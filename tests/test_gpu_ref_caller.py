@@ -120,6 +120,11 @@ def _cmp(prec, kind, arg, facto, extra=(), threads=32, contig=True, timeout=1500
     ("z", 24, "ldlt", ()),
     ("z", 32, "ldlt", (64, 128)),
     ("z", 24, "lu", ()),
+    # the sizes of the configurations themselves (configs[1]: 100^3 dLLt; configs[2]'s factorization at the size one host run
+    # of the reference allows: 100^3 dLU; configs[4]: z LDLt): 250 k tickets of the run launch against the reference
+    ("d", 100, "llt", (64, 128)),
+    ("d", 100, "lu", (64, 128)),
+    ("z", 40, "ldlt", (64, 128)),
 ])
 def test_factors_equal_the_reference_cpu_engine_at_scale(prec, arg, facto, extra):
     c, last = _cmp(prec, "rlap3d", arg, facto, extra)

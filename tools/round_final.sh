@@ -47,7 +47,8 @@ if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then
     echo "## the engine on its own layout of the same matrices (tools/dev_bench.py)"
     for n in 60 80 100; do timeout 200 python tools/dev_bench.py -n $n --reps 3 2>/dev/null | tail -1; done
     echo "## cmp mode: factors of the engine against the reference's CPU engine, entry-wise"
-    timeout 900 bash tools/r04_cmp.sh ) > $O/refcaller_timing.txt 2>&1
+    for c in "d 60 llt" "d 80 llt" "d 100 llt" "d 100 lu" "z 32 ldlt"; do set -- $c
+      echo "== cmp $c"; REF_ORDER_CONTIG=1 timeout 600 oracle/_ref/ref_harness_$1_ob_amd cmp rlap3d $2 $3 32 /dev/null 64 128 2>/dev/null | grep '"cmp"' | tail -1; done ) > $O/refcaller_timing.txt 2>&1
 fi
 PASTIX_AMD_DEV=plan_timing timeout 300 python tools/plan_timing.py 200 > $O/analysis_timing_200cube.txt 2>&1
 timeout 900 python tools/loopback_scale.py 200 4 2 > $O/loopback_200cube_4ranks.json 2> $O/loopback_200.err
