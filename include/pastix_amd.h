@@ -90,7 +90,11 @@ typedef struct pastix_amd_options_s {
   int run_t_workers;     /* unused (kept for the layout of the struct): panel solves are tickets of the run launch */
   int run_d_workers;     /* resident workgroups of the run's diagonal-blok kernel (they pop ready diagonal tasks);
                             <= 0 = default (8) */
-  int reserved[5];
+  int gather_min;        /* a target tile that ONE source cblk reaches with at least this many rectangles (fragmented
+                            layouts: blend on separators numbered across their low-side neighbours) gets them as one
+                            GATHERED piece -- consecutive source rows, scattered landing, gathered while they are staged
+                            (plan.cpp); <= 0 = default (3), -1 = never */
+  int reserved[4];
 } pastix_amd_options_t;
 
 /* Statistics of a plan / a factorization. */
@@ -255,6 +259,12 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t *layout, int factotype, co
  * every task can run when the tickets are served one at a time in order: the schedule cannot deadlock) */
 int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, int floattype, const pastix_amd_options_t *opts,
                              pastix_amd_int_t *info);
+/* host-only (tests): the update pieces of the plan -- rectangles and gathered pieces (options.gather_min) -- against the
+ * reference's definition: every product (rows of blok j) x (rows of blok i)^T, j >= i, of every source cblk subtracted once
+ * where add_contrib_local puts it (sopalin_compute.c:427-429).  Real LLt / LDLt.  out[0..3] = products expected, products the
+ * pieces make, mismatches, gathered pieces. */
+int pastix_amd_plan_check_pieces(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
+                                 pastix_amd_int_t *out);
 /* host-only: the multi-GPU driver's partition -- owner[k] = the rank (GPU) that factorizes cblk k, for `world` <= 64 ranks.
  * Proportional mapping on the cblk elimination tree, blend's idea (splitpart.c:752-1012; GPU colouring
  * blend_distributeOnGPU.c:59-317): a subtree gets a set of candidate ranks; the cblks of the separator at its top are dealt

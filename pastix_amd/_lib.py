@@ -33,7 +33,8 @@ class Options(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("lookahead", ctypes.c_int), ("verbose", ctypes.c_int),
                 ("external_arena", ctypes.c_int), ("schur", ctypes.c_int), ("quadrant_min", ctypes.c_int),
                 ("quadrant_fill_pct", ctypes.c_int), ("run_schedule", ctypes.c_int), ("run_max_cblks", ctypes.c_int),
-                ("run_t_workers", ctypes.c_int), ("run_d_workers", ctypes.c_int), ("reserved", ctypes.c_int * 5)]
+                ("run_t_workers", ctypes.c_int), ("run_d_workers", ctypes.c_int), ("gather_min", ctypes.c_int),
+                ("reserved", ctypes.c_int * 4)]
 
 
 class Stats(ctypes.Structure):
@@ -67,7 +68,7 @@ _lib = None
 
 # every symbol include/pastix_amd.h declares
 EXPORTS = [
-    "pastix_amd_release_cached_plan", "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
+    "pastix_amd_release_cached_plan", "pastix_amd_plan_check_pieces", "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
     "pastix_amd_z_he_sopalin", "pastix_amd_z_ge_sopalin",
     "pastix_amd_s_po_sopalin", "pastix_amd_s_sy_sopalin", "pastix_amd_s_ge_sopalin",
     "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",

@@ -245,6 +245,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
     int r;
     if ((r = to_device(&p->dTasks, H.tasks))) return r;
     if ((r = to_device(&p->dPieces, H.pieces))) return r;
+    if (!H.gmaps.empty() && (r = to_device(&p->dGmap, H.gmaps))) return r;
     phase("task + piece tables -> device");
     if ((r = to_device(&p->dPanel, H.panel_tasks))) return r;
     if ((r = to_device(&p->dTrsm, H.trsm_tasks))) return r;
@@ -484,6 +485,24 @@ int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, i
   return PASTIX_AMD_OK;
 }
 
+// Host-only (tests): the pieces of the plan against the reference's definition of the update -- every product (blok j x
+// blok i of a source cblk, j >= i) subtracted once where add_contrib_local puts it (plan.cpp verify_pieces; real LLt / LDLt).
+int pastix_amd_plan_check_pieces(const pastix_amd_layout_t* layout, int factotype, const pastix_amd_options_t* opts,
+                                 pastix_amd_int_t* out) {
+  if (!layout || !out || (factotype != PASTIX_AMD_FACT_LLT && factotype != PASTIX_AMD_FACT_LDLT)) return PASTIX_AMD_ERR_BADPARAMETER;
+  Plan P;
+  try {
+    int rc = build_plan(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, nullptr, 0, P);
+    if (rc) return rc;
+    int64_t o[4];
+    verify_pieces(P, o);
+    for (int i = 0; i < 4; i++) out[i] = o[i];
+  } catch (const std::bad_alloc&) {
+    return PASTIX_AMD_ERR_ALLOC;
+  }
+  return PASTIX_AMD_OK;
+}
+
 int pastix_amd_fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask) {
   if (!layout || !owner || !mask) return PASTIX_AMD_ERR_BADPARAMETER;
   return fanin_touched(layout, owner, mask);
@@ -575,6 +594,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
   for (hipEvent_t e : {p->evZ, p->evS3}) if (e) (void)hipEventDestroy(e);
+  (void)hipFree(p->dGmap);
   (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunCons); (void)hipFree(p->dRunD);
   (void)hipFree(p->dRunState); (void)hipFree(p->dRunImage); (void)hipFree(p->dRunProf);
   if (p->hResident) (void)hipHostFree(p->hResident);
@@ -741,6 +761,16 @@ static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* c
 // 9 GB in all, took 0.9 s each way).  Real arithmetic, cblks not re-cut; everything else keeps the per-cblk path.
 static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab) {
   const Plan& H = p->host;
+  const SplitMap& M = p->split;
+  // items = the caller's cblks: the plan's own, or -- where cblks wider than 128 columns were re-cut (SplitMap) -- the
+  // original ones: an original cblk that was not re-cut is one panel of the arena as before, a re-cut one goes through
+  // split_cblk_io (its column groups are separate panels)
+  const bool sp = M.active;
+  const int64_t nitem = sp ? M.ocblknbr : H.cblknbr;
+  auto first = [&](int64_t k) { return sp ? M.first[(size_t)k] : k; };
+  auto doff = [&](int64_t k) { return H.poff[(size_t)first(k)]; };            // (k == nitem: the end of the arena)
+  auto owned = [&](int64_t k) { return H.role[(size_t)first(k)] == 1; };
+  auto recut = [&](int64_t k) { return sp && M.first[(size_t)k + 1] - M.first[(size_t)k] > 1; };
   constexpr int NBUF = 4;
   const size_t CH = (size_t)96 << 20;                    // bytes per staging buffer
   struct Stage { char* buf = nullptr; hipEvent_t ev = nullptr; bool busy = false; int64_t k0 = 0, k1 = 0; int arena = 0; };
@@ -750,24 +780,24 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
     x.busy = false;
   }
   const int nthr = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  // pack / unpack the panels [k0, k1) of one arena between the caller's buffers and a staging buffer
+  // pack / unpack the panels of the items [k0, k1) of one arena between the caller's buffers and a staging buffer
   auto move = [&](const Stage& x, bool to_stage) {
     void* const* tab = x.arena ? ucoeftab : coeftab;
-    const int64_t base = H.poff[x.k0];
+    const int64_t base = doff(x.k0);
     std::atomic<int64_t> next{x.k0};
     auto work = [&] {
       for (;;) {
         const int64_t k = next.fetch_add(16);
         if (k >= x.k1) break;
         for (int64_t q = k; q < std::min(x.k1, k + 16); q++) {
-          if (H.role[q] != 1) continue;
-          const size_t bytes = (size_t)(H.poff[q + 1] - H.poff[q]) * p->esz;
-          char* sp = x.buf + (size_t)(H.poff[q] - base) * p->esz;
-          if (to_stage) memcpy(sp, tab[q], bytes); else memcpy(tab[q], sp, bytes);
+          if (!owned(q)) continue;
+          const size_t bytes = (size_t)(doff(q + 1) - doff(q)) * p->esz;
+          char* sp2 = x.buf + (size_t)(doff(q) - base) * p->esz;
+          if (to_stage) memcpy(sp2, tab[q], bytes); else memcpy(tab[q], sp2, bytes);
         }
       }
     };
-    const size_t total = (size_t)(H.poff[x.k1] - base) * p->esz;
+    const size_t total = (size_t)(doff(x.k1) - base) * p->esz;
     const int nt = total < ((size_t)4 << 20) ? 1 : nthr;
     std::vector<std::thread> th;
     for (int t = 1; t < nt; t++) th.emplace_back(work);
@@ -784,15 +814,23 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
   int cur = 0;
   for (int arena = 0; arena < ((p->dU && ucoeftab) ? 2 : 1); arena++) {
     double* dev = arena ? p->dU : p->dL;
-    for (int64_t k0 = 0; k0 < H.cblknbr;) {
+    for (int64_t k0 = 0; k0 < nitem;) {
+      if (recut(k0)) {                                     // (both arenas at once, on the first pass)
+        if (arena == 0 && owned(k0)) {
+          int r = split_cblk_io(p, k0, up, coeftab[k0], ucoeftab ? ucoeftab[k0] : nullptr);
+          if (r) return r;
+        }
+        k0++;
+        continue;
+      }
       int64_t k1 = k0 + 1;                                 // (a panel larger than the buffer travels alone, below)
-      while (k1 < H.cblknbr && (size_t)(H.poff[k1 + 1] - H.poff[k0]) * p->esz <= CH) k1++;
-      const size_t bytes = (size_t)(H.poff[k1] - H.poff[k0]) * p->esz;
+      while (k1 < nitem && !recut(k1) && (size_t)(doff(k1 + 1) - doff(k0)) * p->esz <= CH) k1++;
+      const size_t bytes = (size_t)(doff(k1) - doff(k0)) * p->esz;
       if (bytes > CH) {                                    // one huge panel: straight from / to the caller's memory
-        if (H.role[k0] == 1) {
+        if (owned(k0)) {
           void* h = (arena ? ucoeftab : coeftab)[k0];
-          if (up) HIPCHK(hipMemcpyAsync(p->at(dev, H.poff[k0]), h, bytes, hipMemcpyHostToDevice, p->stream));
-          else HIPCHK(hipMemcpyAsync(h, p->at(dev, H.poff[k0]), bytes, hipMemcpyDeviceToHost, p->stream));
+          if (up) HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), h, bytes, hipMemcpyHostToDevice, p->stream));
+          else HIPCHK(hipMemcpyAsync(h, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, p->stream));
         }
         k0 = k1;
         continue;
@@ -804,9 +842,9 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
       x.k0 = k0; x.k1 = k1; x.arena = arena;
       if (up) {
         move(x, true);
-        HIPCHK(hipMemcpyAsync(p->at(dev, H.poff[k0]), x.buf, bytes, hipMemcpyHostToDevice, p->stream));
+        HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), x.buf, bytes, hipMemcpyHostToDevice, p->stream));
       } else {
-        HIPCHK(hipMemcpyAsync(x.buf, p->at(dev, H.poff[k0]), bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipMemcpyAsync(x.buf, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, p->stream));
       }
       HIPCHK(hipEventRecord(x.ev, p->stream));
       x.busy = true;
@@ -872,14 +910,16 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
   const Plan& H = p->host;
   double t0 = now_s();
   p->factored = false;
-  if (p->split.active) {
+  if (p->split.active && p->cplx) {
     int r = split_io(p, true, coeftab, ucoeftab, nullptr, nullptr);
     p->stats.h2d_time = now_s() - t0;
     return r;
   }
   if (!p->cplx) {
-    for (int64_t k = 0; k < H.cblknbr; k++)
-      if (H.role[k] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k]))) return PASTIX_AMD_ERR_BADPARAMETER;
+    const int64_t nitem = p->split.active ? p->split.ocblknbr : H.cblknbr;
+    for (int64_t k = 0; k < nitem; k++)
+      if (H.role[(size_t)(p->split.active ? p->split.first[(size_t)k] : k)] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k])))
+        return PASTIX_AMD_ERR_BADPARAMETER;
     const int r = staged_tabs_io(p, true, coeftab, ucoeftab);
     p->stats.h2d_time = now_s() - t0;
     return r;
@@ -910,15 +950,18 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
   double t0 = now_s();
-  if (p->split.active) {
+  if (p->split.active && p->cplx) {
     HIPCHK(hipStreamSynchronize(p->stream));
     int r = split_io(p, false, coeftab, ucoeftab, nullptr, nullptr);
     p->stats.d2h_time = now_s() - t0;
     return r;
   }
   if (!p->cplx) {
-    for (int64_t k = 0; k < H.cblknbr; k++)
-      if (H.role[k] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k]))) return PASTIX_AMD_ERR_BADPARAMETER;
+    const int64_t nitem = p->split.active ? p->split.ocblknbr : H.cblknbr;
+    for (int64_t k = 0; k < nitem; k++)
+      if (H.role[(size_t)(p->split.active ? p->split.first[(size_t)k] : k)] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k])))
+        return PASTIX_AMD_ERR_BADPARAMETER;
+    HIPCHK(hipStreamSynchronize(p->stream));
     const int r = staged_tabs_io(p, false, coeftab, ucoeftab);
     p->stats.d2h_time = now_s() - t0;
     return r;

@@ -127,7 +127,8 @@ struct pastix_amd_plan_s {
   size_t esz = sizeof(double);   // bytes per arena entry
   // arena + element offset, whatever the entry size (the pointers are typed double* for the fp64 kernels)
   double* at(double* arena, int64_t off) const { return (double*)((char*)arena + (size_t)off * esz); }
-  Arenas arenas() const { return Arenas{{dL, dU, dLi, dUi}}; }
+  Arenas arenas() const { return Arenas{{dL, dU, dLi, dUi}, dGmap}; }
+  uint32_t* dGmap = nullptr; // row maps of the gathered pieces
   double* dDinv = nullptr;
   Task* dTasks = nullptr;
   Piece* dPieces = nullptr;

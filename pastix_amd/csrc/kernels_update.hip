@@ -314,6 +314,193 @@ __device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], con
   return touched;
 }
 
+// ---- the piece loop of tasks with GATHERED pieces (MODE 3) -----------------------------------------------------------
+// On layouts whose bloks are fragments of a few rows (blend on separators numbered across their low-side neighbours: 2-4
+// rows every 50-60) the contribution of one source cblk to one target tile is dozens of rectangles of 2-4 rows by 2-4
+// columns, each a pass of K / 16 chunks through the loop above for a few percent of a tile's MFMA work.  The SOURCE rows of
+// all of them are consecutive in the source panel (its bloks are stacked), only where they land is scattered.  A gathered
+// piece is the whole set in one pass: the LDS images are laid out by TARGET row / column as always, and every 4-byte DMA
+// lane fetches ITS tile row's half of a double from wherever that row's source is -- global_load_lds_dword, 64 lanes = 32
+// tile rows, four instructions per k-line and operand instead of one; rows without a source copy the zero line.  (The
+// reference's CUDA kernel walks blocktab inside one GEMM to the same end, sparse_gemm.cu:103-479.)  Ordinary pieces of the
+// same task run through this loop too, their maps made up on the fly from (dr, m) / (dc, n).  Accumulation order = the order
+// of the list, as in every other loop: the factors do not depend on which loop ran.
+// the MFMAs of one k-step for ANY set of the wave's sub-tiles (a gathered piece's active column bands need not be a run)
+__device__ __forceinline__ void mfma_any(const int pat, const double (&an)[NI], const double (&bm)[MI]) {
+#define PA_PAT(RM, CM) case (RM | (CM << 2)): mfma_sel<RM, CM>(an, bm); break;
+#define PA_PAT_ROWS(CM) PA_PAT(3u, CM) PA_PAT(1u, CM) PA_PAT(2u, CM)
+  switch (pat) {
+    PA_PAT_ROWS(1u) PA_PAT_ROWS(2u) PA_PAT_ROWS(3u) PA_PAT_ROWS(4u) PA_PAT_ROWS(5u) PA_PAT_ROWS(6u) PA_PAT_ROWS(7u) PA_PAT_ROWS(8u)
+    PA_PAT_ROWS(9u) PA_PAT_ROWS(10u) PA_PAT_ROWS(11u) PA_PAT_ROWS(12u) PA_PAT_ROWS(13u) PA_PAT_ROWS(14u) PA_PAT_ROWS(15u)
+    default: break;
+  }
+#undef PA_PAT_ROWS
+#undef PA_PAT
+}
+#define PASTIX_AMD_GLDS4(gptr, lptr)                                                             \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
+                                   (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0)
+template <bool NEG>
+__device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
+                                                 const Piece* __restrict__ pieces, const int row0, const int col0,
+                                                 const int lane, const int l15, const int g) {
+  constexpr int NL = KC / UW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pend = tk.p0 + tk.pn;
+  int pi = tk.p0;
+  const int li = lane >> 1;                          // this lane's tile rows / columns: li + 32 q, q = 0..3
+  const int half4 = (lane & 1) * 4;                  // which half of the double (bytes)
+  // the packed maps of a piece: byte q = source row of tile row li + 32 q (255: none)
+  auto maps_of = [&](const Piece& pc, uint32_t& ma, uint32_t& mb) {
+    if (pc.flags & PIECE_GATHERED) {
+      const uint32_t* mp = ar.gmap + (size_t)((uint32_t)pc.dr | ((uint32_t)pc.dc << 16)) * 64;
+      ma = mp[li];
+      mb = mp[32 + li];
+    } else {
+      ma = 0; mb = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = li + 32 * q;
+        const uint32_t sa = (r >= (int)pc.dr && r < (int)pc.dr + (int)pc.m) ? (uint32_t)(r - (int)pc.dr) : 255u;
+        const uint32_t sb = (r >= (int)pc.dc && r < (int)pc.dc + (int)pc.n) ? (uint32_t)(r - (int)pc.dc) : 255u;
+        ma |= sa << (8 * q);
+        mb |= sb << (8 * q);
+      }
+    }
+  };
+  // which of the wave's sub-tiles a piece touches: 16-row band b of the tile has a source iff a lane of its half of the
+  // ballot of q = b / 2 has one
+  auto pattern_of = [&](const uint32_t ma, const uint32_t mb) {
+    int p = 0;
+#pragma unroll
+    for (int s = 0; s < MI; s++) {
+      const int b = (wave >> 1) + 4 * s;             // row band
+      const unsigned long long bal = __ballot(((ma >> (8 * (b >> 1))) & 255u) != 255u);
+      if ((uint32_t)(bal >> ((b & 1) * 32)) != 0u) p |= 1 << s;
+    }
+#pragma unroll
+    for (int s = 0; s < NI; s++) {
+      const int b = (wave & 1) + 2 * s;              // column band
+      const unsigned long long bal = __ballot(((mb >> (8 * (b >> 1))) & 255u) != 255u);
+      if ((uint32_t)(bal >> ((b & 1) * 32)) != 0u) p |= 1 << (MI + s);
+    }
+    return ((p & 3) && (p >> MI)) ? p : 0;
+  };
+  Piece cur = pieces[pi];
+  Piece nextp = pieces[min(pi + 1, pend - 1)];
+  uint32_t ma, mb, nma, nmb;
+  maps_of(cur, ma, mb);
+  maps_of(nextp, nma, nmb);
+  int64_t lda = cur.lda;
+  const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+  const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+  int left = ((int)cur.k + KC - 1) / KC;
+  int krem = (int)cur.k;
+  bool negn = (cur.flags & 16) != 0, negc = negn;
+  const char* zl = (const char*)g_zero_line;
+  int patn = pattern_of(ma, mb), patc = patn;
+  unsigned touched = (unsigned)patn;
+  // the DMA of one chunk: k-lines wave, wave + 8 of both operands, four 4-byte instructions each
+  auto dma = [&](double* dA, double* dB) {
+#pragma unroll
+    for (int kq = 0; kq < NL; kq++) {
+      const bool kv = wave + UW * kq < krem;         // wave-uniform
+      const char* ba = (const char*)(pa + (int64_t)kq * UW * lda);
+      const char* bb = (const char*)(pb + (int64_t)kq * UW * lda);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t sa = (ma >> (8 * q)) & 255u, sb = (mb >> (8 * q)) & 255u;
+        const char* ga = (kv && sa != 255u) ? ba + 8 * sa : zl;
+        const char* gb = (kv && sb != 255u) ? bb + 8 * sb : zl;
+        PASTIX_AMD_GLDS4(ga + half4, (char*)(dA + UW * kq * SLD) + 256 * q);
+        PASTIX_AMD_GLDS4(gb + half4, (char*)(dB + UW * kq * SLD) + 256 * q);
+      }
+    }
+  };
+  dma(sh[0][0] + wave * SLD, sh[0][1] + wave * SLD);
+  krem -= KC;
+  const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
+  const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+  double bm0[MI], an0[NI], bm1[MI], an1[NI];
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
+#pragma unroll
+  for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
+  int buf = 0;
+  while (true) {
+    bool has_next = true;
+    negc = negn;
+    patc = patn;
+    if (--left == 0) {
+      if (++pi < pend) {
+        cur = nextp;
+        ma = nma; mb = nmb;
+        lda = cur.lda;
+        pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
+        pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+        left = ((int)cur.k + KC - 1) / KC;
+        krem = (int)cur.k;
+        negn = (cur.flags & 16) != 0;
+        nextp = pieces[min(pi + 1, pend - 1)];
+        maps_of(nextp, nma, nmb);
+        patn = pattern_of(ma, mb);
+        touched |= (unsigned)patn;
+      } else {
+        has_next = false;
+      }
+    } else {
+      pa += (int64_t)KC * lda;
+      pb += (int64_t)KC * lda;
+    }
+    if (has_next) {
+      dma(sh[buf ^ 1][0] + wave * SLD, sh[buf ^ 1][1] + wave * SLD);
+      krem -= KC;
+    }
+    const double* sA = sAw + buf * (2 * KC * SLD);
+    const double* sB = sBw + buf * (2 * KC * SLD);
+#define PA_NEGATE(bm)                                        \
+  if (NEG && negc) {                                         \
+    _Pragma("unroll") for (int s = 0; s < MI; s++) bm[s] = -bm[s]; \
+    asm volatile("s_nop 1");                                 \
+  }
+    PA_NEGATE(bm0)
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
+    mfma_any(patc, an0, bm0);
+    PA_NEGATE(bm1)
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
+    mfma_any(patc, an1, bm1);
+    PA_NEGATE(bm0)
+#pragma unroll
+    for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
+#pragma unroll
+    for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
+    mfma_any(patc, an0, bm0);
+    PA_NEGATE(bm1)
+    __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+    {
+      const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
+      const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
+#pragma unroll
+      for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
+#pragma unroll
+      for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_any(patc, an1, bm1);
+    if (!has_next) break;
+    buf ^= 1;
+  }
+#undef PA_NEGATE
+  return touched;
+}
+
 // KIND 0: the bulk launches.  KIND 1 (`k_update<1>` in profiles): the same code for the few latency-critical tasks of a
 // level that the two-stream driver runs beside the bulk launch of the previous slot; a separate instantiation so that
 // per-kernel profiles of the two do not mix.
@@ -332,7 +519,10 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   // case).  The plan puts the whole-tile pieces of a task first (Task::nfull) and sets Task flag 8 for sign flips.
   unsigned touched;
   const bool neg = (tk.flags & 8u) != 0;
-  if ((int)tk.nfull == tk.pn) {
+  if (tk.flags & TASK_GATHERED) {
+    if (neg) touched = piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    else touched = piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+  } else if ((int)tk.nfull == tk.pn) {
     if (tk.tm == TM && tk.tn == TN) {
       if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
       else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
@@ -723,7 +913,10 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     acc_zero();
     unsigned touched;
     const bool neg = (tk.flags & 8u) != 0;
-    if ((int)tk.nfull == tk.pn) {
+    if (tk.flags & TASK_GATHERED) {
+      if (neg) touched = piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+      else touched = piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    } else if ((int)tk.nfull == tk.pn) {
       if (tk.tm == TM && tk.tn == TN) {
         if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
         else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);

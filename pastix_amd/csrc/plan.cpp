@@ -60,6 +60,7 @@ struct RawPiece {
   int32_t lvl;    // level of the source cblk
   uint8_t carena; // arena (plane) of the target: 0 L, 1 U, 2/3 their imaginary planes
   uint8_t shared; // target receives contributions from several ranks (windowed schedule)
+  uint16_t gtid;  // gathered piece: the host thread whose list holds its row maps (p.dr | p.dc << 16 = index there)
   Piece p;
 };
 
@@ -402,6 +403,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     return std::max(1, std::min(n, 64));
   }();
   std::vector<BlockList<RawPiece>> traw((size_t)nthr);
+  std::vector<std::vector<uint32_t>> tmaps((size_t)nthr);   // gathered pieces: their row maps, 64 words each
+  // (rectangles per tile and source cblk from which they become one gathered piece; options.gather_min, default 3; the
+  // fp32 kernel and the fan-in schedule of the multi-GPU driver take rectangles only)
+  const int64_t gather_min = (owner || floattype == PASTIX_AMD_REALSINGLE || P.opts.gather_min < 0) ? ((int64_t)1 << 40)
+                                                                                                  : (P.opts.gather_min > 0 ? P.opts.gather_min : 3);
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
   std::atomic<int64_t> gen_next{0};
@@ -409,60 +415,146 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     BlockList<RawPiece>& raw = traw[(size_t)tid];
     double uflops = 0, ubytes = 0;
 
-    auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
-                    int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
-      // split the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t into tiles
+    // one piece (all its planes) into tile (rt, ct) of target panel t: target rows [r0, r1) x columns [c0, c1) (panel
+    // coordinates) from the source rows a_src.. / b_src.. of panel k.  gmap >= 0: a GATHERED piece -- r0/r1/c0/c1 then only
+    // count the source rows (m = r1 - r0, n = c1 - c0) and where they land is in this thread's map list at gmap.
+    auto push_tile = [&](int64_t k, int64_t t, int64_t rt, int64_t ct, int64_t a_src, int64_t b_src, int64_t r0, int64_t r1,
+                         int64_t c0, int64_t c1, uint16_t flags, uint8_t carena, int64_t gmap) {
       const int64_t w_t = P.cblk[t].lcolnum - P.cblk[t].fcolnum + 1;
       const int64_t nct = (w_t + TN - 1) / TN;
       const int64_t sk = P.cblk[k].stride;
       const int64_t wk = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+      auto push = [&](uint16_t fl, uint8_t ca) {
+        RawPiece rp;
+        rp.tile = tile_base[t] + rt * nct + ct + (int64_t)ca * ntile;
+        // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
+        // targets: not before `window` levels ahead of the target's own level.
+        rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
+        rp.carena = ca;
+        rp.shared = shared[t];
+        rp.gtid = (uint16_t)tid;
+        rp.p.a_off = P.poff[k] + a_src;
+        rp.p.b_off = P.poff[k] + b_src;
+        rp.p.lda = (int32_t)sk;
+        rp.p.k = (uint16_t)wk;
+        rp.p.m = (uint16_t)(r1 - r0);
+        rp.p.n = (uint16_t)(c1 - c0);
+        if (gmap >= 0) {
+          rp.p.dr = (uint16_t)(gmap & 0xffff);
+          rp.p.dc = (uint16_t)(gmap >> 16);
+          rp.p.flags = (uint16_t)(fl | PIECE_GATHERED);
+        } else {
+          rp.p.dr = (uint16_t)(r0 - rt * TM);
+          rp.p.dc = (uint16_t)(c0 - ct * TN);
+          rp.p.flags = fl;
+        }
+        raw.push_back(rp);
+        uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
+        ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
+      };
+      if (!cplx) {
+        push(flags, carena);
+      } else if (herm) {
+        // Hermitian product on split planes (SOPALIN_GEMM "N","C": the B operand, L D, is conjugated):
+        //   C_re -= A_re B_re^T + A_im B_im^T ;  C_im -= A_im B_re^T - A_re B_im^T
+        const int a = flags & 3, b = (flags >> 2) & 3;
+        push(AB(a, b), carena);
+        push(AB(a + 2, b + 2), carena);
+        push(AB(a + 2, b), (uint8_t)(carena + 2));
+        push((uint16_t)(AB(a, b + 2) | 16), (uint8_t)(carena + 2));
+      } else {
+        // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
+        //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T
+        const int a = flags & 3, b = (flags >> 2) & 3;
+        push(AB(a, b), carena);
+        push((uint16_t)(AB(a + 2, b + 2) | 16), carena);
+        push(AB(a, b + 2), (uint8_t)(carena + 2));
+        push(AB(a + 2, b), (uint8_t)(carena + 2));
+      }
+    };
+    // the rectangle [trow,trow+nrows) x [tcol,tcol+ncols) of target panel t, split into tiles
+    auto emit = [&](int64_t k, int64_t t, int64_t a_row, int64_t b_row, int64_t trow, int64_t nrows,
+                    int64_t tcol, int64_t ncols, uint16_t flags, uint8_t carena) {
       for (int64_t rt = trow / TM; rt * TM < trow + nrows; rt++) {
-        int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
+        const int64_t r0 = std::max(trow, rt * TM), r1 = std::min(trow + nrows, (rt + 1) * TM);
         for (int64_t ct = tcol / TN; ct * TN < tcol + ncols; ct++) {
-          int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
-          auto push = [&](uint16_t fl, uint8_t ca) {
-            RawPiece rp;
-            rp.tile = tile_base[t] + rt * nct + ct + (int64_t)ca * ntile;
-            // "lvl" = launch slot - 1.  Local targets: as soon as the source is factorized.  Shared
-            // targets: not before `window` levels ahead of the target's own level.
-            rp.lvl = shared[t] ? std::max(P.level[k], P.level[t] - 1 - window) : P.level[k];
-            rp.carena = ca;
-            rp.shared = shared[t];
-            rp.p.a_off = P.poff[k] + a_row + (r0 - trow);
-            rp.p.b_off = P.poff[k] + b_row + (c0 - tcol);
-            rp.p.lda = (int32_t)sk;
-            rp.p.k = (uint16_t)wk;
-            rp.p.dr = (uint16_t)(r0 - rt * TM);
-            rp.p.m = (uint16_t)(r1 - r0);
-            rp.p.dc = (uint16_t)(c0 - ct * TN);
-            rp.p.n = (uint16_t)(c1 - c0);
-            rp.p.flags = fl;
-            raw.push_back(rp);
-            uflops += 2.0 * double(r1 - r0) * double(c1 - c0) * double(wk);
-            ubytes += 8.0 * double(wk) * double((r1 - r0) + (c1 - c0));
-          };
-          if (!cplx) {
-            push(flags, carena);
-          } else if (herm) {
-            // Hermitian product on split planes (SOPALIN_GEMM "N","C": the B operand, L D, is conjugated):
-            //   C_re -= A_re B_re^T + A_im B_im^T ;  C_im -= A_im B_re^T - A_re B_im^T
-            const int a = flags & 3, b = (flags >> 2) & 3;
-            push(AB(a, b), carena);
-            push(AB(a + 2, b + 2), carena);
-            push(AB(a + 2, b), (uint8_t)(carena + 2));
-            push((uint16_t)(AB(a, b + 2) | 16), (uint8_t)(carena + 2));
-          } else {
-            // complex symmetric product on split planes (no conjugation, SOPALIN_GEMM "N","T"):
-            //   C_re -= A_re B_re^T - A_im B_im^T ;  C_im -= A_re B_im^T + A_im B_re^T
-            const int a = flags & 3, b = (flags >> 2) & 3;
-            push(AB(a, b), carena);
-            push((uint16_t)(AB(a + 2, b + 2) | 16), carena);
-            push(AB(a, b + 2), (uint8_t)(carena + 2));
-            push(AB(a + 2, b), (uint8_t)(carena + 2));
-          }
+          const int64_t c0 = std::max(tcol, ct * TN), c1 = std::min(tcol + ncols, (ct + 1) * TN);
+          push_tile(k, t, rt, ct, a_row + (r0 - trow), b_row + (c0 - tcol), r0, r1, c0, c1, flags, carena, -1);
         }
       }
     };
+    // ---- gathered pieces -------------------------------------------------------------------------------------------------
+    // What one source cblk k contributes to one tile of target t is a set of rectangles: (runs of its bloks j that land
+    // contiguously in t's panel) x (its bloks i facing t).  On layouts whose bloks are fragments (blend on separators whose
+    // nodes are numbered across their low-side neighbours: 2-4 rows every 50-60) that is dozens of rectangles of a few rows
+    // and columns per tile, each a pass of K / 16 latency-bound chunks through the update loop.  Their SOURCE rows are
+    // consecutive in k's panel (its bloks are stacked) -- only the landing is scattered --, so from `gather_min` rectangles
+    // on the tile gets them as ONE piece: m consecutive source rows, n consecutive source rows for the columns, and two row
+    // maps that say where each lands (Piece flag 32; the update kernel's MODE 3 loop gathers while it stages).  Which
+    // products are formed and in which order they are accumulated per tile entry (source cblks in the order of the list)
+    // does not change.  Real double and complex double on one GPU (the fp32 kernel and the fan-in schedule take rectangles).
+    struct Frag { int64_t src, dst, len; };                  // source row in k's panel, target row / column in t's panel
+    auto clip_tiles = [](const std::vector<Frag>& in, int64_t T, std::vector<std::pair<int64_t, Frag>>& out) {
+      out.clear();                                          // (tile, fragment with dst relative to the panel): dst ascending
+      for (const Frag& f : in)
+        for (int64_t tt = f.dst / T; tt * T < f.dst + f.len; tt++) {
+          const int64_t d0 = std::max(f.dst, tt * T), d1 = std::min(f.dst + f.len, (tt + 1) * T);
+          out.emplace_back(tt, Frag{f.src + (d0 - f.dst), d0, d1 - d0});
+        }
+    };
+    std::vector<std::pair<int64_t, Frag>> ta, tb;
+    auto make_map = [&](const std::pair<int64_t, Frag>* fa, size_t na, const std::pair<int64_t, Frag>* fb, size_t nb) -> int64_t {
+      std::vector<uint32_t>& G = tmaps[(size_t)tid];
+      const int64_t idx = (int64_t)(G.size() / 64);
+      G.resize(G.size() + 64, 0xffffffffu);
+      uint32_t* w = G.data() + idx * 64;
+      auto put = [&](uint32_t* ww, const std::pair<int64_t, Frag>* f, size_t n, int64_t T) {
+        const int64_t s0 = f[0].second.src;
+        for (size_t x = 0; x < n; x++)
+          for (int64_t r = 0; r < f[x].second.len; r++) {
+            const int64_t slot = f[x].second.dst + r - f[x].first * T;         // row / column inside the tile
+            const uint32_t v = (uint32_t)(f[x].second.src + r - s0);
+            uint32_t& word = ww[slot & 31];
+            const int sh = 8 * (int)(slot >> 5);
+            word = (word & ~(0xffu << sh)) | (v << sh);
+          }
+      };
+      put(w, fa, na, TM);
+      put(w + 32, fb, nb, TN);
+      return idx;
+    };
+    // rows `rows` x columns `cols` of target t from source k: per tile either the rectangles or one gathered piece
+    auto emit_set = [&](int64_t k, int64_t t, const std::vector<Frag>& rows, const std::vector<Frag>& cols, uint16_t flags,
+                        uint8_t carena) {
+      clip_tiles(rows, TM, ta);
+      clip_tiles(cols, TN, tb);
+      for (size_t a0 = 0; a0 < ta.size();) {
+        size_t a1 = a0;
+        while (a1 < ta.size() && ta[a1].first == ta[a0].first) a1++;
+        for (size_t b0 = 0; b0 < tb.size();) {
+          size_t b1 = b0;
+          while (b1 < tb.size() && tb[b1].first == tb[b0].first) b1++;
+          const int64_t rt = ta[a0].first, ct = tb[b0].first;
+          if ((int64_t)((a1 - a0) * (b1 - b0)) >= gather_min) {
+            const int64_t g = make_map(&ta[a0], a1 - a0, &tb[b0], b1 - b0);
+            int64_t m = 0, n = 0;
+            for (size_t x = a0; x < a1; x++) m += ta[x].second.len;
+            for (size_t x = b0; x < b1; x++) n += tb[x].second.len;
+            push_tile(k, t, rt, ct, ta[a0].second.src, tb[b0].second.src, 0, m, 0, n, flags, carena, g);
+          } else {
+            for (size_t x = a0; x < a1; x++)
+              for (size_t y = b0; y < b1; y++) {
+                const Frag& fa = ta[x].second;
+                const Frag& fb = tb[y].second;
+                push_tile(k, t, rt, ct, fa.src, fb.src, fa.dst, fa.dst + fa.len, fb.dst, fb.dst + fb.len, flags, carena, -1);
+              }
+          }
+          b0 = b1;
+        }
+        a0 = a1;
+      }
+    };
+    std::vector<Frag> landD, runsB, rowsI, colsG, colI(1);
 
     // (source cblks are handed out from the top of the tree down, a few at a time: the cblks of the top separators have
     // hundreds of bloks -- O(bloks^2) pieces each -- and would otherwise decide which thread finishes last)
@@ -472,54 +564,69 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (int64_t k = nc - 1 - kc; k >= std::max<int64_t>(0, nc - 8 - kc); k--) {
       if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
       const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
-      for (int64_t i = fb + 1; i < lb; i++) {
-        const int64_t t = P.blok[i].cblknum;
+      // groups of consecutive bloks [g0, g1) facing the same cblk t (they land in t's diagonal blok; every later blok of
+      // k lands in an off-diagonal blok of t: containment, sopalin_compute.c:558-559)
+      for (int64_t g0 = fb + 1, g1; g0 < lb; g0 = g1) {
+        const int64_t t = P.blok[g0].cblknum;
+        g1 = g0;
+        while (g1 < lb && P.blok[g1].cblknum == t) g1++;
         const int64_t tf = P.cblk[t].fcolnum;
         const int64_t tfb = P.cblk[t].bloknum, tlb = P.cblk[t + 1].bloknum;
-        const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
-        const int64_t tcol = P.blok[i].frownum - tf;
+        landD.clear();
+        runsB.clear();
+        colsG.clear();
         int64_t b3 = tfb;
-        // runs of source bloks that land contiguously in the target panel
-        int64_t run_src = -1, run_dst = -1, run_len = 0;
-        bool run_diag = false;
-        auto flush = [&]() {
-          if (run_len <= 0) return;
-          if (!lu) {
-            // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
-            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, ldlt ? AB(0, 1) : AB(0, 0), 0);
-          } else if (!run_diag) {
-            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // L U^T -> L arena
-            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(1, 0), 1);   // U L^T -> U arena
-          } else {
-            // target is the diagonal blok of t (sopalin_compute.c:430-435,567-579)
-            emit(k, t, run_src, P.blok[i].coefind, run_dst, run_len, tcol, hi, AB(0, 1), 0);   // lower/diag part
-          }
-          run_len = 0;
-        };
-        for (int64_t j = i; j < lb; j++) {
+        for (int64_t j = g0; j < lb; j++) {
           const int64_t fj = P.blok[j].frownum, lj = P.blok[j].lrownum, hj = lj - fj + 1;
           while (b3 < tlb && !(fj >= P.blok[b3].frownum && lj <= P.blok[b3].lrownum)) b3++;
           if (b3 >= tlb) { terr[tid] = PASTIX_AMD_ERR_LAYOUT; return; }   // containment (sopalin_compute.c:558-559)
           if (P.tcoef[b3] < 0) { terr[tid] = PASTIX_AMD_ERR_LAYOUT; return; }   // (cannot happen: fanin_touched marks exactly these)
           const int64_t dst = P.tcoef[b3] + (fj - P.blok[b3].frownum);
-          const bool diag = (b3 == tfb);
-          if (run_len > 0 && dst == run_dst + run_len && diag == run_diag && !(lu && diag)) {
-            run_len += hj;
+          if ((b3 == tfb) != (j < g1)) { terr[tid] = PASTIX_AMD_ERR_LAYOUT; return; }
+          if (j < g1) {
+            landD.push_back(Frag{P.blok[j].coefind, dst, hj});
+            colsG.push_back(Frag{P.blok[j].coefind, fj - tf, hj});
+          } else if (!runsB.empty() && dst == runsB.back().dst + runsB.back().len) {
+            runsB.back().len += hj;                    // runs of source bloks that land contiguously in the target panel
           } else {
-            flush();
-            run_src = P.blok[j].coefind; run_dst = dst; run_len = hj; run_diag = diag;
+            runsB.push_back(Frag{P.blok[j].coefind, dst, hj});
           }
-          if (lu && diag) {
-            // flush per blok: the transposed U contribution needs (i,j) roles individually
-            flush();
-            if (j != i) {
+        }
+        // the rows BELOW t's diagonal blok: every blok of the group against every run
+        if (!runsB.empty()) {
+          if (!lu) {
+            // LLt: C_L -= L_j L_i^T ; LDLt: C_L -= L_j (L D)_i^T with L D kept in the U arena
+            emit_set(k, t, runsB, colsG, ldlt ? AB(0, 1) : AB(0, 0), 0);
+          } else {
+            emit_set(k, t, runsB, colsG, AB(0, 1), 0);   // L U^T -> L arena
+            emit_set(k, t, runsB, colsG, AB(1, 0), 1);   // U L^T -> U arena
+          }
+        }
+        // t's diagonal blok: blok i against the bloks j >= i of the group
+        for (int64_t i = g0; i < g1; i++) {
+          const int64_t hi = P.blok[i].lrownum - P.blok[i].frownum + 1;
+          const int64_t tcol = P.blok[i].frownum - tf;
+          if (!lu) {
+            rowsI.clear();
+            for (int64_t j = i; j < g1; j++) {
+              const Frag& f = landD[(size_t)(j - g0)];
+              if (!rowsI.empty() && f.dst == rowsI.back().dst + rowsI.back().len) rowsI.back().len += f.len;
+              else rowsI.push_back(f);
+            }
+            colI[0] = Frag{P.blok[i].coefind, tcol, hi};
+            emit_set(k, t, rowsI, colI, ldlt ? AB(0, 1) : AB(0, 0), 0);
+          } else {
+            // LU: per blok pair -- the transposed U contribution needs the (i, j) roles individually
+            // (sopalin_compute.c:430-435,567-579)
+            for (int64_t j = i; j < g1; j++) {
+              const Frag& f = landD[(size_t)(j - g0)];
+              emit(k, t, f.src, P.blok[i].coefind, f.dst, f.len, tcol, hi, AB(0, 1), 0);   // lower/diag part
               // C_L[cols of i as rows, rows of j as cols] -= L_i ... transposed U result:
               // (U_j L_i^T)^T = L_i U_j^T  -> rows = rows of i (tcol..), cols = rows of j (dst..)
-              emit(k, t, P.blok[i].coefind, P.blok[j].coefind, tcol, hi, dst, hj, AB(0, 1), 0);
+              if (j != i) emit(k, t, P.blok[i].coefind, f.src, tcol, hi, f.dst, f.len, AB(0, 1), 0);
             }
           }
         }
-        flush();
       }
       }
     }
@@ -626,14 +733,38 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   advise_huge(P.pieces.data(), P.pieces.capacity() * sizeof(Piece));
   P.pieces.resize(raw.size());
   {
-    std::vector<std::thread> th;
+    // (the row maps of the gathered pieces are numbered in the order of the sorted list: the plan does not depend on which
+    // host thread generated what)
     const size_t n = raw.size(), per = (n + (size_t)nthr - 1) / (size_t)nthr;
-    auto cp = [&](int t) {
-      for (size_t i = (size_t)t * per; i < std::min(n, ((size_t)t + 1) * per); i++) P.pieces[i] = raw[i].p;
+    std::vector<size_t> gcount((size_t)nthr + 1, 0);
+    auto run_par = [&](auto&& fn) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthr; t++) th.emplace_back(fn, t);
+      fn(0);
+      for (auto& x : th) x.join();
     };
-    for (int t = 1; t < nthr; t++) th.emplace_back(cp, t);
-    cp(0);
-    for (auto& x : th) x.join();
+    run_par([&](int t) {
+      size_t c = 0;
+      for (size_t i = (size_t)t * per; i < std::min(n, ((size_t)t + 1) * per); i++) c += (raw[i].p.flags & PIECE_GATHERED) != 0;
+      gcount[(size_t)t + 1] = c;
+    });
+    for (int t = 0; t < nthr; t++) gcount[(size_t)t + 1] += gcount[(size_t)t];
+    P.gmaps.assign(gcount[(size_t)nthr] * 64, 0xffffffffu);
+    run_par([&](int t) {
+      size_t g = gcount[(size_t)t];
+      for (size_t i = (size_t)t * per; i < std::min(n, ((size_t)t + 1) * per); i++) {
+        Piece pc = raw[i].p;
+        if (pc.flags & PIECE_GATHERED) {
+          const size_t loc = (size_t)pc.dr | ((size_t)pc.dc << 16);
+          std::copy_n(tmaps[(size_t)raw[i].gtid].data() + loc * 64, 64, P.gmaps.data() + g * 64);
+          pc.dr = (uint16_t)(g & 0xffff);
+          pc.dc = (uint16_t)(g >> 16);
+          g++;
+        }
+        P.pieces[i] = pc;
+      }
+    });
+    for (auto& v : tmaps) std::vector<uint32_t>().swap(v);
   }
   P.tasks.clear();
   P.slot_task_ptr.assign(NL + 1, 0);
@@ -740,7 +871,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       {   // pieces that cover the whole valid tile (any K: the kernel pads the last chunk with zero lines) first: the kernel runs them
           // through its specialized loop; tk.nfull = how many
         auto isfull = [&](const Piece& pc) {   // covers the whole valid tile (tm x tn; 128 x 128 except at the edges)
-          return pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0;
+          return !(pc.flags & PIECE_GATHERED) && pc.dr == 0 && pc.dc == 0 && pc.m == tk.tm && pc.n == tk.tn && pc.k > 0;
         };
         // (manual stable partition through a reused scratch vector: std::stable_partition allocates per call)
         O.part_tmp.clear();
@@ -753,8 +884,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
         auto mid = P.pieces.begin() + wpos;
         tk.nfull = (uint32_t)(mid - (P.pieces.begin() + q));
         for (auto it = P.pieces.begin() + q; it != mid; ++it) O.full_flops += 2.0 * it->m * (double)it->n * it->k;
-        for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it)
+        for (auto it = P.pieces.begin() + q; it != P.pieces.begin() + e; ++it) {
           if (it->flags & 16) tk.flags |= 8u;            // the update kernel needs its sign-flipping variant
+          if (it->flags & PIECE_GATHERED) tk.flags |= TASK_GATHERED;   // ... its gathering loop, for all pieces of the task
+        }
 
       }
       const uint8_t urg = P.level[t] == slot ? 2 : P.level[t] == slot + 1 ? 1 : 0;
@@ -767,7 +900,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       // is built for latency, not for flops: on blend's layouts (cblks of 60-120 columns, bloks of at most 120 rows:
       // hardly any whole-tile piece, so that the fill rule alone diverted most of the work) the quadrant kernel took
       // 44 % of the time of an 80^3 factorization driven by the real PaStiX.
-      if (quad_on && !raw[q].shared && tk.nfull == 0 && slot < RL0) {     // (the run takes whole tiles only)
+      if (quad_on && !raw[q].shared && tk.nfull == 0 && slot < RL0 && !(tk.flags & TASK_GATHERED)) {     // (the run takes whole tiles only)
         double iters = 0;
         int maxmn = 0;
         for (size_t z = q; z < e; z++) {
@@ -1398,6 +1531,73 @@ int64_t run_verify(const Plan& P) {
     }
   }
   return (done == nr && doned == nd) ? 0 : -2;
+}
+
+// Host-only check of the update schedule against the reference's definition (compute_1dgemm, sopalin_compute.c:865-1032):
+// for every source cblk k, every off-diagonal blok i and every blok j >= i the product (rows of j) x (rows of i)^T is
+// subtracted ONCE from the entries of the facing panel where add_contrib_local puts it (:427-429).  Decodes every piece of
+// the plan -- rectangles and gathered pieces -- into (target entry, source row of A, source row of B) triples and compares
+// the sorted list with the one made from the layout.  Real LLt / LDLt (one plane, one product per pair).
+// out[0] = products expected, out[1] = products the pieces make, out[2] = mismatching entries, out[3] = gathered pieces.
+int verify_pieces(const Plan& P, int64_t out[4]) {
+  struct T3 { int64_t c, a, b; bool operator<(const T3& o) const { return c != o.c ? c < o.c : a != o.a ? a < o.a : b < o.b; }
+              bool operator==(const T3& o) const { return c == o.c && a == o.a && b == o.b; } };
+  std::vector<T3> want, have;
+  const int64_t nc = P.cblknbr;
+  for (int64_t k = 0; k < nc; k++) {
+    if (P.role[k] != 1) continue;
+    const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
+    for (int64_t i = fb + 1; i < lb; i++) {
+      const int64_t t = P.blok[i].cblknum, tf = P.cblk[t].fcolnum;
+      int64_t b3 = P.cblk[t].bloknum;
+      for (int64_t j = i; j < lb; j++) {
+        while (!(P.blok[j].frownum >= P.blok[b3].frownum && P.blok[j].lrownum <= P.blok[b3].lrownum)) b3++;
+        const int64_t dst = P.tcoef[b3] + (P.blok[j].frownum - P.blok[b3].frownum);
+        for (int64_t r = 0; r <= P.blok[j].lrownum - P.blok[j].frownum; r++)
+          for (int64_t c = 0; c <= P.blok[i].lrownum - P.blok[i].frownum; c++)
+            want.push_back(T3{P.poff[t] + dst + r + (P.blok[i].frownum - tf + c) * P.tstride[t],
+                              P.poff[k] + P.blok[j].coefind + r, P.poff[k] + P.blok[i].coefind + c});
+      }
+    }
+  }
+  int64_t ngather = 0;
+  for (size_t ti = 0; ti < P.tasks.size(); ti++) {
+    const Task& tk = P.tasks[ti];
+    for (int z = 0; z < tk.pn; z++) {
+      const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+      if (pc.flags & PIECE_GATHERED) {
+        ngather++;
+        const uint32_t* w = P.gmaps.data() + ((size_t)pc.dr | ((size_t)pc.dc << 16)) * 64;
+        for (int r = 0; r < 128; r++) {
+          const uint32_t sa = (w[r & 31] >> (8 * (r >> 5))) & 255u;
+          if (sa == 255u) continue;
+          for (int c = 0; c < 128; c++) {
+            const uint32_t sb = (w[32 + (c & 31)] >> (8 * (c >> 5))) & 255u;
+            if (sb == 255u) continue;
+            have.push_back(T3{tk.c_off + r + (int64_t)c * tk.ldc, pc.a_off + sa, pc.b_off + sb});
+          }
+        }
+      } else {
+        for (int r = 0; r < pc.m; r++)
+          for (int c = 0; c < pc.n; c++)
+            have.push_back(T3{tk.c_off + pc.dr + r + (int64_t)(pc.dc + c) * tk.ldc, pc.a_off + r, pc.b_off + c});
+      }
+    }
+  }
+  std::sort(want.begin(), want.end());
+  std::sort(have.begin(), have.end());
+  int64_t bad = 0;
+  size_t x = 0, y = 0;
+  while (x < want.size() || y < have.size()) {
+    if (x < want.size() && y < have.size() && want[x] == have[y]) { x++; y++; }
+    else if (y >= have.size() || (x < want.size() && want[x] < have[y])) { bad++; x++; }
+    else { bad++; y++; }
+  }
+  out[0] = (int64_t)want.size();
+  out[1] = (int64_t)have.size();
+  out[2] = bad;
+  out[3] = ngather;
+  return 0;
 }
 
 }  // namespace pastix_amd

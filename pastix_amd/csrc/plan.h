@@ -34,7 +34,13 @@ struct Piece {
   uint16_t dc, n;     // destination cols inside the tile
   uint16_t flags;     // bits 0-1: arena of A, bits 2-3: arena of B, bit 4: contribution is ADDED
                       // arenas: 0 = L (real part), 1 = U / L*D (real part), 2/3 = their imaginary planes
+                      // bit 5: GATHERED piece (plan.cpp "gathered pieces"): A = the m CONSECUTIVE source rows from a_off,
+                      // B = the n consecutive source rows from b_off, scattered over the tile's rows / columns by the row
+                      // maps gmap[64 g .. 64 g + 63], g = dr | dc << 16: word i < 32 holds, one byte each, the source row of
+                      // the tile rows i, i + 32, i + 64, i + 96 (255: none); words 32-63 the same for the tile's columns
 };
+constexpr uint16_t PIECE_GATHERED = 32;
+constexpr uint32_t TASK_GATHERED = 128;   // Task flag: some piece of the task is gathered (the update kernel's MODE 3 loop)
 static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 
 struct Task {
@@ -48,8 +54,10 @@ struct Task {
 };
 static_assert(sizeof(Task) == 32, "Task must be 32 bytes");
 
-struct Arenas { double* p[4]; };
-   // device base pointers of the (up to) four planes
+struct Arenas {
+  double* p[4];              // device base pointers of the (up to) four planes
+  const uint32_t* gmap;      // row maps of the gathered pieces (Piece flag 32): 64 words each, see Piece
+};
 
 struct PanelTask {    // one cblk for the diagonal-block kernel
   int64_t off;        // arena offset of the panel
@@ -208,6 +216,7 @@ struct Plan {
   std::vector<int64_t> slot_usmall_begin;// [nlevels] urgent tasks [slot_usmall_begin[s], slot_urgent_end[s]): the same
   std::vector<Task> tasks;
   std::vector<Piece, NoInitAlloc<Piece>> pieces;   // (filled by parallel copies: no serial zero fill of ~10 GB first)
+  std::vector<uint32_t> gmaps;           // row maps of the gathered pieces, 64 words each (Piece)
   double update_flops = 0;
   double full_flops = 0;                 // part of update_flops in full 128x128 pieces (specialized loop)
   double urgent_flops = 0;               // part of update_flops in the urgent tasks of their slots
@@ -251,6 +260,7 @@ int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
 int64_t run_verify(const Plan& plan);
+int verify_pieces(const Plan& plan, int64_t out[4]);
 int owner_view(const pastix_amd_layout_t* layout, const int32_t* owner, int32_t myrank, Plan& plan);
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);
 int fanin_touched(const pastix_amd_layout_t* layout, const int32_t* owner, uint64_t* mask);

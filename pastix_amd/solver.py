@@ -22,7 +22,7 @@ def fact_flops(cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE):
 
 class Plan:
     def __init__(self, cblk4, blok4, factotype=FACT_LLT, floattype=REALDOUBLE, device=0, lookahead=0, verbose=0,
-                 schur=False, quadrant_min=0, quadrant_fill_pct=0, run_schedule=0, run_max_cblks=0, run_t_workers=0, run_d_workers=0):
+                 schur=False, quadrant_min=0, quadrant_fill_pct=0, run_schedule=0, run_max_cblks=0, run_t_workers=0, run_d_workers=0, gather_min=0):
         self.layout = LayoutArrays(cblk4, blok4)
         self.factotype = factotype
         # panels / CSC values of the plan's arithmetic; the vectors of a solve stay double for single-precision plans
@@ -40,6 +40,7 @@ class Plan:
         opts.run_max_cblks = run_max_cblks
         opts.run_t_workers = run_t_workers
         opts.run_d_workers = run_d_workers
+        opts.gather_min = gather_min
         check(_lib.lib().pastix_amd_plan_create(ctypes.byref(self.layout.c), factotype, floattype,
                                                 ctypes.byref(opts), ctypes.byref(self._h)),
               "pastix_amd_plan_create")
