@@ -1,7 +1,7 @@
 // acc_regs.h -- device-only: the accumulation registers a[0:63] by NAME (inline assembly), outside the compiler's register
-// allocation.  k_update / k_run_update keep their 128 x 128 tile there (kernels_update.hip: why); the panel-solve and
-// diagonal-blok tickets of the run launch, in which the update path's accumulators are idle, PARK their resident tiles
-// there (trsm_parked, diag_lu_body / diag_zsy_body with PARK).  Wait states the compiler cannot insert for code it does not
+// allocation.  k_update / k_run_update keep their 128 x 128 tile there (kernels_update.hip: why); the panel-solve
+// tickets of the run launch, in which the update path's accumulators are idle, PARK their resident tiles
+// there (trsm_parked).  Wait states the compiler cannot insert for code it does not
 // see (cdna_hip_programming.md 5.7 item 2) are in the strings.  tests/test_kernel_audit.py requires that no instruction of
 // the compiler's touches an AGPR in the files that use these.
 #pragma once
@@ -43,15 +43,6 @@ __device__ __forceinline__ double acc_read() {
                : PA_ACC_CLOBBER);
   return __hiloint2double(hi, lo);
 }
-
-// the same with operands a VALU instruction has just written (VALU write -> MFMA operand: 2 wait states)
-template <int T>
-__device__ __forceinline__ void acc_mfma_f(const double an, const double bm) {
-  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(an), "v"(bm), "n"(8 * T), "n"(8 * T + 7)
-               : PA_ACC_CLOBBER);
-}
-// (v_accvgpr_write -> MFMA SrcC: call once between the last acc_write and the first acc_mfma on the written registers)
-__device__ __forceinline__ void acc_written() { asm volatile("s_nop 7" ::: PA_ACC_CLOBBER); }
 
 // Wait states are ours on both sides of an asm statement (cdna_hip_programming.md 5.7 item 2): FRESH = the value was just
 // produced by an MFMA of the compiler's (its D must have retired before a VALU move reads it: the nops lead the string);

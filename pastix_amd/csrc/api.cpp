@@ -279,7 +279,7 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         const char* er = dev_opt("room");                    // (72: see run_sync.h run_pop)
         p->runctl.room = er ? atoi(er) : 72;
         const char* e = dev_opt("onek");
-        p->runctl.onek = !(e && atoi(e) == 0) ? 1 : 0;
+        p->runctl.onek = (!p->cplx && (H.factotype == PASTIX_AMD_FACT_LLT || H.factotype == PASTIX_AMD_FACT_LDLT) && !(e && atoi(e) == 0)) ? 1 : 0;
       }
       {
         std::vector<int32_t> img(p->nRunState, -1);

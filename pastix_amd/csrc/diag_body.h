@@ -7,7 +7,6 @@
 #include "plan.h"
 #include "devmath.h"
 #include "run_sync.h"
-#include "acc_regs.h"
 
 namespace pastix_amd {
 
@@ -375,32 +374,23 @@ __device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* _
 }
 #undef DP
 
-// ---- a wave's NS resident 16 x 16 tile pairs (diag_lu_body: L / U^T planes; diag_zsy_body: Re / Im planes) -----------------
-// As a kernel of its own (PARK = false) the pairs are compiler-allocated VGPRs (80 of the kernel's 128).  As a ticket of the
-// run launch the body lives in k_run_update's 64 VGPRs: pairs 0-3 are PARKED in the accumulation registers a[0:63], idle in
-// such a ticket (pair sl: plane 0 in a[16 sl : 16 sl + 7], plane 1 in a[16 sl + 8 : 16 sl + 15]), their trailing updates are
-// MFMAs on those registers in place (acc_regs.h), only the last pair stays in VGPRs.  Same instructions on the same values
-// in the same order either way: both forms give the same bits.
-template <bool PARK, int NS>
+// ---- a wave's NS resident 16 x 16 tile pairs (diag_lu_body: L / U^T planes; diag_zsy_body: Re / Im planes), in VGPRs --------
+// (Round 5 also tried these bodies as tickets of the run launch, inside k_run_update's 64 VGPRs with four of the five pairs
+// PARKED in the accumulation registers a[0:63]: every test passed and one LU factorization in ten at 48^3 had wrong entries
+// in the last columns of a diagonal blok -- DESIGN.md 9.  LU and complex bloks keep their resident kernel.)
+template <int NS>
 struct TilePairs {
-  static constexpr int NV = PARK ? NS - 4 : NS;           // pairs held in VGPRs (the last NV slots)
-  d4 p[2][NV];
+  d4 p[2][NS];
 };
-template <bool PARK, int NS, int SL, int PL>
-__device__ __forceinline__ void tp_mfma(TilePairs<PARK, NS>& t, const double a, const double b) {
-  if constexpr (PARK && SL < 4) acc_mfma_f<2 * SL + PL>(a, b);
-  else { d4& c = t.p[PL][SL - (NS - TilePairs<PARK, NS>::NV)]; c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <int NS, int SL, int PL>
+__device__ __forceinline__ void tp_mfma(TilePairs<NS>& t, const double a, const double b) {
+  d4& c = t.p[PL][SL];
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
-template <bool PARK, int NS, int SL, int PL, int Q>
-__device__ __forceinline__ double tp_get(const TilePairs<PARK, NS>& t) {
-  if constexpr (PARK && SL < 4) return acc_read<2 * SL + PL, Q>();
-  else return t.p[PL][SL - (NS - TilePairs<PARK, NS>::NV)][Q];
-}
-template <bool PARK, int NS, int SL, int PL, int Q>
-__device__ __forceinline__ void tp_set(TilePairs<PARK, NS>& t, const double v) {
-  if constexpr (PARK && SL < 4) acc_write<2 * SL + PL, Q>(v);
-  else t.p[PL][SL - (NS - TilePairs<PARK, NS>::NV)][Q] = v;
-}
+template <int NS, int SL, int PL, int Q>
+__device__ __forceinline__ double tp_get(const TilePairs<NS>& t) { return t.p[PL][SL][Q]; }
+template <int NS, int SL, int PL, int Q>
+__device__ __forceinline__ void tp_set(TilePairs<NS>& t, const double v) { t.p[PL][SL][Q] = v; }
 
 // ------------------------------------------------------------------------------------------------
 // LU diagonal blok (full w x w square in the L arena; transposed copy into the U arena), w <= 128 (wider cblks are re-cut).
@@ -433,7 +423,7 @@ struct DiagLuLds {
   double Xs[2][16][XR];        // the same, solved: L21 [column][row] and U12^T [row of U][column of U]
 };
 // (512 threads; COH: every store of the blok is write-through -- the run launch hands it to other workgroups)
-template <bool COH, bool PARK = false>
+template <bool COH>
 __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ L, double* __restrict__ U, const PanelTask& tk,
                                              double* __restrict__ dinv_ws, const double critere,
                                              long long* __restrict__ nbpivot, const int tid) {
@@ -445,10 +435,9 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
   const int lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int nbt = (w + 15) >> 4;
   // tile pairs (bi >= bj) but (0, 0), column by column (see diag_zsy_body): wave 1 + id % 7 holds pair id in slot id / 7
-  TilePairs<PARK, NS> tp;                                    // plane 0: the tile of A, plane 1: the tile of A^T
+  TilePairs<NS> tp;                                    // plane 0: the tile of A, plane 1: the tile of A^T
   int tbi[NS], tbj[NS];
   if (wave > 0) {
-    if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_BEGIN");   // (tests/test_kernel_audit.py: no AGPR of the compiler's in here)
     unroll_for<0, NS>([&](auto SLc) {
       constexpr int sl = decltype(SLc)::value;
       int id = (wave - 1) + 7 * sl, bj = 0, cnt = 7;
@@ -470,8 +459,8 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
       }
       unroll_for<0, 4>([&](auto Qc) {
         constexpr int q = decltype(Qc)::value;
-        tp_set<PARK, NS, sl, 0, q>(tp, lo[q]);
-        tp_set<PARK, NS, sl, 1, q>(tp, up[q]);
+        tp_set<NS, sl, 0, q>(tp, lo[q]);
+        tp_set<NS, sl, 1, q>(tp, up[q]);
       });
       if (on && bj == 0) {                                   // what lies below / right of the first tile goes to LDS at once
 #pragma unroll
@@ -481,7 +470,6 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
         }
       }
     });
-    if constexpr (PARK) { acc_written(); asm volatile(";;#PASTIX_AMD_PARKED_END"); }
   }
   // the trailing update of resident pair SL with the solved rows / columns of step tp_: A(r, c) -= L21(r, :) U12(:, c)
   auto update = [&](auto SLc, const int bi, const int bj, const int tp_) {
@@ -492,8 +480,8 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
       const int k = 4 * ks + g;
       const double xr = S.Xs[0][k][ro], xc = S.Xs[0][k][co];                 // L21(r, k), L21(c, k)
       const double yr = S.Xs[1][k][ro], yc = S.Xs[1][k][co];                 // U12(k, r), U12(k, c)
-      tp_mfma<PARK, NS, sl, 0>(tp, -yc, xr);                                  // A(r, c)   -= L21(r, k) U12(k, c)
-      tp_mfma<PARK, NS, sl, 1>(tp, -xc, yr);                                  // A^T(r, c) -= L21(c, k) U12(k, r)
+      tp_mfma<NS, sl, 0>(tp, -yc, xr);                                  // A(r, c)   -= L21(r, k) U12(k, c)
+      tp_mfma<NS, sl, 1>(tp, -xc, yr);                                  // A^T(r, c) -= L21(c, k) U12(k, r)
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -578,7 +566,6 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
     if (lane == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
     return;
   }
-  if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_BEGIN");
   for (int t = 0; t < nbt; t++) {
     const int kb = 16 * t, nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();                                         // (A)
@@ -619,11 +606,10 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
         constexpr int sl = decltype(SLc)::value;
         if (tbi[sl] >= 0 && tbj[sl] == t + 1) {                // (S3a) column band t + 1, then the hand-over
           update(SLc, tbi[sl], tbj[sl], t);
-          if constexpr (PARK && sl < 4) acc_settle();
           unroll_for<0, 4>([&](auto Qc) {
             constexpr int q = decltype(Qc)::value;
             const int c = g + 4 * q;
-            const double v0 = tp_get<PARK, NS, sl, 0, q>(tp), v1 = tp_get<PARK, NS, sl, 1, q>(tp);
+            const double v0 = tp_get<NS, sl, 0, q>(tp), v1 = tp_get<NS, sl, 1, q>(tp);
             if (tbi[sl] == t + 1) { S.Ts[0][l15][c] = v0; S.Ts[1][l15][c] = v1; }
             else { S.Ps[0][c][16 * (tbi[sl] - t - 2) + l15] = v0; S.Ps[1][c][16 * (tbi[sl] - t - 2) + l15] = v1; }
           });
@@ -631,7 +617,6 @@ __device__ __forceinline__ void diag_lu_body(DiagLuLds& S, double* __restrict__ 
       });
     }
   }
-  if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_END");
 }
 // ------------------------------------------------------------------------------------------------
 // k_diag_zsy_w (round 4): the complex diagonal blok on the MFMA pipe.  The blok does not fit LDS twice (Re / Im planes:
@@ -664,7 +649,7 @@ struct DiagZLds {
   double Xs[2][16][XR];        // rows below the tile, solved: L [plane][column][row]
 };
 // (COH: results stored write-through -- the run launch hands the blok to other workgroups, run_sync.h)
-template <bool HERM, bool COH, bool PARK = false>
+template <bool HERM, bool COH>
 __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, const PanelTask& tk, double* __restrict__ dinv_ws,
                                               const double critere, long long* __restrict__ nbpivot, const int tid) {
   constexpr int NS = 5;
@@ -677,10 +662,9 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
   typedef double d4v __attribute__((ext_vector_type(4)));
   // tiles (bi >= bj) but (0, 0), column by column: ids 0-6 (1..7, 0), 7-13 (1..7, 1), 14-19 (2..7, 2), ... 34 (7, 7);
   // wave 1 + id % 7 holds tile id in slot id / 7 -- every column band is spread over the waves
-  TilePairs<PARK, NS> tp;                                    // plane 0: Re, plane 1: Im (diag_lu_body: how they are held)
+  TilePairs<NS> tp;                                    // plane 0: Re, plane 1: Im (diag_lu_body: how they are held)
   int tbi[NS], tbj[NS];
   if (wave > 0) {
-    if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_BEGIN");   // (tests/test_kernel_audit.py: no AGPR of the compiler's in here)
     unroll_for<0, NS>([&](auto SLc) {
       constexpr int sl = decltype(SLc)::value;
       int id = (wave - 1) + 7 * sl, bj = 0, cnt = 7;
@@ -702,8 +686,8 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
       }
       unroll_for<0, 4>([&](auto Qc) {
         constexpr int q = decltype(Qc)::value;
-        tp_set<PARK, NS, sl, 0, q>(tp, vr[q]);
-        tp_set<PARK, NS, sl, 1, q>(tp, vi[q]);
+        tp_set<NS, sl, 0, q>(tp, vr[q]);
+        tp_set<NS, sl, 1, q>(tp, vi[q]);
       });
       if (on && bj == 0) {                                   // the rows below the first tile go to LDS at once
 #pragma unroll
@@ -713,7 +697,6 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
         }
       }
     });
-    if constexpr (PARK) { acc_written(); asm volatile(";;#PASTIX_AMD_PARKED_END"); }
   }
   // the trailing update of resident tile SL with the solved rows of step tp_ (in Xs): C -= (L D)(rows) L(cols)^T|^H
   auto update = [&](auto SLc, const int bi, const int bj, const int tp_) {
@@ -728,16 +711,16 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
       const double dr = Dk[0][k], di = Dk[1][k];
       if (!HERM) {
         const double ldr = xr * dr - xi * di, ldi = xr * di + xi * dr;       // (L D)(r, k)
-        tp_mfma<PARK, NS, sl, 0>(tp, -lr, ldr);
-        tp_mfma<PARK, NS, sl, 0>(tp, li, ldi);
-        tp_mfma<PARK, NS, sl, 1>(tp, -li, ldr);
-        tp_mfma<PARK, NS, sl, 1>(tp, -lr, ldi);
+        tp_mfma<NS, sl, 0>(tp, -lr, ldr);
+        tp_mfma<NS, sl, 0>(tp, li, ldi);
+        tp_mfma<NS, sl, 1>(tp, -li, ldr);
+        tp_mfma<NS, sl, 1>(tp, -lr, ldi);
       } else {
         const double ldr = xr * dr, ldi = xi * dr;                           // L(r, k) Re d;  times conj(L(c, k))
-        tp_mfma<PARK, NS, sl, 0>(tp, -lr, ldr);
-        tp_mfma<PARK, NS, sl, 0>(tp, -li, ldi);
-        tp_mfma<PARK, NS, sl, 1>(tp, -lr, ldi);
-        tp_mfma<PARK, NS, sl, 1>(tp, li, ldr);
+        tp_mfma<NS, sl, 0>(tp, -lr, ldr);
+        tp_mfma<NS, sl, 0>(tp, -li, ldi);
+        tp_mfma<NS, sl, 1>(tp, -lr, ldi);
+        tp_mfma<NS, sl, 1>(tp, li, ldr);
       }
       __builtin_amdgcn_sched_barrier(0);                     // (one k-slice's operands at a time: 80 VGPRs are resident)
     }
@@ -838,7 +821,6 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
     if (lane == 0 && npiv) atomicAdd((unsigned long long*)nbpivot, (unsigned long long)npiv);
     return;
   }
-  if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_BEGIN");
   for (int t = 0; t < nbt; t++) {
     const int kb = 16 * t, nb = min(16, w - kb), rem = w - kb - nb;
     __syncthreads();                                         // (A) Ts / Ps hold column band t
@@ -885,11 +867,10 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
         constexpr int sl = decltype(SLc)::value;
         if (tbi[sl] >= 0 && tbj[sl] == t + 1) {
           update(SLc, tbi[sl], tbj[sl], t);
-          if constexpr (PARK && sl < 4) acc_settle();
           unroll_for<0, 4>([&](auto Qc) {
             constexpr int q = decltype(Qc)::value;
             const int c = g + 4 * q;
-            const double v0 = tp_get<PARK, NS, sl, 0, q>(tp), v1 = tp_get<PARK, NS, sl, 1, q>(tp);
+            const double v0 = tp_get<NS, sl, 0, q>(tp), v1 = tp_get<NS, sl, 1, q>(tp);
             if (tbi[sl] == t + 1) { S.Ts[0][l15][c] = v0; S.Ts[1][l15][c] = v1; }
             else { S.Ps[0][c][16 * (tbi[sl] - t - 2) + l15] = v0; S.Ps[1][c][16 * (tbi[sl] - t - 2) + l15] = v1; }
           });
@@ -897,7 +878,6 @@ __device__ __forceinline__ void diag_zsy_body(DiagZLds& S, const Arenas& ar, con
       });
     }
   }
-  if constexpr (PARK) asm volatile(";;#PASTIX_AMD_PARKED_END");
 }
 
 }  // namespace pastix_amd

@@ -819,9 +819,11 @@ __device__ __forceinline__ void trsm_zsy_parked(const Arenas& ar, double* __rest
 // cannot deadlock: a workgroup without a ticket holds nothing anybody waits for.  (One workgroup per ticket instead of
 // the loop measured 11 % of every slot's time empty between a workgroup's end and its successor's first instruction.)
 // FT: 0 LLt, 1 LDLt, 2 LU, 3 complex LDLt, 4 complex LDLh (which panel solve a panel-solve ticket runs)
-// ONEK: the diagonal-blok tasks are tickets of this launch too (ring entries >= rc.nticket; plan.h RunCtl::onek) -- one
-// kernel, one queue, no second kernel that has to be resident beside this one.  The blok's packed lower triangle takes the
-// place of the operand buffers in LDS (66 of the 73.7 KB), the accumulation registers are idle in such a ticket.
+// ONEK (real LLt / LDLt): the diagonal-blok tasks are tickets of this launch too (ring entries >= rc.nticket; plan.h
+// RunCtl::onek) -- one kernel, one queue, no second kernel that has to be resident beside this one.  The blok's packed lower
+// triangle takes the place of the operand buffers in LDS (66 of the 73.7 KB); diag_llt_body / diag_ldlt_body keep nothing
+// in registers across their barriers, so they fit this kernel's 64 VGPRs as they are.  (LU and complex bloks are resident
+// in REGISTERS -- 80 VGPRs per wave --: they keep the kernel of their own, k_run_diag_lu / k_run_diag_z.)
 template <int FT, bool ONEK>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar, const Task* __restrict__ tasks,
                                                                const Piece* __restrict__ pieces,
@@ -831,8 +833,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
                                                                const RunD* __restrict__ rd, const double critere,
                                                                long long* __restrict__ nbpivot, int* __restrict__ errflag) {
   __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
-  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh) && sizeof(DiagLuLds) <= sizeof(sh) && sizeof(DiagZLds) <= sizeof(sh),
-                "the diagonal blok must fit the operand buffers");
+  static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh), "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
   for (;;) {
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     __syncthreads();
     const int t = __builtin_amdgcn_readfirstlane(*tick);
     if (t < 0) return;                           // (every ticket is taken, or the run is stuck)
-    if constexpr (ONEK) {
+    if constexpr (ONEK && FT <= 1) {
       if (t >= rc.nticket) {
         // a diagonal-blok ticket: k_diag_llt_w / k_diag_ldlt_w's body on this workgroup, then the cblk's panel solves count down
         __syncthreads();                         // (the ticket word in LDS is dead from here on)
@@ -867,9 +868,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
         asm volatile(";;#PASTIX_AMD_DIAG_TICKET_BEGIN");   // (tests/test_kernel_audit.py: what lies between the two markers)
         double* const Dl = &sh[0][0][0];
         if constexpr (FT == 0) diag_llt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, errflag, tid);
-        else if constexpr (FT == 1) diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
-        else if constexpr (FT == 2) diag_lu_body<true, true>(*reinterpret_cast<DiagLuLds*>(Dl), ar.p[0], ar.p[1], d.pt, dinv, critere, nbpivot, tid);
-        else diag_zsy_body<FT == 4, true, true>(*reinterpret_cast<DiagZLds*>(Dl), ar, d.pt, dinv, critere, nbpivot, tid);
+        else diag_ldlt_body<true>(Dl, Dl + DIAG_LDS_DOUBLES, ar.p[0], d.pt, dinv, critere, nbpivot, tid);
         run_drain();
         __syncthreads();
         if (wave == 0) {
@@ -950,14 +949,12 @@ void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Tas
   if (ntasks <= 0) return;
   const dim3 g((unsigned)std::min<int64_t>(ntasks + (rc.onek ? rc.nd : 0), std::max(nwg, 1))), b(64 * UW);
 #define PA_RUN(FT, ONEK) hipLaunchKernelGGL((k_run_update<FT, ONEK>), g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit, rd, critere, nbpivot, errflag)
-#define PA_RUN2(FT) do { if (rc.onek) PA_RUN(FT, true); else PA_RUN(FT, false); } while (0)
   if (ar.p[2]) {                                   // complex double (split planes)
-    if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN2(4);
-    else PA_RUN2(3);
-  } else if (factotype == PASTIX_AMD_FACT_LLT) PA_RUN2(0);
-  else if (factotype == PASTIX_AMD_FACT_LDLT) PA_RUN2(1);
-  else PA_RUN2(2);
-#undef PA_RUN2
+    if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN(4, false);
+    else PA_RUN(3, false);
+  } else if (factotype == PASTIX_AMD_FACT_LLT) { if (rc.onek) PA_RUN(0, true); else PA_RUN(0, false); }
+  else if (factotype == PASTIX_AMD_FACT_LDLT) { if (rc.onek) PA_RUN(1, true); else PA_RUN(1, false); }
+  else PA_RUN(2, false);
 #undef PA_RUN
 }
 

@@ -406,8 +406,8 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   std::vector<std::vector<uint32_t>> tmaps((size_t)nthr);   // gathered pieces: their row maps, 64 words each
   // (rectangles per tile and source cblk from which they become one gathered piece; options.gather_min, default 3; the
   // fp32 kernel and the fan-in schedule of the multi-GPU driver take rectangles only)
-  const int64_t gather_min = (owner || floattype == PASTIX_AMD_REALSINGLE || P.opts.gather_min < 0) ? ((int64_t)1 << 40)
-                                                                                                  : (P.opts.gather_min > 0 ? P.opts.gather_min : 3);
+  const int gmo = dev_opt("gather") ? atoi(dev_opt("gather")) : P.opts.gather_min;     // (developer override of the option)
+  const int64_t gather_min = (owner || floattype == PASTIX_AMD_REALSINGLE || gmo < 0) ? ((int64_t)1 << 40) : (gmo > 0 ? gmo : 3);
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
   std::atomic<int64_t> gen_next{0};

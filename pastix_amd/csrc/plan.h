@@ -143,7 +143,8 @@ constexpr int RUN_SLOT = 32;
 // "1").  Keys: plan_timing, near=<levels>, nearc=<cblks> (near-target task cutting, plan.cpp), dump_slot=<slot>[:file]
 // (tools/replay_slot), run_prof=<file> (clock stamps of every task of the run, tools/run_prof.py), run_debug (keeps the run's
 // dependency tables on the host: a stopped run is replayed and reported, run_debug.cpp), onek=0 (the run's diagonal tasks on
-// a resident kernel of their own, the round-4 form: the tests' oracle for the one-kernel form), room=<workgroups> (run_sync.h).
+// a resident kernel of their own, the round-4 form: the tests' oracle for the one-kernel form), room=<workgroups> (run_sync.h),
+// gather=<n> (overrides options.gather_min; -1: rectangles only).
 // Returns the value (valid until the next call on this thread) or nullptr.
 inline const char* dev_opt(const char* key) {
   static thread_local char buf[512];

@@ -277,13 +277,10 @@ def test_run_complex_ldlt_ldlh_match_reference_golden_and_the_level_schedule(nam
 
 
 # ---- the diagonal-blok tickets of the run launch, every width -------------------------------------------------------------
-# In the run launch a diagonal blok is a ticket of k_run_update: the bodies of k_diag_llt_w / _ldlt_w / k_diag_lu /
-# k_diag_zsy_w inside that kernel's 64 VGPRs, LU and complex bloks with four of a wave's five resident tile pairs PARKED in
-# the accumulation registers a[0:63] (diag_body.h).  Which instructions a wave of such a ticket executes depends on the
-# blok's width only, so the widths 1 .. 128 are ALL its paths: each must give, bit for bit, what the kernels that park
-# nothing give (the level-by-level schedule for real arithmetic; for complex arithmetic, whose two panel-solve kernels
-# differ in rounding, the run with the diagonal tasks on their own resident kernel, PASTIX_AMD_DEV=onek=0).  This is the
-# dynamic counterpart of tests/test_kernel_audit.py: a value of the compiler's in a parked register would show here.
+# In the run launch a real LLt / LDLt diagonal blok is a ticket of k_run_update: the bodies of k_diag_llt_w / _ldlt_w inside
+# that kernel's 64 VGPRs (LU and complex bloks: a resident kernel of their own).  Which instructions a wave of such a ticket
+# executes depends on the blok's width only, so the widths 1 .. 128 are ALL its paths: each must give, bit for bit, what
+# the level-by-level schedule gives with the kernels' own launches.
 def _dense_two(w, facto, cplx):
     from test_gpu_edges import dense_layout, panels_of, spd
     c4, b4, n = dense_layout([24, w])
@@ -300,7 +297,7 @@ def _dense_two(w, facto, cplx):
 
 
 @pytest.mark.parametrize("facto", [0, 1, 2])
-def test_diagonal_tickets_of_every_width_real(facto, run_env):
+def test_diagonal_tickets_of_every_width(facto, run_env):
     for w in range(1, 129):
         c4, b4, L0, U0 = _dense_two(w, facto, False)
         with Plan(c4, b4, facto, run_schedule=1, run_max_cblks=100000) as p:
@@ -315,28 +312,3 @@ def test_diagonal_tickets_of_every_width_real(facto, run_env):
         assert np.array_equal(out["0"][0][0][m], out["1"][0][0][m]), w
         if facto == 2:
             assert np.array_equal(out["0"][0][1], out["1"][0][1]), w
-
-
-@pytest.mark.parametrize("facto", [1, 3])
-def test_diagonal_tickets_of_every_width_complex(facto, run_env):
-    from pastix_amd import COMPLEXDOUBLE
-    keep = os.environ.get("PASTIX_AMD_DEV")
-    run_env["PASTIX_AMD_RUN"] = "1"
-    try:
-        for w in range(1, 129):
-            c4, b4, L0, _ = _dense_two(w, facto, True)
-            out = {}
-            for onek in ("0", "1"):
-                os.environ["PASTIX_AMD_DEV"] = "onek=" + onek   # (read when the plan is made)
-                with Plan(c4, b4, facto, floattype=COMPLEXDOUBLE, run_schedule=1, run_max_cblks=100000) as p:
-                    p.upload(L0)
-                    st = p.factorize(1e-30)
-                    out[onek] = (p.download()[0], st)
-            assert out["1"][1]["run_tickets"] > 0, w
-            m = _lower_mask(c4)
-            assert np.array_equal(out["0"][0][m], out["1"][0][m]), w
-    finally:
-        if keep is None:
-            os.environ.pop("PASTIX_AMD_DEV", None)
-        else:
-            os.environ["PASTIX_AMD_DEV"] = keep

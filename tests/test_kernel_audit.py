@@ -1,10 +1,8 @@
 """The update kernels keep data in the accumulation registers a[0:63] BY NAME (inline assembly: the accumulators of
 k_update, the parked tiles of the run launch's panel solve).  The compiler knows them only as clobbers, so nothing but
 an audit of the generated code shows that it never uses one for a value of its own (cdna_hip_programming.md 5.7 item 4):
-no `v_accvgpr_*` / AGPR operand outside an asm block wherever named registers hold data (the update and panel-solve paths, the
-stretches of a diagonal-blok ticket in which tiles are parked), MFMA builtins in VGPR form, no spills in the level-by-level
-kernels.  The dynamic counterpart is tests/test_gpu_run_schedule.py::test_diagonal_tickets_of_every_width_*: every path of the
-parked stretches (they depend on the blok's width only) against the kernels that park nothing, bit for bit."""
+no `v_accvgpr_*` / AGPR operand outside an asm block wherever named registers hold data (the update and panel-solve paths),
+MFMA builtins in VGPR form, no spills in the level-by-level kernels."""
 import os
 import re
 import shutil
@@ -28,31 +26,23 @@ def test_no_compiler_use_of_the_named_accumulators(tmp_path):
     kernels = [i for i, l in enumerate(lines) if re.match(r"^_ZN10pastix_amd(8k_update|12k_run_update)", l) and l.rstrip().endswith(":") is False and ":" in l]
     assert len(kernels) >= 3
     # Where the compiler MAY use accumulation registers for values of its own: inside a diagonal-blok ticket of the run launch
-    # (between the DIAG_TICKET markers of k_run_update<., true>: the update path's accumulators are dead there), but never in
-    # the stretches of such a ticket in which waves hold PARKED tiles in a[0:63] (the PARKED markers of diag_lu_body /
-    # diag_zsy_body: LU and complex bloks) -- there and everywhere else every AGPR belongs to the asm statements.
+    # (between the DIAG_TICKET markers of k_run_update<0 / 1, true>: real LLt / LDLt bloks live in LDS, the update path's
+    # accumulators are dead there and nothing else is parked) -- everywhere else every AGPR belongs to the asm statements.
     for start in kernels:
         name = lines[start].split(":")[0]
         onek = re.search(r"k_run_updateILi(\d)ELb1", name)
-        inasm = diag = park = False
-        nasm = ndiag = npark = nown = 0
+        inasm = diag = False
+        nasm = ndiag = nown = 0
         for l in lines[start:]:
             if ".Lfunc_end" in l:
                 break
             if "PASTIX_AMD_DIAG_TICKET_BEGIN" in l:
-                assert not diag and not park, name
+                assert not diag, name
                 diag = True
                 ndiag += 1
             elif "PASTIX_AMD_DIAG_TICKET_END" in l:
-                assert diag and not park, name
+                assert diag, name
                 diag = False
-            elif "PASTIX_AMD_PARKED_BEGIN" in l:
-                assert diag and not park, name
-                park = True
-                npark += 1
-            elif "PASTIX_AMD_PARKED_END" in l:
-                assert diag and park, name
-                park = False
             if "ASMSTART" in l:
                 inasm = True
                 nasm += 1
@@ -61,13 +51,12 @@ def test_no_compiler_use_of_the_named_accumulators(tmp_path):
             elif not inasm:
                 code = l.split(";")[0]
                 if "accvgpr" in code or re.search(r"\ba\[?\d", code):
-                    assert diag and not park, (name, l)
+                    assert diag, (name, l)
                     nown += 1
-        assert not diag and not park, name
+        assert not diag, name
         assert nasm > 100, name
         if onek:
-            assert ndiag == 1, name
-            assert npark == (2 if int(onek.group(1)) >= 2 else 0), (name, npark)
+            assert ndiag == 1 and int(onek.group(1)) <= 1, name
         else:
             assert ndiag == 0 and nown == 0, name
     txt = "\n".join(lines)
