@@ -404,10 +404,16 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   }();
   std::vector<BlockList<RawPiece>> traw((size_t)nthr);
   std::vector<std::vector<uint32_t>> tmaps((size_t)nthr);   // gathered pieces: their row maps, 64 words each
-  // (rectangles per tile and source cblk from which they become one gathered piece; options.gather_min, default 3; the
+  // (rectangles per tile and source cblk from which they become one gathered piece; options.gather_min, default 2 for fragmented source cblks; the
   // fp32 kernel and the fan-in schedule of the multi-GPU driver take rectangles only)
   const int gmo = dev_opt("gather") ? atoi(dev_opt("gather")) : P.opts.gather_min;     // (developer override of the option)
-  const int64_t gather_min = (owner || floattype == PASTIX_AMD_REALSINGLE || gmo < 0) ? ((int64_t)1 << 40) : (gmo > 0 ? gmo : 3);
+  const int64_t gather_off = (int64_t)1 << 40;
+  const int64_t gather_on = (owner || floattype == PASTIX_AMD_REALSINGLE || gmo < 0) ? gather_off : (gmo > 0 ? gmo : 2);
+  // ... and only for source cblks whose bloks ARE fragments (mean height of the off-diagonal bloks below 8 rows; with an
+  // explicit options.gather_min every cblk): on layouts with tall bloks the few tiles that two or three rectangles of one
+  // source reach are better off in the rectangle loops (a task with a gathered piece runs ALL its pieces through the
+  // 4-byte gathering loop: 60^3 on this repository's own layout -2.6 % with every cblk gathering)
+  const double gather_frag = gmo > 0 ? 1e30 : 8.0;
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
   std::atomic<int64_t> gen_next{0};
@@ -493,6 +499,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     // maps that say where each lands (Piece flag 32; the update kernel's MODE 3 loop gathers while it stages).  Which
     // products are formed and in which order they are accumulated per tile entry (source cblks in the order of the list)
     // does not change.  Real double and complex double on one GPU (the fp32 kernel and the fan-in schedule take rectangles).
+    int64_t gather_min = gather_off;                          // (set per source cblk)
     struct Frag { int64_t src, dst, len; };                  // source row in k's panel, target row / column in t's panel
     auto clip_tiles = [](const std::vector<Frag>& in, int64_t T, std::vector<std::pair<int64_t, Frag>>& out) {
       out.clear();                                          // (tile, fragment with dst relative to the panel): dst ascending
@@ -535,7 +542,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           size_t b1 = b0;
           while (b1 < tb.size() && tb[b1].first == tb[b0].first) b1++;
           const int64_t rt = ta[a0].first, ct = tb[b0].first;
-          if ((int64_t)((a1 - a0) * (b1 - b0)) >= gather_min) {
+          if ((int64_t)((a1 - a0) * (b1 - b0)) >= gather_min) {                  // (gather_min: per source cblk, below)
             const int64_t g = make_map(&ta[a0], a1 - a0, &tb[b0], b1 - b0);
             int64_t m = 0, n = 0;
             for (size_t x = a0; x < a1; x++) m += ta[x].second.len;
@@ -564,6 +571,10 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       for (int64_t k = nc - 1 - kc; k >= std::max<int64_t>(0, nc - 8 - kc); k--) {
       if (P.role[k] != 1) continue;               // contributions are computed by the source's owner
       const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
+      {
+        const int64_t wk0 = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
+        gather_min = (lb - fb > 1 && double(P.cblk[k].stride - wk0) < gather_frag * double(lb - fb - 1)) ? gather_on : gather_off;
+      }
       // groups of consecutive bloks [g0, g1) facing the same cblk t (they land in t's diagonal blok; every later blok of
       // k lands in an off-diagonal blok of t: containment, sopalin_compute.c:558-559)
       for (int64_t g0 = fb + 1, g1; g0 < lb; g0 = g1) {
