@@ -678,18 +678,45 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
         memcpy(keep->data() + (offj + c) * ow * eb, host + (offj + c) * os * eb, (size_t)offj * eb);
     }
   }
-  std::vector<std::vector<unsigned char>> tmp[2];
+  // the column groups' panels pass through PINNED memory (a bump arena per host thread, grown on demand: the copies then
+  // run at the link's rate), their columns are packed / unpacked by several host threads: blend's 144- / 152-column cblks
+  // hold most of the bytes of a big layout
+  struct Slice { unsigned char* d = nullptr; unsigned char* data() const { return d; } };
+  static thread_local unsigned char* pin_base = nullptr;
+  static thread_local size_t pin_cap = 0;
+  {
+    const size_t need = (size_t)2 * (size_t)os * (size_t)ow * eb + 4096;
+    if (need > pin_cap) {
+      if (pin_base) (void)hipHostFree(pin_base);
+      pin_base = nullptr; pin_cap = 0;
+      HIPCHK(hipHostMalloc((void**)&pin_base, need, hipHostMallocDefault));
+      pin_cap = need;
+    }
+  }
+  size_t pin_used = 0;
+  auto par_cols = [&](int64_t ncol, size_t bytes_per_col, auto&& fn) {
+    const int nt = (size_t)ncol * bytes_per_col < ((size_t)2 << 20) ? 1 : (int)std::min<int64_t>(8, std::max<int64_t>(1, ncol));
+    if (nt == 1) { for (int64_t c = 0; c < ncol; c++) fn(c); return; }
+    std::atomic<int64_t> next{0};
+    auto work = [&] { for (;;) { const int64_t c = next.fetch_add(4); if (c >= ncol) break; for (int64_t q = c; q < std::min(ncol, c + 4); q++) fn(q); } };
+    std::vector<std::thread> th;
+    for (int t2 = 1; t2 < nt; t2++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  };
+  std::vector<Slice> tmp[2];
   for (int a = 0; a < 2; a++) tmp[a].resize((size_t)ns);
   for (int a = 0; a < (haveU ? 2 : 1); a++) {
     unsigned char* host = (unsigned char*)(a ? hostU : hostL);
     for (int64_t j = 0; j < ns; j++) {
       const int64_t s = s0 + j, off = H.cblk[s].fcolnum - fcol, wj = H.cblk[s].lcolnum - H.cblk[s].fcolnum + 1;
       const int64_t nr = H.cblk[s].stride;                      // == os - off
-      std::vector<unsigned char>& t = tmp[a][(size_t)j];
-      t.resize((size_t)(nr * wj) * eb);
+      Slice& t = tmp[a][(size_t)j];
+      t.d = pin_base + pin_used;
+      pin_used += ((size_t)(nr * wj) * eb + 255) & ~(size_t)255;
       if (up) {
-        for (int64_t c = 0; c < wj; c++)
-          memcpy(t.data() + c * nr * eb, host + ((off + c) * os + off) * eb, (size_t)nr * eb);
+        par_cols(wj, (size_t)nr * eb, [&](int64_t c) {
+          memcpy(t.data() + c * nr * eb, host + ((off + c) * os + off) * eb, (size_t)nr * eb); });
         if (a == 1 && H.factotype == PASTIX_AMD_FACT_LU) {
           // LU: the reference keeps the whole square A_kk in coeftab's diagonal blok and zeros in ucoeftab's
           // (csc_intern_solve.c:65-132); the U^T blocks facing the later column groups are the transposes of
@@ -703,8 +730,8 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
       int r = xfer(a, H.poff[s], nr * wj, t.data());
       if (r) return r;
       if (!up) {
-        for (int64_t c = 0; c < wj; c++)
-          memcpy(host + ((off + c) * os + off) * eb, t.data() + c * nr * eb, (size_t)nr * eb);
+        par_cols(wj, (size_t)nr * eb, [&](int64_t c) {
+          memcpy(host + ((off + c) * os + off) * eb, t.data() + c * nr * eb, (size_t)nr * eb); });
       }
     }
   }
@@ -727,7 +754,7 @@ static int split_cblk_io(pastix_amd_plan_t* p, int64_t k, bool up, void* hostL, 
           for (int64_t i = 0; i < j; i++) {                      // rows of the earlier group i, from the OTHER arena's panel of i
             const int64_t offi = H.cblk[s0 + i].fcolnum - fcol, wi = H.cblk[s0 + i].lcolnum - H.cblk[s0 + i].fcolnum + 1;
             const int64_t ldi = H.cblk[s0 + i].stride;
-            const std::vector<unsigned char>& ot = tmp[1 - a][(size_t)i];
+            const Slice& ot = tmp[1 - a][(size_t)i];
             for (int64_t q = 0; q < wi; q++)
               memcpy(col[a] + (offi + q) * eb, ot.data() + ((offj + c - offi) + q * ldi) * eb, eb);
           }

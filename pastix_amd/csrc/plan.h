@@ -99,8 +99,9 @@ struct SolveChunk {            // 64 (forward) / 256 (backward) off-diagonal pan
 // same here for the levels >= run_L0: every task carries a counter of the inputs that do not exist yet; whoever
 // finishes an input decrements the counters of its consumers and pushes the ones that reach zero into a ready queue;
 // the workgroups of ONE launch (k_run_update) each pop one ready ticket -- an update task (a tile of a target panel,
-// its pieces in the plan's order) or a panel-solve task (the off-diagonal rows of one 128-row tile) --, the diagonal
-// tasks are popped by a few resident workgroups of a second kernel (k_run_diag_*).  Nobody waits for a particular
+// its pieces in the plan's order), a panel-solve task (the off-diagonal rows of one 128-row tile) or, for real LLt / LDLt
+// (round 5, RunCtl::onek), a diagonal-blok task; LU and complex diagonal tasks are popped by a few resident workgroups of
+// a second kernel (k_run_diag_lu / k_run_diag_z).  Nobody waits for a particular
 // task: a slot of the chip is idle only when nothing is ready.  Inputs: an update task waits for the previous update
 // of its tile (tile ownership is a chain of tasks, not a mutex) and for the source tiles its pieces read to be solved;
 // a panel-solve task for its cblk's diagonal blok and the last update of its tile; a diagonal task for the last update

@@ -27,15 +27,15 @@ __device__ __forceinline__ void run_st(int32_t* p, int v) {
 }
 // take the NEXT slot of a ring of n slots (a wait-free reservation: an atomic add on the head, ~90 per microsecond on one
 // word where a compare-and-swap loop of 500 contenders managed a fraction of one) and wait for the task that is -- or will
-// be -- pushed there: workgroup i of the launch runs the i-th task to become ready.  Every task is pushed exactly once and
-// there are exactly as many workgroups as tickets, so every reservation is served; a slot of the chip is idle only while
-// fewer tasks are ready than workgroups are waiting.  Returns -1 when the ring is used up or the run is stuck.
+// be -- pushed there: the i-th reservation runs the i-th task to become ready.  Invariant: every task is pushed exactly once,
+// only holders of a reservation wait, and a workgroup keeps looping until the ring is used up, so every push is consumed by a
+// workgroup that already waits for that slot or by one that reserves it later; a slot of the chip is idle only while fewer
+// tasks are ready than workgroups are waiting.  Returns -1 when the ring is used up or the run is stuck.
 // `limit` > 0 bounds the wait (100 MHz ticks; on expiry RUN_STUCK is raised), 0 = no bound of its own.
 // `maxwait` > 0: at most that many workgroups wait at a time -- one that would be the next leaves for good instead (returns
-// -1 without a reservation).  Workgroups that never end leave no room on the chip: waves the hardware scheduler has taken off
-// a CU (CWSR; it happens about once in 500 runs of 0.1 s, more often with more queues in flight) can only come back where
-// something has left, and until then their tickets stand still and everything behind them drains -- which is when the
-// waiting ones pile up and the surplus makes room.
+// -1 without a reservation; the launch has min(tasks, 2 x CUs) workgroups, so the others still serve every push).  Round 4's
+// mitigation of the stop of the TWO-kernel form (a second persistent kernel on another queue; the one-kernel
+// form of real LLt / LDLt has not stopped in 14 000 soaked factorizations): workgroups that never end leave no room on the chip.
 __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit,
                                        const int maxwait = 0) {
   if (maxwait > 0) {

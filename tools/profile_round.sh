@@ -23,8 +23,11 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats
 if [ -z "$NO_PMC" ]; then
-# The counter passes run the DEFAULT schedule: since round 5 every task of the run is a ticket of ONE kernel (k_run_update),
-# so the launch needs nothing beside it on the chip and rocprofv3 --pmc, which serializes kernel launches, can count it.
+# The counter passes run the DEFAULT schedule for real LLt / LDLt: since round 5 every task of their run is a ticket of ONE
+# kernel (k_run_update), so the launch needs nothing beside it on the chip and rocprofv3 --pmc, which serializes kernel
+# launches, can count it.  LU and complex plans still have the resident diagonal kernel beside the tickets' launch: under the
+# counters they take the level-by-level schedule (same kernels' bodies, same tasks, same flops).
+case "$EXTRA" in *elasticity*|*lu*) export PASTIX_AMD_RUN=0;; esac
 pass() {   # name, counters
   rm -rf /tmp/pmc_pass
   timeout 600 rocprofv3 --pmc $2 --output-format csv -d /tmp/pmc_pass -- python3 $ARGS > $OUT/bench_pmc_$1.json 2> $OUT/pmc_$1.err
@@ -36,6 +39,7 @@ pass WRITE_SIZE "WRITE_SIZE"
 pass busy "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64"
 pass waves "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 pass l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+unset PASTIX_AMD_RUN
 fi
 python3 -c "import bench; print(bench.engine_source_sha())" > $OUT/source_sha.txt
 cat $OUT/sum_*.json 2>/dev/null
