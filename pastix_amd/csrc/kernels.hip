@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 4) void k_run_diag(double* __restrict__ L, con
       // (bounded like the tickets' wait, three times as long: a diagonal worker legitimately finds nothing while the levels
       // below the run are factorized; but a tool that serializes kernel launches -- rocprofv3 --pmc does -- never starts the
       // tickets' kernel beside this one, and the workers must not spin for ever: RUN_STUCK, everybody leaves, ERR_DEVICE)
-      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit);
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit, 0, rc.ctl + RUN_GO);
       s_task = v;
       if (v >= 0) run_acquire();
     }

@@ -836,6 +836,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh), "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
+  if (!ONEK && threadIdx.x == 0) run_st(rc.ctl + RUN_GO, 1);       // (the resident diagonal workers' clocks start now)
   for (;;) {
     // (the thread index is laundered per ticket: what is derived from it is recomputed, not kept in registers across the loop)
     int tid = threadIdx.x;

@@ -639,7 +639,7 @@ __global__ __launch_bounds__(512, 4) void k_run_diag_z(const Arenas ar, const Ru
   if (tid == 0) __hip_atomic_fetch_add(resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (;;) {
     if (tid == 0) {
-      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit);   // (see k_run_diag)
+      const int v = run_pop(rc.qd, rc.ctl + RUN_HEAD + 64, rc.nd, rc.ctl + RUN_STUCK, 3 * limit, 0, rc.ctl + RUN_GO);   // (see k_run_diag)
       s_task = v;
       if (v >= 0) run_acquire();
     }

@@ -36,8 +36,11 @@ __device__ __forceinline__ void run_st(int32_t* p, int v) {
 // -1 without a reservation; the launch has min(tasks, 2 x CUs) workgroups, so the others still serve every push).  Round 4's
 // mitigation of the stop of the TWO-kernel form (a second persistent kernel on another queue; the one-kernel
 // form of real LLt / LDLt has not stopped in 14 000 soaked factorizations): workgroups that never end leave no room on the chip.
+// `go` != nullptr (the resident diagonal workers): the wait is timed only once *go is set, i.e. once the tickets' kernel
+// runs; until then only an absolute bound of 60 s applies (a tool that serializes kernel launches never starts that kernel
+// beside this one: the workers must not spin for ever).
 __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const int n, int32_t* stuck, const long long limit,
-                                       const int maxwait = 0) {
+                                       const int maxwait = 0, const int32_t* go = nullptr) {
   if (maxwait > 0) {
     const int waiting = run_ld(head) - run_ld(head + (RUN_TAIL - RUN_HEAD));
     if (waiting >= maxwait) return -1;
@@ -47,7 +50,8 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
   const int32_t* slot = ring + (int64_t)h * RUN_SLOT;
   int v = run_ld(slot);
   if (v >= 0) return v;
-  const long long t0 = wall_clock64();
+  long long t0 = wall_clock64();
+  const long long tstart = t0;
   int it = 0;
   while ((v = run_ld(slot)) < 0) {
     ++it;
@@ -56,6 +60,10 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
       if ((v = __hip_atomic_fetch_or(const_cast<int32_t*>(slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) break;
       if (run_ld(stuck)) return -1;
       const long long now = wall_clock64();
+      if (go && !run_ld(go)) {                        // (the tickets' kernel has not started: no clock yet)
+        t0 = now;
+        if (now - tstart < 6000000000LL) continue;
+      }
       if (limit > 0 && now - t0 > limit) {
         // (the first one to give up leaves a note for the host: which slot it waited for, how long)
         if (__hip_atomic_exchange(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
