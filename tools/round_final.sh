@@ -50,6 +50,11 @@ if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then
     for c in "d 60 llt" "d 80 llt" "d 100 llt" "d 100 lu" "z 32 ldlt"; do set -- $c
       echo "== cmp $c"; REF_ORDER_CONTIG=1 timeout 600 oracle/_ref/ref_harness_$1_ob_amd cmp rlap3d $2 $3 32 /dev/null 64 128 2>/dev/null | grep '"cmp"' | tail -1; done ) > $O/refcaller_timing.txt 2>&1
 fi
+timeout 300 python tools/one_shot_timing.py 100 > $O/one_shot_100cube.json 2> /dev/null
+if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then      # where the time of a fragmented layout goes: the run's tickets by class
+  OPENBLAS_NUM_THREADS=1 PASTIX_AMD_DEV=run_prof=/tmp/prof_lex.bin timeout 300 oracle/_ref/ref_harness_d_ob_amd amd rlap3d 100 llt 1 /dev/null 64 128 > /dev/null 2>&1
+  python tools/run_prof.py /tmp/prof_lex.bin 10 > $O/run_prof_refcaller_lex100.txt 2>&1
+fi
 PASTIX_AMD_DEV=plan_timing timeout 300 python tools/plan_timing.py 200 > $O/analysis_timing_200cube.txt 2>&1
 timeout 900 python tools/loopback_scale.py 200 4 2 > $O/loopback_200cube_4ranks.json 2> $O/loopback_200.err
 tail -3 $O/sweep_sizes.txt
