@@ -533,6 +533,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     // rows `rows` x columns `cols` of target t from source k: per tile either the rectangles or one gathered piece
     auto emit_set = [&](int64_t k, int64_t t, const std::vector<Frag>& rows, const std::vector<Frag>& cols, uint16_t flags,
                         uint8_t carena) {
+      if (gather_min == gather_off) {                       // (this source cblk does not gather: the rectangles as they are)
+        for (const Frag& fr : rows)
+          for (const Frag& fc : cols) emit(k, t, fr.src, fc.src, fr.dst, fr.len, fc.dst, fc.len, flags, carena);
+        return;
+      }
       clip_tiles(rows, TM, ta);
       clip_tiles(cols, TN, tb);
       for (size_t a0 = 0; a0 < ta.size();) {
