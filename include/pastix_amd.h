@@ -93,8 +93,8 @@ typedef struct pastix_amd_options_s {
   int gather_min;        /* a target tile that ONE source cblk reaches with at least this many rectangles (fragmented
                             layouts: blend on separators numbered across their low-side neighbours) gets them as one
                             GATHERED piece -- consecutive source rows, scattered landing, gathered while they are staged
-                            (plan.cpp); 0 = default (from 2 rectangles, and only for source cblks whose off-diagonal bloks
-                            average fewer than 8 rows), > 0 = from this many, every source cblk, -1 = never */
+                            (plan.cpp); 0 = default (from 2 rectangles, on layouts whose off-diagonal bloks per (cblk, facing
+                            cblk) pair average 1.5 or more), > 0 = from this many on any layout, -1 = never */
   int reserved[4];
 } pastix_amd_options_t;
 

@@ -408,12 +408,27 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // fp32 kernel and the fan-in schedule of the multi-GPU driver take rectangles only)
   const int gmo = dev_opt("gather") ? atoi(dev_opt("gather")) : P.opts.gather_min;     // (developer override of the option)
   const int64_t gather_off = (int64_t)1 << 40;
-  const int64_t gather_on = (owner || floattype == PASTIX_AMD_REALSINGLE || gmo < 0) ? gather_off : (gmo > 0 ? gmo : 2);
-  // ... and only for source cblks whose bloks ARE fragments (mean height of the off-diagonal bloks below 8 rows; with an
-  // explicit options.gather_min every cblk): on layouts with tall bloks the few tiles that two or three rectangles of one
-  // source reach are better off in the rectangle loops (a task with a gathered piece runs ALL its pieces through the
-  // 4-byte gathering loop: 60^3 on this repository's own layout -2.6 % with every cblk gathering)
-  const double gather_frag = gmo > 0 ? 1e30 : 8.0;
+  // By default a layout gathers when it IS fragmented: its off-diagonal bloks per (source cblk, facing cblk) pair average 1.5
+  // or more (blend on lexicographically numbered separators: 3-4; blend on contiguously numbered ones and this repository's
+  // own layouts: 1.0-1.2, and there the few tiles that two or three rectangles of one source reach are better off in the
+  // rectangle loops -- a task with a gathered piece runs ALL its pieces through the 4-byte gathering loop: 60^3 on the own
+  // layout -1.7 ... -2.6 % with gathering on).  An explicit options.gather_min gathers whatever the layout looks like.
+  // Source cblks whose off-diagonal bloks average 48 rows or more emit their rectangles directly in any case.
+  double frag = 0;
+  {
+    int64_t noff = 0, ngrp = 0;
+    for (int64_t k = 0; k < nc; k++) {
+      if (P.role[k] != 1) continue;
+      for (int64_t b = P.cblk[k].bloknum + 1; b < P.cblk[k + 1].bloknum; b++) {
+        noff++;
+        ngrp += (b == P.cblk[k].bloknum + 1) || P.blok[b].cblknum != P.blok[b - 1].cblknum;
+      }
+    }
+    frag = ngrp > 0 ? double(noff) / double(ngrp) : 0.0;
+  }
+  const int64_t gather_on = (owner || floattype == PASTIX_AMD_REALSINGLE || gmo < 0 || (gmo == 0 && frag < 1.5)) ? gather_off
+                                                                                                          : (gmo > 0 ? gmo : 2);
+  const double gather_tall = gmo > 0 ? 1e30 : 48.0;
   std::vector<double> tuf((size_t)nthr, 0.0), tub((size_t)nthr, 0.0);
   std::vector<int> terr((size_t)nthr, 0);
   std::atomic<int64_t> gen_next{0};
@@ -547,11 +562,11 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           size_t b1 = b0;
           while (b1 < tb.size() && tb[b1].first == tb[b0].first) b1++;
           const int64_t rt = ta[a0].first, ct = tb[b0].first;
-          if ((int64_t)((a1 - a0) * (b1 - b0)) >= gather_min) {                  // (gather_min: per source cblk, below)
+          int64_t m = 0, n = 0;
+          for (size_t x = a0; x < a1; x++) m += ta[x].second.len;
+          for (size_t x = b0; x < b1; x++) n += tb[x].second.len;
+          if ((int64_t)((a1 - a0) * (b1 - b0)) >= gather_min) {
             const int64_t g = make_map(&ta[a0], a1 - a0, &tb[b0], b1 - b0);
-            int64_t m = 0, n = 0;
-            for (size_t x = a0; x < a1; x++) m += ta[x].second.len;
-            for (size_t x = b0; x < b1; x++) n += tb[x].second.len;
             push_tile(k, t, rt, ct, ta[a0].second.src, tb[b0].second.src, 0, m, 0, n, flags, carena, g);
           } else {
             for (size_t x = a0; x < a1; x++)
@@ -578,7 +593,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       const int64_t fb = P.cblk[k].bloknum, lb = P.cblk[k + 1].bloknum;
       {
         const int64_t wk0 = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
-        gather_min = (lb - fb > 1 && double(P.cblk[k].stride - wk0) < gather_frag * double(lb - fb - 1)) ? gather_on : gather_off;
+        gather_min = (lb - fb > 1 && double(P.cblk[k].stride - wk0) < gather_tall * double(lb - fb - 1)) ? gather_on : gather_off;
       }
       // groups of consecutive bloks [g0, g1) facing the same cblk t (they land in t's diagonal blok; every later blok of
       // k lands in an off-diagonal blok of t: containment, sopalin_compute.c:558-559)
