@@ -292,9 +292,10 @@ def test_quadrant_tasks_match_reference_golden(name, fill, golden):
     from pastix_amd import COMPLEXDOUBLE, REALDOUBLE
     g = golden(name)
     cplx = np.iscomplexobj(g["L1"])
-    # (run_schedule=-1: the run launch takes whole tiles only, and on these small layouts it would take every level)
+    # (run_schedule=-1: the run launch takes whole tiles only, and on these small layouts it would take every level;
+    # gather_min=-1: on these fragmented layouts the tasks would otherwise be gathered ones, which are not cut)
     with Plan(g["cblk4"], g["blok4"], g["facto"], floattype=COMPLEXDOUBLE if cplx else REALDOUBLE, quadrant_min=1,
-              quadrant_fill_pct=fill, run_schedule=-1) as p:
+              quadrant_fill_pct=fill, run_schedule=-1, gather_min=-1) as p:
         assert p.stats()["nquadrant_tasks"] > 0
         p.upload(g["L0"], g["U0"] if g["facto"] == 2 else None)
         st = p.factorize(g["critere"])
