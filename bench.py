@@ -226,6 +226,7 @@ def one_shot_cost(grid, blocksize, local):
     """What a drop-in caller pays (configs[1] through pastix_amd_d_po_sopalin = D_po_sopalin_thread: host panels in, host
     panels out): the first call analyses the layout and allocates, later calls on the same layout reuse the cached plan."""
     from pastix_amd.solver import sopalin_tabs
+    import numpy as np
     from pastix_amd import _lib, Plan
     from pastix_amd import symbolic as sy
     n, cp, r, v = sy.laplacian_3d(grid)
