@@ -135,3 +135,23 @@ def test_factors_equal_the_reference_cpu_engine_at_scale(prec, arg, facto, extra
     assert c["static_pivots_gpu"] == c["static_pivots_ref"]
     assert c["inertia_gpu"] == c["inertia_ref"]
     assert last["residual"] <= 1e-10                   # the reference's updo on the GPU's factors
+
+
+# The same comparison on FRAGMENTED layouts: the harness's default numbering of the separator nodes (lexicographic) gives
+# blend bloks of 2-4 rows every 50-60 -- 2.9 x the bloks of the contiguous numbering --, which the plan turns into GATHERED
+# pieces (plan.cpp; round 5).  Real and complex arithmetic, every factorization that gathers.
+@pytest.mark.parametrize("prec,arg,facto,extra", [
+    ("d", 60, "llt", ()),
+    ("d", 60, "ldlt", (64, 128)),
+    ("d", 60, "lu", (64, 128)),
+    ("z", 24, "ldlt", ()),
+])
+def test_gathered_pieces_equal_the_reference_cpu_engine(prec, arg, facto, extra):
+    c, last = _cmp(prec, "rlap3d", arg, facto, extra, contig=False)
+    assert c["gpu_engine_calls"] == 1 and c["gpu_engine_rc"] == 0
+    assert c["rel_L"] <= 1e-12, c
+    if facto == "lu":
+        assert c["rel_U"] <= 1e-12, c
+    assert c["static_pivots_gpu"] == c["static_pivots_ref"]
+    assert c["inertia_gpu"] == c["inertia_ref"]
+    assert last["residual"] <= 1e-10
