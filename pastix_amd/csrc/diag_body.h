@@ -56,10 +56,14 @@ __device__ __forceinline__ void diag_llt_body(double* __restrict__ D, double* __
     for (int c0 = 0; c0 < w16; c0 += 64) {
       double v[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
-        if (c0 + 4 * q >= w16) break;
-        const int c = min(c0 + ch + 4 * q, w - 1);
-        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      for (int q = 0; q < 16; q++) {                     // loads from clamped addresses
+        // (every element is DEFINED in every pass: a partly written array became a 32-register value carried around the
+        // ticket loop of k_run_update, spilled at every pop and reloaded in the update tickets' epilogue)
+        v[q] = 0.0;
+        if (c0 + 4 * q < w16) {
+          const int c = min(c0 + ch + 4 * q, w - 1);
+          v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) {
@@ -239,10 +243,14 @@ __device__ __forceinline__ void diag_ldlt_body(double* __restrict__ D, double* _
     for (int c0 = 0; c0 < w16; c0 += 64) {
       double v[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) {                     // unconditional loads from clamped addresses
-        if (c0 + 4 * q >= w16) break;
-        const int c = min(c0 + ch + 4 * q, w - 1);
-        v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+      for (int q = 0; q < 16; q++) {                     // loads from clamped addresses
+        // (every element is DEFINED in every pass: a partly written array became a 32-register value carried around the
+        // ticket loop of k_run_update, spilled at every pop and reloaded in the update tickets' epilogue)
+        v[q] = 0.0;
+        if (c0 + 4 * q < w16) {
+          const int c = min(c0 + ch + 4 * q, w - 1);
+          v[q] = A[min(r, w - 1) + (int64_t)c * ld];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) {

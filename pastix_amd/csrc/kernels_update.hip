@@ -87,40 +87,49 @@ __device__ __forceinline__ void mfma_pat(const int pat, const double (&an)[NI], 
 // latency per band, not per element); ATOMIC: tiles that several workgroups update in the same launch (split piece
 // lists of the multi-GPU fan-in schedule) combine with f64 atomics instead of an exclusive read-modify-write.
 // COH: the stores are write-through (the run launch: the tile is handed to another workgroup of the same launch).
-template <int MIX, bool ATOMIC, bool COH = false>
-__device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsigned touched, const int row0, const int col0,
+template <int MIX, bool ATOMIC, bool COH, int NI0>
+__device__ __forceinline__ void epilogue_half(double* __restrict__ C, const unsigned touched, const int row0, const int col0,
                                               const int l15, const int g, const int tm1, const int tn1, const int ldc) {
-  if (!((touched >> MIX) & 1u)) return;
+  // the column bands NI0, NI0 + 1 of the row band MIX: eight loads in flight, then the eight stores -- sixteen values of
+  // the tile at a time (a whole band) are half of the 64 VGPRs the kernels have, and the run launch's instances spilled
+  if (!((touched >> (MI + NI0)) & 3u)) return;
   const int r = row0 + MIX * RS + l15;
   const int rc = min(r, tm1);
-  double cv[NI][4];
+  double cv[2][4];
   if (!ATOMIC) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ni++)
+    for (int h = 0; h < 2; h++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = min(col0 + ni * CS + g + 4 * q, tn1);
-        cv[ni][q] = C[rc + (int64_t)c * ldc];
+        const int c = min(col0 + (NI0 + h) * CS + g + 4 * q, tn1);
+        cv[h][q] = C[rc + (int64_t)c * ldc];
       }
   }
   // (the accumulator registers are read one at a time, next to their use: 64 VGPRs are all there is beside the AGPRs)
-  auto put = [&](auto ni_c, auto q_c) {
-    constexpr int ni = decltype(ni_c)::value, q = decltype(q_c)::value;
+  auto put = [&](auto h_c, auto q_c) {
+    constexpr int h = decltype(h_c)::value, ni = NI0 + h, q = decltype(q_c)::value;
     if (!((touched >> (MI + ni)) & 1u)) return;
     const int c = col0 + ni * CS + g + 4 * q;
     if (r <= tm1 && c <= tn1) {
       const double a = acc_read<4 * MIX + ni, q>();
       if (ATOMIC) unsafeAtomicAdd(&C[r + (int64_t)c * ldc], -a);
-      else pst<COH>(&C[r + (int64_t)c * ldc], cv[ni][q] - a);
+      else pst<COH>(&C[r + (int64_t)c * ldc], cv[h][q] - a);
     }
   };
-#define PA_PUT4(ni)                                                              \
-  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 0>{});      \
-  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 1>{});      \
-  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 2>{});      \
-  put(std::integral_constant<int, ni>{}, std::integral_constant<int, 3>{});
-  PA_PUT4(0) PA_PUT4(1) PA_PUT4(2) PA_PUT4(3)
+#define PA_PUT4(h)                                                              \
+  put(std::integral_constant<int, h>{}, std::integral_constant<int, 0>{});      \
+  put(std::integral_constant<int, h>{}, std::integral_constant<int, 1>{});      \
+  put(std::integral_constant<int, h>{}, std::integral_constant<int, 2>{});      \
+  put(std::integral_constant<int, h>{}, std::integral_constant<int, 3>{});
+  PA_PUT4(0) PA_PUT4(1)
 #undef PA_PUT4
+}
+template <int MIX, bool ATOMIC, bool COH = false>
+__device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsigned touched, const int row0, const int col0,
+                                              const int l15, const int g, const int tm1, const int tn1, const int ldc) {
+  if (!((touched >> MIX) & 1u)) return;
+  epilogue_half<MIX, ATOMIC, COH, 0>(C, touched, row0, col0, l15, g, tm1, tn1, ldc);
+  epilogue_half<MIX, ATOMIC, COH, 2>(C, touched, row0, col0, l15, g, tm1, tn1, ldc);
 }
 
 // ---- the piece loop ------------------------------------------------------------------------------
@@ -320,8 +329,9 @@ __device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], con
 // columns, each a pass of K / 16 chunks through the loop above for a few percent of a tile's MFMA work.  The SOURCE rows of
 // all of them are consecutive in the source panel (its bloks are stacked), only where they land is scattered.  A gathered
 // piece is the whole set in one pass: the LDS images are laid out by TARGET row / column as always, and every 4-byte DMA
-// lane fetches ITS tile row's half of a double from wherever that row's source is -- global_load_lds_dword, 64 lanes = 32
-// tile rows, four instructions per k-line and operand instead of one; rows without a source copy the zero line.  (The
+// lane fetches ITS tile row's half of a double from wherever that row's source is -- buffer_load_dword ... lds, 64 lanes =
+// 32 tile rows, four instructions per k-line and operand instead of one; rows without a source read out of the
+// descriptor's range, i.e. zeros.  (The
 // reference's CUDA kernel walks blocktab inside one GEMM to the same end, sparse_gemm.cu:103-479.)  Ordinary pieces of the
 // same task run through this loop too, their maps made up on the fly from (dr, m) / (dc, n).  Accumulation order = the order
 // of the list, as in every other loop: the factors do not depend on which loop ran.
@@ -337,9 +347,6 @@ __device__ __forceinline__ void mfma_any(const int pat, const double (&an)[NI], 
 #undef PA_PAT_ROWS
 #undef PA_PAT
 }
-#define PASTIX_AMD_GLDS4(gptr, lptr)                                                             \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
-                                   (__attribute__((address_space(3))) void*)(lptr), 4, 0, 0)
 template <bool NEG>
 __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
@@ -391,34 +398,49 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
   uint32_t ma, mb, nma, nmb;
   maps_of(cur, ma, mb);
   maps_of(nextp, nma, nmb);
-  int64_t lda = cur.lda;
-  const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-  const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+  // The gathering DMA is a BUFFER load to LDS (buffer_load_dword ... offen lds): one descriptor per operand and piece whose
+  // range is exactly the piece's source rows over its K columns, the lane's offset = 8 x (its source row) + its half, the
+  // k-line in the scalar offset.  A lane without a source gets an offset beyond the range, and so does every lane of a
+  // k-line beyond K: the hardware writes ZEROS into LDS for those (probed on gfx950) -- no zero line, no selects, no 64-bit
+  // address arithmetic on the vector unit, no k-tail test.
+  __amdgpu_buffer_rsrc_t ra, rb;
+  uint32_t va[4], vb[4];
+  int lda8 = 0;                                      // bytes between k-lines (wave-uniform)
+  auto setup = [&](const Piece& pc, const uint32_t pa_map, const uint32_t pb_map) {
+    lda8 = __builtin_amdgcn_readfirstlane(pc.lda * 8);
+    const int kk = __builtin_amdgcn_readfirstlane((int)pc.k), mm = __builtin_amdgcn_readfirstlane((int)pc.m),
+              nn = __builtin_amdgcn_readfirstlane((int)pc.n);
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[pc.flags & 3] + pc.a_off), (short)0, (kk - 1) * lda8 + 8 * mm, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[(pc.flags >> 2) & 3] + pc.b_off), (short)0, (kk - 1) * lda8 + 8 * nn, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t sa = (pa_map >> (8 * q)) & 255u, sb = (pb_map >> (8 * q)) & 255u;
+      va[q] = sa != 255u ? 8u * sa + (uint32_t)half4 : 0x80000000u;
+      vb[q] = sb != 255u ? 8u * sb + (uint32_t)half4 : 0x80000000u;
+    }
+  };
+  setup(cur, ma, mb);
+  int kb = 0;                                        // first k-line of the chunk being copied
   int left = ((int)cur.k + KC - 1) / KC;
-  int krem = (int)cur.k;
   bool negn = (cur.flags & 16) != 0, negc = negn;
-  const char* zl = (const char*)g_zero_line;
   int patn = pattern_of(ma, mb), patc = patn;
   unsigned touched = (unsigned)patn;
-  // the DMA of one chunk: k-lines wave, wave + 8 of both operands, four 4-byte instructions each
+  // the DMA of one chunk: k-lines kb + wave, kb + wave + 8 of both operands, four 4-byte instructions each
   auto dma = [&](double* dA, double* dB) {
 #pragma unroll
     for (int kq = 0; kq < NL; kq++) {
-      const bool kv = wave + UW * kq < krem;         // wave-uniform
-      const char* ba = (const char*)(pa + (int64_t)kq * UW * lda);
-      const char* bb = (const char*)(pb + (int64_t)kq * UW * lda);
+      const uint32_t so = (uint32_t)((kb + wave + UW * kq) * lda8);      // wave-uniform
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const uint32_t sa = (ma >> (8 * q)) & 255u, sb = (mb >> (8 * q)) & 255u;
-        const char* ga = (kv && sa != 255u) ? ba + 8 * sa : zl;
-        const char* gb = (kv && sb != 255u) ? bb + 8 * sb : zl;
-        PASTIX_AMD_GLDS4(ga + half4, (char*)(dA + UW * kq * SLD) + 256 * q);
-        PASTIX_AMD_GLDS4(gb + half4, (char*)(dB + UW * kq * SLD) + 256 * q);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)((char*)(dA + UW * kq * SLD) + 256 * q), 4,
+                                                 va[q], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)((char*)(dB + UW * kq * SLD) + 256 * q), 4,
+                                                 vb[q], so, 0, 0);
       }
     }
   };
   dma(sh[0][0] + wave * SLD, sh[0][1] + wave * SLD);
-  krem -= KC;
+  kb += KC;
   const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
   const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
   double bm0[MI], an0[NI], bm1[MI], an1[NI];
@@ -436,11 +458,9 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
       if (++pi < pend) {
         cur = nextp;
         ma = nma; mb = nmb;
-        lda = cur.lda;
-        pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda;
-        pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda;
+        setup(cur, ma, mb);
+        kb = 0;
         left = ((int)cur.k + KC - 1) / KC;
-        krem = (int)cur.k;
         negn = (cur.flags & 16) != 0;
         nextp = pieces[min(pi + 1, pend - 1)];
         maps_of(nextp, nma, nmb);
@@ -449,13 +469,10 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
       } else {
         has_next = false;
       }
-    } else {
-      pa += (int64_t)KC * lda;
-      pb += (int64_t)KC * lda;
     }
     if (has_next) {
       dma(sh[buf ^ 1][0] + wave * SLD, sh[buf ^ 1][1] + wave * SLD);
-      krem -= KC;
+      kb += KC;
     }
     const double* sA = sAw + buf * (2 * KC * SLD);
     const double* sB = sBw + buf * (2 * KC * SLD);
@@ -507,7 +524,8 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
 template <int KIND>
 __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, const Task* __restrict__ tasks,
                                                            const Piece* __restrict__ pieces) {
-  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+  extern __shared__ double sh_dyn[];            // UPDATE_LDS_BYTES, dynamic: see the Makefile (register budget)
+  double (&sh)[2][2][KC * SLD] = *reinterpret_cast<double (*)[2][2][KC * SLD]>(sh_dyn);   // [buffer][A|B]  73,728 bytes
   if (KIND == 1) PANEL_PRIO();
   const Task tk = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -832,7 +850,8 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
                                                                double* __restrict__ dinv, const long long limit,
                                                                const RunD* __restrict__ rd, const double critere,
                                                                long long* __restrict__ nbpivot, int* __restrict__ errflag) {
-  __shared__ double sh[2][2][KC * SLD];         // [buffer][A|B]  73,728 bytes
+  extern __shared__ double sh_dyn[];
+  double (&sh)[2][2][KC * SLD] = *reinterpret_cast<double (*)[2][2][KC * SLD]>(sh_dyn);   // [buffer][A|B]  73,728 bytes
   static_assert(sizeof(double) * (DIAG_LDS_DOUBLES + 320) <= sizeof(sh), "the diagonal blok must fit the operand buffers");
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
@@ -944,12 +963,30 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   }
 }
 
+// The operand buffers are DYNAMIC LDS: the compiler then does not know the 73.7 KB that cap the kernels at four waves per
+// SIMD, and the register budget of the kernels can be stated as what it is (Makefile: 64 VGPRs, no AGPR of the compiler's).
+constexpr unsigned UPDATE_LDS_BYTES = 2 * 2 * KC * SLD * sizeof(double);
+template <class K>
+static void allow_lds(K kernel) {
+  static bool done[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && done[dev]) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UPDATE_LDS_BYTES);
+  if (dev >= 0 && dev < 64) done[dev] = true;
+}
+
 void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
                        const int32_t* cons, const RunCtl& rc, double* dinv, int64_t ntasks, int nwg, long long limit, const RunD* rd,
                        double critere, long long* nbpivot, int* errflag) {
   if (ntasks <= 0) return;
   const dim3 g((unsigned)std::min<int64_t>(ntasks + (rc.onek ? rc.nd : 0), std::max(nwg, 1))), b(64 * UW);
-#define PA_RUN(FT, ONEK) hipLaunchKernelGGL((k_run_update<FT, ONEK>), g, b, 0, s, ar, tasks, pieces, info, cons, rc, dinv, limit, rd, critere, nbpivot, errflag)
+#define PA_RUN(FT, ONEK)                                                                                                  \
+  do {                                                                                                                    \
+    allow_lds(k_run_update<FT, ONEK>);                                                                                    \
+    hipLaunchKernelGGL((k_run_update<FT, ONEK>), g, b, UPDATE_LDS_BYTES, s, ar, tasks, pieces, info, cons, rc, dinv, limit, rd, \
+                       critere, nbpivot, errflag);                                                                        \
+  } while (0)
   if (ar.p[2]) {                                   // complex double (split planes)
     if (factotype == PASTIX_AMD_FACT_LDLH) PA_RUN(4, false);
     else PA_RUN(3, false);
@@ -963,8 +1000,13 @@ void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Pie
                    bool urgent) {
   if (ntasks <= 0) return;
   const dim3 g((unsigned)ntasks);
-  if (urgent) hipLaunchKernelGGL((k_update<1>), g, dim3(64 * UW), 0, s, ar, tasks, pieces);
-  else hipLaunchKernelGGL((k_update<0>), g, dim3(64 * UW), 0, s, ar, tasks, pieces);
+  if (urgent) {
+    allow_lds(k_update<1>);
+    hipLaunchKernelGGL((k_update<1>), g, dim3(64 * UW), UPDATE_LDS_BYTES, s, ar, tasks, pieces);
+  } else {
+    allow_lds(k_update<0>);
+    hipLaunchKernelGGL((k_update<0>), g, dim3(64 * UW), UPDATE_LDS_BYTES, s, ar, tasks, pieces);
+  }
 }
 
 }  // namespace pastix_amd
