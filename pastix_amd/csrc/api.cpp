@@ -441,6 +441,31 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
     return PASTIX_AMD_ERR_ALLOC;
   }
   if (rc) return rc;
+  if (dev_opt("mode_stats")) {
+    // developer aid: update flops and 16-deep chunks by the loop instance that runs them
+    const char* nm[7] = {"mode0 full tile", "mode1 smaller tile", "mixed: full pieces", "mixed: partial pieces", "all partial", "quadrant", "gathered"};
+    double fl[7] = {0}, ch[7] = {0}; int64_t nt[7] = {0};
+    for (const Task& tk : P.tasks) {
+      int cls;
+      if (tk.flags & TASK_GATHERED) cls = 6;
+      else if (tk.flags & 32u) cls = 5;
+      else if ((int)tk.nfull == tk.pn) cls = (tk.tm == TM && tk.tn == TN) ? 0 : 1;
+      else if (tk.nfull > 0) cls = 2;
+      else cls = 4;
+      nt[cls]++;
+      for (int z = 0; z < tk.pn; z++) {
+        const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+        const int c2 = (cls == 2 && z >= (int)tk.nfull) ? 3 : cls;
+        fl[c2] += 2.0 * pc.m * (double)pc.n * pc.k;
+        ch[c2] += (pc.k + 15) / 16;
+      }
+    }
+    double tf = 0, tc = 0;
+    for (int i = 0; i < 7; i++) { tf += fl[i]; tc += ch[i]; }
+    for (int i = 0; i < 7; i++)
+      fprintf(stderr, "mode_stats %-22s tasks %9lld flops %6.2f %% chunks %6.2f %% flop/chunk %8.0f (full tile chunk = 524288)\n", nm[i],
+              (long long)nt[i], 100 * fl[i] / tf, 100 * ch[i] / tc, ch[i] > 0 ? fl[i] / ch[i] : 0.0);
+  }
   *nlevels = P.nlevels;
   for (int l = 0; l < P.nlevels && l < maxlevels; l++) {
     if (slot_flops) slot_flops[l] = P.slot_flops[l];

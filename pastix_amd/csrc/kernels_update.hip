@@ -518,6 +518,47 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
   return touched;
 }
 
+// Which loop runs a task's pieces.  Tasks of whole-tile pieces take MODE 0 / 1, a gathered task the gathering loop; a task
+// that MIXES whole-tile pieces (the plan lists them first: Task::nfull) with partial ones runs its head on the branch-free
+// loop and its tail on the masked one (round 5; before, every piece of such a task went through the masked loop: 7-10 % of
+// the chunks at 100^3 / 60^3) -- the accumulators stay where they are between the two, the order of the list is kept, so
+// the factors do not change.  One call site per instance (the loops are inlined).
+__device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
+                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
+                                                  const int lane, const int l15, const int g) {
+  const bool neg = (tk.flags & 8u) != 0;
+  if (tk.flags & TASK_GATHERED) {
+    if (neg) return piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    return piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+  }
+  const bool fullt = tk.tm == TM && tk.tn == TN;
+  Task t = tk;
+  int left = tk.pn, nfull = (int)tk.nfull;
+  unsigned touched = 0;
+  for (;;) {
+    int mode;
+    if (nfull == left) { mode = fullt ? 0 : 1; t.pn = left; }
+    else if (nfull > 0 && fullt) { mode = 0; t.pn = nfull; }
+    else { mode = 2; t.pn = left; }
+    if (mode == 0) {
+      if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+    } else if (mode == 1) {
+      if (neg) touched |= piece_loop<1, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop<1, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+    } else {
+      if (neg) touched |= piece_loop<2, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop<2, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+    }
+    left -= t.pn;
+    if (left <= 0) break;
+    t.p0 += t.pn;
+    nfull = 0;
+    __syncthreads();        // (the head's last chunk is read before the tail's first DMA overwrites its buffer)
+  }
+  return touched;
+}
+
 // KIND 0: the bulk launches.  KIND 1 (`k_update<1>` in profiles): the same code for the few latency-critical tasks of a
 // level that the two-stream driver runs beside the bulk launch of the previous slot; a separate instantiation so that
 // per-kernel profiles of the two do not mix.
@@ -532,26 +573,9 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;      // this wave's first row / col band
   const int l15 = lane & 15, g = lane >> 4;
   acc_zero();
-  // Exactly one instance of the loop runs per task: tasks made of whole-tile pieces only (the bulk of the flops) take
-  // MODE 0 / 1, a task with any partial piece runs all its pieces through MODE 2 (a whole-tile piece is its special
-  // case).  The plan puts the whole-tile pieces of a task first (Task::nfull) and sets Task flag 8 for sign flips.
-  unsigned touched;
-  const bool neg = (tk.flags & 8u) != 0;
-  if (tk.flags & TASK_GATHERED) {
-    if (neg) touched = piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    else touched = piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-  } else if ((int)tk.nfull == tk.pn) {
-    if (tk.tm == TM && tk.tn == TN) {
-      if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    } else {
-      if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    }
-  } else {
-    if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-  }
+  // (update_pieces: which loop instance runs which pieces.  The plan puts the whole-tile pieces of a task first, Task::nfull,
+  // and sets Task flag 8 for sign flips.)
+  const unsigned touched = update_pieces(sh, ar, tk, pieces, row0, col0, lane, l15, g);
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column)
   acc_settle();
@@ -930,23 +954,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
     const int l15 = lane & 15, g = lane >> 4;
     acc_zero();
-    unsigned touched;
-    const bool neg = (tk.flags & 8u) != 0;
-    if (tk.flags & TASK_GATHERED) {
-      if (neg) touched = piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    } else if ((int)tk.nfull == tk.pn) {
-      if (tk.tm == TM && tk.tn == TN) {
-        if (neg) touched = piece_loop<0, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-        else touched = piece_loop<0, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      } else {
-        if (neg) touched = piece_loop<1, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-        else touched = piece_loop<1, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      }
-    } else {
-      if (neg) touched = piece_loop<2, true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-      else touched = piece_loop<2, false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    }
+    const unsigned touched = update_pieces(sh, ar, tk, pieces, row0, col0, lane, l15, g);
     acc_settle();
     double* C = ar.p[tk.flags & 3] + tk.c_off;
     const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
