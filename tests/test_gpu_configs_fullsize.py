@@ -2,8 +2,8 @@
 suite pins the factors at fixture sizes against the reference's own output; here the size-independent properties the
 domain offers are checked where the oracle cannot follow -- ||Ax - b|| / ||b|| <= 1e-10 after one device solve (SURVEY
 8d), no static pivot, and a bitwise-equal refactorization (tile ownership: the summation order is part of the plan).
-configs[1] = 100^3 dLLt; configs[2] = dLU with static pivoting (80^3 here: the test suite's memory and time budget; the
-bench line carries 192^3, the largest grid whose L and U panels fit one device); configs[4] = z LDLt on the 3-dof
+configs[1] = 100^3 dLLt; configs[2] = dLU with static pivoting (80^3 with the factors downloaded twice, 128^3 through the
+solutions; the bench line carries 192^3, the largest grid whose L and U panels fit one device); configs[4] = z LDLt on the 3-dof
 elasticity pattern (40^3 nodes, n = 192 000)."""
 import numpy as np
 import pytest
@@ -57,6 +57,34 @@ def test_config3_laplacian_80_dlu_static_pivoting():
     n, cp, r, v = sy.laplacian_3d(N, full=True)
     perm, _ = sy.order_grid(N, N, N)
     _run(n, cp, r, v, perm, 2, 1, 6.0 * 2 * np.sqrt(1e-31), True)
+
+
+def test_config3_laplacian_128_dlu_static_pivoting_without_downloads():
+    """configs[2] at 128^3 (n = 2.1 M, 47 GB of L and U panels, 250 k tickets in the run): too much to bring back to the
+    host twice, so the refactorization is compared through what it produces -- the solution of the same right-hand side must
+    be BITWISE the same (any entry of L or U that differed would show in it) -- beside the residual and the pivot count."""
+    N = 128
+    n, cp, r, v = sy.laplacian_3d(N, full=True)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    crit = 6.0 * 2 * np.sqrt(1e-31)
+    with Plan(s["cblk4"], s["blok4"], 2) as p:
+        p.fill_csc(0, n, cp, r, v, s["perm"])
+        st = p.factorize(crit)
+        rng = np.random.default_rng(7)
+        b = rng.random(n)
+        bp = np.empty(n)
+        bp[s["perm"]] = b
+        x1 = p.solve(bp.copy())
+        p.refill()
+        st2 = p.factorize(crit)
+        x2 = p.solve(bp.copy())
+    A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
+    x = x1[s["perm"]]
+    resid = float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
+    assert st["nbpivot"] == 0 and st2["nbpivot"] == 0
+    assert resid <= 1e-10, resid
+    assert np.array_equal(x1, x2)
 
 
 def test_config5_elasticity_40_zldlt():
