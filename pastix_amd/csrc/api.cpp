@@ -436,15 +436,33 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
   Plan P;
   int rc;
   try {
-    rc = build_plan(layout, factotype, PASTIX_AMD_REALDOUBLE, opts, owner, myrank, P);
+    // (cblks wider than the panel kernels take are re-cut into column groups, as pastix_amd_plan_create does)
+    SplitMap sm;
+    pastix_amd_layout_t sl = *layout;
+    std::vector<int32_t> sowner;
+    rc = build_split(layout, opts && opts->schur, sm);
+    if (!rc && sm.active) {
+      if (owner) {
+        sowner.resize(sm.cblk.size() - 1);
+        for (int64_t k = 0; k < sm.ocblknbr; k++)
+          for (int64_t q = sm.first[k]; q < sm.first[k + 1]; q++) sowner[(size_t)q] = owner[k];
+        owner = sowner.data();
+      }
+      sl.cblknbr = (pastix_amd_int_t)sm.cblk.size() - 1;
+      sl.bloknbr = (pastix_amd_int_t)sm.blok.size();
+      sl.cblktab = sm.cblk.data();
+      sl.bloktab = sm.blok.data();
+    }
+    if (!rc) rc = build_plan(&sl, factotype, PASTIX_AMD_REALDOUBLE, opts, owner, myrank, P);
   } catch (const std::bad_alloc&) {
     return PASTIX_AMD_ERR_ALLOC;
   }
   if (rc) return rc;
   if (dev_opt("mode_stats")) {
     // developer aid: update flops and 16-deep chunks by the loop instance that runs them
-    const char* nm[7] = {"mode0 full tile", "mode1 smaller tile", "mixed: full pieces", "mixed: partial pieces", "all partial", "quadrant", "gathered"};
-    double fl[7] = {0}, ch[7] = {0}; int64_t nt[7] = {0};
+    const char* nm[9] = {"mode0 full tile", "mode1 smaller tile", "mixed: full pieces", "mixed: partial pieces", "all partial", "quadrant",
+                         "gathered: gathered pieces", "gathered: whole-tile pieces", "gathered: rectangles"};
+    double fl[9] = {0}, ch[9] = {0}; int64_t nt[9] = {0};
     for (const Task& tk : P.tasks) {
       int cls;
       if (tk.flags & TASK_GATHERED) cls = 6;
@@ -455,15 +473,15 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
       nt[cls]++;
       for (int z = 0; z < tk.pn; z++) {
         const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
-        const int c2 = (cls == 2 && z >= (int)tk.nfull) ? 3 : cls;
+        const int c2 = (cls == 2 && z >= (int)tk.nfull) ? 3 : cls == 6 ? ((pc.flags & PIECE_GATHERED) ? 6 : z < (int)tk.nfull ? 7 : 8) : cls;
         fl[c2] += 2.0 * pc.m * (double)pc.n * pc.k;
         ch[c2] += (pc.k + 15) / 16;
       }
     }
     double tf = 0, tc = 0;
-    for (int i = 0; i < 7; i++) { tf += fl[i]; tc += ch[i]; }
-    for (int i = 0; i < 7; i++)
-      fprintf(stderr, "mode_stats %-22s tasks %9lld flops %6.2f %% chunks %6.2f %% flop/chunk %8.0f (full tile chunk = 524288)\n", nm[i],
+    for (int i = 0; i < 9; i++) { tf += fl[i]; tc += ch[i]; }
+    for (int i = 0; i < 9; i++)
+      fprintf(stderr, "mode_stats %-28s tasks %9lld flops %6.2f %% chunks %6.2f %% flop/chunk %8.0f (full tile chunk = 524288)\n", nm[i],
               (long long)nt[i], 100 * fl[i] / tf, 100 * ch[i] / tc, ch[i] > 0 ? fl[i] / ch[i] : 0.0);
   }
   *nlevels = P.nlevels;

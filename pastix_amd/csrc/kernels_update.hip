@@ -522,33 +522,40 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
 // that MIXES whole-tile pieces (the plan lists them first: Task::nfull) with partial ones runs its head on the branch-free
 // loop and its tail on the masked one (round 5; before, every piece of such a task went through the masked loop: 7-10 % of
 // the chunks at 100^3 / 60^3) -- the accumulators stay where they are between the two, the order of the list is kept, so
-// the factors do not change.  One call site per instance (the loops are inlined).
+// the factors do not change.  The same for a task with gathered pieces: its whole-tile head (15 % of the flops of a
+// fragmented 60^3 layout) on the branch-free loop, the rest through the gathering loop.  One call site per instance (the
+// loops are inlined).
 __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
-                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
-                                                  const int lane, const int l15, const int g) {
+                                                  const Piece* __restrict__ pieces) {
   const bool neg = (tk.flags & 8u) != 0;
-  if (tk.flags & TASK_GATHERED) {
-    if (neg) return piece_loop_g<true>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-    return piece_loop_g<false>(sh, ar, tk, pieces, row0, col0, lane, l15, g);
-  }
+  const bool gath = (tk.flags & TASK_GATHERED) != 0;   // the tail of such a task (everything but whole-tile pieces) gathers
   const bool fullt = tk.tm == TM && tk.tn == TN;
   Task t = tk;
   int left = tk.pn, nfull = (int)tk.nfull;
   unsigned touched = 0;
   for (;;) {
+    // (what derives from the thread index is recomputed per pass, not kept in registers across the loops: 64 VGPRs)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
+    const int l15 = lane & 15, g = lane >> 4;
     int mode;
-    if (nfull == left) { mode = fullt ? 0 : 1; t.pn = left; }
+    if (nfull == left && !gath) { mode = fullt ? 0 : 1; t.pn = left; }
     else if (nfull > 0 && fullt) { mode = 0; t.pn = nfull; }
-    else { mode = 2; t.pn = left; }
+    else { mode = gath ? 3 : 2; t.pn = left; }
     if (mode == 0) {
       if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
       else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
     } else if (mode == 1) {
       if (neg) touched |= piece_loop<1, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
       else touched |= piece_loop<1, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-    } else {
+    } else if (mode == 2) {
       if (neg) touched |= piece_loop<2, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
       else touched |= piece_loop<2, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+    } else {
+      if (neg) touched |= piece_loop_g<true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop_g<false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
     }
     left -= t.pn;
     if (left <= 0) break;
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   acc_zero();
   // (update_pieces: which loop instance runs which pieces.  The plan puts the whole-tile pieces of a task first, Task::nfull,
   // and sets Task flag 8 for sign flips.)
-  const unsigned touched = update_pieces(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+  const unsigned touched = update_pieces(sh, ar, tk, pieces);
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column)
   acc_settle();
@@ -954,7 +961,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
     const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
     const int l15 = lane & 15, g = lane >> 4;
     acc_zero();
-    const unsigned touched = update_pieces(sh, ar, tk, pieces, row0, col0, lane, l15, g);
+    const unsigned touched = update_pieces(sh, ar, tk, pieces);
     acc_settle();
     double* C = ar.p[tk.flags & 3] + tk.c_off;
     const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;

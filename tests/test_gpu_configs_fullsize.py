@@ -61,8 +61,10 @@ def test_config3_laplacian_80_dlu_static_pivoting():
 
 def test_config3_laplacian_128_dlu_static_pivoting_without_downloads():
     """configs[2] at 128^3 (n = 2.1 M, 47 GB of L and U panels, 250 k tickets in the run): too much to bring back to the
-    host twice, so the refactorization is compared through what it produces -- the solution of the same right-hand side must
-    be BITWISE the same (any entry of L or U that differed would show in it) -- beside the residual and the pivot count."""
+    host twice, so the refactorization is compared through what it produces -- the solutions of the same right-hand side
+    (the fused thin-level sweeps combine contributions with atomics, so two solves agree to rounding, not bitwise: 1e-12 of
+    the largest entry, the bound tests/test_gpu_configs_fullsize.py uses for repeated solves) -- beside the residual of BOTH
+    and the pivot counts."""
     N = 128
     n, cp, r, v = sy.laplacian_3d(N, full=True)
     perm, _ = sy.order_grid(N, N, N)
@@ -80,11 +82,11 @@ def test_config3_laplacian_128_dlu_static_pivoting_without_downloads():
         st2 = p.factorize(crit)
         x2 = p.solve(bp.copy())
     A = sp.csc_matrix((v, r - 1, cp - 1), shape=(n, n))
-    x = x1[s["perm"]]
-    resid = float(np.linalg.norm(A @ x - b) / np.linalg.norm(b))
     assert st["nbpivot"] == 0 and st2["nbpivot"] == 0
-    assert resid <= 1e-10, resid
-    assert np.array_equal(x1, x2)
+    for xs in (x1, x2):
+        resid = float(np.linalg.norm(A @ xs[s["perm"]] - b) / np.linalg.norm(b))
+        assert resid <= 1e-10, resid
+    assert np.abs(x1 - x2).max() <= 1e-12 * np.abs(x1).max()
 
 
 def test_config5_elasticity_40_zldlt():
