@@ -62,6 +62,56 @@ def cpu_baseline(sample_grid, threads):
             "sample": "oracle restatement (plain C, no BLAS), 3-D Laplacian %d^3 dLLt" % N}
 
 
+class PowerWatch:
+    """Socket power and shader clock while the timed steps run (rocm-smi in a child process every 0.5 s, text output; a box
+    without rocm-smi, or one whose output has another shape, reports nulls).  VERDICT r4 item 8: the sustained clock beside
+    the rate -- the fp64 MFMA peak is quoted at 2.4 GHz, the chip holds about 2.29 under this kernel at its power cap."""
+
+    def __init__(self, enabled=True):
+        self.pw, self.ck, self.stop, self.th = [], [], False, None
+        import shutil
+        self.exe = shutil.which("rocm-smi") if enabled else None
+
+    def _loop(self):
+        import re
+        import subprocess
+        while not self.stop:
+            try:
+                out = subprocess.run([self.exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                for line in out.splitlines():
+                    if "sclk" in line:
+                        m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                        if m:
+                            self.ck.append(float(m.group(1)))
+                            break
+                for line in out.splitlines():
+                    if "Power" in line and "(W)" in line:
+                        m = re.search(r"([0-9]+(?:\.[0-9]+)?)\s*$", line.strip())
+                        if m:
+                            self.pw.append(float(m.group(1)))
+                            break
+            except Exception:
+                pass
+            time.sleep(0.5)
+
+    def __enter__(self):
+        if self.exe:
+            import threading
+            self.th = threading.Thread(target=self._loop, daemon=True)
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.th:
+            self.th.join(timeout=6)
+
+    def summary(self):
+        f = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"socket_power_w_avg": f(self.pw), "sclk_mhz_avg": f(self.ck), "samples": len(self.ck),
+                "source": "rocm-smi --showclocks --showpower every 0.5 s during the timed steps" if self.exe else None}
+
+
 def engine_source_sha():
     """Identity of the code the HBM-traffic counters were collected on: sha256 over EVERY engine source
     (pastix_amd/csrc/*.hip, *.cpp, *.h, the Makefile) and the values of the PASTIX_AMD_* environment knobs that shape the
@@ -121,7 +171,7 @@ def self_launch(a, argv):
     raise SystemExit(subprocess.call(cmd))
 
 
-def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, local, f32=False):
+def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, local, f32=False, power=False):
     """One configuration on one GPU: analysis, plan, device fill, `warmup` untimed and `steps` timed steps (a step =
     device re-fill + factorization, inputs resident in HBM), then the end-to-end check ||Ax - b|| / ||b|| with the device
     solve on the last factors.  Returns the raw figures the JSON line is made of."""
@@ -169,7 +219,9 @@ def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, 
     nrun = 0            # steps whose thin levels ran as the run launch (a step whose run stopped is redone level by level: run_time 0)
     run_flops = 0.0
     st = None
-    for _ in range(steps):
+    watch = PowerWatch(enabled=power)
+    with watch:
+      for _ in range(steps):
         plan.refill()
         st = plan.factorize(crit)
         ft += st["fact_time"]
@@ -179,8 +231,8 @@ def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, 
         rnt += st["run_time"]
         nrun += st["run_time"] > 0
         run_flops = max(run_flops, st["run_flops"])
-    torch.cuda.synchronize()
-    wall = time.time() - t0
+      torch.cuda.synchronize()
+      wall = time.time() - t0
     # end-to-end check on the last factorization: ||Ax-b||/||b|| with the device solve
     rng = np.random.default_rng(1)
     b = rng.random(n) + (1j * rng.random(n) if zel else 0)
@@ -203,7 +255,8 @@ def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, 
                run_time=rnt, run_steps=nrun, run_flops=run_flops, run_tickets=st["run_tickets"], run_first_level=st["run_first_level"],
                nlaunch=st["nupdate_launches"], solve_s=solve_s, solve_dev_s=ps["solve_time"], resid=resid, nbpivot=st["nbpivot"], n=n, cblk=len(c4) - 1,
                blok=len(b4), nnzl=s["nnzl"], coefnbr=ps["coefnbr"], t_matrix=t_matrix, t_sym=t_sym, t_plan=t_plan, t_fill=t_fill,
-               ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu", facto=facto_name)
+               ntasks=ps["ntasks"], npieces=ps["npieces"], nlevels=ps["nlevels"], parallelism="single-gpu", facto=facto_name,
+               power=watch.summary())
     plan.close()
     del plan, A, Ax, x, b, bp, s, c4, b4
     import gc
@@ -297,6 +350,7 @@ def main():
                          "complex double LDLt on the 3-dof elasticity pattern of a grid^3 node mesh (n = 3 grid^3)")
     ap.add_argument("--cpu-sample-grid", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (socket power, shader clock) during the timed steps")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32: the single-precision engine (the reference's S_ build; kernels_f32.hip), reported against the "
                          "fp32 matrix peak; one GPU, laplacian workload")
@@ -359,7 +413,8 @@ def main():
     else:
         if a.dtype == "f32" and a.workload != "laplacian":
             raise SystemExit("bench.py: --dtype f32 is the real single-precision engine (laplacian workload)")
-        res = single_gpu_job(a.grid, a.workload, a.facto, a.steps, a.warmup, a.blocksize, a.chunk, local, f32=a.dtype == "f32")
+        res = single_gpu_job(a.grid, a.workload, a.facto, a.steps, a.warmup, a.blocksize, a.chunk, local, f32=a.dtype == "f32",
+                             power=not a.no_power)
         a.facto = res["facto"]
 
     if rank == 0:
@@ -418,6 +473,7 @@ def main():
                        "residual": res["resid"], "solve_s": round(res["solve_s"], 4) if "solve_s" in res else None, "logdet_rel_err": res.get("logdet_rel_err"),
                        "static_pivots": res["nbpivot"],
                        "steps_redone_level_by_level": (K - res.get("run_steps", K)) if res.get("run_time", 0.0) > 0 else 0,
+                       "power": res.get("power"),
                        "analysis_s": {"symbolic": round(res["t_sym"], 2), "plan": round(res["t_plan"], 2),
                                       "fill_prepare": round(res["t_fill"], 2), "input_matrix": round(res.get("t_matrix", 0.0), 2)}},
             "roofline": {"bound": "mfma", "kernel": "k_update_s" if PEAK == MFMA_F32_PEAK else "k_run_update" if run_on else "k_update",

@@ -29,6 +29,8 @@ def test_bench_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "GFLOP/s"
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert "workload" in d["config"] and d["config"]["residual"] < 1e-10
+    # socket power / shader clock during the timed steps (nulls where rocm-smi is absent or silent)
+    assert set(d["config"]["power"]) >= {"socket_power_w_avg", "sclk_mhz_avg", "samples"}
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
