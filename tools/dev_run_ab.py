@@ -21,6 +21,7 @@ ap.add_argument("--look", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--nocheck", action="store_true")
 ap.add_argument("--verbose", type=int, default=0)
+ap.add_argument("--force-run", action="store_true", help="options.run_schedule = 1: build the run whatever the size")
 a = ap.parse_args()
 for N in a.n:
     n, cp, r, v = sy.laplacian_3d(N)
@@ -28,7 +29,10 @@ for N in a.n:
     s = sy.symbolic(n, cp, r, perm, max_blocksize=a.bs)
     c4, b4 = s["cblk4"], s["blok4"]
     fl = fact_flops(c4, b4, 0)
-    p = Plan(c4, b4, 0, run_max_cblks=a.maxc, run_t_workers=a.tw, run_d_workers=a.dw, lookahead=a.look, verbose=a.verbose)
+    import time as _t
+    _t0 = _t.time()
+    p = Plan(c4, b4, 0, run_max_cblks=a.maxc, run_t_workers=a.tw, run_d_workers=a.dw, lookahead=a.look, verbose=a.verbose, run_schedule=1 if a.force_run else 0)
+    print("N=%d plan created in %.2f s (maxc %d, force_run %s)" % (N, _t.time() - _t0, a.maxc, a.force_run), flush=True)
     res = {}
     for mode in ("0", "1"):
         os.environ["PASTIX_AMD_RUN"] = mode
