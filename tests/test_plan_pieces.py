@@ -51,3 +51,18 @@ def test_pieces_on_produced_layouts(N, bs):
         for kw in ({}, {"run_schedule": -1}, {"quadrant_min": 1, "quadrant_fill_pct": 200}):
             o = check(s["cblk4"], s["blok4"], 0, gm, **kw)
             assert o[0] == o[1] and o[2] == 0, (gm, kw, o)
+
+
+def test_plan_profile_recuts_cblks_wider_than_the_panel_kernels_take():
+    """pastix_amd_plan_profile (host only) on a layout with a 590-column cblk (blend's split rule leaves the root whole):
+    the cblk is re-cut into column groups as pastix_amd_plan_create does -- it used to return UNSUPPORTED, which kept the
+    schedule statistics (and PASTIX_AMD_DEV=mode_stats) away from the reference's own layouts."""
+    from pastix_amd import dist as pd
+    N = 24
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=512, blend_split=True)
+    c = s["cblk4"]
+    assert (c[:-1, 1] - c[:-1, 0] + 1).max() > 256
+    sf, sm, stn, pf, uf = pd.plan_profile(s["cblk4"], s["blok4"], None, 0)
+    assert len(sf) > 1 and sf.sum() > 0 and pf.sum() > 0 and stn.sum() > 0

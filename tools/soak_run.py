@@ -28,6 +28,7 @@ ap.add_argument("--reps", type=int, default=1000)
 ap.add_argument("--check", type=int, default=0, help="hash the factors every this many steps (0: first and last only)")
 ap.add_argument("--timeout", type=float, default=0.5, help="PASTIX_AMD_RUN_TIMEOUT for the soak (s): what a stop costs")
 ap.add_argument("--tag", default="")
+ap.add_argument("--force-run", action="store_true", help="options.run_schedule = 1: build the run whatever the size (200^3)")
 a = ap.parse_args()
 os.environ.setdefault("PASTIX_AMD_RUN_TIMEOUT", str(a.timeout))
 os.environ.setdefault("PASTIX_AMD_LAUNCH_EVENTS", "1")
@@ -47,7 +48,7 @@ stops = errors = 0
 digests = {}
 times = []
 t0 = time.time()
-with Plan(s["cblk4"], s["blok4"], a.facto, floattype=ft) as p:
+with Plan(s["cblk4"], s["blok4"], a.facto, floattype=ft, run_schedule=1 if a.force_run else 0) as p:
     p.fill_csc(sym, n, cp, r, v, s["perm"])
     st = p.factorize(1e-14)
     has_run = st["run_time"] > 0
