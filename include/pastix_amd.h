@@ -266,6 +266,12 @@ int pastix_amd_plan_run_info(const pastix_amd_layout_t *layout, int factotype, i
  * pieces make, mismatches, gathered pieces. */
 int pastix_amd_plan_check_pieces(const pastix_amd_layout_t *layout, int factotype, const pastix_amd_options_t *opts,
                                  pastix_amd_int_t *out);
+/* tests: a digest of the run schedule's dependency tables as they stand ON THE DEVICE (the counterpart of indtab /
+ * TASK_CTRBCNT, solverMatrixGen.c:667-760, solver.h:71-75).  Round 6 builds the reader lists of the run on the GPU
+ * (csrc/run_edges.hip); with PASTIX_AMD_DEV=run_host_edges the host builds them as before: both must give the same digest.
+ * out[0] = (panel-solve ticket, reading update ticket) pairs, out[1] = order-independent hash of the pairs, out[2] = hash of
+ * the tickets' initial counters, out[3] = tickets ready when the run starts; -1s when the plan has no run. */
+int pastix_amd_plan_run_edges_digest(pastix_amd_plan_t *plan, pastix_amd_int_t *out);
 /* host-only: the multi-GPU driver's partition -- owner[k] = the rank (GPU) that factorizes cblk k, for `world` <= 64 ranks.
  * Proportional mapping on the cblk elimination tree, blend's idea (splitpart.c:752-1012; GPU colouring
  * blend_distributeOnGPU.c:59-317): a subtree gets a set of candidate ranks; the cblks of the separator at its top are dealt

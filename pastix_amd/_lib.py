@@ -68,7 +68,7 @@ _lib = None
 
 # every symbol include/pastix_amd.h declares
 EXPORTS = [
-    "pastix_amd_release_cached_plan", "pastix_amd_plan_check_pieces", "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
+    "pastix_amd_release_cached_plan", "pastix_amd_plan_check_pieces", "pastix_amd_plan_run_edges_digest", "pastix_amd_d_po_sopalin", "pastix_amd_d_sy_sopalin", "pastix_amd_d_ge_sopalin", "pastix_amd_z_sy_sopalin",
     "pastix_amd_z_he_sopalin", "pastix_amd_z_ge_sopalin",
     "pastix_amd_s_po_sopalin", "pastix_amd_s_sy_sopalin", "pastix_amd_s_ge_sopalin",
     "pastix_amd_c_sy_sopalin", "pastix_amd_c_he_sopalin", "pastix_amd_c_ge_sopalin",

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -161,6 +163,9 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         }
       });
     }
+    // (the reader lists of the run schedule are built on the device, run_edges.hip; the host builds them for the host-only
+    // entry points, for the stopped-run replay and on request: PASTIX_AMD_DEV=run_host_edges)
+    p->host.defer_run_edges = !owner && !dev_opt("run_debug") && !dev_opt("run_host_edges");
     if (!rc) rc = build_plan(p->split.active ? &sl : layout, factotype, floattype, opts, owner, myrank, p->host);
   } catch (const std::bad_alloc&) {
     rc = PASTIX_AMD_ERR_ALLOC;
@@ -265,7 +270,21 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
       // the run schedule: its tables, its flags, two more streams for the resident panel kernels
       if ((r = to_device(&p->dRunTasks, H.run_tasks))) return r;
       if ((r = to_device(&p->dRunInfo, H.run_info))) return r;
-      if ((r = to_device(&p->dRunCons, H.run_cons))) return r;
+      if (H.run_edges_deferred) {
+        // the reader lists, the panel-solve tickets' offsets into them and the readers' counters: on the device, from the
+        // tables just uploaded (run_edges.hip)
+        size_t cn = 0;
+        if ((r = run_edges_device(p->stream, p->dRunTasks, p->dRunInfo, p->dPieces, H, &p->dRunCons, &cn))) return r;
+        p->nRunCons = cn;
+        const size_t nr0 = H.run_tasks.size();
+        H.run_ready.clear();
+        for (size_t i = 0; i < nr0; i++) if (H.run_dep[i] == 0) H.run_ready.push_back((int32_t)i);
+        phase("run: reader lists on the device");
+      } else {
+        if ((r = to_device(&p->dRunCons, H.run_cons))) return r;
+        p->nRunCons = H.run_cons.size();
+      }
+      p->runDep0.assign(H.run_dep.begin(), H.run_dep.begin() + (ptrdiff_t)H.run_tasks.size());
       if ((r = to_device(&p->dRunD, H.run_d))) return r;
       // the run's state: [counters of the tickets and diagonal tasks | ticket ring | diagonal ring | control words] (a ring slot
       // is one 128-byte line, plan.h RUN_SLOT),
@@ -282,24 +301,35 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         p->runctl.onek = (!p->cplx && (H.factotype == PASTIX_AMD_FACT_LLT || H.factotype == PASTIX_AMD_FACT_LDLT) && !(e && atoi(e) == 0)) ? 1 : 0;
       }
       {
-        std::vector<int32_t> img(p->nRunState, -1);
-        std::copy(H.run_dep.begin(), H.run_dep.end(), img.begin() + (ptrdiff_t)o_cnt);
-        for (size_t c = 0; c < (size_t)RUN_CTL_INTS; c++) img[o_ctl + c] = 0;
-        if (p->runctl.onek) {
-          // (the diagonal tasks that are ready at the start come first: they head the chains)
-          size_t n = 0;
-          for (size_t i = 0; i < H.run_dready.size(); i++) img[o_q + (n++) * RUN_SLOT] = (int32_t)nr + H.run_dready[i];
-          for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + (n++) * RUN_SLOT] = H.run_ready[i];
-          img[o_ctl + RUN_TAIL] = (int32_t)n;
-        } else {
-          for (size_t i = 0; i < H.run_ready.size(); i++) img[o_q + i * RUN_SLOT] = H.run_ready[i];
-          img[o_ctl + RUN_TAIL] = (int32_t)H.run_ready.size();
-          for (size_t i = 0; i < H.run_dready.size(); i++) img[o_qd + i * RUN_SLOT] = H.run_dready[i];
-          img[o_ctl + RUN_TAIL + 64] = (int32_t)H.run_dready.size();
-        }
+        // (the image is a GB at 200^3 -- 8 M ring slots of one 128-byte line each --: it is made on the device: -1 everywhere,
+        // the counters, the control words, and the few thousand tasks that are ready at the start scattered into their slots)
         HIPCHK(hipMalloc((void**)&p->dRunImage, p->nRunState * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&p->dRunState, p->nRunState * sizeof(int32_t)));
-        HIPCHK(hipMemcpy(p->dRunImage, img.data(), p->nRunState * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(p->dRunImage, 0xff, p->nRunState * sizeof(int32_t), p->stream));
+        HIPCHK(hipMemcpyAsync(p->dRunImage + o_cnt, H.run_dep.data(), H.run_dep.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+        std::vector<int32_t> ctl((size_t)RUN_CTL_INTS, 0), rq, rqd;
+        if (p->runctl.onek) {
+          // (the diagonal tasks that are ready at the start come first: they head the chains)
+          for (size_t i = 0; i < H.run_dready.size(); i++) rq.push_back((int32_t)nr + H.run_dready[i]);
+          rq.insert(rq.end(), H.run_ready.begin(), H.run_ready.end());
+        } else {
+          rq = H.run_ready;
+          rqd = H.run_dready;
+          ctl[RUN_TAIL + 64] = (int32_t)rqd.size();
+        }
+        ctl[RUN_TAIL] = (int32_t)rq.size();
+        HIPCHK(hipMemcpyAsync(p->dRunImage + o_ctl, ctl.data(), ctl.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+        for (int w = 0; w < 2; w++) {
+          const std::vector<int32_t>& v = w ? rqd : rq;
+          if (v.empty()) continue;
+          int32_t* dv = nullptr;
+          HIPCHK(hipMalloc((void**)&dv, v.size() * sizeof(int32_t)));
+          HIPCHK(hipMemcpyAsync(dv, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, p->stream));
+          launch_ring_scatter(p->stream, p->dRunImage + (w ? o_qd : o_q), dv, v.size());
+          HIPCHK(hipStreamSynchronize(p->stream));
+          HIPCHK(hipFree(dv));
+        }
+        HIPCHK(hipStreamSynchronize(p->stream));
       }
       p->runctl.cnt = p->dRunState + o_cnt;
       p->runctl.q = p->dRunState + o_q;
@@ -325,6 +355,33 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
         p->nRunProf = 4 * (H.run_tasks.size() + H.run_d.size());
         HIPCHK(hipMalloc((void**)&p->dRunProf, p->nRunProf * sizeof(long long)));
         HIPCHK(hipMemset(p->dRunProf, 0, p->nRunProf * sizeof(long long)));
+        // per ticket, for tools/run_fit.py: flops, chunks on the branch-free loop, chunks of whole pieces of a smaller tile,
+        // chunks of partial pieces, the same two weighted by the busiest wave's share of its eight sub-tiles, pieces, tm * tn
+        std::vector<long long>& ft = p->runFeat;
+        ft.assign(8 * H.run_tasks.size(), 0);
+        for (size_t i = 0; i < H.run_tasks.size(); i++) {
+          if (H.run_info[i].kind & 4) continue;
+          const Task& tk = H.run_tasks[i];
+          const bool fullt = tk.tm == TM && tk.tn == TN;
+          long long* o = &ft[8 * i];
+          for (int z = 0; z < tk.pn; z++) {
+            const Piece& pc = H.pieces[(size_t)tk.p0 + (size_t)z];
+            const long long c = (pc.k + 15) / 16;
+            o[0] += 2LL * pc.m * pc.n * pc.k;
+            int busiest = 0;                             // sub-tiles of the busiest wave (of 8)
+            for (int w = 0; w < 8; w++) {
+              int nr = 0, nc = 0;
+              for (int q = 0; q < 2; q++) { const int r0 = (w >> 1) * 16 + 64 * q; nr += r0 < pc.dr + pc.m && r0 + 16 > pc.dr; }
+              for (int q = 0; q < 4; q++) { const int c0 = (w & 1) * 16 + 32 * q; nc += c0 < pc.dc + pc.n && c0 + 16 > pc.dc; }
+              busiest = std::max(busiest, nr * nc);
+            }
+            if (z < (int)tk.nfull && fullt) o[1] += c;
+            else if (z < (int)tk.nfull && (int)tk.nfull == tk.pn) { o[2] += c; o[4] += c * busiest; }
+            else { o[3] += c; o[5] += c * busiest; }
+          }
+          o[6] = tk.pn;
+          o[7] = (long long)tk.tm * tk.tn;
+        }
       }
       p->runctl.prof = p->dRunProf;
       p->run_ready = true;
@@ -484,6 +541,36 @@ int pastix_amd_plan_profile(const pastix_amd_layout_t* layout, int factotype, co
       fprintf(stderr, "mode_stats %-28s tasks %9lld flops %6.2f %% chunks %6.2f %% flop/chunk %8.0f (full tile chunk = 524288)\n", nm[i],
               (long long)nt[i], 100 * fl[i] / tf, 100 * ch[i] / tc, ch[i] > 0 ? fl[i] / ch[i] : 0.0);
   }
+  if (dev_opt("piece_hist")) {
+    // developer aid: the chunks of the pieces that do not run on the branch-free loop, by the 16-row / 16-column bands of the
+    // tile they touch (rows: bands, columns: bands; weight = 16-deep chunks), and how many of them touch <= 4 x <= 4 bands
+    double h[9][9] = {{0}}, hk[5] = {0}, tot = 0, small = 0, allc = 0, hf[9][9] = {{0}};
+    for (const Task& tk : P.tasks) {
+      const bool whole = (int)tk.nfull == tk.pn && tk.tm == TM && tk.tn == TN;
+      for (int z = 0; z < tk.pn; z++) {
+        const Piece& pc = P.pieces[(size_t)tk.p0 + (size_t)z];
+        const double c = (pc.k + 15) / 16;
+        allc += c;
+        if (whole || (z < (int)tk.nfull && tk.tm == TM && tk.tn == TN) || (pc.flags & PIECE_GATHERED)) continue;
+        const int rb = (pc.dr + pc.m - 1) / 16 - pc.dr / 16 + 1, cb = (pc.dc + pc.n - 1) / 16 - pc.dc / 16 + 1;
+        h[rb][cb] += c;
+        hf[rb][cb] += 2.0 * pc.m * pc.n * pc.k;
+        tot += c;
+        if (rb <= 4 && cb <= 4) small += c;
+        hk[pc.k <= 16 ? 0 : pc.k <= 32 ? 1 : pc.k <= 64 ? 2 : pc.k <= 96 ? 3 : 4] += c;
+      }
+    }
+    fprintf(stderr, "piece_hist: %.1f %% of all chunks are not branch-free whole tiles; of those %.1f %% touch <= 4 x 4 bands\n",
+            100 * tot / allc, 100 * small / tot);
+    fprintf(stderr, "piece_hist: K <= 16 / 32 / 64 / 96 / 128: %.1f %.1f %.1f %.1f %.1f %%\n", 100 * hk[0] / tot, 100 * hk[1] / tot,
+            100 * hk[2] / tot, 100 * hk[3] / tot, 100 * hk[4] / tot);
+    fprintf(stderr, "piece_hist: %% of those chunks (fill of the touched bands in %%) by row bands (down) x column bands (across, 1..8)\n");
+    for (int r = 1; r <= 8; r++) {
+      fprintf(stderr, "piece_hist: %d |", r);
+      for (int c = 1; c <= 8; c++) fprintf(stderr, " %5.1f(%3.0f)", 100 * h[r][c] / tot, h[r][c] > 0 ? 100 * hf[r][c] / (h[r][c] * 2.0 * 16 * 16 * 16 * r * c) : 0.0);
+      fprintf(stderr, "\n");
+    }
+  }
   *nlevels = P.nlevels;
   for (int l = 0; l < P.nlevels && l < maxlevels; l++) {
     if (slot_flops) slot_flops[l] = P.slot_flops[l];
@@ -525,6 +612,37 @@ int pastix_amd_plan_run_info(const pastix_amd_layout_t* layout, int factotype, i
   } catch (const std::bad_alloc&) {
     return PASTIX_AMD_ERR_ALLOC;
   }
+  return PASTIX_AMD_OK;
+}
+
+// Tests: a digest of the run's dependency tables as they stand on the device (include/pastix_amd.h).
+int pastix_amd_plan_run_edges_digest(pastix_amd_plan_t* p, pastix_amd_int_t* out) {
+  if (!p || !out) return PASTIX_AMD_ERR_BADPARAMETER;
+  for (int i = 0; i < 4; i++) out[i] = -1;
+  if (!p->run_ready || !p->dRunInfo) return PASTIX_AMD_OK;
+  HIPCHK(hipSetDevice(p->device));
+  const size_t nr = (size_t)p->run_nticket;
+  std::vector<RunInfo> info(nr);
+  std::vector<int32_t> cons(std::max<size_t>(p->nRunCons, 1));
+  HIPCHK(hipMemcpy(info.data(), p->dRunInfo, nr * sizeof(RunInfo), hipMemcpyDeviceToHost));
+  if (p->nRunCons) HIPCHK(hipMemcpy(cons.data(), p->dRunCons, p->nRunCons * sizeof(int32_t), hipMemcpyDeviceToHost));
+  auto mix = [](uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; };
+  uint64_t npair = 0, h = 0, hd = 0, nready = 0;
+  for (size_t i = 0; i < nr; i++) {
+    if (!(info[i].kind & 4)) continue;
+    if (info[i].cn < 0 || (size_t)info[i].cptr + (size_t)info[i].cn > p->nRunCons) return PASTIX_AMD_ERR_LAYOUT;
+    for (int32_t q = 0; q < info[i].cn; q++) {
+      const int32_t c = cons[(size_t)info[i].cptr + (size_t)q];
+      if (q > 0 && c <= cons[(size_t)info[i].cptr + (size_t)q - 1]) return PASTIX_AMD_ERR_LAYOUT;   // (lists are ordered by ticket)
+      h += mix(((uint64_t)i << 32) | (uint32_t)c);
+      npair++;
+    }
+  }
+  for (size_t i = 0; i < p->runDep0.size(); i++) { hd += mix(((uint64_t)i << 32) | (uint32_t)p->runDep0[i]); nready += p->runDep0[i] == 0; }
+  out[0] = (pastix_amd_int_t)npair;
+  out[1] = (pastix_amd_int_t)(h >> 1);
+  out[2] = (pastix_amd_int_t)(hd >> 1);
+  out[3] = (pastix_amd_int_t)nready;
   return PASTIX_AMD_OK;
 }
 
@@ -844,9 +962,12 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
   constexpr int NBUF = 4;
   const size_t CH = (size_t)96 << 20;                    // bytes per staging buffer
   struct Stage { char* buf = nullptr; hipEvent_t ev = nullptr; bool busy = false; int64_t k0 = 0, k1 = 0; int arena = 0; };
-  static thread_local Stage st[NBUF];                    // (kept for the thread's life: pinning 384 MB costs ~0.1 s)
+  // (kept for the thread's life: pinning 384 MB costs ~0.1 s; one set per DEVICE -- an event belongs to the device it was
+  // created on, and a thread may drive plans on several)
+  static thread_local std::map<int, std::array<Stage, NBUF>> st_by_dev;
+  std::array<Stage, NBUF>& st = st_by_dev[p->device];
   for (auto& x : st) {
-    if (!x.buf) { HIPCHK(hipHostMalloc((void**)&x.buf, CH, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming)); }
+    if (!x.buf) { HIPCHK(hipHostMalloc((void**)&x.buf, CH, hipHostMallocPortable)); HIPCHK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming)); }
     x.busy = false;
   }
   const int nthr = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -893,8 +1014,13 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
         k0++;
         continue;
       }
+      // Distributed plans: only OWNED panels travel.  A fan-in buffer (role 2) has a size in the arena and must keep what
+      // the device holds (zeros before a factorization: dist.py upload_owned relies on it), so a chunk is a run of owned
+      // panels; absent cblks (size 0) may lie inside one.
+      if (!owned(k0)) { k0++; continue; }
+      auto carried = [&](int64_t k) { return owned(k) || doff(k + 1) == doff(k); };
       int64_t k1 = k0 + 1;                                 // (a panel larger than the buffer travels alone, below)
-      while (k1 < nitem && !recut(k1) && (size_t)(doff(k1 + 1) - doff(k0)) * p->esz <= CH) k1++;
+      while (k1 < nitem && !recut(k1) && carried(k1) && (size_t)(doff(k1 + 1) - doff(k0)) * p->esz <= CH) k1++;
       const size_t bytes = (size_t)(doff(k1) - doff(k0)) * p->esz;
       if (bytes > CH) {                                    // one huge panel: straight from / to the caller's memory
         if (owned(k0)) {
@@ -973,6 +1099,23 @@ int pastix_amd_download_packed(pastix_amd_plan_t* p, void* L, void* U) {
   return PASTIX_AMD_OK;
 }
 
+// distributed plans: the fan-in buffers (role 2: accumulators for remote cblks, add_contrib_target's lazily zero-allocated
+// ftgttab[].coeftab, sopalin_compute.c:622-638) start a factorization from zeros; an upload of the owned panels clears them
+static int zero_fanin_buffers(pastix_amd_plan_t* p) {
+  const Plan& H = p->host;
+  double* arenas[4] = {p->dL, p->dU, p->dLi, p->dUi};
+  for (int64_t k = 0; k < H.cblknbr;) {
+    if (H.role[(size_t)k] != 2) { k++; continue; }
+    int64_t k1 = k + 1;
+    while (k1 < H.cblknbr && H.role[(size_t)k1] != 1) k1++;
+    const size_t bytes = (size_t)(H.poff[(size_t)k1] - H.poff[(size_t)k]) * p->esz;
+    for (double* a : arenas)
+      if (a && bytes) HIPCHK(hipMemsetAsync(p->at(a, H.poff[(size_t)k]), 0, bytes, p->stream));
+    k = k1;
+  }
+  return PASTIX_AMD_OK;
+}
+
 int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
   if (p) p->refillable = false;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -980,6 +1123,7 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
   const Plan& H = p->host;
   double t0 = now_s();
   p->factored = false;
+  if (p->distributed) { int r = zero_fanin_buffers(p); if (r) return r; }
   if (p->split.active && p->cplx) {
     int r = split_io(p, true, coeftab, ucoeftab, nullptr, nullptr);
     p->stats.h2d_time = now_s() - t0;
@@ -1554,6 +1698,8 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
         std::vector<long long> cl(H.run_cat.size());
         for (size_t i = 0; i < cl.size(); i++) cl[i] = (long long)H.run_cat[i] | ((long long)H.run_lvl[i] << 8);
         fwrite(cl.data(), sizeof(long long), cl.size(), f);
+        const std::vector<long long>& ft = p->runFeat;
+        fwrite(ft.data(), sizeof(long long), ft.size(), f);
         fclose(f);
       }
     }

@@ -12,6 +12,11 @@
 #include "plan.h"
 
 namespace pastix_amd {
+// run_edges.hip: the reader lists of the run schedule built on the device (plan.h Plan::run_edges_deferred)
+size_t run_edges_device_bytes(const Plan& H, size_t nr, size_t npieces_run);
+int run_edges_device(hipStream_t s, const Task* dRunTasks, RunInfo* dRunInfo, const Piece* dPieces, Plan& H, int32_t** cons_out,
+                     size_t* ncons_out);
+void launch_ring_scatter(hipStream_t s, int32_t* ring, const int32_t* vals, size_t n);   // ring[i * RUN_SLOT] = vals[i]
 void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks,
                    bool urgent);
 // the quadrant tasks of a slot (Task flag 32, kernels_small.hip)
@@ -175,6 +180,8 @@ struct pastix_amd_plan_s {
   std::vector<int32_t> dbg_cons, dbg_dep;
   std::vector<RunD> dbg_d;
   Task* dRunTasks = nullptr; RunInfo* dRunInfo = nullptr; int32_t* dRunCons = nullptr;
+  size_t nRunCons = 0;                  // entries of dRunCons
+  std::vector<int32_t> runDep0;         // the tickets' initial counters (what the state image was made of)
   RunD* dRunD = nullptr;
   int32_t *dRunState = nullptr, *dRunImage = nullptr;   // the counters / rings / control words and their initial image
   size_t nRunState = 0;
@@ -184,6 +191,7 @@ struct pastix_amd_plan_s {
   hipStream_t stream3 = nullptr;
   int64_t run_nticket = 0;
   int* hResident = nullptr;            // host memory the panel kernels' workgroups count themselves in
+  std::vector<long long> runFeat;       // (run_prof) per ticket: what tools/run_fit.py fits the stamps against
   long long* dRunProf = nullptr;       // PASTIX_AMD_RUN_PROF: clock stamps of the run's tasks (developer aid)
   size_t nRunProf = 0;
   hipEvent_t evZ = nullptr, evS3 = nullptr;

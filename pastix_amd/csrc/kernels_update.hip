@@ -30,6 +30,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
 #include <utility>
 
@@ -130,6 +132,72 @@ __device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsi
   if (!((touched >> MIX) & 1u)) return;
   epilogue_half<MIX, ATOMIC, COH, 0>(C, touched, row0, col0, l15, g, tm1, tn1, ldc);
   epilogue_half<MIX, ATOMIC, COH, 2>(C, touched, row0, col0, l15, g, tm1, tn1, ldc);
+}
+
+// ---- one 16-deep chunk of a piece that covers PART of the tile, for ONE pattern of active sub-tiles ------------------
+// Round 6.  The masked loops used to pick the pattern's MFMAs with a scalar switch PER K-STEP (four per chunk): on the
+// structurized control flow the compiler makes of it that is ~30 scalar instructions and ~10 branches per k-step and wave,
+// and a sparse chunk cost 0.29 of a whole one whatever it multiplied (DESIGN.md 9 "where the chunks go": the floor was the
+// instruction stream of a barrier-to-barrier iteration).  Now the switch is taken ONCE per chunk and every arm is the
+// chunk's whole body as straight-line code for its pattern: the operand reads of the k-steps 1-3 fetch only the bands the
+// pattern multiplies, the chunk barrier and the prefetch of the next chunk's first k-step (all six operands: the next
+// chunk may belong to a piece with another pattern) sit in front of the last k-step's MFMAs as in the branch-free loop.
+template <unsigned RM, unsigned CM>
+__device__ __forceinline__ void read_sel(double (&bm)[MI], double (&an)[NI], const double* sA, const double* sB) {
+#pragma unroll
+  for (int s = 0; s < MI; s++) if ((RM >> s) & 1u) bm[s] = sA[s * RS];
+#pragma unroll
+  for (int s = 0; s < NI; s++) if ((CM >> s) & 1u) an[s] = sB[s * CS];
+}
+template <unsigned RM, bool NEG>
+__device__ __forceinline__ void negate_sel(double (&bm)[MI], const bool neg) {
+  // (NEG: a v_xor result feeds the MFMA inside an asm statement: its wait states are ours)
+  if (NEG && neg) {
+#pragma unroll
+    for (int s = 0; s < MI; s++) if ((RM >> s) & 1u) bm[s] = -bm[s];
+    asm volatile("s_nop 1");
+  }
+}
+template <unsigned RM, unsigned CM, bool NEG>
+__device__ __forceinline__ void chunk_arm(const double* sA, const double* sB, const double* nA, const double* nB,
+                                          double (&bm0)[MI], double (&an0)[NI], double* fixb, const int fix, const bool neg) {
+  double bm1[MI], an1[NI];
+  negate_sel<RM, NEG>(bm0, neg);
+  read_sel<RM, CM>(bm1, an1, sA + 4 * SLD, sB + 4 * SLD);
+  mfma_sel<RM, CM>(an0, bm0);                       // ks0
+  negate_sel<RM, NEG>(bm1, neg);
+  read_sel<RM, CM>(bm0, an0, sA + 8 * SLD, sB + 8 * SLD);
+  mfma_sel<RM, CM>(an1, bm1);                       // ks1
+  negate_sel<RM, NEG>(bm0, neg);
+  read_sel<RM, CM>(bm1, an1, sA + 12 * SLD, sB + 12 * SLD);
+  mfma_sel<RM, CM>(an0, bm0);                       // ks2
+  negate_sel<RM, NEG>(bm1, neg);
+  __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+  if (fix >= 0) {        // (the stray element of the next chunk's piece, before this wave's reads of that buffer)
+    // (the zero is made here: as a constant the compiler keeps it in a register pair across the whole kernel -- and spills it)
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    fixb[fix] = __hiloint2double(z, z);
+  }
+#pragma unroll
+  for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
+#pragma unroll
+  for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
+  __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
+  mfma_sel<RM, CM>(an1, bm1);                       // ks3 from registers
+}
+template <bool NEG>
+__device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const double* sB, const double* nA, const double* nB,
+                                          double (&bm0)[MI], double (&an0)[NI], double* fixb, const int fix, const bool neg) {
+#define PA_PAT(RM, CM) case (RM | (CM << 2)): chunk_arm<RM, CM, NEG>(sA, sB, nA, nB, bm0, an0, fixb, fix, neg); break;
+#define PA_PAT_ROWS(CM) PA_PAT(3u, CM) PA_PAT(1u, CM) PA_PAT(2u, CM)
+  switch (pat) {
+    PA_PAT_ROWS(15u) PA_PAT_ROWS(3u) PA_PAT_ROWS(6u) PA_PAT_ROWS(12u) PA_PAT_ROWS(7u) PA_PAT_ROWS(14u)
+    PA_PAT_ROWS(1u) PA_PAT_ROWS(2u) PA_PAT_ROWS(4u) PA_PAT_ROWS(8u)
+    default: chunk_arm<0u, 0u, NEG>(sA, sB, nA, nB, bm0, an0, fixb, fix, neg); break;   // no sub-tile of this wave in the chunk's piece
+  }
+#undef PA_PAT_ROWS
+#undef PA_PAT
 }
 
 // ---- the piece loop ------------------------------------------------------------------------------
@@ -320,6 +388,127 @@ __device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], con
     buf ^= 1;
   }
 #undef PA_NEGATE
+  return touched;
+}
+
+// ---- the piece loop of the MASKED instances (round 6) ---------------------------------------------------------------
+// PART = false: whole-tile pieces of a smaller valid tile (MODE 1 above: lane masks and pattern fixed per task); PART = true:
+// partial pieces (MODE 2: per piece).  Same pipeline as piece_loop -- DMA(i+1) | ks0..ks2 | barrier | read (i+1, ks0) | ks3 --,
+// but (a) the pattern switch is taken once per CHUNK (chunk_pat) and (b) the DMA is a BUFFER load to LDS
+// (buffer_load_dwordx4 ... offen lds): one descriptor per operand and piece, the lane's byte offset a 32-bit register
+// computed once per piece -- 0x80000000, i.e. out of the descriptor's range, for lanes whose two rows lie outside the piece:
+// the hardware writes zeros into LDS for those, and for every lane of a k-line beyond K (scalar offset 0x40000000) --: no
+// zero line, no 64-bit address selects per DMA.  The descriptors cover whole 16-byte lanes: a lane that straddles an odd
+// piece boundary brings the neighbouring source row along as before (zeroed in LDS, fixn).  The plan bounds a source
+// panel's (width + 16) x stride x 8 below 2^30, so a valid offset never reaches the out-of-range markers and their sum does
+// not wrap.
+template <bool PART, bool NEG>
+__device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
+                                                 const Piece* __restrict__ pieces, const int row0, const int col0,
+                                                 const int lane, const int l15, const int g) {
+  constexpr int NL = KC / UW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wrow0 = (wave >> 1) * 16, wcol0 = (wave & 1) * 16;
+  const int pend = tk.p0 + tk.pn;
+  int pi = tk.p0;
+  Piece cur = pieces[pi];
+  Piece nextp = pieces[min(pi + 1, pend - 1)];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  uint32_t va = 0, vb = 0;                         // this lane's byte offsets inside a k-line (0x80000000: none)
+  int lda8 = 0, kk = 0, kb = 0;                    // bytes between k-lines, K, first k-line of the chunk being copied
+  int patn = 0, fixn = -1;
+  unsigned touched = 0;
+  auto band_pattern = [&](const int r_lo, const int r_hi, const int c_lo, const int c_hi) {   // scalar arithmetic
+    int p = 0;
+#pragma unroll
+    for (int s = 0; s < MI; s++) if (wrow0 + s * RS < r_hi && wrow0 + s * RS + 16 > r_lo) p |= 1 << s;
+#pragma unroll
+    for (int s = 0; s < NI; s++) if (wcol0 + s * CS < c_hi && wcol0 + s * CS + 16 > c_lo) p |= 1 << (MI + s);
+    return ((p & 3) && (p >> MI)) ? p : 0;
+  };
+  auto setup = [&](const Piece& pc) {
+    const int dr = PART ? (int)pc.dr : 0, re = PART ? (int)pc.dr + (int)pc.m : (int)tk.tm;
+    const int dc = PART ? (int)pc.dc : 0, ce = PART ? (int)pc.dc + (int)pc.n : (int)tk.tn;
+    const int dre = dr & ~1, dce = dc & ~1;        // the tile row / column of lane 0's first element of the operand image
+    lda8 = __builtin_amdgcn_readfirstlane(pc.lda * 8);
+    kk = __builtin_amdgcn_readfirstlane((int)pc.k);
+    const int ext = (kk - 1) * lda8 + 8;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[pc.flags & 3] + pc.a_off - (dr - dre)), (short)0, ext + 8 * (re - dre), 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[(pc.flags >> 2) & 3] + pc.b_off - (dc - dce)), (short)0, ext + 8 * (ce - dce), 0x00020000);
+    // (what derives from the lane index is recomputed per piece from a laundered copy, not kept in registers across the
+    // chunks: the arms of the chunk switch need the 64 VGPRs for operands)
+    int ln = threadIdx.x;
+    asm volatile("" : "+v"(ln));
+    ln &= 63;
+    const int l2 = 2 * ln;
+    const uint32_t oa = !(l2 + 1 >= dr && l2 < re), ob = !(l2 + 1 >= dc && l2 < ce);
+    // (in range: < 1024; bit 31 = out of the descriptor's range, and nothing above bit 9 that could wrap the sum with the
+    // scalar offset back into it)
+    va = ((uint32_t)(8 * (l2 - dre)) & 0x3ffu) | (oa << 31);
+    vb = ((uint32_t)(8 * (l2 - dce)) & 0x3ffu) | (ob << 31);
+    kb = 0;
+    if (PART) {
+      patn = band_pattern(dr, re, dc, ce);
+      // stray elements: a lane that straddles an odd boundary brings the source row next to the piece along (lanes 0-15 /
+      // 16-31 / 32-47 / 48-63 look after the rows dr-1, dr+m of A and dc-1, dc+n of B, one k-line each)
+      const int j = ln >> 4;
+      const int e = j == 0 ? dr - 1 : j == 1 ? re : j == 2 ? dc - 1 : ce;      // the row next to the boundary
+      const bool odd = (j == 0 || j == 2) ? (e & 1) == 0 && e >= 0 : (e & 1) != 0 && e < 128;   // shares a lane with a piece row
+      fixn = odd ? (j >= 2 ? KC * SLD : 0) + (ln & 15) * SLD + e : -1;
+      touched |= (unsigned)patn;
+    }
+  };
+  // the DMA of one chunk: k-lines kb + wave, kb + wave + 8 of both operands
+  auto dma = [&](double* dA, double* dB) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+      const int kl = kb + wave + UW * q;                                   // wave-uniform
+      const uint32_t so = kl < kk ? (uint32_t)(kl * lda8) : 0x40000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dA + UW * q * SLD), 16, va, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dB + UW * q * SLD), 16, vb, so, 0, 0);
+    }
+    kb += KC;
+  };
+  if (!PART) {
+    patn = band_pattern(0, (int)tk.tm, 0, (int)tk.tn);
+    touched = (unsigned)patn;
+  }
+  setup(cur);
+  int left = ((int)cur.k + KC - 1) / KC;
+  bool negn = (cur.flags & 16) != 0, negc = negn;
+  int patc = patn;
+  dma(sh[0][0] + wave * SLD, sh[0][1] + wave * SLD);
+  const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
+  const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+  double bm0[MI], an0[NI];
+  __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
+  if (PART && fixn >= 0) sh[0][0][fixn] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
+#pragma unroll
+  for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
+#pragma unroll
+  for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
+  int buf = 0;
+  while (true) {
+    bool has_next = true;
+    negc = negn;
+    patc = patn;
+    if (--left == 0) {
+      if (++pi < pend) {
+        cur = nextp;
+        setup(cur);
+        left = ((int)cur.k + KC - 1) / KC;
+        negn = (cur.flags & 16) != 0;
+        nextp = pieces[min(pi + 1, pend - 1)];
+      } else {
+        has_next = false;
+      }
+    }
+    if (has_next) dma(sh[buf ^ 1][0] + wave * SLD, sh[buf ^ 1][1] + wave * SLD);
+    chunk_pat<NEG>(patc, sAw + buf * (2 * KC * SLD), sBw + buf * (2 * KC * SLD), sAw + (buf ^ 1) * (2 * KC * SLD),
+                   sBw + (buf ^ 1) * (2 * KC * SLD), bm0, an0, &sh[buf ^ 1][0][0], (PART && has_next) ? fixn : -1, negc);
+    if (!has_next) break;
+    buf ^= 1;
+  }
   return touched;
 }
 
@@ -548,11 +737,11 @@ __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], 
       if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
       else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
     } else if (mode == 1) {
-      if (neg) touched |= piece_loop<1, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop<1, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop_m<false, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop_m<false, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
     } else if (mode == 2) {
-      if (neg) touched |= piece_loop<2, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop<2, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop_m<true, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      else touched |= piece_loop_m<true, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
     } else {
       if (neg) touched |= piece_loop_g<true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
       else touched |= piece_loop_g<false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
@@ -981,15 +1170,18 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
 // The operand buffers are DYNAMIC LDS: the compiler then does not know the 73.7 KB that cap the kernels at four waves per
 // SIMD, and the register budget of the kernels can be stated as what it is (Makefile: 64 VGPRs, no AGPR of the compiler's).
 constexpr unsigned UPDATE_LDS_BYTES = 2 * 2 * KC * SLD * sizeof(double);
-template <class K>
-static void allow_lds(K kernel) {
-  static bool done[64] = {};
+// (once per kernel and device, keyed on the kernel's ADDRESS: the instances of a template share one function-pointer type)
+static void allow_lds_addr(const void* kernel) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 64 && done[dev]) return;
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UPDATE_LDS_BYTES);
-  if (dev >= 0 && dev < 64) done[dev] = true;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!done.insert({dev, kernel}).second) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)UPDATE_LDS_BYTES);
 }
+template <class K>
+static void allow_lds(K kernel) { allow_lds_addr((const void*)kernel); }
 
 void launch_run_update(hipStream_t s, int factotype, const Arenas& ar, const Task* tasks, const Piece* pieces, const RunInfo* info,
                        const int32_t* cons, const RunCtl& rc, double* dinv, int64_t ntasks, int nwg, long long limit, const RunD* rd,

@@ -258,13 +258,19 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   // Where the run schedule is built (below) launches have no tails to balance, and what a task costs besides its chunks
   // weighs more than parallelism: longer tasks from 4e12 flop (MI355X, run schedule: 100^3 1024 -> 133.4 ms, 2048 -> 131.9;
   // 130^3 548.6 -> 533.9; 160^3 1815 -> 1774; 80^3 43.8 -> 45.4: stays 1024; 60^3 512 -> 14.56, 1024 -> 14.38).
+  // Up to which size the run is built by default.  Round 5: 2e14 flop (200^3 has 4.1e14) -- its reader lists, 366 M pairs at
+  // 200^3, cost 2.5 s of host analysis there for +1.3-1.6 % of the rate.  Round 6: where the lists are built on the device
+  // (defer_run_edges, run_edges.hip) and the run is ONE kernel (real LLt / LDLt: no second persistent kernel)
+  // there is no such price: the cap is the 32-bit range of the tables' indices.
+  const double run_cap = (P.defer_run_edges && floattype == PASTIX_AMD_REALDOUBLE &&
+                          (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT)) ? 1.5e15 : 2e14;
   const bool run_built = !owner && P.opts.run_schedule >= 0 &&
                          ((floattype == PASTIX_AMD_REALDOUBLE &&
                            (factotype == PASTIX_AMD_FACT_LLT || factotype == PASTIX_AMD_FACT_LDLT ||
                             factotype == PASTIX_AMD_FACT_LU)) ||
                           (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
   if (P.opts.lookahead <= 0)
-    P.opts.lookahead = (run_built && (P.opts.run_schedule == 1 || fl_total <= 2e14)) ? (fl_total > 4e12 ? 2048 : 1024)
+    P.opts.lookahead = (run_built && (P.opts.run_schedule == 1 || fl_total <= run_cap)) ? (fl_total > 4e12 ? 2048 : 1024)
                                                                                      : (big ? 2048 : fl_total > 1e12 ? 1024 : 512);
   const double chunk_work = double(TM) * TN * double(P.opts.lookahead);
   const int max_pieces = P.opts.lookahead >= 4096 ? 32 : P.opts.lookahead >= 2048 ? 16 : 8;
@@ -329,7 +335,7 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
                                   (cplx && (factotype == PASTIX_AMD_FACT_LDLT || factotype == PASTIX_AMD_FACT_LDLH)));
     // Above 2e14 flop (200^3: 4.1e14) the run is on request only: launches of tens of rounds of workgroups have little to
     // gain (200^3: +0.6 %) and the run's tables cost there (366 M dependency edges: 1.8 s of analysis, 3 GB).
-    if (built && P.opts.run_schedule >= 0 && (P.opts.run_schedule == 1 || fl_total <= 2e14)) {
+    if (built && P.opts.run_schedule >= 0 && (P.opts.run_schedule == 1 || fl_total <= run_cap)) {
       const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
       int L0 = NL;
       auto narrow = [&](int l) {       // (the run's panel kernel takes cblks of at most 128 columns, like k_diag_llt_w)
@@ -595,6 +601,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
       {
         const int64_t wk0 = P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1;
         gather_min = (lb - fb > 1 && double(P.cblk[k].stride - wk0) < gather_tall * double(lb - fb - 1)) ? gather_on : gather_off;
+        // (the gathering loop's buffer descriptors and k-line offsets are 32-bit byte counts, kernels_update.hip piece_loop_g:
+        // a source panel whose (width + one chunk) k-lines do not fit 2^31 bytes keeps its rectangles)
+        if ((wk0 + 16) * (int64_t)P.cblk[k].stride * 8 >= ((int64_t)1 << 31)) gather_min = gather_off;
       }
       // groups of consecutive bloks [g0, g1) facing the same cblk t (they land in t's diagonal blok; every later blok of
       // k lands in an off-diagonal blok of t: containment, sopalin_compute.c:558-559)
@@ -1338,6 +1347,18 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           }
           P.run_dchk[d] = {dtile0[d], 0};
         }
+        P.run_edges_deferred = P.defer_run_edges;
+        if (P.run_edges_deferred) {
+          // the reader lists are built on the device from the uploaded tables (run_edges.hip, api.cpp): what it needs
+          P.run_tile_ticket.assign(tile_ticket.begin(), tile_ticket.end());
+          P.run_tile_base.resize((size_t)nc + 1);
+          for (int64_t k = 0; k <= nc; k++) P.run_tile_base[(size_t)k] = (int32_t)tile_base[(size_t)k];
+          P.run_flops = 0;
+          for (int sl = L0; sl < NL; sl++) P.run_flops += P.slot_flops[(size_t)sl];
+          P.run_waits.clear();
+          P.run_cons.clear();
+          phase("run: tables for the device");
+        } else {
         // source tiles an update ticket reads: the 128-row tiles of the source panels of its pieces (A rows, B rows),
         // sources of the run's levels only -- older panels are final when the run starts
         std::vector<std::vector<int32_t>> tw((size_t)nthr);
@@ -1446,11 +1467,14 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
           });
         }
         phase("run: consumer lists");
+        }
         P.run_tile_nt.assign(tile_nt.begin(), tile_nt.end());
-        // what is ready when the run starts, in ticket order
+        // what is ready when the run starts, in ticket order (deferred reader lists: the caller does this once the device
+        // has added the source inputs to the counters)
         P.run_ready.clear();
         P.run_dready.clear();
-        for (size_t i = 0; i < nr; i++) if (P.run_dep[i] == 0) P.run_ready.push_back((int32_t)i);
+        if (!P.run_edges_deferred)
+          for (size_t i = 0; i < nr; i++) if (P.run_dep[i] == 0) P.run_ready.push_back((int32_t)i);
         for (size_t d = 0; d < nd; d++) if (P.run_dep[nr + d] == 0) P.run_dready.push_back((int32_t)d);
       }
     }

@@ -250,6 +250,14 @@ struct Plan {
   double run_flops = 0;                  // update flops inside the run
   std::vector<RunCheck> run_chk;         // host only (run_verify)
   std::vector<uint8_t> run_tile_nt;      // ... panel-solve tickets per tile
+  // Round 6: the reader lists of the run (run_cons, the panel-solve tickets' cptr / cn, the readers' share of run_dep) built
+  // on the DEVICE from the uploaded tickets and pieces (run_edges.hip) instead of on host threads.  defer_run_edges is set by
+  // the caller of build_plan (api.cpp, when it has a device); run_edges_deferred says that build_plan left them out: then
+  // run_waits / run_cons / run_ready are empty, run_chk has no source tiles, and the three tables below are what the device
+  // builder reads.
+  bool defer_run_edges = false, run_edges_deferred = false;
+  std::vector<int32_t> run_tile_ticket;  // [ntile] first panel-solve ticket of a tile (-1: none; run_tile_nt: how many, consecutive)
+  std::vector<int32_t> run_tile_base;    // [cblknbr + 1] first tile of a cblk's panel
   std::vector<std::pair<int32_t, int32_t>> run_dchk;   // ... per diagonal task: its tile counter and the value it must find
   std::vector<int32_t> run_waits;
   std::vector<uint8_t> run_cat;          // (PASTIX_AMD_RUN_PROF) per ticket: 0 A, 1 B.next, 2 B.rest, 3 panel solve; its slot / level
@@ -265,6 +273,7 @@ int build_plan(const pastix_amd_layout_t* layout, int factotype, int floattype,
                const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank, Plan& plan);
 
 int64_t run_verify(const Plan& plan);
+
 int verify_pieces(const Plan& plan, int64_t out[4]);
 int owner_view(const pastix_amd_layout_t* layout, const int32_t* owner, int32_t myrank, Plan& plan);
 double fact_flops(const pastix_amd_layout_t* layout, int factotype, int floattype);

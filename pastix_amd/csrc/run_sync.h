@@ -60,11 +60,14 @@ __device__ __forceinline__ int run_pop(const int32_t* ring, int32_t* head, const
       if ((v = __hip_atomic_fetch_or(const_cast<int32_t*>(slot), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= 0) break;
       if (run_ld(stuck)) return -1;
       const long long now = wall_clock64();
+      bool never_started = false;
       if (go && !run_ld(go)) {                        // (the tickets' kernel has not started: no clock yet)
         t0 = now;
         if (now - tstart < 6000000000LL) continue;
+        never_started = true;                         // 60 s and still no tickets' kernel: give up (the note says how long)
+        t0 = tstart;
       }
-      if (limit > 0 && now - t0 > limit) {
+      if (never_started || (limit > 0 && now - t0 > limit)) {
         // (the first one to give up leaves a note for the host: which slot it waited for, how long)
         if (__hip_atomic_exchange(stuck, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           run_st(stuck + 2, h);

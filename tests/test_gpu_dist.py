@@ -76,6 +76,31 @@ def test_native_driver_loopback_matches_reference(name, world, golden):
             p.close()
 
 
+@pytest.mark.parametrize("name,world", [("rlap3d_14_llt_bs24", 3), ("rlap3d_12_ldlt", 2), ("rlap3d_20_lu_bs128", 4),
+                                        ("zrlap3d_12_ldlt", 2)])
+def test_upload_owned_then_factorize_dist(name, world, golden):
+    """pastix_amd_upload_tabs on DISTRIBUTED plans (the caller's per-cblk buffers instead of the device fill): only owned
+    panels travel, and the fan-in buffers that lie between them in the arena start from zeros -- twice, so that what the
+    first factorization left in them, and what the staging buffers hold of another rank's panels, would show."""
+    g = golden(name)
+    c4, b4 = g["cblk4"], g["blok4"]
+    cz = np.iscomplexobj(g["L0"])
+    owner = pd.partition(c4, b4, world)
+    plans = [pd.DistPlan(c4, b4, owner, r, 0, factotype=g["facto"], floattype=3 if cz else 1) for r in range(world)]
+    try:
+        pd.attach_local(plans)
+        for rep in range(2):
+            for p in plans:
+                p.upload_owned(g["L0"], g["U0"] if g["facto"] == 2 else None)
+            sts = pd.factorize_local(plans, g["critere"])
+            assert sum(s["nbpivot"] for s in sts) == g["nbpivot"]
+            for r, p in enumerate(plans):
+                _check_owned(g, p, owner, r)
+    finally:
+        for p in plans:
+            p.close()
+
+
 @pytest.mark.parametrize("name,world", [("rlap3d_14_llt_bs24", 2), ("rlap3d_14_llt_bs24", 4), ("rlap3d_12_ldlt", 3),
                                         ("rlap3d_12_lu", 2), ("rlap3d_20_lu_bs128", 4), ("rlap3d_20_llt_bs128", 3)])
 def test_distributed_solve_matches_reference(name, world, golden):

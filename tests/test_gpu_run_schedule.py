@@ -312,3 +312,49 @@ def test_diagonal_tickets_of_every_width(facto, run_env):
         assert np.array_equal(out["0"][0][0][m], out["1"][0][0][m]), w
         if facto == 2:
             assert np.array_equal(out["0"][0][1], out["1"][0][1]), w
+
+
+def _edges_digest(p):
+    import ctypes
+    from pastix_amd import _lib
+    out = (ctypes.c_int64 * 4)()
+    rc = _lib.lib().pastix_amd_plan_run_edges_digest(p._h, out)
+    assert rc == 0, rc
+    return tuple(out)
+
+
+@pytest.mark.parametrize("N,bs,facto", [(24, 64, 0), (40, 128, 0), (32, 128, 1), (28, 64, 2), (60, 128, 0)])
+def test_reader_lists_built_on_the_device_equal_the_host_built_ones(N, bs, facto, run_env):
+    """Round 6: the reader lists of the run (which update tickets read which solved 128-row tile, and every ticket's
+    initial counter) are built on the GPU from the uploaded tables (csrc/run_edges.hip: key = tile << 32 | ticket, radix
+    sort, unique).  PASTIX_AMD_DEV=run_host_edges builds them on host threads as rounds 4-5 did: same pairs, same counters,
+    same ready set -- and bitwise the same factors (LU: the tables only, the symmetric fill does not apply)."""
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=bs)
+    c4, b4 = s["cblk4"], s["blok4"]
+    res = {}
+    keep = os.environ.get("PASTIX_AMD_DEV")
+    try:
+        for mode in ("device", "host"):
+            if mode == "host":
+                os.environ["PASTIX_AMD_DEV"] = "run_host_edges"
+            else:
+                os.environ.pop("PASTIX_AMD_DEV", None)
+            with Plan(c4, b4, facto, run_schedule=1) as p:
+                dig = _edges_digest(p)
+                if facto != 2:
+                    p.fill_csc(1, n, cp, r, v, s["perm"])
+                    st = p.factorize(1e-14)
+                    res[mode] = (dig, p.download()[0], st["run_time"] > 0)
+                else:
+                    res[mode] = (dig, None, True)
+    finally:
+        if keep is None:
+            os.environ.pop("PASTIX_AMD_DEV", None)
+        else:
+            os.environ["PASTIX_AMD_DEV"] = keep
+    assert res["device"][0] == res["host"][0], (res["device"][0], res["host"][0])
+    assert res["device"][0][0] > 0 and res["device"][0][3] > 0
+    if facto != 2:
+        assert np.array_equal(res["device"][1], res["host"][1])

@@ -1,9 +1,22 @@
 // Synthetic micro-benchmark of k_update: N tasks x P full pieces (128x128xK), operands drawn from a
 // pool of `pool` source panels.  Build: hipcc --offload-arch=gfx950 -O3 -I pastix_amd/csrc -o tools/bench_update tools/bench_update.hip
+// -DUSE_LIB: time the LIBRARY's own build of the kernel (csrc/Makefile: every accumulation register reserved) instead of a
+// plain hipcc build of its source:  hipcc --offload-arch=gfx950 -O3 -DUSE_LIB -I pastix_amd/csrc -o tools/bench_update_lib
+// tools/bench_update.hip -L pastix_amd/lib -lpastix_amd -Wl,-rpath,'$ORIGIN/../pastix_amd/lib'
+#ifdef USE_LIB
+#include <hip/hip_runtime.h>
+#include "../pastix_amd/csrc/plan.h"
+namespace pastix_amd {
+void launch_update(hipStream_t s, const Arenas& ar, const Task* tasks, const Piece* pieces, int64_t ntasks, bool urgent);
+}
+#else
 #include "../pastix_amd/csrc/kernels_update.hip"
+#endif
 #include <cstdio>
 #include <vector>
 #include <random>
+#include <cmath>
+#include <algorithm>
 using namespace pastix_amd;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
@@ -57,6 +70,29 @@ int main(int argc, char** argv) {
   int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5; CK(hipEventRecord(e0));
   for (int r = 0; r < reps; r++) launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask, false);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  if (getenv("CHECK")) {
+    // the first and the last tile against the host (one launch on fresh C values)
+    CK(hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    launch_update(0, Arenas{{d, d, d, d}}, dt, dp, ntask, false); CK(hipDeviceSynchronize());
+    std::vector<double> c(128 * 128);
+    double worst = 0;
+    for (int t : {0, ntask / 2, ntask - 1}) {
+      CK(hipMemcpy(c.data(), d + src_elems + (int64_t)t * 128 * 128, 128 * 128 * 8, hipMemcpyDeviceToHost));
+      for (int j = 0; j < 128; j++)
+        for (int i = 0; i < 128; i++) {
+          double ref = h[src_elems + (int64_t)t * 128 * 128 + i + 128 * j];
+          if (i >= pdr && i < pdr + pm && j >= pdc && j < pdc + pn)
+            for (int p = 0; p < P; p++) {
+              const Piece& pc = pieces[(size_t)t * P + p];
+              double acc = 0;
+              for (int k = 0; k < K; k++) acc += h[pc.a_off + (i - pdr) + (int64_t)k * rows] * h[pc.b_off + (j - pdc) + (int64_t)k * rows];
+              ref -= acc;
+            }
+          worst = std::max(worst, std::fabs(ref - c[i + 128 * j]));
+        }
+    }
+    printf("CHECK: worst |device - host| over 3 tiles = %.3e %s\n", worst, worst < 1e-9 ? "ok" : "WRONG");
+  }
   double fl = 2.0 * pm * pn * K * (double)P * ntask * reps;
   printf("tasks=%d pieces/task=%d K=%d pool=%d: %.3f ms/launch, %.1f TFLOP/s (%.1f%% of 78.6)\n", ntask, P, K, pool, ms / reps,
          fl / (ms * 1e-3) * 1e-12, fl / (ms * 1e-3) / 78.6e12 * 100);
