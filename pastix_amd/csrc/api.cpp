@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <memory>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -970,7 +971,9 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
     if (!x.buf) { HIPCHK(hipHostMalloc((void**)&x.buf, CH, hipHostMallocPortable)); HIPCHK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming)); }
     x.busy = false;
   }
-  const int nthr = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  // (host threads that pack / unpack a chunk: developer override PASTIX_AMD_DEV=io_threads=<n>)
+  const int nthr = dev_opt("io_threads") ? std::max(1, atoi(dev_opt("io_threads")))
+                                         : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   // pack / unpack the panels of the items [k0, k1) of one arena between the caller's buffers and a staging buffer
   auto move = [&](const Stage& x, bool to_stage) {
     void* const* tab = x.arena ? ucoeftab : coeftab;
@@ -2227,13 +2230,22 @@ int pastix_amd_solve_device(pastix_amd_plan_t* p, void* dx, pastix_amd_int_t nrh
 // The one-shot entry points keep the plan of their last call: pastix() re-factorizes on one analysis (pastix.c:3439-3575 --
 // same SolverMatrix, new values), and the plan is a pure function of the layout, so the second and later calls of a
 // time-stepping or Newton loop skip the host analysis (seconds at 100^3), the device tables and the allocation of the
-// arenas.  The key is a fingerprint of everything the plan depends on; one plan is kept (pastix_amd_release_cached_plan).
+// arenas.  One plan is kept PER DEVICE (round 6: a thread per GPU no longer destroys the other's plan, and callers on
+// different devices do not wait for one another); a hit is a match of the fingerprint of everything the plan depends on AND
+// of the layout itself, entry by entry.  What is kept is the plan with its device arenas -- the panels' size, twice for
+// LDLt / LU -- until pastix_amd_release_cached_plan() or the end of the process.
 namespace {
-struct OneShotCache {
-  std::mutex mu;
+struct OneShotEntry {
+  std::mutex mu;                                            // one one-shot call at a time per device
   pastix_amd_plan_t* plan = nullptr;
   uint64_t key = 0;
-  ~OneShotCache() { /* (the process is ending: the runtime may already be gone -- nothing is released here) */ }
+  std::vector<pastix_amd_cblk_t> cblk;                      // the caller's layout the plan was made for
+  std::vector<pastix_amd_blok_t> blok;
+};
+struct OneShotCache {
+  std::mutex mu;                                            // guards the map only
+  std::map<int, std::unique_ptr<OneShotEntry>> by_dev;
+  ~OneShotCache() { for (auto& e : by_dev) (void)e.second.release(); /* (the process is ending: the runtime may already be gone -- nothing is released here) */ }
 } g_one_shot;
 uint64_t fnv(uint64_t h, const void* d, size_t n) {
   const unsigned char* q = (const unsigned char*)d;
@@ -2244,38 +2256,60 @@ uint64_t one_shot_key(int factotype, int floattype, const pastix_amd_layout_t* L
   uint64_t h = 1469598103934665603ull;
   const int64_t head[4] = {factotype, floattype, L->cblknbr, L->bloknbr};
   h = fnv(h, head, sizeof(head));
-  h = fnv(h, L->cblktab, (size_t)(L->cblknbr + 1) * sizeof(pastix_amd_cblk_t));
-  h = fnv(h, L->bloktab, (size_t)L->bloknbr * sizeof(pastix_amd_blok_t));
   if (opts) h = fnv(h, opts, sizeof(*opts));
   if (const char* e = getenv("PASTIX_AMD_DEV")) h = fnv(h, e, strlen(e));
   return h;
 }
+OneShotEntry* one_shot_entry(int device) {
+  std::lock_guard<std::mutex> g(g_one_shot.mu);
+  std::unique_ptr<OneShotEntry>& e = g_one_shot.by_dev[device];
+  if (!e) e.reset(new OneShotEntry());
+  return e.get();
+}
 }  // namespace
 void pastix_amd_release_cached_plan(void) {
-  std::lock_guard<std::mutex> g(g_one_shot.mu);
-  if (g_one_shot.plan) pastix_amd_plan_destroy(g_one_shot.plan);
-  g_one_shot.plan = nullptr;
+  std::vector<OneShotEntry*> all;
+  {
+    std::lock_guard<std::mutex> g(g_one_shot.mu);
+    for (auto& e : g_one_shot.by_dev) all.push_back(e.second.get());
+  }
+  for (OneShotEntry* e : all) {
+    std::lock_guard<std::mutex> g(e->mu);
+    if (e->plan) pastix_amd_plan_destroy(e->plan);
+    e->plan = nullptr;
+    std::vector<pastix_amd_cblk_t>().swap(e->cblk);
+    std::vector<pastix_amd_blok_t>().swap(e->blok);
+  }
 }
 
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                     pastix_amd_stats_t* stats, int floattype = PASTIX_AMD_REALDOUBLE) {
   if (!layout || !layout->cblktab || (layout->bloknbr > 0 && !layout->bloktab) || layout->cblknbr < 0) return PASTIX_AMD_ERR_BADPARAMETER;
-  std::lock_guard<std::mutex> g(g_one_shot.mu);            // (one one-shot call at a time: they share the cached plan)
+  OneShotEntry& E = *one_shot_entry(opts ? opts->device : 0);
+  std::lock_guard<std::mutex> g(E.mu);                      // (one one-shot call at a time per device: they share its plan)
   const double t0 = now_s();
   const uint64_t key = one_shot_key(factotype, floattype, layout, opts);
   pastix_amd_plan_t* plan = nullptr;
   int rc = 0;
   double plan_time = 0;
-  if (g_one_shot.plan && g_one_shot.key == key) {
-    plan = g_one_shot.plan;
+  const size_t ncb = (size_t)layout->cblknbr + 1, nbl = (size_t)layout->bloknbr;
+  const bool hit = E.plan && E.key == key && E.cblk.size() == ncb && E.blok.size() == nbl &&
+                   !memcmp(E.cblk.data(), layout->cblktab, ncb * sizeof(pastix_amd_cblk_t)) &&
+                   (nbl == 0 || !memcmp(E.blok.data(), layout->bloktab, nbl * sizeof(pastix_amd_blok_t)));
+  if (hit) {
+    plan = E.plan;
   } else {
-    if (g_one_shot.plan) { pastix_amd_plan_destroy(g_one_shot.plan); g_one_shot.plan = nullptr; }
+    if (E.plan) { pastix_amd_plan_destroy(E.plan); E.plan = nullptr; }
     rc = pastix_amd_plan_create(layout, factotype, floattype, opts, &plan);
     if (rc) return rc;
     plan_time = now_s() - t0;
-    g_one_shot.plan = plan;
-    g_one_shot.key = key;
+    try {
+      E.cblk.assign(layout->cblktab, layout->cblktab + ncb);
+      E.blok.assign(layout->bloktab, layout->bloktab + nbl);
+    } catch (const std::bad_alloc&) { pastix_amd_plan_destroy(plan); return PASTIX_AMD_ERR_ALLOC; }
+    E.plan = plan;
+    E.key = key;
   }
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
@@ -2300,7 +2334,7 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
             plan->stats.total_time);
   if (rc || (rcf && rcf != PASTIX_AMD_ERR_NUMERIC)) {        // (a plan that failed is not kept)
     pastix_amd_plan_destroy(plan);
-    g_one_shot.plan = nullptr;
+    E.plan = nullptr;
   }
   return rc ? rc : rcf;
 }
