@@ -336,7 +336,9 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
     // Above 2e14 flop (200^3: 4.1e14) the run is on request only: launches of tens of rounds of workgroups have little to
     // gain (200^3: +0.6 %) and the run's tables cost there (366 M dependency edges: 1.8 s of analysis, 3 GB).
     if (built && P.opts.run_schedule >= 0 && (P.opts.run_schedule == 1 || fl_total <= run_cap)) {
-      const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : 32;
+      // (where the run begins: levels of at most 32 cblks; 128 from 1e14 flop -- 200^3, one box, run_max_cblks 32 / 64 / 128 /
+      // 512: 6640 / 6617 / 6604 / 6616 ms; 130^3 32 / 128 / 1024: 527.4 / 527.0 / 527.4: flat below)
+      const int64_t maxc = P.opts.run_max_cblks > 0 ? P.opts.run_max_cblks : (fl_total > 1e14 ? 128 : 32);
       int L0 = NL;
       auto narrow = [&](int l) {       // (the run's panel kernel takes cblks of at most 128 columns, like k_diag_llt_w)
         for (int64_t q = P.lvl_cblk_ptr[l]; q < P.lvl_cblk_ptr[l + 1]; q++) {
