@@ -58,6 +58,22 @@ __device__ double g_zero_line[128];
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// The thread's index WITHOUT a register that lives across the kernel: threadIdx.x arrives in v0, and every later use keeps a
+// copy of it alive through all the loops -- one of the values the allocator ended up spilling inside the chunk arms.  The
+// lane comes from v_mbcnt (asm volatile: recomputed where it is needed, never hoisted), the wave from the scalar side.
+__device__ __forceinline__ int lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+__device__ __forceinline__ int tid_now(const int wave_s) { return (wave_s << 6) | lane_now(); }
+// (a double zero made in place: as a constant the compiler keeps it in a register pair across the whole kernel -- and spills it)
+__device__ __forceinline__ double zero_now() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return __hiloint2double(z, z);
+}
+
 // the MFMAs of one k-step for the sub-tiles RM (row bands, MI bits) x CM (col bands, NI bits) of this wave
 template <unsigned RM, unsigned CM>
 __device__ __forceinline__ void mfma_sel(const double (&an)[NI], const double (&bm)[MI]) {
@@ -158,33 +174,49 @@ __device__ __forceinline__ void negate_sel(double (&bm)[MI], const bool neg) {
     asm volatile("s_nop 1");
   }
 }
+// (A k-step in two halves -- the wave's lower two column bands, then its upper two: the operands of the NEXT k-step are
+// read half by half as well, so that at most 20 operand registers are live at a time instead of 24; with all eight
+// sub-tiles active the arm otherwise spilled four registers around itself, behind a vmcnt(0) that waited for the DMA just
+// issued.  Every sub-tile still receives its MFMAs in k order: the factors do not change.)
+template <unsigned RM, unsigned CM, bool NEG>
+__device__ __forceinline__ void kstep_halves(const double (&an)[NI], const double (&bm)[MI], double (&ann)[NI], double (&bmn)[MI],
+                                             const double* nA, const double* nB, const bool neg) {
+  constexpr unsigned CL = CM & 3u, CH = CM & 12u;
+  read_sel<RM, CL>(bmn, ann, nA, nB);
+  if constexpr (CH != 0u) __builtin_amdgcn_sched_barrier(0);
+  mfma_sel<RM, CL>(an, bm);
+  if constexpr (CH != 0u) {
+    read_sel<0u, CH>(bmn, ann, nA, nB);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_sel<RM, CH>(an, bm);
+  }
+  negate_sel<RM, NEG>(bmn, neg);
+}
 template <unsigned RM, unsigned CM, bool NEG>
 __device__ __forceinline__ void chunk_arm(const double* sA, const double* sB, const double* nA, const double* nB,
                                           double (&bm0)[MI], double (&an0)[NI], double* fixb, const int fix, const bool neg) {
   double bm1[MI], an1[NI];
   negate_sel<RM, NEG>(bm0, neg);
-  read_sel<RM, CM>(bm1, an1, sA + 4 * SLD, sB + 4 * SLD);
-  mfma_sel<RM, CM>(an0, bm0);                       // ks0
-  negate_sel<RM, NEG>(bm1, neg);
-  read_sel<RM, CM>(bm0, an0, sA + 8 * SLD, sB + 8 * SLD);
-  mfma_sel<RM, CM>(an1, bm1);                       // ks1
-  negate_sel<RM, NEG>(bm0, neg);
-  read_sel<RM, CM>(bm1, an1, sA + 12 * SLD, sB + 12 * SLD);
-  mfma_sel<RM, CM>(an0, bm0);                       // ks2
-  negate_sel<RM, NEG>(bm1, neg);
+  kstep_halves<RM, CM, NEG>(an0, bm0, an1, bm1, sA + 4 * SLD, sB + 4 * SLD, neg);     // ks0, operands of ks1 read beside it
+  kstep_halves<RM, CM, NEG>(an1, bm1, an0, bm0, sA + 8 * SLD, sB + 8 * SLD, neg);     // ks1
+  kstep_halves<RM, CM, NEG>(an0, bm0, an1, bm1, sA + 12 * SLD, sB + 12 * SLD, neg);   // ks2
   __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
   if (fix >= 0) {        // (the stray element of the next chunk's piece, before this wave's reads of that buffer)
-    // (the zero is made here: as a constant the compiler keeps it in a register pair across the whole kernel -- and spills it)
-    int z;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-    fixb[fix] = __hiloint2double(z, z);
+    fixb[fix] = zero_now();
   }
+  // ks3 from registers, the next chunk's first k-step read beside it (all six operands: the next chunk may belong to a
+  // piece with another pattern), again in halves
+  constexpr unsigned CL = CM & 3u, CH = CM & 12u;
 #pragma unroll
   for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
-#pragma unroll
-  for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
+  an0[0] = nB[0 * CS];
+  an0[1] = nB[1 * CS];
   __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
-  mfma_sel<RM, CM>(an1, bm1);                       // ks3 from registers
+  mfma_sel<RM, CL>(an1, bm1);
+  an0[2] = nB[2 * CS];
+  an0[3] = nB[3 * CS];
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_sel<RM, CH>(an1, bm1);
 }
 template <bool NEG>
 __device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const double* sB, const double* nA, const double* nB,
@@ -219,13 +251,13 @@ __device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const
 template <int MODE, bool NEG>
 __device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
                                                const Piece* __restrict__ pieces, const int row0, const int col0,
-                                               const int lane, const int l15, const int g) {
+                                               const int lane, const int l15, const int g, const int wave_s) {
   constexpr bool FULLT = MODE == 0;
   constexpr bool PART = MODE == 2;
   constexpr int NL = KC / UW;                    // k-lines per wave per operand per chunk
   constexpr int PALL = 0x3F;
   // (wave-uniform copy: the k-line tests, the per-wave operand offsets and the pattern go to the scalar unit)
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_s;
   const int wrow0 = (wave >> 1) * 16, wcol0 = (wave & 1) * 16;       // = row0, col0, as scalars
   const int pend = tk.p0 + tk.pn;
   int pi = tk.p0;
@@ -405,9 +437,9 @@ __device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], con
 template <bool PART, bool NEG>
 __device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
-                                                 const int lane, const int l15, const int g) {
+                                                 const int lane, const int l15, const int g, const int wave_s) {
   constexpr int NL = KC / UW;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_s;
   const int wrow0 = (wave >> 1) * 16, wcol0 = (wave & 1) * 16;
   const int pend = tk.p0 + tk.pn;
   int pi = tk.p0;
@@ -437,9 +469,7 @@ __device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], c
     rb = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[(pc.flags >> 2) & 3] + pc.b_off - (dc - dce)), (short)0, ext + 8 * (ce - dce), 0x00020000);
     // (what derives from the lane index is recomputed per piece from a laundered copy, not kept in registers across the
     // chunks: the arms of the chunk switch need the 64 VGPRs for operands)
-    int ln = threadIdx.x;
-    asm volatile("" : "+v"(ln));
-    ln &= 63;
+    const int ln = lane_now();
     const int l2 = 2 * ln;
     const uint32_t oa = !(l2 + 1 >= dr && l2 < re), ob = !(l2 + 1 >= dc && l2 < ce);
     // (in range: < 1024; bit 31 = out of the descriptor's range, and nothing above bit 9 that could wrap the sum with the
@@ -482,7 +512,7 @@ __device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], c
   const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
   double bm0[MI], an0[NI];
   __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
-  if (PART && fixn >= 0) sh[0][0][fixn] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
+  if (PART && fixn >= 0) sh[0][0][fixn] = zero_now();    // (every wave, before its own reads: LDS is in order per wave)
 #pragma unroll
   for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
 #pragma unroll
@@ -539,9 +569,9 @@ __device__ __forceinline__ void mfma_any(const int pat, const double (&an)[NI], 
 template <bool NEG>
 __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
-                                                 const int lane, const int l15, const int g) {
+                                                 const int lane, const int l15, const int g, const int wave_s) {
   constexpr int NL = KC / UW;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave_s;
   const int pend = tk.p0 + tk.pn;
   int pi = tk.p0;
   const int li = lane >> 1;                          // this lane's tile rows / columns: li + 32 q, q = 0..3
@@ -571,13 +601,13 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
 #pragma unroll
     for (int s = 0; s < MI; s++) {
       const int b = (wave >> 1) + 4 * s;             // row band
-      const unsigned long long bal = __ballot(((ma >> (8 * (b >> 1))) & 255u) != 255u);
+      const unsigned long long bal = __ballot(__builtin_amdgcn_ubfe(ma, 8 * (b >> 1), 8) != 255u);
       if ((uint32_t)(bal >> ((b & 1) * 32)) != 0u) p |= 1 << s;
     }
 #pragma unroll
     for (int s = 0; s < NI; s++) {
       const int b = (wave & 1) + 2 * s;              // column band
-      const unsigned long long bal = __ballot(((mb >> (8 * (b >> 1))) & 255u) != 255u);
+      const unsigned long long bal = __ballot(__builtin_amdgcn_ubfe(mb, 8 * (b >> 1), 8) != 255u);
       if ((uint32_t)(bal >> ((b & 1) * 32)) != 0u) p |= 1 << (MI + s);
     }
     return ((p & 3) && (p >> MI)) ? p : 0;
@@ -603,9 +633,10 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
     rb = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[(pc.flags >> 2) & 3] + pc.b_off), (short)0, (kk - 1) * lda8 + 8 * nn, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint32_t sa = (pa_map >> (8 * q)) & 255u, sb = (pb_map >> (8 * q)) & 255u;
-      va[q] = sa != 255u ? 8u * sa + (uint32_t)half4 : 0x80000000u;
-      vb[q] = sb != 255u ? 8u * sb + (uint32_t)half4 : 0x80000000u;
+      // (v_bfe_u32 and a shift-or: no mask or marker constants for the compiler to keep in registers across the kernel)
+      const uint32_t sa = __builtin_amdgcn_ubfe(pa_map, 8 * q, 8), sb = __builtin_amdgcn_ubfe(pb_map, 8 * q, 8);
+      va[q] = (8u * sa + (uint32_t)half4) | ((uint32_t)(sa == 255u) << 31);
+      vb[q] = (8u * sb + (uint32_t)half4) | ((uint32_t)(sb == 255u) << 31);
     }
   };
   setup(cur, ma, mb);
@@ -715,7 +746,7 @@ __device__ __forceinline__ unsigned piece_loop_g(double (&sh)[2][2][KC * SLD], c
 // fragmented 60^3 layout) on the branch-free loop, the rest through the gathering loop.  One call site per instance (the
 // loops are inlined).
 __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
-                                                  const Piece* __restrict__ pieces) {
+                                                  const Piece* __restrict__ pieces, const int wave) {
   const bool neg = (tk.flags & 8u) != 0;
   const bool gath = (tk.flags & TASK_GATHERED) != 0;   // the tail of such a task (everything but whole-tile pieces) gathers
   const bool fullt = tk.tm == TM && tk.tn == TN;
@@ -724,9 +755,7 @@ __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], 
   unsigned touched = 0;
   for (;;) {
     // (what derives from the thread index is recomputed per pass, not kept in registers across the loops: 64 VGPRs)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = lane_now();
     const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
     const int l15 = lane & 15, g = lane >> 4;
     int mode;
@@ -734,17 +763,17 @@ __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], 
     else if (nfull > 0 && fullt) { mode = 0; t.pn = nfull; }
     else { mode = gath ? 3 : 2; t.pn = left; }
     if (mode == 0) {
-      if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     } else if (mode == 1) {
-      if (neg) touched |= piece_loop_m<false, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop_m<false, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop_m<false, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop_m<false, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     } else if (mode == 2) {
-      if (neg) touched |= piece_loop_m<true, true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop_m<true, false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop_m<true, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop_m<true, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     } else {
-      if (neg) touched |= piece_loop_g<true>(sh, ar, t, pieces, row0, col0, lane, l15, g);
-      else touched |= piece_loop_g<false>(sh, ar, t, pieces, row0, col0, lane, l15, g);
+      if (neg) touched |= piece_loop_g<true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop_g<false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     }
     left -= t.pn;
     if (left <= 0) break;
@@ -765,16 +794,18 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_update(const Arenas ar, con
   double (&sh)[2][2][KC * SLD] = *reinterpret_cast<double (*)[2][2][KC * SLD]>(sh_dyn);   // [buffer][A|B]  73,728 bytes
   if (KIND == 1) PANEL_PRIO();
   const Task tk = tasks[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;      // this wave's first row / col band
-  const int l15 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: the only use of threadIdx in the kernel)
   acc_zero();
   // (update_pieces: which loop instance runs which pieces.  The plan puts the whole-tile pieces of a task first, Task::nfull,
   // and sets Task flag 8 for sign flips.)
-  const unsigned touched = update_pieces(sh, ar, tk, pieces);
+  const unsigned touched = update_pieces(sh, ar, tk, pieces, wave);
 
   // ---- epilogue: C -= acc (each register = 16 consecutive rows of one column)
   acc_settle();
+  // (the thread's coordinates are made here, behind the loops: lane_now)
+  const int lane = lane_now();
+  const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;      // this wave's first row / col band
+  const int l15 = lane & 15, g = lane >> 4;
   double* C = ar.p[tk.flags & 3] + tk.c_off;
   const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
   if (tk.flags & 4) {
@@ -1076,11 +1107,12 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
   int* tick = (int*)&sh[0][0][0];
   const int nring = ONEK ? rc.nticket + rc.nd : rc.nticket;
   if (!ONEK && threadIdx.x == 0) run_st(rc.ctl + RUN_GO, 1);       // (the resident diagonal workers' clocks start now)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar, for the whole launch)
   for (;;) {
-    // (the thread index is laundered per ticket: what is derived from it is recomputed, not kept in registers across the loop)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
+    // (the thread index is made anew per ticket -- lane_now --: what is derived from it is recomputed, not kept in registers
+    // across the loop)
+    int lane = lane_now();
+    int tid = (wave << 6) | lane;
     if (tid == 0) {
       // (the stamps of the developer profile are written here, at once: nothing of them is live across the ticket)
       const long long tdraw = rc.prof ? wall_clock64() : 0;
@@ -1132,8 +1164,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid);
       else if constexpr (FT == 2) {
         trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
-        int tid2 = threadIdx.x;                    // (laundered again: the two solves must not share hoisted index arithmetic)
-        asm volatile("" : "+v"(tid2));
+        const int tid2 = tid_now(wave);            // (made again: the two solves must not share hoisted index arithmetic)
         trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2);
       } else {
         trsm_zsy_parked<FT == 4, true>(ar, &sh[0][0][0], tt, dinv, tid);
@@ -1147,11 +1178,13 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       __syncthreads();
       continue;
     }
+    acc_zero();
+    const unsigned touched = update_pieces(sh, ar, tk, pieces, wave);
+    acc_settle();
+    lane = lane_now();                           // (again, behind the loops)
+    tid = (wave << 6) | lane;
     const int row0 = (wave >> 1) * 16, col0 = (wave & 1) * 16;
     const int l15 = lane & 15, g = lane >> 4;
-    acc_zero();
-    const unsigned touched = update_pieces(sh, ar, tk, pieces);
-    acc_settle();
     double* C = ar.p[tk.flags & 3] + tk.c_off;
     const int tm1 = (int)tk.tm - 1, tn1 = (int)tk.tn - 1;
     epilogue_band<0, false, true>(C, touched, row0, col0, l15, g, tm1, tn1, tk.ldc);
