@@ -232,6 +232,116 @@ __device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const
 #undef PA_PAT
 }
 
+// ---- the piece loop of whole tiles, without sign flips (round 6) ------------------------------------------------------
+// Whole-tile pieces of a full 128 x 128 tile (97.6 % of the update flops at 200^3; NEG tasks -- the "+=" pieces of complex
+// products -- keep piece_loop<0, true> below).  Same pipeline as there -- DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+barrier |
+// read (i+1, ks0) | MFMA ks3 -- with two changes:
+// (a) the DMA is a buffer load to LDS on one descriptor per operand and piece (as in the masked loops): the lane's offset
+//     is ONE 32-bit register for the whole task, the k-line goes into the scalar offset, and a k-line beyond K gets a
+//     scalar offset out of the descriptor's range (zeros land in LDS): no zero line, no 64-bit lane addresses;
+// (b) the operand reads and their waits are OURS (inline assembly).  With plain C++ loads the compiler puts
+//     `s_waitcnt lgkmcnt(0)` between the reads of k-step s + 1 and the MFMAs of k-step s in two of the four k-steps -- once a
+//     scalar load (the next piece's record) may be in flight on some path into the loop it cannot count on the in-order
+//     return of LDS reads --, so those reads were not under the MFMAs.  Here every read is a `ds_read_b64` with an
+//     immediate offset from one base register per operand image (the loop is unrolled over the two buffers: every offset is
+//     a constant) and the waits are counted: `lgkmcnt(6)` = "all but the six reads just issued" (LDS returns in order; an
+//     outstanding scalar load only makes such a wait stricter, never wrong).  Nothing is in flight across the back edge.
+template <int OFF>
+__device__ __forceinline__ double lds_rd(const uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64 has a 16-bit offset");
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+// the six operands of k-step KS of buffer B: rows of the wave's two row bands (A image), of its four column bands (B image)
+template <int B, int KS>
+__device__ __forceinline__ void lds_operands(double (&bm)[MI], double (&an)[NI], const uint32_t aA, const uint32_t aB) {
+  constexpr int O = (B * 2 * KC * SLD + 4 * KS * SLD) * 8;
+  bm[0] = lds_rd<O>(aA);
+  bm[1] = lds_rd<O + RS * 8>(aA);
+  an[0] = lds_rd<O>(aB);
+  an[1] = lds_rd<O + CS * 8>(aB);
+  an[2] = lds_rd<O + 2 * CS * 8>(aB);
+  an[3] = lds_rd<O + 3 * CS * 8>(aB);
+}
+__device__ __forceinline__ unsigned piece_loop_w(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
+                                                 const Piece* __restrict__ pieces, const int row0, const int col0,
+                                                 const int lane, const int l15, const int g, const int wave_s) {
+  constexpr int NL = KC / UW;                    // k-lines per wave per operand per chunk
+  const int wave = wave_s;
+  const int pend = tk.p0 + tk.pn;
+  int pi = tk.p0;
+  Piece cur = pieces[pi];
+  Piece nextp = pieces[min(pi + 1, pend - 1)];
+  __amdgpu_buffer_rsrc_t ra, rb;
+  int lda8 = 0, kk = 0, kb = 0;                  // bytes between k-lines, K, first k-line of the chunk being copied
+  const uint32_t vo = 16u * (uint32_t)lane;      // this lane's 16 bytes of a k-line
+  auto setup = [&](const Piece& pc) {
+    lda8 = __builtin_amdgcn_readfirstlane(pc.lda * 8);
+    kk = __builtin_amdgcn_readfirstlane((int)pc.k);
+    const int ext = (kk - 1) * lda8 + 8 * TM;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[pc.flags & 3] + pc.a_off), (short)0, ext, 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)(ar.p[(pc.flags >> 2) & 3] + pc.b_off), (short)0, ext, 0x00020000);
+    kb = 0;
+  };
+  auto dma = [&](double* dA, double* dB) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) {
+      const int kl = kb + wave + UW * q;                                   // wave-uniform
+      const uint32_t so = kl < kk ? (uint32_t)(kl * lda8) : 0x40000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(dA + UW * q * SLD), 16, vo, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(dB + UW * q * SLD), 16, vo, so, 0, 0);
+    }
+    kb += KC;
+  };
+  setup(cur);
+  int left = ((int)cur.k + KC - 1) / KC;
+  // the piece bookkeeping of one chunk iteration: which piece the NEXT chunk belongs to; false: there is none
+  auto advance = [&]() -> bool {
+    if (--left == 0) {
+      if (++pi < pend) {
+        cur = nextp;
+        setup(cur);
+        left = ((int)cur.k + KC - 1) / KC;
+        nextp = pieces[min(pi + 1, pend - 1)];
+      } else {
+        return false;
+      }
+    }
+    return true;
+  };
+  dma(sh[0][0] + wave * SLD, sh[0][1] + wave * SLD);
+  // LDS byte addresses of this lane's first A / B operand (buffer 0, k-step 0)
+  const uint32_t aA = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(sh[0][0] + row0 + l15 + g * SLD);
+  const uint32_t aB = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(sh[0][1] + col0 + l15 + g * SLD);
+  double bm0[MI], an0[NI], bm1[MI], an1[NI];
+  __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
+  lds_operands<0, 0>(bm0, an0, aA, aB);
+  asm volatile("s_waitcnt lgkmcnt(0)");
+  // one chunk iteration on buffer B (returns false after the last chunk)
+  auto step = [&](auto BC) -> bool {
+    constexpr int B = decltype(BC)::value;
+    const bool has_next = advance();
+    if (has_next) dma(sh[B ^ 1][0] + wave * SLD, sh[B ^ 1][1] + wave * SLD);
+    lds_operands<B, 1>(bm1, an1, aA, aB);
+    mfma_sel<3u, 15u>(an0, bm0);                  // ks0 (its operands were waited for behind the previous chunk's ks3)
+    lds_operands<B, 2>(bm0, an0, aA, aB);
+    asm volatile("s_waitcnt lgkmcnt(6)");         // ks1's operands are in; ks2's six may be on their way
+    mfma_sel<3u, 15u>(an1, bm1);                  // ks1
+    lds_operands<B, 3>(bm1, an1, aA, aB);
+    asm volatile("s_waitcnt lgkmcnt(6)");
+    mfma_sel<3u, 15u>(an0, bm0);                  // ks2
+    __syncthreads();         // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read, ks3's operands in
+    // (unconditional: after the last chunk it re-reads a landed buffer; the values are not used)
+    lds_operands<B ^ 1, 0>(bm0, an0, aA, aB);
+    mfma_sel<3u, 15u>(an1, bm1);                  // ks3 from registers
+    asm volatile("s_waitcnt lgkmcnt(0)");         // (nothing in flight across the back edge; hidden by the MFMAs above)
+    return has_next;
+  };
+  while (step(std::integral_constant<int, 0>{}) && step(std::integral_constant<int, 1>{})) {}
+  return 0x3Fu;
+}
+
 // ---- the piece loop ------------------------------------------------------------------------------
 // One software-pipelined LDS-DMA loop, three instantiations (MODE), each with and without sign flips (NEG: the task has
 // "+=" pieces, the cross terms of complex products; real factorizations never do):
@@ -764,7 +874,7 @@ __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], 
     else { mode = gath ? 3 : 2; t.pn = left; }
     if (mode == 0) {
       if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
-      else touched |= piece_loop<0, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop_w(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     } else if (mode == 1) {
       if (neg) touched |= piece_loop_m<false, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
       else touched |= piece_loop_m<false, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
