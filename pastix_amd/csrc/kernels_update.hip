@@ -50,14 +50,6 @@ constexpr int UW = 8;         // waves per workgroup
 constexpr int MI = 2, NI = 4; // 16-row / 16-col sub-tiles per wave
 constexpr int RS = 64, CS = 32;   // distance between a wave's consecutive row / col bands
 
-// 1 KiB of zeros: the DMA source of k-lines beyond a piece's K (the last chunk of a piece with K % 16 != 0)
-__device__ double g_zero_line[128];
-
-// LDS-DMA helper: one wave-instruction copies 64 lanes x 16 B = one 128-row k-line straight into LDS (no VGPRs).
-#define PASTIX_AMD_GLDS(gptr, lptr)                                                              \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),        \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
 // The thread's index WITHOUT a register that lives across the kernel: threadIdx.x arrives in v0, and every later use keeps a
 // copy of it alive through all the loops -- one of the values the allocator ended up spilling inside the chunk arms.  The
 // lane comes from v_mbcnt (asm volatile: recomputed where it is needed, never hoisted), the wave from the scalar side.
@@ -86,20 +78,6 @@ __device__ __forceinline__ void mfma_sel(const double (&an)[NI], const double (&
   if constexpr ((RM & 2u) && (CM & 4u)) acc_mfma<6>(an[2], bm[1]);
   if constexpr ((RM & 2u) && (CM & 8u)) acc_mfma<7>(an[3], bm[1]);
 }
-// A piece is a rectangle of the tile: the wave's active row bands are any subset of its two, its active column bands a
-// contiguous run of its four -- 3 x 10 non-empty patterns `pat` = row bits | col bits << 2 (wave-uniform, in an SGPR).
-__device__ __forceinline__ void mfma_pat(const int pat, const double (&an)[NI], const double (&bm)[MI]) {
-#define PA_PAT(RM, CM) case (RM | (CM << 2)): mfma_sel<RM, CM>(an, bm); break;
-#define PA_PAT_ROWS(CM) PA_PAT(3u, CM) PA_PAT(1u, CM) PA_PAT(2u, CM)
-  switch (pat) {
-    PA_PAT_ROWS(15u) PA_PAT_ROWS(3u) PA_PAT_ROWS(6u) PA_PAT_ROWS(12u) PA_PAT_ROWS(7u) PA_PAT_ROWS(14u)
-    PA_PAT_ROWS(1u) PA_PAT_ROWS(2u) PA_PAT_ROWS(4u) PA_PAT_ROWS(8u)
-    default: break;                            // the wave has no sub-tile in this chunk's piece
-  }
-#undef PA_PAT_ROWS
-#undef PA_PAT
-}
-
 // ---- epilogue ------------------------------------------------------------------------------------
 // C -= acc for the row band MIX of the wave: loads of one 16-row band are issued together from clamped addresses (one
 // latency per band, not per element); ATOMIC: tiles that several workgroups update in the same launch (split piece
@@ -233,9 +211,10 @@ __device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const
 }
 
 // ---- the piece loop of whole tiles, without sign flips (round 6) ------------------------------------------------------
-// Whole-tile pieces of a full 128 x 128 tile (97.6 % of the update flops at 200^3; NEG tasks -- the "+=" pieces of complex
-// products -- keep piece_loop<0, true> below).  Same pipeline as there -- DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+barrier |
-// read (i+1, ks0) | MFMA ks3 -- with two changes:
+// Whole-tile pieces of a full 128 x 128 tile (97.6 % of the update flops at 200^3).  The pipeline of rounds 1-5 -- DMA(i+1) |
+// ks0..ks2 | vmcnt(0)+lgkmcnt(0)+barrier | read (i+1, ks0) | MFMA ks3; RAW: own vmcnt(0), then the barrier, then the read; WAR:
+// buffer i is re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired -- with two
+// changes:
 // (a) the DMA is a buffer load to LDS on one descriptor per operand and piece (as in the masked loops): the lane's offset
 //     is ONE 32-bit register for the whole task, the k-line goes into the scalar offset, and a k-line beyond K gets a
 //     scalar offset out of the descriptor's range (zeros land in LDS): no zero line, no 64-bit lane addresses;
@@ -264,6 +243,25 @@ __device__ __forceinline__ void lds_operands(double (&bm)[MI], double (&an)[NI],
   an[2] = lds_rd<O + 2 * CS * 8>(aB);
   an[3] = lds_rd<O + 3 * CS * 8>(aB);
 }
+// (NEG: the task has "+=" pieces, the cross terms of complex products.  The A operands of such a piece are negated on the
+// vector unit between their arrival and the MFMAs: the counted wait takes them as operands, so that the sign flip cannot be
+// scheduled in front of it.)
+template <bool NEG, int N>
+__device__ __forceinline__ void lds_wait(double (&bm)[MI], const bool neg) {
+  if constexpr (NEG) {
+    if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bm[0]), "+v"(bm[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bm[0]), "+v"(bm[1]));
+    if (neg) {
+      bm[0] = -bm[0];
+      bm[1] = -bm[1];
+      asm volatile("s_nop 1" : "+v"(bm[0]), "+v"(bm[1]));   // (a v_xor result feeds the MFMA inside an asm statement: its wait states are ours)
+    }
+  } else {
+    if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)");
+    else asm volatile("s_waitcnt lgkmcnt(0)");
+  }
+}
+template <bool NEG>
 __device__ __forceinline__ unsigned piece_loop_w(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
                                                  const Piece* __restrict__ pieces, const int row0, const int col0,
                                                  const int lane, const int l15, const int g, const int wave_s) {
@@ -296,6 +294,7 @@ __device__ __forceinline__ unsigned piece_loop_w(double (&sh)[2][2][KC * SLD], c
   };
   setup(cur);
   int left = ((int)cur.k + KC - 1) / KC;
+  bool negn = NEG && (cur.flags & 16) != 0;       // sign of the piece whose chunk is being COPIED
   // the piece bookkeeping of one chunk iteration: which piece the NEXT chunk belongs to; false: there is none
   auto advance = [&]() -> bool {
     if (--left == 0) {
@@ -303,6 +302,7 @@ __device__ __forceinline__ unsigned piece_loop_w(double (&sh)[2][2][KC * SLD], c
         cur = nextp;
         setup(cur);
         left = ((int)cur.k + KC - 1) / KC;
+        negn = NEG && (cur.flags & 16) != 0;
         nextp = pieces[min(pi + 1, pend - 1)];
       } else {
         return false;
@@ -317,225 +317,36 @@ __device__ __forceinline__ unsigned piece_loop_w(double (&sh)[2][2][KC * SLD], c
   double bm0[MI], an0[NI], bm1[MI], an1[NI];
   __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
   lds_operands<0, 0>(bm0, an0, aA, aB);
-  asm volatile("s_waitcnt lgkmcnt(0)");
+  lds_wait<NEG, 0>(bm0, negn);
   // one chunk iteration on buffer B (returns false after the last chunk)
   auto step = [&](auto BC) -> bool {
     constexpr int B = decltype(BC)::value;
+    const bool negc = negn;                       // sign of the chunk being MULTIPLIED (its ks0 operands carry it already)
     const bool has_next = advance();
     if (has_next) dma(sh[B ^ 1][0] + wave * SLD, sh[B ^ 1][1] + wave * SLD);
     lds_operands<B, 1>(bm1, an1, aA, aB);
     mfma_sel<3u, 15u>(an0, bm0);                  // ks0 (its operands were waited for behind the previous chunk's ks3)
     lds_operands<B, 2>(bm0, an0, aA, aB);
-    asm volatile("s_waitcnt lgkmcnt(6)");         // ks1's operands are in; ks2's six may be on their way
+    lds_wait<NEG, 6>(bm1, negc);                  // ks1's operands are in; ks2's six may be on their way
     mfma_sel<3u, 15u>(an1, bm1);                  // ks1
     lds_operands<B, 3>(bm1, an1, aA, aB);
-    asm volatile("s_waitcnt lgkmcnt(6)");
+    lds_wait<NEG, 6>(bm0, negc);
     mfma_sel<3u, 15u>(an0, bm0);                  // ks2
     __syncthreads();         // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read, ks3's operands in
+    if constexpr (NEG) lds_wait<NEG, 0>(bm1, negc);
     // (unconditional: after the last chunk it re-reads a landed buffer; the values are not used)
     lds_operands<B ^ 1, 0>(bm0, an0, aA, aB);
     mfma_sel<3u, 15u>(an1, bm1);                  // ks3 from registers
-    asm volatile("s_waitcnt lgkmcnt(0)");         // (nothing in flight across the back edge; hidden by the MFMAs above)
+    lds_wait<NEG, 0>(bm0, negn);                  // (nothing in flight across the back edge; hidden by the MFMAs above)
     return has_next;
   };
   while (step(std::integral_constant<int, 0>{}) && step(std::integral_constant<int, 1>{})) {}
   return 0x3Fu;
 }
 
-// ---- the piece loop ------------------------------------------------------------------------------
-// One software-pipelined LDS-DMA loop, three instantiations (MODE), each with and without sign flips (NEG: the task has
-// "+=" pieces, the cross terms of complex products; real factorizations never do):
-//   0  whole-tile pieces of a full 128 x 128 tile: no masks at all;
-//   1  whole-tile pieces of a smaller valid tile (last row tile of a panel, target cblks narrower than 128 columns):
-//      lane masks and the sub-tile pattern fixed per task;
-//   2  partial pieces (any rectangle [dr, dr+m) x [dc, dc+n) of the tile): lane masks, pattern and the operand shift are
-//      recomputed per piece (every K / 16 chunks), the stray element a 16-byte DMA lane drags in at an odd piece boundary
-//      is zeroed in LDS before anything reads it.
-// Every wave copies KC/UW k-lines of A and of B per chunk with global_load_lds_dwordx4 (no staging registers, no
-// ds_write), the MFMA operands are double-buffered in registers so that the ds_reads of k-step s+1 are in flight under
-// the MFMAs of k-step s, and the chunk barrier sits in front of the LAST k-step's MFMAs (operands already in
-// registers), so no wave leaves the barrier without matrix work.  Order: DMA(i+1) | ks0..ks2 | vmcnt(0)+lgkmcnt(0)+
-// barrier | read (i+1, ks0) | MFMA ks3.  RAW: own vmcnt(0), then the barrier, then the read.  WAR: buffer i is
-// re-filled by DMA(i+2), issued after this barrier, which every wave passes with its reads retired.
-// Returns the union of the patterns (which sub-tiles the epilogue has to write).
-template <int MODE, bool NEG>
-__device__ __forceinline__ unsigned piece_loop(double (&sh)[2][2][KC * SLD], const Arenas& ar, const Task& tk,
-                                               const Piece* __restrict__ pieces, const int row0, const int col0,
-                                               const int lane, const int l15, const int g, const int wave_s) {
-  constexpr bool FULLT = MODE == 0;
-  constexpr bool PART = MODE == 2;
-  constexpr int NL = KC / UW;                    // k-lines per wave per operand per chunk
-  constexpr int PALL = 0x3F;
-  // (wave-uniform copy: the k-line tests, the per-wave operand offsets and the pattern go to the scalar unit)
-  const int wave = wave_s;
-  const int wrow0 = (wave >> 1) * 16, wcol0 = (wave & 1) * 16;       // = row0, col0, as scalars
-  const int pend = tk.p0 + tk.pn;
-  int pi = tk.p0;
-  Piece cur = pieces[pi];
-  Piece nextp = pieces[min(pi + 1, pend - 1)];
-  int64_t lda = cur.lda;
-  // (wave-uniform pointers: the address arithmetic of the DMA stays on the scalar unit, the lane's 16 bytes are the
-  // vector offset of the load).  Partial pieces: tile row r holds source row r - dr, so the pointers are shifted by
-  // -dr / -dc; lanes wholly outside the piece copy the zero line instead and never use them.
-  const double* pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
-  const double* pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
-  const int lo2 = 2 * lane;
-  int left = ((int)cur.k + KC - 1) / KC;
-  int krem = (int)cur.k;                          // k-lines of the piece not yet issued
-  bool negn = (cur.flags & 16) != 0, negc = negn;
-  const double* zl = g_zero_line;
-  // MODE 1 pieces cover the whole VALID tile: tm x tn.  Lanes beyond tm / tn copy the zero line; with an odd tm (tn)
-  // the last lane brings one element of the next panel row along, which only reaches accumulator rows (columns) the
-  // epilogue never stores.  Bands beyond the valid tile are skipped on the MFMA pipe.
-  bool la = FULLT || 2 * lane < (int)tk.tm, lb = FULLT || 2 * lane < (int)tk.tn;
-  int patc = PALL, patn = PALL;                  // pattern of the chunk in the MFMA section / of the one being copied
-  int fixn = -1;                                 // PART: LDS element (relative to the A image of a buffer) this lane zeroes
-  unsigned touched = 0;
-  auto band_pattern = [&](const int r_lo, const int r_hi, const int c_lo, const int c_hi) {   // scalar arithmetic
-    int p = 0;
-#pragma unroll
-    for (int s = 0; s < MI; s++) if (wrow0 + s * RS < r_hi && wrow0 + s * RS + 16 > r_lo) p |= 1 << s;
-#pragma unroll
-    for (int s = 0; s < NI; s++) if (wcol0 + s * CS < c_hi && wcol0 + s * CS + 16 > c_lo) p |= 1 << (MI + s);
-    // (no sub-tile unless both a row band and a column band are active)
-    return ((p & 3) && (p >> MI)) ? p : 0;
-  };
-  // per-piece set-up of a partial piece: lanes 2l, 2l+1 of a k-line intersect the piece; the pattern; stray elements: a
-  // lane that straddles an odd boundary brings the source row next to the piece along (lanes 0-15 / 16-31 / 32-47 /
-  // 48-63 look after the rows dr-1, dr+m of A and dc-1, dc+n of B, one k-line each)
-  auto piece_setup = [&](const Piece& pc) {
-    const int dr = pc.dr, re = (int)pc.dr + (int)pc.m, dc = pc.dc, ce = (int)pc.dc + (int)pc.n;
-    la = lo2 + 1 >= dr && lo2 < re;
-    lb = lo2 + 1 >= dc && lo2 < ce;
-    patn = band_pattern(dr, re, dc, ce);
-    const int j = lane >> 4;
-    const int e = j == 0 ? dr - 1 : j == 1 ? re : j == 2 ? dc - 1 : ce;      // the row next to the boundary
-    const bool odd = (j == 0 || j == 2) ? (e & 1) == 0 && e >= 0 : (e & 1) != 0 && e < 128;   // shares a lane with a piece row
-    fixn = odd ? (j >= 2 ? KC * SLD : 0) + (lane & 15) * SLD + e : -1;
-    touched |= (unsigned)patn;
-  };
-  if (PART) {
-    piece_setup(cur);
-  } else {
-    patn = FULLT ? PALL : band_pattern(0, (int)tk.tm, 0, (int)tk.tn);
-    touched = (unsigned)patn;
-  }
-  patc = patn;
-  int fixc = fixn;
-#pragma unroll
-  for (int q = 0; q < NL; q++) {
-    const bool kv = wave + UW * q < krem;        // wave-uniform
-    PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * UW * lda : zl) + lo2, sh[0][0] + (wave + UW * q) * SLD);
-    PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * UW * lda : zl) + lo2, sh[0][1] + (wave + UW * q) * SLD);
-  }
-  krem -= KC;
-  const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
-  const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
-  double bm0[MI], an0[NI], bm1[MI], an1[NI];
-  __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
-  if (PART && fixc >= 0) sh[0][0][fixc] = 0.0;    // (every wave, before its own reads: LDS is in order per wave)
-#pragma unroll
-  for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
-#pragma unroll
-  for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
-  int buf = 0;
-  while (true) {
-    bool has_next = true;
-    negc = negn;
-    if (PART) { patc = patn; fixc = fixn; }
-    if (--left == 0) {
-      if (++pi < pend) {
-        cur = nextp;
-        lda = cur.lda;
-        pa = ar.p[cur.flags & 3] + cur.a_off + (int64_t)wave * lda - (PART ? (int)cur.dr : 0);
-        pb = ar.p[(cur.flags >> 2) & 3] + cur.b_off + (int64_t)wave * lda - (PART ? (int)cur.dc : 0);
-        left = ((int)cur.k + KC - 1) / KC;
-        krem = (int)cur.k;
-        negn = (cur.flags & 16) != 0;
-        nextp = pieces[min(pi + 1, pend - 1)];
-        if (PART) piece_setup(cur);
-      } else {
-        has_next = false;
-      }
-    } else {
-      pa += (int64_t)KC * lda;
-      pb += (int64_t)KC * lda;
-    }
-    if (has_next) {
-      double* dA = sh[buf ^ 1][0] + wave * SLD;
-      double* dB = sh[buf ^ 1][1] + wave * SLD;
-#pragma unroll
-      for (int q = 0; q < NL; q++) {
-        const bool kv = wave + UW * q < krem;
-        if (FULLT) {                     // kv is wave-uniform: a scalar branch instead of 64-bit vector selects
-          if (kv) {
-            PASTIX_AMD_GLDS(pa + (int64_t)q * UW * lda + lo2, dA + UW * q * SLD);
-            PASTIX_AMD_GLDS(pb + (int64_t)q * UW * lda + lo2, dB + UW * q * SLD);
-          } else {
-            PASTIX_AMD_GLDS(zl + lo2, dA + UW * q * SLD);
-            PASTIX_AMD_GLDS(zl + lo2, dB + UW * q * SLD);
-          }
-        } else {
-          PASTIX_AMD_GLDS(((kv && la) ? pa + (int64_t)q * UW * lda : zl) + lo2, dA + UW * q * SLD);
-          PASTIX_AMD_GLDS(((kv && lb) ? pb + (int64_t)q * UW * lda : zl) + lo2, dB + UW * q * SLD);
-        }
-      }
-      krem -= KC;
-    }
-    const double* sA = sAw + buf * (2 * KC * SLD);
-    const double* sB = sBw + buf * (2 * KC * SLD);
-    // (NEG: a v_xor result feeds the MFMA inside an asm statement: its wait states are ours)
-#define PA_NEGATE(bm)                                        \
-  if (NEG && negc) {                                         \
-    _Pragma("unroll") for (int s = 0; s < MI; s++) bm[s] = -bm[s]; \
-    asm volatile("s_nop 1");                                 \
-  }
-    PA_NEGATE(bm0)
-    // ks0 (operands in *0), prefetch ks1 into *1
-#pragma unroll
-    for (int s = 0; s < MI; s++) bm1[s] = sA[4 * SLD + s * RS];
-#pragma unroll
-    for (int s = 0; s < NI; s++) an1[s] = sB[4 * SLD + s * CS];
-    if (FULLT) mfma_sel<3u, 15u>(an0, bm0); else mfma_pat(patc, an0, bm0);
-    PA_NEGATE(bm1)
-    // ks1, prefetch ks2 into *0
-#pragma unroll
-    for (int s = 0; s < MI; s++) bm0[s] = sA[8 * SLD + s * RS];
-#pragma unroll
-    for (int s = 0; s < NI; s++) an0[s] = sB[8 * SLD + s * CS];
-    if (FULLT) mfma_sel<3u, 15u>(an1, bm1); else mfma_pat(patc, an1, bm1);
-    PA_NEGATE(bm0)
-    // ks2, prefetch ks3 into *1
-#pragma unroll
-    for (int s = 0; s < MI; s++) bm1[s] = sA[12 * SLD + s * RS];
-#pragma unroll
-    for (int s = 0; s < NI; s++) an1[s] = sB[12 * SLD + s * CS];
-    if (FULLT) mfma_sel<3u, 15u>(an0, bm0); else mfma_pat(patc, an0, bm0);
-    PA_NEGATE(bm1)
-    __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
-    if (PART && has_next && fixn >= 0) sh[buf ^ 1][0][fixn] = 0.0;
-    {
-      // unconditional (after the last chunk it re-reads a landed buffer; the values are not used)
-      const double* nA = sAw + (buf ^ 1) * (2 * KC * SLD);
-      const double* nB = sBw + (buf ^ 1) * (2 * KC * SLD);
-#pragma unroll
-      for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
-#pragma unroll
-      for (int s = 0; s < NI; s++) an0[s] = nB[s * CS];
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
-    // ks3 from registers
-    if (FULLT) mfma_sel<3u, 15u>(an1, bm1); else mfma_pat(patc, an1, bm1);
-    if (!has_next) break;
-    buf ^= 1;
-  }
-#undef PA_NEGATE
-  return touched;
-}
-
 // ---- the piece loop of the MASKED instances (round 6) ---------------------------------------------------------------
 // PART = false: whole-tile pieces of a smaller valid tile (MODE 1 above: lane masks and pattern fixed per task); PART = true:
-// partial pieces (MODE 2: per piece).  Same pipeline as piece_loop -- DMA(i+1) | ks0..ks2 | barrier | read (i+1, ks0) | ks3 --,
+// partial pieces (MODE 2: per piece).  Same pipeline as piece_loop_w -- DMA(i+1) | ks0..ks2 | barrier | read (i+1, ks0) | ks3 --,
 // but (a) the pattern switch is taken once per CHUNK (chunk_pat) and (b) the DMA is a BUFFER load to LDS
 // (buffer_load_dwordx4 ... offen lds): one descriptor per operand and piece, the lane's byte offset a 32-bit register
 // computed once per piece -- 0x80000000, i.e. out of the descriptor's range, for lanes whose two rows lie outside the piece:
@@ -873,8 +684,8 @@ __device__ __forceinline__ unsigned update_pieces(double (&sh)[2][2][KC * SLD], 
     else if (nfull > 0 && fullt) { mode = 0; t.pn = nfull; }
     else { mode = gath ? 3 : 2; t.pn = left; }
     if (mode == 0) {
-      if (neg) touched |= piece_loop<0, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
-      else touched |= piece_loop_w(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      if (neg) touched |= piece_loop_w<true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
+      else touched |= piece_loop_w<false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
     } else if (mode == 1) {
       if (neg) touched |= piece_loop_m<false, true>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
       else touched |= piece_loop_m<false, false>(sh, ar, t, pieces, row0, col0, lane, l15, g, wave);
