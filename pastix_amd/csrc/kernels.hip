@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256) void k_solve_off_fwd64(const T* __restrict__ L
   const int ld = ck.stride, w = ck.width, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NR * MAXW; i += 256) {
     const int q = i / MAXW, c = i - q * MAXW;
-    if (c < w) xs[q][c] = x[q * ldx + ck.fcol + c];
+    // (the columns beyond the cblk's width are multiplied by zeros below: they must not hold what another kernel left in
+    // LDS -- integer keys read as doubles are NaNs, and 0 x NaN poisoned the right-hand sides of a multi-vector solve)
+    xs[q][c] = c < w ? x[q * ldx + ck.fcol + c] : 0.0;
   }
   __syncthreads();
   const int p = ck.row0 + lane;
