@@ -136,75 +136,94 @@ __device__ __forceinline__ void epilogue_band(double* __restrict__ C, const unsi
 // chunk's whole body as straight-line code for its pattern: the operand reads of the k-steps 1-3 fetch only the bands the
 // pattern multiplies, the chunk barrier and the prefetch of the next chunk's first k-step (all six operands: the next
 // chunk may belong to a piece with another pattern) sit in front of the last k-step's MFMAs as in the branch-free loop.
-template <unsigned RM, unsigned CM>
-__device__ __forceinline__ void read_sel(double (&bm)[MI], double (&an)[NI], const double* sA, const double* sB) {
-#pragma unroll
-  for (int s = 0; s < MI; s++) if ((RM >> s) & 1u) bm[s] = sA[s * RS];
-#pragma unroll
-  for (int s = 0; s < NI; s++) if ((CM >> s) & 1u) an[s] = sB[s * CS];
+// Second step (same round): the operand reads and their waits are OURS, as in the whole-tile loop below (piece_loop_w: why):
+// `ds_read_b64` with immediate offsets from the byte address of the lane's first operand in the chunk's buffer, and ONE
+// counted wait per k-step -- "all but the reads just issued".
+template <int OFF>
+__device__ __forceinline__ double lds_rd(const uint32_t a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64 has a 16-bit offset");
+  double v;
+  asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
 }
-template <unsigned RM, bool NEG>
-__device__ __forceinline__ void negate_sel(double (&bm)[MI], const bool neg) {
-  // (NEG: a v_xor result feeds the MFMA inside an asm statement: its wait states are ours)
-  if (NEG && neg) {
-#pragma unroll
-    for (int s = 0; s < MI; s++) if ((RM >> s) & 1u) bm[s] = -bm[s];
-    asm volatile("s_nop 1");
+constexpr int popc4(const unsigned x) { return (int)((x & 1u) + ((x >> 1) & 1u) + ((x >> 2) & 1u) + ((x >> 3) & 1u)); }
+// the operands of the row bands RM / column bands CM of the k-step at byte offset OFF of the buffer at (aA, aB)
+template <unsigned RM, unsigned CM, int OFF>
+__device__ __forceinline__ void read_sel(double (&bm)[MI], double (&an)[NI], const uint32_t aA, const uint32_t aB) {
+  if constexpr (RM & 1u) bm[0] = lds_rd<OFF>(aA);
+  if constexpr (RM & 2u) bm[1] = lds_rd<OFF + RS * 8>(aA);
+  if constexpr (CM & 1u) an[0] = lds_rd<OFF>(aB);
+  if constexpr (CM & 2u) an[1] = lds_rd<OFF + CS * 8>(aB);
+  if constexpr (CM & 4u) an[2] = lds_rd<OFF + 2 * CS * 8>(aB);
+  if constexpr (CM & 8u) an[3] = lds_rd<OFF + 3 * CS * 8>(aB);
+}
+// wait until at most N LDS reads are outstanding; NEG: then flip the sign of the A operands (the wait takes them as
+// operands, so that the flip cannot be scheduled in front of it; a v_xor result feeds the MFMA inside an asm statement: its
+// wait states are ours)
+template <int N, unsigned RM, bool NEG>
+__device__ __forceinline__ void wait_sel(double (&bm)[MI], const bool neg) {
+  if constexpr (NEG && RM == 3u) asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(bm[0]), "+v"(bm[1]) : "n"(N));
+  else if constexpr (NEG && RM == 1u) asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(bm[0]) : "n"(N));
+  else if constexpr (NEG && RM == 2u) asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(bm[1]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N));
+  if constexpr (NEG && RM != 0u) {
+    if (neg) {
+      if constexpr (RM & 1u) bm[0] = -bm[0];
+      if constexpr (RM & 2u) bm[1] = -bm[1];
+      if constexpr (RM == 3u) asm volatile("s_nop 1" : "+v"(bm[0]), "+v"(bm[1]));
+      else if constexpr (RM == 1u) asm volatile("s_nop 1" : "+v"(bm[0]));
+      else asm volatile("s_nop 1" : "+v"(bm[1]));
+    }
   }
 }
 // (A k-step in two halves -- the wave's lower two column bands, then its upper two: the operands of the NEXT k-step are
 // read half by half as well, so that at most 20 operand registers are live at a time instead of 24; with all eight
 // sub-tiles active the arm otherwise spilled four registers around itself, behind a vmcnt(0) that waited for the DMA just
 // issued.  Every sub-tile still receives its MFMAs in k order: the factors do not change.)
-template <unsigned RM, unsigned CM, bool NEG>
-__device__ __forceinline__ void kstep_halves(const double (&an)[NI], const double (&bm)[MI], double (&ann)[NI], double (&bmn)[MI],
-                                             const double* nA, const double* nB, const bool neg) {
+template <unsigned RM, unsigned CM, bool NEG, int OFFN>
+__device__ __forceinline__ void kstep_halves(double (&an)[NI], double (&bm)[MI], double (&ann)[NI], double (&bmn)[MI],
+                                             const uint32_t aA, const uint32_t aB, const bool neg) {
   constexpr unsigned CL = CM & 3u, CH = CM & 12u;
-  read_sel<RM, CL>(bmn, ann, nA, nB);
-  if constexpr (CH != 0u) __builtin_amdgcn_sched_barrier(0);
+  read_sel<RM, CL, OFFN>(bmn, ann, aA, aB);
+  wait_sel<popc4(RM) + popc4(CL), RM, NEG>(bm, neg);       // this k-step's operands are in (read one k-step ago)
   mfma_sel<RM, CL>(an, bm);
   if constexpr (CH != 0u) {
-    read_sel<0u, CH>(bmn, ann, nA, nB);
-    __builtin_amdgcn_sched_barrier(0);
+    read_sel<0u, CH, OFFN>(bmn, ann, aA, aB);
     mfma_sel<RM, CH>(an, bm);
   }
-  negate_sel<RM, NEG>(bmn, neg);
 }
 template <unsigned RM, unsigned CM, bool NEG>
-__device__ __forceinline__ void chunk_arm(const double* sA, const double* sB, const double* nA, const double* nB,
+__device__ __forceinline__ void chunk_arm(const uint32_t aA, const uint32_t aB, const uint32_t nA, const uint32_t nB,
                                           double (&bm0)[MI], double (&an0)[NI], double* fixb, const int fix, const bool neg) {
   double bm1[MI], an1[NI];
-  negate_sel<RM, NEG>(bm0, neg);
-  kstep_halves<RM, CM, NEG>(an0, bm0, an1, bm1, sA + 4 * SLD, sB + 4 * SLD, neg);     // ks0, operands of ks1 read beside it
-  kstep_halves<RM, CM, NEG>(an1, bm1, an0, bm0, sA + 8 * SLD, sB + 8 * SLD, neg);     // ks1
-  kstep_halves<RM, CM, NEG>(an0, bm0, an1, bm1, sA + 12 * SLD, sB + 12 * SLD, neg);   // ks2
-  __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read
+  constexpr int KB = 4 * SLD * 8;                          // bytes between k-steps of a buffer
+  // (ks0's operands -- all six -- were waited for at the end of the previous chunk's arm / of the prologue)
+  kstep_halves<RM, CM, NEG, 1 * KB>(an0, bm0, an1, bm1, aA, aB, neg);     // ks0, operands of ks1 read beside it
+  kstep_halves<RM, CM, NEG, 2 * KB>(an1, bm1, an0, bm0, aA, aB, neg);     // ks1
+  kstep_halves<RM, CM, NEG, 3 * KB>(an0, bm0, an1, bm1, aA, aB, neg);     // ks2
+  __syncthreads();       // vmcnt(0) lgkmcnt(0) s_barrier: next chunk landed, this buffer fully read, ks3's operands in
   if (fix >= 0) {        // (the stray element of the next chunk's piece, before this wave's reads of that buffer)
     fixb[fix] = zero_now();
   }
   // ks3 from registers, the next chunk's first k-step read beside it (all six operands: the next chunk may belong to a
-  // piece with another pattern), again in halves
+  // piece with another pattern), again in halves; nothing stays in flight across the pattern switch
   constexpr unsigned CL = CM & 3u, CH = CM & 12u;
-#pragma unroll
-  for (int s = 0; s < MI; s++) bm0[s] = nA[s * RS];
-  an0[0] = nB[0 * CS];
-  an0[1] = nB[1 * CS];
-  __builtin_amdgcn_sched_barrier(0);   // keep these reads in front of the MFMAs that hide their latency
+  read_sel<3u, 3u, 0>(bm0, an0, nA, nB);
+  wait_sel<4, RM, NEG>(bm1, neg);
   mfma_sel<RM, CL>(an1, bm1);
-  an0[2] = nB[2 * CS];
-  an0[3] = nB[3 * CS];
-  __builtin_amdgcn_sched_barrier(0);
+  read_sel<0u, 12u, 0>(bm0, an0, nA, nB);
   mfma_sel<RM, CH>(an1, bm1);
+  asm volatile("s_waitcnt lgkmcnt(0)");
 }
 template <bool NEG>
-__device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const double* sB, const double* nA, const double* nB,
+__device__ __forceinline__ void chunk_pat(const int pat, const uint32_t aA, const uint32_t aB, const uint32_t nA, const uint32_t nB,
                                           double (&bm0)[MI], double (&an0)[NI], double* fixb, const int fix, const bool neg) {
-#define PA_PAT(RM, CM) case (RM | (CM << 2)): chunk_arm<RM, CM, NEG>(sA, sB, nA, nB, bm0, an0, fixb, fix, neg); break;
+#define PA_PAT(RM, CM) case (RM | (CM << 2)): chunk_arm<RM, CM, NEG>(aA, aB, nA, nB, bm0, an0, fixb, fix, neg); break;
 #define PA_PAT_ROWS(CM) PA_PAT(3u, CM) PA_PAT(1u, CM) PA_PAT(2u, CM)
   switch (pat) {
     PA_PAT_ROWS(15u) PA_PAT_ROWS(3u) PA_PAT_ROWS(6u) PA_PAT_ROWS(12u) PA_PAT_ROWS(7u) PA_PAT_ROWS(14u)
     PA_PAT_ROWS(1u) PA_PAT_ROWS(2u) PA_PAT_ROWS(4u) PA_PAT_ROWS(8u)
-    default: chunk_arm<0u, 0u, NEG>(sA, sB, nA, nB, bm0, an0, fixb, fix, neg); break;   // no sub-tile of this wave in the chunk's piece
+    default: chunk_arm<0u, 0u, NEG>(aA, aB, nA, nB, bm0, an0, fixb, fix, neg); break;   // no sub-tile of this wave in the chunk's piece
   }
 #undef PA_PAT_ROWS
 #undef PA_PAT
@@ -225,13 +244,6 @@ __device__ __forceinline__ void chunk_pat(const int pat, const double* sA, const
 //     immediate offset from one base register per operand image (the loop is unrolled over the two buffers: every offset is
 //     a constant) and the waits are counted: `lgkmcnt(6)` = "all but the six reads just issued" (LDS returns in order; an
 //     outstanding scalar load only makes such a wait stricter, never wrong).  Nothing is in flight across the back edge.
-template <int OFF>
-__device__ __forceinline__ double lds_rd(const uint32_t a) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64 has a 16-bit offset");
-  double v;
-  asm volatile("ds_read_b64 %0, %1 offset:%c2" : "=v"(v) : "v"(a), "n"(OFF));
-  return v;
-}
 // the six operands of k-step KS of buffer B: rows of the wave's two row bands (A image), of its four column bands (B image)
 template <int B, int KS>
 __device__ __forceinline__ void lds_operands(double (&bm)[MI], double (&an)[NI], const uint32_t aA, const uint32_t aB) {
@@ -429,15 +441,14 @@ __device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], c
   bool negn = (cur.flags & 16) != 0, negc = negn;
   int patc = patn;
   dma(sh[0][0] + wave * SLD, sh[0][1] + wave * SLD);
-  const double* sAw = sh[0][0] + row0 + l15 + g * SLD;
-  const double* sBw = sh[0][1] + col0 + l15 + g * SLD;
+  // LDS byte addresses of this lane's first A / B operand (buffer 0, k-step 0)
+  const uint32_t aA0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(sh[0][0] + row0 + l15 + g * SLD);
+  const uint32_t aB0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(sh[0][1] + col0 + l15 + g * SLD);
   double bm0[MI], an0[NI];
   __syncthreads();                                // (emits vmcnt(0): the DMA of chunk 0 has landed)
   if (PART && fixn >= 0) sh[0][0][fixn] = zero_now();    // (every wave, before its own reads: LDS is in order per wave)
-#pragma unroll
-  for (int s = 0; s < MI; s++) bm0[s] = sAw[s * RS];
-#pragma unroll
-  for (int s = 0; s < NI; s++) an0[s] = sBw[s * CS];
+  read_sel<3u, 15u, 0>(bm0, an0, aA0, aB0);
+  asm volatile("s_waitcnt lgkmcnt(0)");
   int buf = 0;
   while (true) {
     bool has_next = true;
@@ -455,8 +466,9 @@ __device__ __forceinline__ unsigned piece_loop_m(double (&sh)[2][2][KC * SLD], c
       }
     }
     if (has_next) dma(sh[buf ^ 1][0] + wave * SLD, sh[buf ^ 1][1] + wave * SLD);
-    chunk_pat<NEG>(patc, sAw + buf * (2 * KC * SLD), sBw + buf * (2 * KC * SLD), sAw + (buf ^ 1) * (2 * KC * SLD),
-                   sBw + (buf ^ 1) * (2 * KC * SLD), bm0, an0, &sh[buf ^ 1][0][0], (PART && has_next) ? fixn : -1, negc);
+    constexpr uint32_t BB = 2 * KC * SLD * 8;      // bytes between the two buffers
+    chunk_pat<NEG>(patc, aA0 + buf * BB, aB0 + buf * BB, aA0 + (buf ^ 1) * BB, aB0 + (buf ^ 1) * BB, bm0, an0, &sh[buf ^ 1][0][0],
+                   (PART && has_next) ? fixn : -1, negc);
     if (!has_next) break;
     buf ^= 1;
   }

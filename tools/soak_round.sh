@@ -11,6 +11,8 @@ run d100_llt   -n 100 --facto 0 --reps 3000
 run d60_lu     -n 60  --facto 2 --reps 6000
 run z32_ldlt   -n 32  --facto 1 --complex --reps 5000
 run d60_ldlt   -n 60  --facto 1 --reps 3000
+# round 6: the run is the default at 200^3 (its reader lists are built on the device): the metric's own configuration
+run d200_llt   -n 200 --facto 0 --reps 40
 # every factorization's factors hashed (bitwise determinism of the schedule, step by step), at sizes where the download is cheap
 run det_d40_llt  -n 40 --facto 0 --reps 400 --check 1
 run det_d40_ldlt -n 40 --facto 1 --reps 400 --check 1
