@@ -270,7 +270,7 @@ def single_gpu_job(grid, workload, facto_name, steps, warmup, blocksize, chunk, 
 OTHER_CONFIGS = [
     dict(config="configs[1]", workload="laplacian", grid=100, facto="llt", steps=3, warmup=1),
     dict(config="configs[2] at the largest grid one GPU holds (200^3 dLU: 2 x 150 GB of panels + tables > 288 GB)",
-         workload="laplacian", grid=192, facto="lu", steps=1, warmup=0),
+         workload="laplacian", grid=192, facto="lu", steps=2, warmup=1),
     dict(config="configs[4]", workload="elasticity", grid=48, facto="ldlt", steps=3, warmup=1),
 ]
 
