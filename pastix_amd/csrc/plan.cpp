@@ -279,6 +279,12 @@ int build_plan(const pastix_amd_layout_t* L, int factotype, int floattype,
   P.bloknbr = L->bloknbr;
   P.cblk.assign(L->cblktab, L->cblktab + nc + 1);
   P.blok.assign(L->bloktab, L->bloktab + L->bloknbr);
+  // (the update kernels' LDS-DMA runs on 32-bit buffer descriptors whose out-of-range markers are 2^30 and 2^31,
+  // kernels_update.hip: a source panel's k-lines -- width + one chunk of them -- must stay below 2^30 bytes; a panel of 10^6
+  // rows by 128 columns: no layout that fits a device comes near)
+  if (floattype != PASTIX_AMD_REALSINGLE)
+    for (int64_t k = 0; k < nc; k++)
+      if ((P.cblk[k].lcolnum - P.cblk[k].fcolnum + 1 + 16) * (int64_t)P.cblk[k].stride * 8 >= ((int64_t)1 << 30)) return PASTIX_AMD_ERR_UNSUPPORTED;
   if ((rc = owner_view(L, owner, myrank, P))) return rc;
   // cblks that receive contributions from more than one rank ("shared"): their contributions are
   // scheduled left-looking with a window (see below): a source older than `window` levels before the target
