@@ -773,19 +773,48 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   3 LU    U side: X = A' (L_d^T)^-1, unit   (in / out in the U arena, the second set of tile inverses)
 template <int MODE, bool COH>
 __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __restrict__ U, const TrsmTask& tk,
-                                            const double* __restrict__ dinv_ws, const int tid) {
+                                            const double* __restrict__ dinv_ws, const int tid, double* __restrict__ ldsT = nullptr) {
   constexpr int NT = 8;
+  // Round 6 (LLt / LDLt, MODE 0 / 1): the triangular factor in LDS.  Every one of the 36 steps below multiplies four operand
+  // entries per lane of L_d (or of a tile inverse), and a step cannot start before they are there: read from memory that
+  // was ONE L2 round trip per step on the chain of the top separator -- 31 us per ticket, a third of the period of a level at
+  // 60^3.  The 28 off-diagonal 16 x 16 tiles of L_d and the 8 tile inverses are exactly the 73,728 bytes of the update
+  // path's operand buffers, idle in such a ticket: all eight waves copy them in by LDS-DMA (72 wave-instructions of 1 KiB:
+  // two per tile, 8 columns x 16 rows each), one barrier, and the steps read LDS (conflict-free: a wave reads 4 columns x
+  // 16 rows = 512 contiguous bytes).
+  constexpr bool LDST = MODE <= 1;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int ld = tk.stride, w = tk.width;
   const int rloc = wave * 16 + l15;
-  if (wave * 16 >= tk.nrows) return;
+  const double* Ld = L + tk.off;                     // diagonal blok (factored; always in the L arena)
+  const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)((w + 15) >> 4) * 256 : 0);
+  if constexpr (LDST) {
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    const int nb1 = ((w + 15) >> 4) - 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int j = ws + 8 * k;                      // wave-uniform: tile j >> 1, its columns 8 (j & 1) ...
+      int t = j >> 1;
+      const int h = j & 1;
+      const double* src;
+      if (t < 28) {
+        int ct = 1;
+        while (t >= ct) { t -= ct; ct++; }           // (ct, p = t): tile index ct (ct - 1) / 2 + p
+        const int row = min(ct * 16 + (lane & 7) * 2, w - 1), col = min(t * 16 + 8 * h + (lane >> 3), w - 1);
+        src = Ld + row + (int64_t)col * ld;
+      } else {
+        src = Ti + min(t - 28, nb1) * 256 + h * 128 + lane * 2;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(ldsT + (j >> 1) * 256 + h * 128), 16, 0, 0);
+    }
+  }
+  if (!LDST && wave * 16 >= tk.nrows) return;
   const bool rvalid = rloc < tk.nrows;
   double* X = (MODE == 3 ? U : L) + tk.off + tk.row0;
   double* Ap = X + rloc;                             // panel row of this lane
   const double* Apc = X + min(rloc, tk.nrows - 1);   // clamped: always readable
-  const double* Ld = L + tk.off;                     // diagonal blok (factored; always in the L arena)
-  const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)((w + 15) >> 4) * 256 : 0);
   static_for<NT>([&](auto CT) {
     constexpr int ct = decltype(CT)::value;
     double v[4];
@@ -799,6 +828,10 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
     acc_write<ct, 3>((rvalid && ct * 16 + g + 12 < w) ? v[3] : 0.0);
     if (ct & 1) __builtin_amdgcn_sched_barrier(0);     // (two tiles' loads in flight at a time: the registers are few)
   });
+  if constexpr (LDST) {
+    __syncthreads();                                   // (vmcnt(0): the factor has landed in LDS, for every wave)
+    if (wave * 16 >= tk.nrows) return;
+  }
   // 36 steps in order: for ct = 0..7 the products with the finished tiles p < ct, then the tile's own step with Tinv[ct].
   // Every step multiplies four operand entries per lane read from memory (T[ct, p] or Tinv[ct]): the loads of step i + 1
   // are issued in front of the MFMAs of step i (two operand sets live; the scheduling barrier per step keeps the compiler
@@ -813,7 +846,15 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
     // front and kept in registers -- 67 spilled VGPRs)
     int lds = ld, ws = w;
     asm volatile("" : "+s"(lds), "+s"(ws));
-    if constexpr (p < ct) {
+    if constexpr (LDST) {
+      constexpr int tile = p < ct ? ct * (ct - 1) / 2 + p : 28 + ct;
+      const int li = ct * 16 + l15;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double lv = ldsT[tile * 256 + (g + 4 * q) * 16 + l15];
+        o[q] = p < ct ? ((li < ws) ? -lv : 0.0) : lv;
+      }
+    } else if constexpr (p < ct) {
       const int li = ct * 16 + l15, lic = min(li, ws - 1);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -1093,8 +1134,8 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       // a panel-solve ticket (the Task record holds a TrsmTask): 128 panel rows, a wave per 16
       TrsmTask tt;
       __builtin_memcpy(&tt, &tk, sizeof(tt));
-      if constexpr (FT == 0) trsm_parked<0, true>(ar.p[0], ar.p[1], tt, dinv, tid);
-      else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid);
+      if constexpr (FT == 0) trsm_parked<0, true>(ar.p[0], ar.p[1], tt, dinv, tid, &sh[0][0][0]);
+      else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid, &sh[0][0][0]);
       else if constexpr (FT == 2) {
         trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
         const int tid2 = tid_now(wave);            // (made again: the two solves must not share hoisted index arithmetic)
