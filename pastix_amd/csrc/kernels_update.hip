@@ -782,7 +782,9 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
   // path's operand buffers, idle in such a ticket: all eight waves copy them in by LDS-DMA (72 wave-instructions of 1 KiB:
   // two per tile, 8 columns x 16 rows each), one barrier, and the steps read LDS (conflict-free: a wave reads 4 columns x
   // 16 rows = 512 contiguous bytes).
-  constexpr bool LDST = MODE <= 1;
+  // (MODE 3, the U side of LU, reads its factor plain like LLt and takes the same path; MODE 2 reads U_d transposed -- a
+  // 16-byte DMA lane cannot transpose, and a transposed read of a plain tile is an 8-way bank conflict: it keeps its loads)
+  constexpr bool LDST = MODE <= 1 || MODE == 3;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int ld = tk.stride, w = tk.width;
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       else if constexpr (FT == 2) {
         trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
         const int tid2 = tid_now(wave);            // (made again: the two solves must not share hoisted index arithmetic)
-        trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2);
+        trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2, &sh[0][0][0]);
       } else {
         trsm_zsy_parked<FT == 4, true>(ar, &sh[0][0][0], tt, dinv, tid);
       }
