@@ -37,6 +37,7 @@ done
 python tools/level_rows.py /tmp/trz 30 > $O/level_timeline_z48.txt 2>&1
 PASTIX_AMD_DEV=run_prof=/tmp/prof_z.bin timeout 300 python bench.py --grid 48 --workload elasticity --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > /dev/null 2>&1
 python tools/run_prof.py /tmp/prof_z.bin 40 >> $O/level_timeline_z48.txt 2>&1
+[ -x tools/bench_diag ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DDIAG_PROFILE -I pastix_amd/csrc -I include -o tools/bench_diag tools/bench_diag.hip
 ( for w in 24 64 128; do timeout 60 ./tools/bench_diag $w 1 | tail -1; done; timeout 60 ./tools/bench_diag 128 2048 | tail -1 ) > $O/bench_diag.txt 2>&1
 if [ -x oracle/_ref/ref_harness_d_ob_amd ]; then
   ( export OPENBLAS_NUM_THREADS=1
