@@ -474,12 +474,14 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
 
 int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int floattype,
                            const pastix_amd_options_t* opts, pastix_amd_plan_t** out) {
+  HostAffinity host_affinity;
   return plan_create_common(layout, factotype, floattype, opts, nullptr, 0, out);
 }
 
 int pastix_amd_plan_create_dist(const pastix_amd_layout_t* layout, int factotype, int floattype,
                                 const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank,
                                 pastix_amd_plan_t** out) {
+  HostAffinity host_affinity;
   if (!owner) return PASTIX_AMD_ERR_BADPARAMETER;
   return plan_create_common(layout, factotype, floattype, opts, owner, myrank, out);
 }
@@ -755,6 +757,7 @@ void pastix_amd_plan_destroy(pastix_amd_plan_t* p) {
   for (auto& e : p->evB) if (e) (void)hipEventDestroy(e);
   if (p->stream2) { (void)hipStreamSynchronize(p->stream2); (void)hipStreamDestroy(p->stream2); }
   if (p->stream3) { (void)hipStreamSynchronize(p->stream3); (void)hipStreamDestroy(p->stream3); }
+  if (p->stream_io) { (void)hipStreamSynchronize(p->stream_io); (void)hipStreamDestroy(p->stream_io); }
   for (hipEvent_t e : {p->evZ, p->evS3}) if (e) (void)hipEventDestroy(e);
   (void)hipFree(p->dGmap);
   (void)hipFree(p->dRunTasks); (void)hipFree(p->dRunInfo); (void)hipFree(p->dRunCons); (void)hipFree(p->dRunD);
@@ -948,9 +951,12 @@ static int split_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* c
 // so a CHUNK of them is packed by host threads into one pinned buffer and travels as one copy; four buffers, so that the
 // packing of the next chunks runs beside the copies in flight (per-cblk copies from pageable memory: 100^3, 16 k panels of
 // 9 GB in all, took 0.9 s each way).  Real arithmetic, cblks not re-cut; everything else keeps the per-cblk path.
-static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab) {
+// part: 0 = every panel; 1 = the panels of the levels below the run (not re-cut ones), on `strm`; 2 = the others.
+static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, void* const* ucoeftab, const int part = 0,
+                          hipStream_t strm = nullptr) {
   const Plan& H = p->host;
   const SplitMap& M = p->split;
+  if (!strm) strm = p->stream;
   // items = the caller's cblks: the plan's own, or -- where cblks wider than 128 columns were re-cut (SplitMap) -- the
   // original ones: an original cblk that was not re-cut is one panel of the arena as before, a re-cut one goes through
   // split_cblk_io (its column groups are separate panels)
@@ -958,8 +964,23 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
   const int64_t nitem = sp ? M.ocblknbr : H.cblknbr;
   auto first = [&](int64_t k) { return sp ? M.first[(size_t)k] : k; };
   auto doff = [&](int64_t k) { return H.poff[(size_t)first(k)]; };            // (k == nitem: the end of the arena)
-  auto owned = [&](int64_t k) { return H.role[(size_t)first(k)] == 1; };
   auto recut = [&](int64_t k) { return sp && M.first[(size_t)k + 1] - M.first[(size_t)k] > 1; };
+  // A re-cut cblk's column groups are consecutive panels of the arena like any run of cblks: they travel through the same
+  // staging, the packing threads cutting the caller's one panel into the groups' panels (split_cblk_io's layout).
+  // LU: the blocks of a re-cut cblk's diagonal blok above a column group live in the OTHER arena's panels (transposed): on
+  // the way in the U panels gather them from the caller's coeftab, on the way out a host pass over the two returned
+  // buffers puts them back (below).  Only a download BEFORE any factorization (ucoeftab's diagonal blok is zeros then)
+  // keeps split_cblk_io.
+  const bool lu = H.factotype == PASTIX_AMD_FACT_LU;
+  // (part 1 runs inside a factorization, on panels that are final: the factors, whatever p->factored says yet)
+  const bool recut_staged = sp && (!lu || (p->dU && ucoeftab && (up || p->factored || part == 1)));
+  auto last_sub = [&](int64_t k) { return sp ? M.first[(size_t)k + 1] - 1 : k; };
+  auto below_run = [&](int64_t k) {
+    return H.run_L0 > 0 && (!recut(k) || recut_staged) && H.level[(size_t)last_sub(k)] < H.run_L0;
+  };
+  auto owned = [&](int64_t k) {
+    return H.role[(size_t)first(k)] == 1 && (part == 0 || (part == 1) == below_run(k));
+  };
   constexpr int NBUF = 4;
   const size_t CH = (size_t)96 << 20;                    // bytes per staging buffer
   struct Stage { char* buf = nullptr; hipEvent_t ev = nullptr; bool busy = false; int64_t k0 = 0, k1 = 0; int arena = 0; };
@@ -978,12 +999,87 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
   auto move = [&](const Stage& x, bool to_stage) {
     void* const* tab = x.arena ? ucoeftab : coeftab;
     const int64_t base = doff(x.k0);
-    std::atomic<int64_t> next{x.k0};
+    // work items of about 1 MB: runs of small panels, slices of big ones (a chunk of the top separators is a handful of
+    // 10 MB panels -- handed out panel-wise, one thread packed all of it: 25 GB/s for those chunks against 42 for the rest)
+    struct Seg { int64_t q0, q1; size_t off, n; int64_t j, c0, c1; };   // panels [q0, q1) whole | bytes [off, off + n) of panel
+    constexpr size_t SEG = (size_t)1 << 20;                               // q0 | columns [c0, c1) of group j of re-cut cblk q0
+    std::vector<Seg> segs;
+    {
+      int64_t q0 = x.k0;
+      size_t acc = 0;
+      for (int64_t q = x.k0; q < x.k1; q++) {
+        const size_t bytes = owned(q) ? (size_t)(doff(q + 1) - doff(q)) * p->esz : 0;
+        if (bytes && recut(q)) {
+          if (q > q0) segs.push_back(Seg{q0, q, 0, 0, -1, 0, 0});
+          for (int64_t s2 = M.first[(size_t)q]; s2 < M.first[(size_t)q + 1]; s2++) {
+            const int64_t wj = H.cblk[(size_t)s2].lcolnum - H.cblk[(size_t)s2].fcolnum + 1;
+            const int64_t per = std::max<int64_t>(1, (int64_t)(SEG / std::max<size_t>(1, (size_t)H.cblk[(size_t)s2].stride * p->esz)));
+            for (int64_t c = 0; c < wj; c += per) segs.push_back(Seg{q, q, 0, 0, s2 - M.first[(size_t)q], c, std::min(wj, c + per)});
+          }
+          q0 = q + 1;
+          acc = 0;
+        } else if (bytes > SEG) {
+          if (q > q0) segs.push_back(Seg{q0, q, 0, 0, -1, 0, 0});
+          for (size_t o = 0; o < bytes; o += SEG) segs.push_back(Seg{q, q, o, std::min(SEG, bytes - o), -1, 0, 0});
+          q0 = q + 1;
+          acc = 0;
+        } else if ((acc += bytes) >= SEG) {
+          segs.push_back(Seg{q0, q + 1, 0, 0, -1, 0, 0});
+          q0 = q + 1;
+          acc = 0;
+        }
+      }
+      if (x.k1 > q0) segs.push_back(Seg{q0, x.k1, 0, 0, -1, 0, 0});
+    }
+    std::atomic<size_t> next{0};
     auto work = [&] {
       for (;;) {
-        const int64_t k = next.fetch_add(16);
-        if (k >= x.k1) break;
-        for (int64_t q = k; q < std::min(x.k1, k + 16); q++) {
+        const size_t i = next.fetch_add(1);
+        if (i >= segs.size()) break;
+        const Seg& g = segs[i];
+        if (g.j >= 0) {
+          // columns [c0, c1) of column group j of the re-cut cblk q0 (split_cblk_io: column c' of the group's panel is the
+          // tail [off, ostride) of original column off + c'; the part of the diagonal blok above the group is not on the
+          // device -- kept in SplitMap::upper on the way in, put back (or zeros) on the way out)
+          const int64_t q = g.q0, s0 = M.first[(size_t)q], sj = s0 + g.j;
+          const int64_t os = M.ostride[(size_t)q], ow = M.owidth[(size_t)q];
+          const int64_t off = H.cblk[(size_t)sj].fcolnum - H.cblk[(size_t)s0].fcolnum, nr = H.cblk[(size_t)sj].stride;
+          const size_t eb = p->esz;
+          char* host = (char*)tab[q];
+          char* stg = x.buf + (size_t)(H.poff[(size_t)sj] - base) * eb;
+          std::vector<unsigned char>* keep = (x.arena == 0 && !p->split.upper.empty() && !p->split.upper[(size_t)q].empty())
+                                                 ? &p->split.upper[(size_t)q] : nullptr;
+          const int64_t wj = H.cblk[(size_t)sj].lcolnum - H.cblk[(size_t)sj].fcolnum + 1;
+          for (int64_t c = g.c0; c < g.c1; c++) {
+            char* hc = host + (size_t)((off + c) * os) * eb;                // original column off + c
+            if (to_stage) {
+              memcpy(stg + (size_t)(c * nr) * eb, hc + (size_t)off * eb, (size_t)nr * eb);
+              if (keep && off) memcpy(keep->data() + (size_t)((off + c) * ow) * eb, hc, (size_t)off * eb);
+              if (lu && x.arena == 1) {
+                // (the reference keeps the whole square A_kk in coeftab's diagonal blok and zeros in ucoeftab's,
+                // csc_intern_solve.c:65-132: the U^T blocks facing the later column groups are the transposes of coeftab's
+                // blocks right of this group's diagonal)
+                const char* hl = (const char*)coeftab[q];
+                for (int64_t pr = off + wj; pr < ow; pr++)
+                  memcpy(stg + (size_t)((pr - off) + c * nr) * eb, hl + (size_t)((off + c) + pr * os) * eb, eb);
+              }
+            } else {
+              memcpy(hc + (size_t)off * eb, stg + (size_t)(c * nr) * eb, (size_t)nr * eb);
+              if (off && !lu) {
+                if (keep) memcpy(hc, keep->data() + (size_t)((off + c) * ow) * eb, (size_t)off * eb);
+                else memset(hc, 0, (size_t)off * eb);
+              }
+            }
+          }
+          continue;
+        }
+        if (g.q1 == g.q0) {
+          char* sp2 = x.buf + (size_t)(doff(g.q0) - base) * p->esz + g.off;
+          char* h = (char*)tab[g.q0] + g.off;
+          if (to_stage) memcpy(sp2, h, g.n); else memcpy(h, sp2, g.n);
+          continue;
+        }
+        for (int64_t q = g.q0; q < g.q1; q++) {
           if (!owned(q)) continue;
           const size_t bytes = (size_t)(doff(q + 1) - doff(q)) * p->esz;
           char* sp2 = x.buf + (size_t)(doff(q) - base) * p->esz;
@@ -1006,10 +1102,15 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
     return 0;
   };
   int cur = 0;
+  double moved = 0;
+  const double t_io = now_s();
   for (int arena = 0; arena < ((p->dU && ucoeftab) ? 2 : 1); arena++) {
     double* dev = arena ? p->dU : p->dL;
     for (int64_t k0 = 0; k0 < nitem;) {
-      if (recut(k0)) {                                     // (both arenas at once, on the first pass)
+      auto by_hand = [&](int64_t k) {                      // re-cut cblks that keep split_cblk_io
+        return recut(k) && (!recut_staged || (size_t)(doff(k + 1) - doff(k)) * p->esz > CH);
+      };
+      if (by_hand(k0)) {                                   // (both arenas at once, on the first pass)
         if (arena == 0 && owned(k0)) {
           int r = split_cblk_io(p, k0, up, coeftab[k0], ucoeftab ? ucoeftab[k0] : nullptr);
           if (r) return r;
@@ -1023,13 +1124,14 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
       if (!owned(k0)) { k0++; continue; }
       auto carried = [&](int64_t k) { return owned(k) || doff(k + 1) == doff(k); };
       int64_t k1 = k0 + 1;                                 // (a panel larger than the buffer travels alone, below)
-      while (k1 < nitem && !recut(k1) && carried(k1) && (size_t)(doff(k1 + 1) - doff(k0)) * p->esz <= CH) k1++;
+      while (k1 < nitem && !by_hand(k1) && carried(k1) && (size_t)(doff(k1 + 1) - doff(k0)) * p->esz <= CH) k1++;
       const size_t bytes = (size_t)(doff(k1) - doff(k0)) * p->esz;
+      moved += (double)bytes;
       if (bytes > CH) {                                    // one huge panel: straight from / to the caller's memory
         if (owned(k0)) {
           void* h = (arena ? ucoeftab : coeftab)[k0];
-          if (up) HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), h, bytes, hipMemcpyHostToDevice, p->stream));
-          else HIPCHK(hipMemcpyAsync(h, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, p->stream));
+          if (up) HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), h, bytes, hipMemcpyHostToDevice, strm));
+          else HIPCHK(hipMemcpyAsync(h, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, strm));
         }
         k0 = k1;
         continue;
@@ -1041,17 +1143,52 @@ static int staged_tabs_io(pastix_amd_plan_t* p, bool up, void* const* coeftab, v
       x.k0 = k0; x.k1 = k1; x.arena = arena;
       if (up) {
         move(x, true);
-        HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), x.buf, bytes, hipMemcpyHostToDevice, p->stream));
+        HIPCHK(hipMemcpyAsync(p->at(dev, doff(k0)), x.buf, bytes, hipMemcpyHostToDevice, strm));
       } else {
-        HIPCHK(hipMemcpyAsync(x.buf, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(hipMemcpyAsync(x.buf, p->at(dev, doff(k0)), bytes, hipMemcpyDeviceToHost, strm));
       }
-      HIPCHK(hipEventRecord(x.ev, p->stream));
+      HIPCHK(hipEventRecord(x.ev, strm));
       x.busy = true;
       k0 = k1;
     }
   }
   for (int i = 0; i < NBUF; i++) { int r = drain(st[(cur + i) % NBUF]); if (r) return r; }
-  HIPCHK(hipStreamSynchronize(p->stream));
+  HIPCHK(hipStreamSynchronize(strm));
+  if (!up && lu && recut_staged) {
+    // LU, after both arenas are home: in a re-cut cblk's diagonal blok the rows of a column above its own group belong to
+    // an earlier group's OTHER factor -- coeftab's square blok holds U there, ucoeftab's the transpose of L (both bloks are
+    // full squares in the reference, transposes of each other, csc_intern_solve.c:65-132).  Both are in the other
+    // buffer's lower part, transposed.
+    std::atomic<int64_t> nextq{0};
+    auto fix = [&] {
+      for (;;) {
+        const int64_t q = nextq.fetch_add(8);
+        if (q >= nitem) break;
+        for (int64_t k = q; k < std::min(nitem, q + 8); k++) {
+          if (!recut(k) || !owned(k) || (size_t)(doff(k + 1) - doff(k)) * p->esz > CH) continue;
+          const int64_t s0 = M.first[(size_t)k], ns = M.first[(size_t)k + 1] - s0, os = M.ostride[(size_t)k];
+          char* hl = (char*)coeftab[k];
+          char* hu = (char*)ucoeftab[k];
+          const size_t eb = p->esz;
+          for (int64_t j = 1; j < ns; j++) {
+            const int64_t offj = H.cblk[(size_t)(s0 + j)].fcolnum - H.cblk[(size_t)s0].fcolnum;
+            const int64_t wj = H.cblk[(size_t)(s0 + j)].lcolnum - H.cblk[(size_t)(s0 + j)].fcolnum + 1;
+            for (int64_t c = offj; c < offj + wj; c++)
+              for (int64_t r = 0; r < offj; r++) {
+                memcpy(hl + (size_t)(c * os + r) * eb, hu + (size_t)(r * os + c) * eb, eb);
+                memcpy(hu + (size_t)(c * os + r) * eb, hl + (size_t)(r * os + c) * eb, eb);
+              }
+          }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; t++) th.emplace_back(fix);
+    fix();
+    for (auto& t : th) t.join();
+  }
+  static const bool verbose = getenv("PASTIX_AMD_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "pastix_amd: staged panels %s, part %d: %.3f GB in %.3f s\n", up ? "in" : "out", part, moved * 1e-9, now_s() - t_io);
   return PASTIX_AMD_OK;
 }
 
@@ -1120,6 +1257,7 @@ static int zero_fanin_buffers(pastix_amd_plan_t* p) {
 }
 
 int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
+  HostAffinity host_affinity;
   if (p) p->refillable = false;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
@@ -1163,6 +1301,7 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
 }
 
 int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
+  HostAffinity host_affinity;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
@@ -1179,8 +1318,12 @@ int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* c
       if (H.role[(size_t)(p->split.active ? p->split.first[(size_t)k] : k)] == 1 && (!coeftab[k] || (p->dU && ucoeftab && !ucoeftab[k])))
         return PASTIX_AMD_ERR_BADPARAMETER;
     HIPCHK(hipStreamSynchronize(p->stream));
-    const int r = staged_tabs_io(p, false, coeftab, ucoeftab);
-    p->stats.d2h_time = now_s() - t0;
+    // (early_done: this very caller's panels below the run went home during the factorization, pastix_amd_factorize)
+    const bool rest = p->early_done && p->early_tab == coeftab && p->early_utab == ucoeftab;
+    const double early_s = rest ? p->stats.d2h_time : 0.0;
+    const int r = staged_tabs_io(p, false, coeftab, ucoeftab, rest ? 2 : 0);
+    p->early_done = false;
+    p->stats.d2h_time = now_s() - t0 + early_s;
     return r;
   }
   for (int64_t k = 0; k < H.cblknbr; k++) {
@@ -1234,6 +1377,7 @@ int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, 
 // the device.
 int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const pastix_amd_int_t* colptr,
                         const pastix_amd_int_t* rows, const void* vals_, const pastix_amd_int_t* perm) {
+  HostAffinity host_affinity;
   if (!p || !colptr || !rows || !vals_ || !perm) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -1879,6 +2023,18 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
     HIPCHK(hipEventRecord(p->evB[0], s2));
     HIPCHK(hipStreamWaitEvent(s1, p->evB[0], 0));
   }
+  p->early_done = false;
+  if (use_run && L0 > 0 && p->early_tab && !p->cplx && !p->distributed) {
+    // (the one-shot entry points: the caller's thread has nothing to do until the run ends -- it carries the panels of the
+    // levels below the run home meanwhile; they are final behind the panel kernels of level L0 - 1)
+    if (!p->stream_io) HIPCHK(hipStreamCreateWithFlags(&p->stream_io, hipStreamNonBlocking));
+    HIPCHK(hipStreamWaitEvent(p->stream_io, p->evP[L0 - 1], 0));
+    const double te = now_s();
+    const int r = staged_tabs_io(p, false, p->early_tab, p->early_utab, 1, p->stream_io);
+    if (r) { (void)hipDeviceSynchronize(); return r; }
+    p->stats.d2h_time = now_s() - te;
+    p->early_done = true;
+  }
   return pastix_amd_factorize_end(p, stats);
 }
 
@@ -2285,6 +2441,7 @@ void pastix_amd_release_cached_plan(void) {
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                     pastix_amd_stats_t* stats, int floattype = PASTIX_AMD_REALDOUBLE) {
+  HostAffinity host_affinity;
   if (!layout || !layout->cblktab || (layout->bloknbr > 0 && !layout->bloktab) || layout->cblknbr < 0) return PASTIX_AMD_ERR_BADPARAMETER;
   OneShotEntry& E = *one_shot_entry(opts ? opts->device : 0);
   std::lock_guard<std::mutex> g(E.mu);                      // (one one-shot call at a time per device: they share its plan)
@@ -2314,7 +2471,11 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
   plan->caller_restores = true;                             // (a stopped run is redone below from the caller's buffers)
+  plan->early_tab = (void* const*)coeftab;                  // (finished panels go home while the run factorizes the rest --
+  plan->early_utab = (void* const*)ucoeftab;                //  PASTIX_AMD_DEV=no_early_out: all of them afterwards)
+  if (dev_opt("no_early_out")) plan->early_tab = nullptr;
   if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
+  if (rc || rcf) plan->early_done = false;
   if (!rc && rcf == PASTIX_AMD_ERR_DEVICE && plan->run_stuck) {      // (see pastix_amd_factorize: the caller's buffers are intact)
     fprintf(stderr, "pastix_amd: uploading the panels again and factorizing on the level-by-level schedule\n");
     rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
@@ -2324,6 +2485,8 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   }
   if (!rc && (rcf == 0 || rcf == PASTIX_AMD_ERR_NUMERIC))
     rc = pastix_amd_download_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+  plan->early_tab = plan->early_utab = nullptr;
+  plan->early_done = false;
   plan->stats.plan_time = plan_time;
   plan->stats.total_time = now_s() - t0;
   if (stats) pastix_amd_plan_stats(plan, stats);
@@ -2374,6 +2537,7 @@ int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* co
 static int one_shot_single(int factotype, const pastix_amd_layout_t* layout, void* const* coeftab,
                            void* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                            pastix_amd_stats_t* stats, bool cplx) {
+  HostAffinity host_affinity;
   if (!layout || !coeftab || !layout->cblktab) return PASTIX_AMD_ERR_BADPARAMETER;
   // real single precision: the fp32 engine on the caller's float panels, nothing is widened (kernels_f32.hip);
   // complex single precision is still widened on the host and factorized by the fp64 engine

@@ -189,6 +189,12 @@ struct pastix_amd_plan_s {
   int run_nwg = 512;                   // workgroups of the run launch: two per CU
   RunCtl runctl{};
   hipStream_t stream3 = nullptr;
+  // one-shot entry points: the panels below the run are FINAL when the run's launch starts; they travel to the caller's
+  // buffers on a stream of their own while it factorizes the rest (api.cpp staged_tabs_io, part 1 / part 2)
+  hipStream_t stream_io = nullptr;
+  void* const* early_tab = nullptr;
+  void* const* early_utab = nullptr;
+  bool early_done = false;
   int64_t run_nticket = 0;
   int* hResident = nullptr;            // host memory the panel kernels' workgroups count themselves in
   std::vector<long long> runFeat;       // (run_prof) per ticket: what tools/run_fit.py fits the stamps against
