@@ -474,14 +474,12 @@ static int plan_create_common(const pastix_amd_layout_t* layout, int factotype, 
 
 int pastix_amd_plan_create(const pastix_amd_layout_t* layout, int factotype, int floattype,
                            const pastix_amd_options_t* opts, pastix_amd_plan_t** out) {
-  HostAffinity host_affinity;
   return plan_create_common(layout, factotype, floattype, opts, nullptr, 0, out);
 }
 
 int pastix_amd_plan_create_dist(const pastix_amd_layout_t* layout, int factotype, int floattype,
                                 const pastix_amd_options_t* opts, const int32_t* owner, int32_t myrank,
                                 pastix_amd_plan_t** out) {
-  HostAffinity host_affinity;
   if (!owner) return PASTIX_AMD_ERR_BADPARAMETER;
   return plan_create_common(layout, factotype, floattype, opts, owner, myrank, out);
 }
@@ -1257,7 +1255,6 @@ static int zero_fanin_buffers(pastix_amd_plan_t* p) {
 }
 
 int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
-  HostAffinity host_affinity;
   if (p) p->refillable = false;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
@@ -1301,7 +1298,6 @@ int pastix_amd_upload_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* con
 }
 
 int pastix_amd_download_tabs(pastix_amd_plan_t* p, void* const* coeftab, void* const* ucoeftab) {
-  HostAffinity host_affinity;
   if (!p || !coeftab) return PASTIX_AMD_ERR_BADPARAMETER;
   HIPCHK(hipSetDevice(p->device));
   const Plan& H = p->host;
@@ -1377,7 +1373,6 @@ int pastix_amd_download_cblk(pastix_amd_plan_t* p, pastix_amd_int_t k, void* L, 
 // the device.
 int pastix_amd_fill_csc(pastix_amd_plan_t* p, int sym, pastix_amd_int_t n, const pastix_amd_int_t* colptr,
                         const pastix_amd_int_t* rows, const void* vals_, const pastix_amd_int_t* perm) {
-  HostAffinity host_affinity;
   if (!p || !colptr || !rows || !vals_ || !perm) return PASTIX_AMD_ERR_BADPARAMETER;
   const Plan& H = p->host;
   if (n != H.ncol) return PASTIX_AMD_ERR_BADPARAMETER;
@@ -2441,7 +2436,6 @@ void pastix_amd_release_cached_plan(void) {
 static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* const* coeftab,
                     double* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                     pastix_amd_stats_t* stats, int floattype = PASTIX_AMD_REALDOUBLE) {
-  HostAffinity host_affinity;
   if (!layout || !layout->cblktab || (layout->bloknbr > 0 && !layout->bloktab) || layout->cblknbr < 0) return PASTIX_AMD_ERR_BADPARAMETER;
   OneShotEntry& E = *one_shot_entry(opts ? opts->device : 0);
   std::lock_guard<std::mutex> g(E.mu);                      // (one one-shot call at a time per device: they share its plan)
@@ -2537,7 +2531,6 @@ int pastix_amd_d_ge_sopalin(const pastix_amd_layout_t* layout, double* const* co
 static int one_shot_single(int factotype, const pastix_amd_layout_t* layout, void* const* coeftab,
                            void* const* ucoeftab, double critere, const pastix_amd_options_t* opts,
                            pastix_amd_stats_t* stats, bool cplx) {
-  HostAffinity host_affinity;
   if (!layout || !coeftab || !layout->cblktab) return PASTIX_AMD_ERR_BADPARAMETER;
   // real single precision: the fp32 engine on the caller's float panels, nothing is widened (kernels_f32.hip);
   // complex single precision is still widened on the host and factorized by the fp64 engine

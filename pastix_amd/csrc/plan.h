@@ -5,8 +5,6 @@
 // sopalin3d.c:790-1025): dependencies become launch slots, the linear facing-blok search
 // (sopalin_compute.c:938-945) becomes precomputed piece descriptors.
 #pragma once
-#include <sched.h>
-#include <unistd.h>
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -18,31 +16,6 @@
 #include "../../include/pastix_amd.h"
 
 namespace pastix_amd {
-
-// Entry points that hand work to host threads (plan analysis, the pinned staging of the panels, the fill) run under this
-// guard.  A caller like the reference pins its calling thread to ONE core (sopalin_thread binds the threads it starts from and
-// the main thread with them), and threads created from a pinned thread inherit the pin: eight "workers" took turns on that
-// core -- the real PaStiX as the caller measured 0.49 s for the 8.8 GB of 100^3 that the same code moves in 0.16 s from an
-// unpinned thread, and 0.43 s for a plan of 0.08.  While an entry point runs, a calling thread allowed on fewer than 8 CPUs
-// is allowed on all of them (the kernel intersects the request with the process's cpuset); its own mask is put back on
-// return.  PASTIX_AMD_HOST_AFFINITY=0 leaves every mask alone.
-struct HostAffinity {
-  cpu_set_t saved;
-  bool changed = false;
-  HostAffinity() {
-    static const bool on = [] { const char* e = getenv("PASTIX_AMD_HOST_AFFINITY"); return !e || atoi(e) != 0; }();
-    if (!on || sched_getaffinity(0, sizeof(saved), &saved)) return;
-    const int ncpu = (int)std::min<long>(sysconf(_SC_NPROCESSORS_CONF), CPU_SETSIZE);
-    if (CPU_COUNT(&saved) >= std::min(ncpu, 8)) return;
-    cpu_set_t all;
-    CPU_ZERO(&all);
-    for (int c = 0; c < ncpu; c++) CPU_SET(c, &all);
-    changed = sched_setaffinity(0, sizeof(all), &all) == 0;
-  }
-  ~HostAffinity() { if (changed) (void)sched_setaffinity(0, sizeof(saved), &saved); }
-  HostAffinity(const HostAffinity&) = delete;
-  HostAffinity& operator=(const HostAffinity&) = delete;
-};
 
 
 

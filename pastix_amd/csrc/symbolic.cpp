@@ -111,7 +111,6 @@ int pastix_amd_order_grid(pastix_amd_int_t nx, pastix_amd_int_t ny, pastix_amd_i
 // after both of its parts.
 int pastix_amd_order_graph(pastix_amd_int_t n, const pastix_amd_int_t* colptr, const pastix_amd_int_t* rows, int leaf,
                            pastix_amd_int_t* perm, pastix_amd_int_t* invp) {
-  pastix_amd::HostAffinity host_affinity;
   if (n <= 0 || !colptr || !rows || !perm || !invp || n > 0x7ffffff0LL) return PASTIX_AMD_ERR_BADPARAMETER;
   if (leaf <= 0) leaf = 64;
   try {
@@ -261,7 +260,6 @@ int pastix_amd_symbol_info(const pastix_amd_symbol_t* s, pastix_amd_int_t* info)
 int pastix_amd_symbolic(pastix_amd_int_t n, const pastix_amd_int_t* colptr, const pastix_amd_int_t* rows,
                         const pastix_amd_int_t* perm_in, const pastix_amd_symbolic_options_t* opts_in,
                         pastix_amd_symbol_t** out) {
-  pastix_amd::HostAffinity host_affinity;
   if (!out || n <= 0 || !colptr || !rows || n > 0x7ffffff0LL) return PASTIX_AMD_ERR_BADPARAMETER;
   *out = nullptr;
   pastix_amd_symbolic_options_t o{};
