@@ -2465,14 +2465,44 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   int rcf = 0;
   plan->caller_restores = true;                             // (a stopped run is redone below from the caller's buffers)
-  plan->early_tab = (void* const*)coeftab;                  // (finished panels go home while the run factorizes the rest --
-  plan->early_utab = (void* const*)ucoeftab;                //  PASTIX_AMD_DEV=no_early_out: all of them afterwards)
-  if (dev_opt("no_early_out")) plan->early_tab = nullptr;
+  // Finished panels go home while the run factorizes the rest (pastix_amd_factorize, staged_tabs_io part 1;
+  // PASTIX_AMD_DEV=no_early_out: all of them afterwards).  They overwrite the caller's input, which is what a stopped run is
+  // redone from: with early copies the input is kept on the DEVICE instead -- a copy of the arenas taken now (100^3: 8.8 GB,
+  // 5 ms), freed when the call returns; no room for it, no early copies.
+  void* snap[2] = {nullptr, nullptr};
+  const size_t arena_bytes = (size_t)plan->host.coefnbr * plan->esz;
+  plan->early_tab = plan->early_utab = nullptr;
+  if (!rc && !dev_opt("no_early_out") && !plan->cplx && !plan->distributed && plan->run_ready && plan->host.run_L0 > 0) {
+    size_t fr = 0, tot = 0;
+    const int na = (plan->dU && ucoeftab) ? 2 : 1;
+    bool ok = hipMemGetInfo(&fr, &tot) == hipSuccess && fr > (size_t)na * arena_bytes + ((size_t)2 << 30);
+    for (int a = 0; ok && a < na; a++) ok = hipMalloc(&snap[a], arena_bytes) == hipSuccess;
+    if (ok) {
+      for (int a = 0; ok && a < na; a++)
+        ok = hipMemcpyAsync(snap[a], plan->at(a ? plan->dU : plan->dL, 0), arena_bytes, hipMemcpyDeviceToDevice, plan->stream) == hipSuccess;
+    }
+    if (ok) {
+      plan->early_tab = (void* const*)coeftab;
+      plan->early_utab = (void* const*)ucoeftab;
+    } else {
+      (void)hipGetLastError();
+      for (void*& x : snap) { if (x) (void)hipFree(x); x = nullptr; }
+    }
+  }
   if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
+  const bool went_early = plan->early_done;
   if (rc || rcf) plan->early_done = false;
-  if (!rc && rcf == PASTIX_AMD_ERR_DEVICE && plan->run_stuck) {      // (see pastix_amd_factorize: the caller's buffers are intact)
-    fprintf(stderr, "pastix_amd: uploading the panels again and factorizing on the level-by-level schedule\n");
-    rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+  if (!rc && rcf == PASTIX_AMD_ERR_DEVICE && plan->run_stuck) {      // (see pastix_amd_factorize)
+    if (went_early) {
+      fprintf(stderr, "pastix_amd: restoring the panels from the device copy and factorizing on the level-by-level schedule\n");
+      for (int a = 0; a < 2 && !rc; a++)
+        if (snap[a] && hipMemcpyAsync(plan->at(a ? plan->dU : plan->dL, 0), snap[a], arena_bytes, hipMemcpyDeviceToDevice, plan->stream) != hipSuccess)
+          rc = PASTIX_AMD_ERR_DEVICE;
+      plan->factored = false;
+    } else {
+      fprintf(stderr, "pastix_amd: uploading the panels again and factorizing on the level-by-level schedule\n");
+      rc = pastix_amd_upload_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
+    }
     plan->run_off_once = true;
     if (!rc) rcf = pastix_amd_factorize(plan, critere, nullptr);
     plan->run_off_once = false;
@@ -2481,6 +2511,7 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
     rc = pastix_amd_download_tabs(plan, (void* const*)coeftab, (void* const*)ucoeftab);
   plan->early_tab = plan->early_utab = nullptr;
   plan->early_done = false;
+  for (void* x : snap) if (x) (void)hipFree(x);
   plan->stats.plan_time = plan_time;
   plan->stats.total_time = now_s() - t0;
   if (stats) pastix_amd_plan_stats(plan, stats);

@@ -156,6 +156,46 @@ def test_a_run_that_trips_its_bounded_wait_is_redone_on_the_level_schedule(run_e
         assert np.array_equal(p.download()[0], L_level)
 
 
+@pytest.mark.parametrize("facto", [0, 2])
+def test_one_shot_call_whose_run_trips_is_redone_although_finished_panels_went_home_early(facto, run_env):
+    """The one-shot entry points copy the panels of the levels below the run into the caller's buffers WHILE the run
+    factorizes the rest -- over the input a stopped run would be redone from.  The input is therefore kept on the device
+    for the call: with the forced expiry the call restores it from there, factorizes level by level and returns what the
+    level schedule returns, bit for bit (LLt: one arena; LU: two, with re-cut cblks' blocks exchanged between them)."""
+    from pastix_amd.solver import sopalin_tabs
+    from pastix_amd import _lib
+    N = 40
+    n, cp, r, v = sy.laplacian_3d(N)
+    perm, _ = sy.order_grid(N, N, N)
+    s = sy.symbolic(n, cp, r, perm, max_blocksize=128)
+    c4, b4 = s["cblk4"], s["blok4"]
+    with Plan(c4, b4, facto) as p:
+        p.fill_csc(1 if facto == 0 else 0, n, cp, r, v, s["perm"])
+        L0, U0 = p.download()
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+
+    def call():
+        tabs = [L0[off[k]:off[k + 1]].copy() for k in range(len(w))]
+        utabs = [U0[off[k]:off[k + 1]].copy() for k in range(len(w))] if facto == 2 else None
+        st = sopalin_tabs(facto, c4, b4, tabs, utabs, critere=1e-14)
+        return np.concatenate(tabs), (np.concatenate(utabs) if utabs else None), st
+
+    try:
+        run_env["PASTIX_AMD_RUN"] = "0"
+        Ll, Ul, _ = call()
+        run_env["PASTIX_AMD_RUN"] = "1"
+        Lr, Ur, st = call()
+        assert st["run_time"] > 0.0 and np.array_equal(Lr, Ll) and (Ul is None or np.array_equal(Ur, Ul))
+        run_env["PASTIX_AMD_RUN_TIMEOUT"] = "0.00001"
+        Lb, Ub, st = call()
+        if st["run_time"] != 0.0:
+            pytest.skip("the run finished before the forced expiry could strike")
+        assert np.array_equal(Lb, Ll) and (Ul is None or np.array_equal(Ub, Ul))
+    finally:
+        _lib.lib().pastix_amd_release_cached_plan()
+
+
 @pytest.mark.parametrize("name", ["rlap3d_20_lu_bs128", "rlap3d_12_ldlt", "zrlap3d_20_ldlt_bs128", "zrlap3d_12_ldlh"])
 def test_the_way_back_restores_every_arena(name, golden, run_env):
     """The same forced expiry for LU (two arenas), LDLt and complex LDLt / LDLh (Re / Im planes, the L D copies): the cached
