@@ -1719,7 +1719,8 @@ int pastix_amd_factorize_end(pastix_amd_plan_t* p, pastix_amd_stats_t* stats) {
     HIPCHK(hipEventRecord(p->evB[0], p->stream2));
     HIPCHK(hipStreamWaitEvent(s, p->evB[0], 0));
   }
-  HIPCHK(hipEventRecord(p->ev1, s));
+  if (!p->ev1_recorded) HIPCHK(hipEventRecord(p->ev1, s));
+  p->ev1_recorded = false;
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   p->factored = true;
@@ -2023,6 +2024,8 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
     // (the one-shot entry points: the caller's thread has nothing to do until the run ends -- it carries the panels of the
     // levels below the run home meanwhile; they are final behind the panel kernels of level L0 - 1)
     if (!p->stream_io) HIPCHK(hipStreamCreateWithFlags(&p->stream_io, hipStreamNonBlocking));
+    HIPCHK(hipEventRecord(p->ev1, s1));                 // (fact_time ends with the last kernel, not with these copies)
+    p->ev1_recorded = true;
     HIPCHK(hipStreamWaitEvent(p->stream_io, p->evP[L0 - 1], 0));
     const double te = now_s();
     const int r = staged_tabs_io(p, false, p->early_tab, p->early_utab, 1, p->stream_io);
@@ -2472,7 +2475,10 @@ static int one_shot(int factotype, const pastix_amd_layout_t* layout, double* co
   void* snap[2] = {nullptr, nullptr};
   const size_t arena_bytes = (size_t)plan->host.coefnbr * plan->esz;
   plan->early_tab = plan->early_utab = nullptr;
-  if (!rc && !dev_opt("no_early_out") && !plan->cplx && !plan->distributed && plan->run_ready && plan->host.run_L0 > 0) {
+  // (from 2e12 flop: every copy that ends beside a running kernel costs it a write-back of the L2s -- 60^3, a run of 10 ms:
+  // 17 -> 20 ms with the early copies, 100^3: +1 ms of 121 for 80 ms less in the call)
+  if (!rc && !dev_opt("no_early_out") && !plan->cplx && !plan->distributed && plan->run_ready && plan->host.run_L0 > 0 &&
+      plan->host.fact_flops >= (dev_opt("early_out_min") ? atof(dev_opt("early_out_min")) : 2e12)) {
     size_t fr = 0, tot = 0;
     const int na = (plan->dU && ucoeftab) ? 2 : 1;
     bool ok = hipMemGetInfo(&fr, &tot) == hipSuccess && fr > (size_t)na * arena_bytes + ((size_t)2 << 30);

@@ -195,6 +195,7 @@ struct pastix_amd_plan_s {
   void* const* early_tab = nullptr;
   void* const* early_utab = nullptr;
   bool early_done = false;
+  bool ev1_recorded = false;            // the factorization's end event is already on the stream (pastix_amd_factorize_end)
   int64_t run_nticket = 0;
   int* hResident = nullptr;            // host memory the panel kernels' workgroups count themselves in
   std::vector<long long> runFeat;       // (run_prof) per ticket: what tools/run_fit.py fits the stamps against

@@ -181,6 +181,8 @@ def test_one_shot_call_whose_run_trips_is_redone_although_finished_panels_went_h
         st = sopalin_tabs(facto, c4, b4, tabs, utabs, critere=1e-14)
         return np.concatenate(tabs), (np.concatenate(utabs) if utabs else None), st
 
+    keep_dev = os.environ.get("PASTIX_AMD_DEV")
+    os.environ["PASTIX_AMD_DEV"] = "early_out_min=0"       # (early copies are made from 2e12 flop on; this problem has 3e10)
     try:
         run_env["PASTIX_AMD_RUN"] = "0"
         Ll, Ul, _ = call()
@@ -194,6 +196,10 @@ def test_one_shot_call_whose_run_trips_is_redone_although_finished_panels_went_h
         assert np.array_equal(Lb, Ll) and (Ul is None or np.array_equal(Ub, Ul))
     finally:
         _lib.lib().pastix_amd_release_cached_plan()
+        if keep_dev is None:
+            os.environ.pop("PASTIX_AMD_DEV", None)
+        else:
+            os.environ["PASTIX_AMD_DEV"] = keep_dev
 
 
 @pytest.mark.parametrize("name", ["rlap3d_20_lu_bs128", "rlap3d_12_ldlt", "zrlap3d_20_ldlt_bs128", "zrlap3d_12_ldlh"])
