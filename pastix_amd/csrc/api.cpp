@@ -1616,6 +1616,7 @@ int pastix_amd_factorize_begin(pastix_amd_plan_t* p, double critere) {
   HIPCHK(hipMemsetAsync(p->dErr, 0, sizeof(int), s));
   HIPCHK(hipEventRecord(p->ev0, s));
   p->refillable = false;                                     // (from here on the panels are being overwritten)
+  p->ev1_recorded = false;
   p->nupd_run = 0;
   p->run_used = false;
   p->launch_events = true;
@@ -2029,7 +2030,7 @@ static int factorize_once(pastix_amd_plan_t* p, double critere, pastix_amd_stats
     HIPCHK(hipStreamWaitEvent(p->stream_io, p->evP[L0 - 1], 0));
     const double te = now_s();
     const int r = staged_tabs_io(p, false, p->early_tab, p->early_utab, 1, p->stream_io);
-    if (r) { (void)hipDeviceSynchronize(); return r; }
+    if (r) { (void)hipDeviceSynchronize(); p->ev1_recorded = false; return r; }
     p->stats.d2h_time = now_s() - te;
     p->early_done = true;
   }
