@@ -137,7 +137,11 @@ typedef struct pastix_amd_plan_s pastix_amd_plan_t;
 /* ---- one-shot drop-ins for {po,ge,sy}_sopalin_thread (double real) -------------------------
  * coeftab[k] / ucoeftab[k]: host panel of cblk k, column-major stride(k) x width(k), already filled
  * (CoefMatrix_Init, coefinit.c:283-296); factorized in place, as the reference leaves them for
- * updo.c.  critere: pivot threshold (sopalin3d.c:586-606).  nbpivot -> sopar->diagchange. */
+ * updo.c.  critere: pivot threshold (sopalin3d.c:586-606).  nbpivot -> sopar->diagchange.
+ * The buffers are overwritten WHILE the call runs (from 2e12 flop on, the panels of the lower levels are copied back beside
+ * the factorization of the upper ones); during the call the device holds one more copy of the panels than the plan keeps
+ * between calls.  h2d_time / d2h_time of the stats: the copies in and out, d2h_time including the part
+ * that ran beside the factorization. */
 int pastix_amd_d_po_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab,
                             double critere, const pastix_amd_options_t *opts, pastix_amd_stats_t *stats);
 int pastix_amd_d_sy_sopalin(const pastix_amd_layout_t *layout, double *const *coeftab,
