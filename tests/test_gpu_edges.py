@@ -138,6 +138,42 @@ def test_cblks_wider_than_256_are_factorized_in_column_groups(widths, facto):
     assert np.abs(xs - x).max() <= 1e-9 * np.abs(x).max()
 
 
+@pytest.mark.parametrize("widths", [[334, 20], [300, 177, 40], [40, 600, 30, 290]])
+@pytest.mark.parametrize("facto", [0, 1, 2])
+def test_wide_cblks_through_the_one_shot_entry_points(widths, facto):
+    """The same layouts through {po,sy,ge}_sopalin with one host buffer per cblk: the staging cuts a re-cut cblk's panel into
+    its column groups' panels on the way in and joins them on the way out (LU: the diagonal blok's upper blocks come back as
+    the transposes held by the other arena)."""
+    from pastix_amd.solver import sopalin_tabs
+    from pastix_amd import _lib
+    c4, b4, n = dense_layout(widths)
+    A = spd(n, 77 + n)
+    if facto == 2:
+        A = A + np.triu(np.random.default_rng(5).standard_normal((n, n)), 1) * 0.1
+    L0 = panels_of(A, c4)
+    U0 = None
+    w = c4[:-1, 1] - c4[:-1, 0] + 1
+    off = np.concatenate([[0], np.cumsum(w * c4[:-1, 3])])
+    if facto == 2:
+        U0 = panels_of(A.T, c4)
+        for k in range(len(w)):
+            U0[off[k]:off[k + 1]].reshape(int(w[k]), int(c4[k, 3]))[:, :int(w[k])] = 0.0
+    Lo, Uo, nbo = oracle_lib.sopalin(facto, c4, b4, L0, U0, 1e-30)
+    tabs = [L0[off[k]:off[k + 1]].copy() for k in range(len(w))]
+    utabs = [U0[off[k]:off[k + 1]].copy() for k in range(len(w))] if facto == 2 else None
+    try:
+        st = sopalin_tabs(facto, c4, b4, tabs, utabs, critere=1e-30)
+    finally:
+        _lib.lib().pastix_amd_release_cached_plan()
+    L1 = np.concatenate(tabs)
+    assert st["nbpivot"] == nbo == 0
+    lm = lower_mask(c4)
+    m = lm if facto != 2 else np.ones(L1.size, bool)
+    assert np.abs(L1 - Lo)[m].max() <= TOL * np.abs(Lo[m]).max()
+    if facto == 2:
+        assert np.abs(np.concatenate(utabs) - Uo).max() <= TOL * np.abs(Uo).max()
+
+
 @pytest.mark.parametrize("facto", [1, 3, 2])
 def test_complex_cblks_wider_than_256(facto):
     """The column-group path on the split planes: z LDLt (complex symmetric), LDLh (Hermitian) and LU."""
