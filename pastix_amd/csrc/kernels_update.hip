@@ -782,42 +782,16 @@ __device__ __forceinline__ void trsm_parked(double* __restrict__ L, double* __re
   // path's operand buffers, idle in such a ticket: all eight waves copy them in by LDS-DMA (72 wave-instructions of 1 KiB:
   // two per tile, 8 columns x 16 rows each), one barrier, and the steps read LDS (conflict-free: a wave reads 4 columns x
   // 16 rows = 512 contiguous bytes).
-  // (MODE 3, the U side of LU, reads its factor plain like LLt and takes the same path.  MODE 2, the L side, reads U_d
-  // TRANSPOSED: a 16-byte DMA lane cannot transpose and a transposed read of a plain tile is an 8-way bank conflict, so its
-  // 28 off-diagonal tiles go through registers -- 14 coalesced 8-byte loads per thread, written to LDS at the transposed
-  // position (the conflict is on these 14 writes, once) -- and the steps read them exactly as the other modes do; the tile
-  // inverses are read plain and come by DMA.)
-  constexpr bool LDST = true;
+  // (MODE 3, the U side of LU, reads its factor plain like LLt and takes the same path; MODE 2 reads U_d transposed -- a
+  // 16-byte DMA lane cannot transpose, and a transposed read of a plain tile is an 8-way bank conflict: it keeps its loads)
+  constexpr bool LDST = MODE <= 1 || MODE == 3;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int ld = tk.stride, w = tk.width;
   const int rloc = wave * 16 + l15;
   const double* Ld = L + tk.off;                     // diagonal blok (factored; always in the L arena)
   const double* Ti = dinv_ws + tk.dinv_off + (MODE == 3 ? (int64_t)((w + 15) >> 4) * 256 : 0);
-  if constexpr (MODE == 2) {
-    const int ws = __builtin_amdgcn_readfirstlane(wave);
-    const int nb1 = ((w + 15) >> 4) - 1;
-    const int cl = lane & 15, rl = ((tid & 255) >> 4);   // entry (column cl of the LDS tile's 16-blocks, row rl): see load_step
-    double v[14];
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-      int t = 2 * k + (ws >> 2);                          // tile of this wave in pass k (two tiles per pass of 512 threads)
-      int ct = 1;
-      while (t >= ct) { t -= ct; ct++; }                 // (ct, p = t)
-      // LDS tile entry [c * 16 + r] = what MODE 0 would read there for (row ct * 16 + r, col p * 16 + c), transposed:
-      // U_d(p * 16 + c, ct * 16 + r)
-      v[k] = Ld[min(t * 16 + cl, w - 1) + (int64_t)min(ct * 16 + rl, w - 1) * ld];
-    }
-#pragma unroll
-    for (int k = 0; k < 14; k++) ldsT[(2 * k + (ws >> 2)) * 256 + cl * 16 + rl] = v[k];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {                        // the 8 tile inverses: 16 DMA instructions, two per wave
-      const int j = ws + 8 * k, t = j >> 1, h = j & 1;
-      const double* src = Ti + min(t, nb1) * 256 + h * 128 + lane * 2;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(ldsT + (28 + t) * 256 + h * 128), 16, 0, 0);
-    }
-  } else if constexpr (LDST) {
+  if constexpr (LDST) {
     const int ws = __builtin_amdgcn_readfirstlane(wave);
     const int nb1 = ((w + 15) >> 4) - 1;
 #pragma unroll
@@ -1165,8 +1139,7 @@ __global__ __launch_bounds__(64 * UW, UW / 2) void k_run_update(const Arenas ar,
       if constexpr (FT == 0) trsm_parked<0, true>(ar.p[0], ar.p[1], tt, dinv, tid, &sh[0][0][0]);
       else if constexpr (FT == 1) trsm_parked<1, true>(ar.p[0], ar.p[1], tt, dinv, tid, &sh[0][0][0]);
       else if constexpr (FT == 2) {
-        trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid, &sh[0][0][0]);
-        __syncthreads();                           // (every wave is done reading the first solve's factor in LDS)
+        trsm_parked<2, true>(ar.p[0], ar.p[1], tt, dinv, tid);
         const int tid2 = tid_now(wave);            // (made again: the two solves must not share hoisted index arithmetic)
         trsm_parked<3, true>(ar.p[0], ar.p[1], tt, dinv, tid2, &sh[0][0][0]);
       } else {
